@@ -1,0 +1,167 @@
+/*
+ * rgbx_hip.h — C ABI of librgbx_hip.so, the MI355X (gfx950) native library behind the
+ * message-passing hot path of rgb-experiment.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference repo root;
+ * "[PyG]" = the arithmetic lives in the un-vendored torch_geometric dependency the reference
+ * imports at that line):
+ *
+ *   rgbx_csr_*            self-loop rewrite + grouping of edges by aggregation index that
+ *                         MessagePassing.propagate performs implicitly on every call
+ *                         (models/gcn.py:27,29; models/graphsage.py:53-58; models/gat.py:28,30;
+ *                         models/appnp_stack.py:29), restated in-repo by models/dagnn.py:20-24.
+ *   rgbx_gcn_norm_f32     gcn_norm, models/dagnn.py:12-31 (degree over the target index,
+ *                         deg^-1/2 with inf -> 0, w = dis[src] * dis[tgt]).
+ *   rgbx_inv_degree_f32   the 1/max(count,1) of aggr='mean' (models/graphsage.py:39,58) [PyG].
+ *   rgbx_spmm_csr_f32     MessagePassing.propagate with aggr='add' / 'mean' and message
+ *                         norm * x_j (models/dagnn.py:34-36,46,57-59; models/graphsage.py:58).
+ *   rgbx_appnp_f32        APPNP.forward's K-step recurrence (models/appnp_stack.py:29),
+ *                         restated in-repo by models/pta.py:79-84.
+ *   rgbx_gat_*            GATConv.forward/message + segment softmax (models/gat.py:28,30) [PyG].
+ *   rgbx_gather_rows_f32 / rgbx_scatter_rows_f32
+ *                         halo pack / unpack for the 1-D node partition (new capability; the
+ *                         reference is single-device, itexperiments.py:246).
+ *
+ * Conventions
+ *   - Plain C types only. Every pointer except `rgbx_last_error_string`'s result is a DEVICE
+ *     pointer owned by the caller; the library never allocates or frees device memory.
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null
+ *     stream); nothing inside synchronises the device.
+ *   - Return value: 0 = OK; < 0 = argument/shape/alignment error (RGBX_E_*); > 0 = hipError_t.
+ *     `rgbx_last_error_string()` describes the calling thread's last failure.
+ *   - Feature matrices are fp32 row-major with an explicit leading dimension in ELEMENTS.
+ *   - Indices inside the library are int32 (requires N < 2^31 and E' < 2^31); `edge_index`
+ *     arrives as the reference's int64 [2, E].
+ */
+#ifndef RGBX_HIP_H
+#define RGBX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGBX_VERSION 100 /* major*10000 + minor*100 + patch */
+
+#define RGBX_OK 0
+#define RGBX_E_ARG (-1)    /* null pointer / negative size / bad enum */
+#define RGBX_E_RANGE (-2)  /* N or E' does not fit int32 */
+#define RGBX_E_ALIGN (-3)  /* pointer or leading dimension not aligned for the vector path */
+#define RGBX_E_WS (-4)     /* workspace too small */
+#define RGBX_E_SHAPE (-5)  /* unsupported shape (e.g. heads*channels combination) */
+
+typedef void* rgbx_stream_t;
+
+/* Self-loop rewrite applied while grouping edges (what the conv layers do before propagate). */
+enum {
+  RGBX_LOOPS_KEEP = 0,          /* edges as given (SAGEConv [PyG], models/graphsage2.py:20-23) */
+  RGBX_LOOPS_ADD_REMAINING = 1, /* add_remaining_self_loops, fill 1 (models/dagnn.py:20-24) */
+  RGBX_LOOPS_REMOVE_ADD = 2     /* remove_self_loops + add_self_loops (models/graphsage.py:53-56) */
+};
+/* For unweighted graphs modes 1 and 2 give the same edge list: the non-loop edges in their
+ * original order followed by one self-loop per node, nodes ascending. */
+
+int rgbx_version(void);
+const char* rgbx_last_error_string(void);
+
+/* ---- graph preparation: int64 edge list -> CSR grouped by `agg_row` ------------------------ */
+
+/* Bytes of scratch `rgbx_csr_build` needs for E input edges over N nodes. */
+int rgbx_csr_workspace_bytes(int64_t E, int64_t N, size_t* bytes);
+
+/* Group edges by aggregation index with a STABLE sort.
+ *   agg_row[e]   = index the edge aggregates INTO  (edge_index[1] forward, edge_index[0] for the
+ *                  transposed graph used by backward)
+ *   other_row[e] = index the edge gathers FROM
+ * Outputs (capacity E + N entries each for col / perm; rowptr has N + 1):
+ *   rowptr[i]..rowptr[i+1]  edges aggregating into node i; rowptr[N] = E'
+ *   col[p]                  gather index of CSR slot p
+ *   perm[p]                 id of the edge in slot p: e in [0,E) = column of edge_index,
+ *                           E + i = the added self-loop of node i
+ * Within a row, slots keep the order of the rewritten edge list (original edges first, in
+ * input order; the added self-loop last). */
+int rgbx_csr_build(const int64_t* agg_row, const int64_t* other_row, int64_t E, int64_t N,
+                   int loops_mode, int32_t* rowptr, int32_t* col, int32_t* perm, void* workspace,
+                   size_t workspace_bytes, rgbx_stream_t stream);
+
+/* dis[i] = (rowptr[i+1]-rowptr[i])^-1/2, 0 where the count is 0 (models/dagnn.py:27-30). */
+int rgbx_deg_inv_sqrt_f32(const int32_t* rowptr, int64_t N, float* dis, rgbx_stream_t stream);
+
+/* w[p] = dis[col[p]] * dis[i] for every slot p of row i (models/dagnn.py:31). `dis` must come
+ * from the FORWARD (target-grouped) CSR also when (rowptr, col) is the transposed one. */
+int rgbx_gcn_norm_f32(const int32_t* rowptr, const int32_t* col, int64_t N, const float* dis,
+                      float* w, rgbx_stream_t stream);
+
+/* inv[i] = 1 / max(rowptr[i+1]-rowptr[i], 1) — the divisor of aggr='mean'. */
+int rgbx_inv_degree_f32(const int32_t* rowptr, int64_t N, float* inv, rgbx_stream_t stream);
+
+/* ---- aggregation ------------------------------------------------------------------------- */
+
+/* out[i,:] = a * rs[i] * sum_{p in row i} w[p] * x[col[p],:]  +  b * y[i,:]
+ *   w  == NULL -> every weight is 1;  rs == NULL -> every row scale is 1;
+ *   y  == NULL -> no additive term (b ignored).  `out` may alias `y` but not `x`.
+ * N rows, d columns; x has n_src rows (col[] < n_src is the caller's contract). */
+int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
+                      const float* x, int64_t ldx, const float* y, int64_t ldy, float* out,
+                      int64_t ldo, int64_t N, int64_t d, float a, float b, rgbx_stream_t stream);
+
+/* z_0 = h;  z_{k+1} = (1-alpha) * A_hat z_k + alpha * h, k = 0..K-1; result in `out`.
+ * `tmp` is an [N, d] scratch (ld = ldo); h, out, tmp must not alias. K >= 0. */
+int rgbx_appnp_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* h,
+                   int64_t ldh, float* out, float* tmp, int64_t ldo, int64_t N, int64_t d, int K,
+                   float alpha, rgbx_stream_t stream);
+
+/* ---- GAT: fused score + edge-softmax + aggregate ------------------------------------------ */
+
+/* a_src[n,h] = <hfeat[n,h,:], att_src[h,:]>, a_dst likewise; hfeat is [n, H*C] (ld = ldh). */
+int rgbx_gat_scores_f32(const float* hfeat, int64_t ldh, const float* att_src,
+                        const float* att_dst, float* a_src, float* a_dst, int64_t n, int H, int C,
+                        rgbx_stream_t stream);
+
+/* Forward over the target-grouped CSR. For every target i and head h:
+ *   e_p   = leaky_relu(a_src[col[p],h] + a_dst[i,h], slope)
+ *   alpha = exp(e_p - max_p e_p) / (sum_p exp(e_p - max) + 1e-16)
+ *   out[i,h,:] = sum_p alpha_p * hfeat[col[p],h,:]
+ * Saves m[i,h] = max and rden[i,h] = 1/(sum + 1e-16) for backward (both [N,H]).
+ * Rows without edges produce 0 (m = 0, rden = 0). */
+int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
+                               int64_t ldh, const float* a_src, const float* a_dst, float* out,
+                               int64_t ldo, float* m, float* rden, int64_t N, int H, int C,
+                               float slope, rgbx_stream_t stream);
+
+/* Backward, target side (same CSR as forward). Per target i, head h:
+ *   dsum[i,h]   = <gout[i,h,:], out[i,h,:]>
+ *   g_a_dst[i,h] = sum_p alpha_p * (<gout[i,h,:], hfeat[col[p],h,:]> - dsum[i,h]) * lrelu'(s_p)
+ * `dsum` ([N,H]) is an output consumed by the source-side pass. */
+int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
+                         int64_t ldh, const float* a_src, const float* a_dst, const float* m,
+                         const float* rden, const float* out, int64_t ldo, const float* gout,
+                         int64_t ldg, float* dsum, float* g_a_dst, int64_t N, int H, int C,
+                         float slope, rgbx_stream_t stream);
+
+/* Backward, source side, over the TRANSPOSED CSR (rows = sources j, col = targets i):
+ *   g_hfeat[j,h,:] = sum_{p: j->i} alpha_p * gout[i,h,:]
+ *   g_a_src[j,h]   = sum_{p: j->i} alpha_p * (<gout[i,h,:], hfeat[j,h,:]> - dsum[i,h]) * lrelu'(s_p)
+ * alpha is recomputed from a_src, a_dst, m, rden; no edge-sized tensor is kept. */
+int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const float* hfeat,
+                         int64_t ldh, const float* a_src, const float* a_dst, const float* m,
+                         const float* rden, const float* dsum, const float* gout, int64_t ldg,
+                         float* g_hfeat, int64_t ldgh, float* g_a_src, int64_t N, int H, int C,
+                         float slope, rgbx_stream_t stream);
+
+/* ---- halo pack / unpack (multi-GPU node partition) ----------------------------------------- */
+
+/* dst[r,:] = src[idx[r],:] for r in [0,n) — pack boundary rows into a send buffer. */
+int rgbx_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, int64_t n, int64_t d,
+                         float* dst, int64_t ldd, rgbx_stream_t stream);
+
+/* dst[idx[r],:] += src[r,:] for r in [0,n); idx entries must be unique (no atomics). */
+int rgbx_scatter_add_rows_f32(const float* src, int64_t lds, const int32_t* idx, int64_t n,
+                              int64_t d, float* dst, int64_t ldd, rgbx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBX_HIP_H */

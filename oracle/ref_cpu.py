@@ -1,0 +1,252 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the product.
+
+A plain-torch (CPU, fp32, edge-parallel gather -> multiply -> index_add_) restatement of the
+message-passing path the reference delegates to torch_geometric. Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module, and
+only as the checker / the timed CPU baseline; ``rgb_experiment_amd`` never imports it.
+
+PINNING STATUS:
+  * ``gcn_norm`` / ``propagate`` / ``appnp`` are pinned against golden vectors produced by the
+    reference's own PyG-free code run in the build container (tests/golden/make_golden.py):
+    G1 ``normalize_adj`` (itexperiments.py:677-684), G2 ``label_propagation`` (:698-719),
+    G3 ``PTA.inference`` (models/pta.py:79-84).
+  * ``gat_conv`` and ``sage_conv`` restate PyG's documented GATConv / SAGEConv formulas; the
+    reference holds no in-repo statement, test or fixture for them and PyG is not installable here:
+    **parity unpinned** for those two (checked only against hand-derived known answers).
+
+Every function cites the reference file:line it follows. `edge_index` is int64 [2, E] with
+row 0 = source j and row 1 = target i (the aggregation index), as in PyG.
+"""
+import torch
+
+
+# ---- self-loop rewrites ---------------------------------------------------------------------
+
+def remove_self_loops(edge_index, edge_weight=None):
+    """PyG remove_self_loops as called at models/graphsage.py:55."""
+    keep = edge_index[0] != edge_index[1]
+    return edge_index[:, keep], (None if edge_weight is None else edge_weight[keep])
+
+
+def add_self_loops(edge_index, edge_weight=None, fill_value=1.0, num_nodes=None):
+    """PyG add_self_loops as called at models/graphsage.py:56: append (i, i) for every node."""
+    n = int(num_nodes)
+    loops = torch.arange(n, dtype=edge_index.dtype).unsqueeze(0).repeat(2, 1)
+    ei = torch.cat([edge_index, loops], dim=1)
+    if edge_weight is not None:
+        edge_weight = torch.cat([edge_weight, edge_weight.new_full((n,), fill_value)])
+    return ei, edge_weight
+
+
+def add_remaining_self_loops(edge_index, edge_weight=None, fill_value=1.0, num_nodes=None):
+    """PyG add_remaining_self_loops as called at models/dagnn.py:21-22: non-loop edges keep their
+    order; every node then gets exactly one loop whose weight is the existing loop's weight if it had
+    one (the last one, if several), else `fill_value`."""
+    n = int(num_nodes)
+    row, col = edge_index[0], edge_index[1]
+    keep = row != col
+    loop_w = None
+    if edge_weight is not None:
+        loop_w = edge_weight.new_full((n,), fill_value)
+        loop_w[row[~keep]] = edge_weight[~keep]
+        edge_weight = torch.cat([edge_weight[keep], loop_w])
+    loops = torch.arange(n, dtype=edge_index.dtype).unsqueeze(0).repeat(2, 1)
+    return torch.cat([edge_index[:, keep], loops], dim=1), edge_weight
+
+
+def rewrite_edges(edge_index, num_nodes, loops_mode):
+    """Edge list a conv layer aggregates over, plus for every rewritten edge the id of the input
+    edge it came from (e in [0,E); E + i for the self-loop added for node i).
+    loops_mode: 0 keep (SAGEConv), 1 add_remaining_self_loops (GCNConv/APPNP), 2 remove+add
+    (my_SAGEConv, GATConv)."""
+    E = edge_index.size(1)
+    ids = torch.arange(E, dtype=torch.int64)
+    if loops_mode == 0:
+        return edge_index, ids
+    keep = edge_index[0] != edge_index[1]
+    if loops_mode == 1:
+        ei, _ = add_remaining_self_loops(edge_index, None, 1.0, num_nodes)
+    elif loops_mode == 2:
+        ei, _ = remove_self_loops(edge_index)
+        ei, _ = add_self_loops(ei, num_nodes=num_nodes)
+    else:
+        raise ValueError(loops_mode)
+    return ei, torch.cat([ids[keep], E + torch.arange(num_nodes, dtype=torch.int64)])
+
+
+def csr_from_edges(agg_index, other_index, edge_ids, num_nodes):
+    """Group a (rewritten) edge list by `agg_index` with a STABLE sort: the index bookkeeping
+    propagate does implicitly. Returns int32 rowptr [N+1], col [E'], perm [E'] — the bit-exact
+    expectation for rgbx_csr_build."""
+    order = torch.sort(agg_index, stable=True)[1]
+    counts = torch.bincount(agg_index, minlength=num_nodes)
+    rowptr = torch.zeros(num_nodes + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    return rowptr.to(torch.int32), other_index[order].to(torch.int32), edge_ids[order].to(torch.int32)
+
+
+# ---- gcn_norm + propagate ---------------------------------------------------------------------
+
+def gcn_norm(edge_index, edge_weight=None, num_nodes=None, add_loops=True, dtype=torch.float32):
+    """models/dagnn.py:12-31 line by line (improved=False -> fill 1)."""
+    n = int(edge_index.max()) + 1 if num_nodes is None else int(num_nodes)
+    if edge_weight is None:
+        edge_weight = torch.ones(edge_index.size(1), dtype=dtype)
+    if add_loops:
+        edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, 1.0, n)
+    row, col = edge_index[0], edge_index[1]
+    deg = torch.zeros(n, dtype=edge_weight.dtype).index_add_(0, col, edge_weight)  # scatter_add over col
+    dis = deg.pow(-0.5)
+    dis.masked_fill_(dis == float("inf"), 0)
+    return edge_index, dis[row] * edge_weight * dis[col]
+
+
+def propagate(edge_index, x, num_nodes, edge_weight=None, aggr="add"):
+    """MessagePassing.propagate: x_j = x[edge_index[0]]; message = norm.view(-1,1) * x_j
+    (models/dagnn.py:57-59); aggregate at edge_index[1] by 'add' (dagnn.py:36) or 'mean'
+    (graphsage.py:39; mean = sum / max(count, 1)). Materialises [E, d] like the PyG path."""
+    src, dst = edge_index[0], edge_index[1]
+    msg = x.index_select(0, src)
+    if edge_weight is not None:
+        msg = edge_weight.view(-1, 1) * msg
+    out = torch.zeros((num_nodes, x.size(1)), dtype=x.dtype).index_add_(0, dst, msg)
+    if aggr == "mean":
+        cnt = torch.bincount(dst, minlength=num_nodes).clamp(min=1).to(x.dtype)
+        out = out / cnt.view(-1, 1)
+    elif aggr != "add":
+        raise ValueError(aggr)
+    return out
+
+
+def gcn_dense_adj(edge_index, num_nodes):
+    """Dense A_hat with A_hat[i, j] = weight of edge j -> i (so that A_hat @ x == propagate)."""
+    ei, w = gcn_norm(edge_index, None, num_nodes)
+    a = torch.zeros(num_nodes, num_nodes, dtype=torch.float32)
+    a.index_put_((ei[1], ei[0]), w, accumulate=True)
+    return a
+
+
+# ---- conv layers ------------------------------------------------------------------------------
+
+def gcn_conv(x, edge_index, weight, bias):
+    """GCNConv.forward [PyG] behind models/gcn.py:27: gcn_norm, x @ W^T, propagate(add), + bias."""
+    n = x.size(0)
+    ei, w = gcn_norm(edge_index, None, n)
+    out = propagate(ei, x @ weight.t(), n, w, "add")
+    return out if bias is None else out + bias
+
+
+def my_sage_conv(x, edge_index, w_l, b_l, w_r, b_r):
+    """models/graphsage.py:49-62."""
+    n = x.size(0)
+    x_l = x @ w_l.t() + b_l
+    x_r = x @ w_r.t() + b_r
+    ei, _ = remove_self_loops(edge_index)
+    ei, _ = add_self_loops(ei, num_nodes=n)
+    return propagate(ei, x_l, n, None, "mean") + x_r
+
+
+def sage_conv(x, edge_index, w_l, b_l, w_r):
+    """SAGEConv.forward [PyG] behind models/graphsage2.py:29: lin_l(mean_j x_j) + lin_r(x_i).
+    PARITY UNPINNED (no in-repo statement)."""
+    n = x.size(0)
+    return propagate(edge_index, x, n, None, "mean") @ w_l.t() + b_l + x @ w_r.t()
+
+
+def segment_softmax(e, index, num_nodes):
+    """torch_geometric.utils.softmax [PyG]: exp(e - max_i) / (sum_i + 1e-16) per target segment."""
+    H = e.size(1)
+    mx = torch.full((num_nodes, H), float("-inf"), dtype=e.dtype)
+    mx = mx.scatter_reduce(0, index.view(-1, 1).expand(-1, H), e, reduce="amax", include_self=True)
+    ex = (e - mx[index]).exp()
+    den = torch.zeros((num_nodes, H), dtype=e.dtype).index_add_(0, index, ex)
+    return ex / (den[index] + 1e-16)
+
+
+def gat_conv(x, edge_index, weight, att_src, att_dst, bias, heads, concat=True, negative_slope=0.2):
+    """GATConv.forward/message [PyG] behind models/gat.py:28,30. PARITY UNPINNED."""
+    n = x.size(0)
+    H = heads
+    C = weight.size(0) // H
+    h = (x @ weight.t()).view(n, H, C)
+    a_s = (h * att_src.view(1, H, C)).sum(-1)
+    a_d = (h * att_dst.view(1, H, C)).sum(-1)
+    ei, _ = remove_self_loops(edge_index)
+    ei, _ = add_self_loops(ei, num_nodes=n)
+    src, dst = ei[0], ei[1]
+    e = torch.nn.functional.leaky_relu(a_s[src] + a_d[dst], negative_slope)
+    alpha = segment_softmax(e, dst, n)
+    msg = h[src] * alpha.unsqueeze(-1)
+    out = torch.zeros((n, H, C), dtype=x.dtype).index_add_(0, dst, msg)
+    out = out.reshape(n, H * C) if concat else out.mean(dim=1)
+    return out if bias is None else out + bias
+
+
+def appnp(x, edge_index, K, alpha):
+    """APPNP.forward [PyG] behind models/appnp_stack.py:29, recurrence as models/pta.py:79-84:
+    gcn_norm once, then z <- (1-alpha) * A_hat z + alpha * x, K times."""
+    n = x.size(0)
+    ei, w = gcn_norm(edge_index, None, n)
+    z = x
+    for _ in range(K):
+        z = (1 - alpha) * propagate(ei, z, n, w, "add") + alpha * x
+    return z
+
+
+# ---- model forwards from a product state_dict ---------------------------------------------------
+
+def batch_norm(x, sd, prefix, training, eps=1e-5):
+    """nn.BatchNorm1d over the node axis (models/gcn.py:23,28): batch statistics (biased variance)
+    in training, running statistics in eval."""
+    if training:
+        mean, var = x.mean(0), x.var(0, unbiased=False)
+    else:
+        mean, var = sd[prefix + "running_mean"], sd[prefix + "running_var"]
+    return (x - mean) / torch.sqrt(var + eps) * sd[prefix + "weight"] + sd[prefix + "bias"]
+
+
+def _finish(x):
+    return {"out": torch.log_softmax(x, dim=1), "emb": x}
+
+
+def _stack(sd, x, edge_index, num_layers, training, conv):
+    for i in range(num_layers - 1):
+        x = batch_norm(conv(i, x), sd, f"bns.{i}.", training)
+    return _finish(conv(num_layers - 1, x))
+
+
+def gcn_forward(sd, x, edge_index, num_layers, training=False):
+    """models/gcn.py:25-31."""
+    return _stack(sd, x, edge_index, num_layers, training,
+                  lambda i, v: gcn_conv(v, edge_index, sd[f"convs.{i}.lin.weight"], sd[f"convs.{i}.bias"]))
+
+
+def graphsage_forward(sd, x, edge_index, num_layers, training=False):
+    """models/graphsage.py:26-32."""
+    return _stack(sd, x, edge_index, num_layers, training,
+                  lambda i, v: my_sage_conv(v, edge_index, sd[f"convs.{i}.lin_l.weight"], sd[f"convs.{i}.lin_l.bias"],
+                                            sd[f"convs.{i}.lin_r.weight"], sd[f"convs.{i}.lin_r.bias"]))
+
+
+def graphsage2_forward(sd, x, edge_index, num_layers, training=False):
+    """models/graphsage2.py:27-33."""
+    return _stack(sd, x, edge_index, num_layers, training,
+                  lambda i, v: sage_conv(v, edge_index, sd[f"convs.{i}.lin_l.weight"], sd[f"convs.{i}.lin_l.bias"],
+                                         sd[f"convs.{i}.lin_r.weight"]))
+
+
+def gat_forward(sd, x, edge_index, num_layers, heads, training=False):
+    """models/gat.py:26-32: hidden layers `heads` heads concatenated, last layer 1 head, concat=False."""
+    def conv(i, v):
+        last = i == num_layers - 1
+        return gat_conv(v, edge_index, sd[f"convs.{i}.lin_src.weight"], sd[f"convs.{i}.att_src"],
+                        sd[f"convs.{i}.att_dst"], sd[f"convs.{i}.bias"], 1 if last else heads, concat=not last)
+    return _stack(sd, x, edge_index, num_layers, training, conv)
+
+
+def appnp_stack_forward(sd, x, edge_index, K, alpha, training=False):
+    """models/appnp_stack.py:25-31."""
+    h = x @ sd["lin1.weight"].t() + sd["lin1.bias"]
+    h = batch_norm(h, sd, "bn.", training)
+    h = h @ sd["lin2.weight"].t() + sd["lin2.bias"]
+    return _finish(appnp(h, edge_index, K, alpha))

@@ -1,0 +1,96 @@
+"""ctypes binding of librgbx_hip.so (C ABI: include/rgbx_hip.h).
+
+There is no CPU fallback: if the library is missing, or a tensor is not on a HIP device, the
+callers raise ``RuntimeError`` (the reference's sweep scripts treat ``RuntimeError`` as a failed
+run, examples/all_dataset_baseline.py:65).
+"""
+import ctypes
+import os
+
+import torch  # must be imported first: its bundled libamdhip64.so.7 is the one HIP runtime in the process
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librgbx_hip.so")
+
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> argtypes, exactly the declarations of include/rgbx_hip.h
+SIGNATURES = {
+    "rgbx_csr_workspace_bytes": [_I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
+    "rgbx_csr_build": [_P, _P, _I64, _I64, _I, _P, _P, _P, _P, ctypes.c_size_t, _P],
+    "rgbx_deg_inv_sqrt_f32": [_P, _I64, _P, _P],
+    "rgbx_gcn_norm_f32": [_P, _P, _I64, _P, _P, _P],
+    "rgbx_inv_degree_f32": [_P, _I64, _P, _P],
+    "rgbx_spmm_csr_f32": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _F, _F, _P],
+    "rgbx_appnp_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _F, _P],
+    "rgbx_gat_scores_f32": [_P, _I64, _P, _P, _P, _P, _I64, _I, _I, _P],
+    "rgbx_gat_aggregate_fwd_f32": [_P, _P, _P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I, _I, _F, _P],
+    "rgbx_gat_bwd_dst_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I,
+                             _F, _P],
+    "rgbx_gat_bwd_src_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _I,
+                             _F, _P],
+    "rgbx_gather_rows_f32": [_P, _I64, _P, _I64, _I64, _P, _I64, _P],
+    "rgbx_scatter_add_rows_f32": [_P, _I64, _P, _I64, _I64, _P, _I64, _P],
+}
+EXPORTS = ["rgbx_version", "rgbx_last_error_string"] + list(SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise RuntimeError (never fall back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"rgb_experiment_amd: {LIB_PATH} is not built — run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C rgb_experiment_amd/csrc`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.rgbx_version.restype = _I
+    lib.rgbx_version.argtypes = []
+    lib.rgbx_last_error_string.restype = ctypes.c_char_p
+    lib.rgbx_last_error_string.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = _I
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rgbx_last_error_string().decode(errors="replace")
+        kind = "argument error" if rc < 0 else "hipError"
+        raise RuntimeError(f"{what} failed ({kind} {rc}): {msg}")
+
+
+def require_device(*tensors):
+    """The product path runs on the GPU only."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "rgb_experiment_amd: the message-passing path runs in HIP kernels on an MI355X device; "
+                f"got a tensor on '{t.device}'. There is no CPU fallback (oracle/ is test-only).")
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def mat(t, name="tensor"):
+    """Row-major fp32 matrix -> (pointer, leading dimension in elements)."""
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise RuntimeError(f"{name}: expected a 2-D float32 tensor, got {t.dtype} {tuple(t.shape)}")
+    if t.size(1) > 1 and t.stride(1) != 1:
+        raise RuntimeError(f"{name}: rows must be contiguous (stride {t.stride()})")
+    ld = t.stride(0) if t.size(0) > 1 else max(t.size(1), 1)
+    return t.data_ptr(), ld

@@ -1,0 +1,462 @@
+// GAT: fused attention score + edge-softmax + weighted aggregation, forward and backward, for
+// gfx950. Replaces GATConv.forward/message + torch_geometric.utils.softmax behind reference
+// models/gat.py:18-21,28,30 [PyG]: the four edge-sized temporaries ([E',H] x3, [E',H,C]) of that
+// path never exist here. One wave owns one row of the (target- or source-grouped) CSR.
+//
+// Lane layout (host-computed `GatLayout`): a head occupies LPH = pow2ceil(C / VEC) consecutive
+// lanes, each holding VEC channels; HPC heads sit side by side in a group of G lanes that reads
+// one neighbour row per step; NG = 64 / G neighbours are read per wave-instruction. Heads beyond
+// HPC are covered by an outer loop (softmax is per head, so head chunks are independent).
+// Softmax runs online (running max / sum per lane, merged across the NG groups at the end);
+// backward recomputes alpha from the saved per-(node, head) max and 1/sum.
+#include "rgbx_common.h"
+
+namespace rgbx {
+namespace {
+
+struct GatLayout {
+  int H, C;
+  int LPH;  // lanes per head (power of two)
+  int HPC;  // heads per chunk
+  int G;    // lanes per neighbour row (power of two, >= HPC * LPH)
+};
+
+constexpr float kNegBig = -1.0e30f;
+constexpr int U = 4;
+
+template <int VEC>
+__device__ __forceinline__ float dot_vec(const float (&a)[VEC], const float (&b)[VEC]) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s = fmaf(a[i], b[i], s);
+  return s;
+}
+
+// Sum over the LPH lanes of a head; every lane of the head ends with the total.
+__device__ __forceinline__ float head_sum(float v, int LPH) {
+  for (int off = LPH >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// scores: a_src[n,h] = <hfeat[n,h,:], att_src[h,:]>, a_dst likewise. One wave per node.
+__global__ void __launch_bounds__(256)
+gat_scores_kernel(const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ att_src,
+                  const float* __restrict__ att_dst, float* __restrict__ a_src,
+                  float* __restrict__ a_dst, int n, int H, int C) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += gridDim.x * wpb) {
+    const float* x = hfeat + (int64_t)row * ldh;
+    for (int h = 0; h < H; ++h) {
+      float ss = 0.f, sd = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float v = x[h * C + c];
+        ss = fmaf(v, att_src[h * C + c], ss);
+        sd = fmaf(v, att_dst[h * C + c], sd);
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        ss += __shfl_xor(ss, off);
+        sd += __shfl_xor(sd, off);
+      }
+      if (lane == 0) {
+        a_src[(int64_t)row * H + h] = ss;
+        a_dst[(int64_t)row * H + h] = sd;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256)
+gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+               const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
+               const float* __restrict__ a_dst, float* __restrict__ out, int64_t ldo,
+               float* __restrict__ m_out, float* __restrict__ rden_out, int N, float slope,
+               const GatLayout L) {
+  const int lane = threadIdx.x & 63;
+  const int NG = kWave / L.G;
+  const int g = lane / L.G;
+  const int t = lane % L.G;
+  const int hl = t / L.LPH;
+  const int ch = (t % L.LPH) * VEC;
+  const int wpb = blockDim.x >> 6;
+
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < N; row += gridDim.x * wpb) {
+    const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
+    const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+    for (int hbase = 0; hbase < L.H; hbase += L.HPC) {
+      const int head = hbase + hl;
+      const bool active = hl < L.HPC && head < L.H && ch < L.C;
+      const int cofs = head * L.C + ch;
+      const float ad = active ? a_dst[(int64_t)row * L.H + head] : 0.f;
+      float m = kNegBig, l = 0.f;
+      float acc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+
+      for (int base = start; base < end; base += kWave) {
+        const int n = min(kWave, end - base);
+        const int mycol = lane < n ? col[base + lane] : 0;
+        for (int k = 0; k < n; k += NG * U) {
+          float v[U][VEC];
+          float as[U];
+          bool ok[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int idx = k + u * NG + g;
+            const int src = __shfl(mycol, idx & 63);
+            ok[u] = active && idx < n;
+            as[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+            if (ok[u]) {
+              as[u] = a_src[(int64_t)src * L.H + head];
+              load_vec<VEC>(v[u], hfeat + (int64_t)src * ldh + cofs);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const float s = as[u] + ad;
+            const float e = s > 0.f ? s : slope * s;
+            const float mn = ok[u] ? fmaxf(m, e) : m;
+            const float sc = expf(m - mn);
+            const float p = ok[u] ? expf(e - mn) : 0.f;
+            l = fmaf(l, sc, p);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(acc[i], sc, p * v[u][i]);
+            m = mn;
+          }
+        }
+      }
+      // merge the NG online-softmax states
+      for (int off = 32; off >= L.G; off >>= 1) {
+        const float m2 = __shfl_xor(m, off);
+        const float l2 = __shfl_xor(l, off);
+        const float mn = fmaxf(m, m2);
+        const float s1 = expf(m - mn), s2 = expf(m2 - mn);
+        l = l * s1 + l2 * s2;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float a2 = __shfl_xor(acc[i], off);
+          acc[i] = acc[i] * s1 + a2 * s2;
+        }
+        m = mn;
+      }
+      if (g == 0 && active) {
+        const float rd = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
+        float r[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r[i] = acc[i] * rd;
+        store_vec<VEC>(out + (int64_t)row * ldo + cofs, r);
+        if (ch == 0) {
+          m_out[(int64_t)row * L.H + head] = l > 0.f ? m : 0.f;
+          rden_out[(int64_t)row * L.H + head] = rd;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward, target side: dsum[i,h] = <gout_i, out_i>, g_a_dst[i,h] = sum_p ds_p.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+gat_bwd_dst_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                   const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
+                   const float* __restrict__ a_dst, const float* __restrict__ m_in,
+                   const float* __restrict__ rden_in, const float* __restrict__ out, int64_t ldo,
+                   const float* __restrict__ gout, int64_t ldg, float* __restrict__ dsum_out,
+                   float* __restrict__ g_a_dst, int N, float slope, const GatLayout L) {
+  const int lane = threadIdx.x & 63;
+  const int NG = kWave / L.G;
+  const int g = lane / L.G;
+  const int t = lane % L.G;
+  const int hl = t / L.LPH;
+  const int ch = (t % L.LPH) * VEC;
+  const int wpb = blockDim.x >> 6;
+
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < N; row += gridDim.x * wpb) {
+    const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
+    const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+    for (int hbase = 0; hbase < L.H; hbase += L.HPC) {
+      const int head = hbase + hl;
+      const bool active = hl < L.HPC && head < L.H && ch < L.C;
+      const int cofs = head * L.C + ch;
+      float go[VEC], o[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) go[i] = o[i] = 0.f;
+      float ad = 0.f, mi = 0.f, rd = 0.f;
+      if (active) {
+        load_vec<VEC>(go, gout + (int64_t)row * ldg + cofs);
+        load_vec<VEC>(o, out + (int64_t)row * ldo + cofs);
+        ad = a_dst[(int64_t)row * L.H + head];
+        mi = m_in[(int64_t)row * L.H + head];
+        rd = rden_in[(int64_t)row * L.H + head];
+      }
+      const float dsum = head_sum(dot_vec<VEC>(go, o), L.LPH);
+      float acc = 0.f;
+
+      for (int base = start; base < end; base += kWave) {
+        const int n = min(kWave, end - base);
+        const int mycol = lane < n ? col[base + lane] : 0;
+        for (int k = 0; k < n; k += NG * U) {
+          float v[U][VEC];
+          float as[U];
+          bool ok[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int idx = k + u * NG + g;
+            const int src = __shfl(mycol, idx & 63);
+            ok[u] = active && idx < n;
+            as[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+            if (ok[u]) {
+              as[u] = a_src[(int64_t)src * L.H + head];
+              load_vec<VEC>(v[u], hfeat + (int64_t)src * ldh + cofs);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const float dal = head_sum(dot_vec<VEC>(go, v[u]), L.LPH);
+            const float s = as[u] + ad;
+            const float e = s > 0.f ? s : slope * s;
+            const float alpha = ok[u] ? expf(e - mi) * rd : 0.f;
+            acc = fmaf(alpha * (dal - dsum), s > 0.f ? 1.f : slope, acc);
+          }
+        }
+      }
+      for (int off = 32; off >= L.G; off >>= 1) acc += __shfl_xor(acc, off);
+      if (g == 0 && active && ch == 0) {
+        dsum_out[(int64_t)row * L.H + head] = dsum;
+        g_a_dst[(int64_t)row * L.H + head] = acc;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward, source side, over the transposed CSR: row = source j, col_t[p] = target i.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+gat_bwd_src_kernel(const int* __restrict__ rowptr_t, const int* __restrict__ col_t,
+                   const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
+                   const float* __restrict__ a_dst, const float* __restrict__ m_in,
+                   const float* __restrict__ rden_in, const float* __restrict__ dsum_in,
+                   const float* __restrict__ gout, int64_t ldg, float* __restrict__ g_hfeat,
+                   int64_t ldgh, float* __restrict__ g_a_src, int N, float slope,
+                   const GatLayout L) {
+  const int lane = threadIdx.x & 63;
+  const int NG = kWave / L.G;
+  const int g = lane / L.G;
+  const int t = lane % L.G;
+  const int hl = t / L.LPH;
+  const int ch = (t % L.LPH) * VEC;
+  const int wpb = blockDim.x >> 6;
+
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < N; row += gridDim.x * wpb) {
+    const int start = __builtin_amdgcn_readfirstlane(rowptr_t[row]);
+    const int end = __builtin_amdgcn_readfirstlane(rowptr_t[row + 1]);
+    for (int hbase = 0; hbase < L.H; hbase += L.HPC) {
+      const int head = hbase + hl;
+      const bool active = hl < L.HPC && head < L.H && ch < L.C;
+      const int cofs = head * L.C + ch;
+      float hj[VEC], acc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) hj[i] = acc[i] = 0.f;
+      float as = 0.f;
+      if (active) {
+        load_vec<VEC>(hj, hfeat + (int64_t)row * ldh + cofs);
+        as = a_src[(int64_t)row * L.H + head];
+      }
+      float acc_as = 0.f;
+
+      for (int base = start; base < end; base += kWave) {
+        const int n = min(kWave, end - base);
+        const int mycol = lane < n ? col_t[base + lane] : 0;
+        for (int k = 0; k < n; k += NG * U) {
+          float v[U][VEC];
+          float ad[U], mi[U], rd[U], dsm[U];
+          bool ok[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int idx = k + u * NG + g;
+            const int tgt = __shfl(mycol, idx & 63);
+            ok[u] = active && idx < n;
+            ad[u] = mi[u] = rd[u] = dsm[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+            if (ok[u]) {
+              const int64_t q = (int64_t)tgt * L.H + head;
+              ad[u] = a_dst[q];
+              mi[u] = m_in[q];
+              rd[u] = rden_in[q];
+              dsm[u] = dsum_in[q];
+              load_vec<VEC>(v[u], gout + (int64_t)tgt * ldg + cofs);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const float dal = head_sum(dot_vec<VEC>(v[u], hj), L.LPH);
+            const float s = as + ad[u];
+            const float e = s > 0.f ? s : slope * s;
+            const float alpha = ok[u] ? expf(e - mi[u]) * rd[u] : 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(alpha, v[u][i], acc[i]);
+            acc_as = fmaf(alpha * (dal - dsm[u]), s > 0.f ? 1.f : slope, acc_as);
+          }
+        }
+      }
+      for (int off = 32; off >= L.G; off >>= 1) {
+        acc_as += __shfl_xor(acc_as, off);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
+      }
+      if (g == 0 && active) {
+        store_vec<VEC>(g_hfeat + (int64_t)row * ldgh + cofs, acc);
+        if (ch == 0) g_a_src[(int64_t)row * L.H + head] = acc_as;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+int pow2ceil(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+// VEC must divide C so that a lane's channels stay inside one head.
+int pick_vec(int C, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
+  for (int v : {4, 2}) {
+    bool ok = C % v == 0;
+    for (const void* p : ptrs) ok = ok && (reinterpret_cast<uintptr_t>(p) % (v * 4) == 0);
+    for (int64_t ld : lds) ok = ok && (ld % v == 0);
+    if (ok) return v;
+  }
+  return 1;
+}
+
+int make_layout(int H, int C, int vec, GatLayout* L, const char* name) {
+  const int lph = pow2ceil((C + vec - 1) / vec);
+  if (lph > kWave)
+    return fail(RGBX_E_SHAPE, "%s: C=%d needs %d lanes per head (> 64) at vector width %d", name, C,
+                lph, vec);
+  L->H = H;
+  L->C = C;
+  L->LPH = lph;
+  L->HPC = std::min(H, kWave / lph);
+  L->G = pow2ceil(L->HPC * lph);
+  return RGBX_OK;
+}
+
+int gat_grid(int64_t N) {
+  int64_t b = cdiv(N, 4);
+  return (int)(b < kMaxGrid ? b : kMaxGrid);
+}
+
+int check_common(int64_t N, int H, int C, const char* name) {
+  if (N < 0 || H <= 0 || C <= 0) return fail(RGBX_E_ARG, "%s: bad size", name);
+  if (N >= INT32_MAX || (int64_t)H * C >= INT32_MAX) return fail(RGBX_E_RANGE, "%s: size exceeds int32", name);
+  return RGBX_OK;
+}
+
+}  // namespace
+}  // namespace rgbx
+
+using namespace rgbx;
+
+extern "C" int rgbx_gat_scores_f32(const float* hfeat, int64_t ldh, const float* att_src,
+                                   const float* att_dst, float* a_src, float* a_dst, int64_t n, int H,
+                                   int C, rgbx_stream_t stream) {
+  if (int rc = check_common(n, H, C, "gat_scores")) return rc;
+  if (n == 0) return RGBX_OK;
+  if (!hfeat || !att_src || !att_dst || !a_src || !a_dst) return fail(RGBX_E_ARG, "gat_scores: null pointer");
+  if (ldh < (int64_t)H * C) return fail(RGBX_E_ARG, "gat_scores: leading dimension < H*C");
+  gat_scores_kernel<<<gat_grid(n), 256, 0, (hipStream_t)stream>>>(hfeat, ldh, att_src, att_dst, a_src,
+                                                                 a_dst, (int)n, H, C);
+  RGBX_CHECK_LAUNCH("gat_scores_kernel");
+  return RGBX_OK;
+}
+
+extern "C" int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
+                                          int64_t ldh, const float* a_src, const float* a_dst,
+                                          float* out, int64_t ldo, float* m, float* rden, int64_t N,
+                                          int H, int C, float slope, rgbx_stream_t stream) {
+  if (int rc = check_common(N, H, C, "gat_fwd")) return rc;
+  if (N == 0) return RGBX_OK;
+  if (!rowptr || !col || !hfeat || !a_src || !a_dst || !out || !m || !rden)
+    return fail(RGBX_E_ARG, "gat_fwd: null pointer");
+  if (ldh < (int64_t)H * C || ldo < (int64_t)H * C) return fail(RGBX_E_ARG, "gat_fwd: leading dimension < H*C");
+  const int vec = pick_vec(C, {hfeat, out}, {ldh, ldo});
+  GatLayout L;
+  if (int rc = make_layout(H, C, vec, &L, "gat_fwd")) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = gat_grid(N);
+#define RGBX_GAT_FWD(V) \
+  gat_fwd_kernel<V><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, a_dst, out, ldo, m, rden, (int)N, slope, L)
+  if (vec == 4) RGBX_GAT_FWD(4);
+  else if (vec == 2) RGBX_GAT_FWD(2);
+  else RGBX_GAT_FWD(1);
+#undef RGBX_GAT_FWD
+  RGBX_CHECK_LAUNCH("gat_fwd_kernel");
+  return RGBX_OK;
+}
+
+extern "C" int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
+                                    int64_t ldh, const float* a_src, const float* a_dst, const float* m,
+                                    const float* rden, const float* out, int64_t ldo, const float* gout,
+                                    int64_t ldg, float* dsum, float* g_a_dst, int64_t N, int H, int C,
+                                    float slope, rgbx_stream_t stream) {
+  if (int rc = check_common(N, H, C, "gat_bwd_dst")) return rc;
+  if (N == 0) return RGBX_OK;
+  if (!rowptr || !col || !hfeat || !a_src || !a_dst || !m || !rden || !out || !gout || !dsum || !g_a_dst)
+    return fail(RGBX_E_ARG, "gat_bwd_dst: null pointer");
+  const int64_t F = (int64_t)H * C;
+  if (ldh < F || ldo < F || ldg < F) return fail(RGBX_E_ARG, "gat_bwd_dst: leading dimension < H*C");
+  const int vec = pick_vec(C, {hfeat, out, gout}, {ldh, ldo, ldg});
+  GatLayout L;
+  if (int rc = make_layout(H, C, vec, &L, "gat_bwd_dst")) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = gat_grid(N);
+#define RGBX_GAT_BD(V)                                                                              \
+  gat_bwd_dst_kernel<V><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, a_dst, m, rden, out, ldo, \
+                                             gout, ldg, dsum, g_a_dst, (int)N, slope, L)
+  if (vec == 4) RGBX_GAT_BD(4);
+  else if (vec == 2) RGBX_GAT_BD(2);
+  else RGBX_GAT_BD(1);
+#undef RGBX_GAT_BD
+  RGBX_CHECK_LAUNCH("gat_bwd_dst_kernel");
+  return RGBX_OK;
+}
+
+extern "C" int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const float* hfeat,
+                                    int64_t ldh, const float* a_src, const float* a_dst, const float* m,
+                                    const float* rden, const float* dsum, const float* gout, int64_t ldg,
+                                    float* g_hfeat, int64_t ldgh, float* g_a_src, int64_t N, int H, int C,
+                                    float slope, rgbx_stream_t stream) {
+  if (int rc = check_common(N, H, C, "gat_bwd_src")) return rc;
+  if (N == 0) return RGBX_OK;
+  if (!rowptr_t || !col_t || !hfeat || !a_src || !a_dst || !m || !rden || !dsum || !gout || !g_hfeat ||
+      !g_a_src)
+    return fail(RGBX_E_ARG, "gat_bwd_src: null pointer");
+  const int64_t F = (int64_t)H * C;
+  if (ldh < F || ldg < F || ldgh < F) return fail(RGBX_E_ARG, "gat_bwd_src: leading dimension < H*C");
+  const int vec = pick_vec(C, {hfeat, gout, g_hfeat}, {ldh, ldg, ldgh});
+  GatLayout L;
+  if (int rc = make_layout(H, C, vec, &L, "gat_bwd_src")) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = gat_grid(N);
+#define RGBX_GAT_BS(V)                                                                                \
+  gat_bwd_src_kernel<V><<<grid, 256, 0, s>>>(rowptr_t, col_t, hfeat, ldh, a_src, a_dst, m, rden, dsum,  \
+                                             gout, ldg, g_hfeat, ldgh, g_a_src, (int)N, slope, L)
+  if (vec == 4) RGBX_GAT_BS(4);
+  else if (vec == 2) RGBX_GAT_BS(2);
+  else RGBX_GAT_BS(1);
+#undef RGBX_GAT_BS
+  RGBX_CHECK_LAUNCH("gat_bwd_src_kernel");
+  return RGBX_OK;
+}

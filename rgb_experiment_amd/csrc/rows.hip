@@ -1,0 +1,67 @@
+// Halo pack / unpack for the 1-D node partition: whole-row gather and unique-index scatter-add.
+// New capability (the reference is single-device, itexperiments.py:246); the rows moved here
+// are the boundary features the RCCL all-to-all ships between GPUs.
+#include "rgbx_common.h"
+
+namespace rgbx {
+namespace {
+
+// One wave moves one row at a time; lanes stride the columns VEC floats each.
+template <int VEC, bool SCATTER_ADD>
+__global__ void __launch_bounds__(256)
+rows_kernel(const float* __restrict__ src, int64_t lds, const int* __restrict__ idx, int n, int d,
+            float* __restrict__ dst, int64_t ldd) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < n; r += gridDim.x * wpb) {
+    const int64_t j = idx[r];
+    const float* s = SCATTER_ADD ? src + (int64_t)r * lds : src + j * lds;
+    float* o = SCATTER_ADD ? dst + j * ldd : dst + (int64_t)r * ldd;
+    for (int c = lane * VEC; c < d; c += 64 * VEC) {
+      if constexpr (VEC == 4) {
+        float4 v = *reinterpret_cast<const float4*>(s + c);
+        if constexpr (SCATTER_ADD) {
+          const float4 a = *reinterpret_cast<const float4*>(o + c);
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        *reinterpret_cast<float4*>(o + c) = v;
+      } else {
+        float v = s[c];
+        if constexpr (SCATTER_ADD) v += o[c];
+        o[c] = v;
+      }
+    }
+  }
+}
+
+template <bool SCATTER_ADD>
+int run(const float* src, int64_t lds, const int32_t* idx, int64_t n, int64_t d, float* dst,
+        int64_t ldd, hipStream_t s, const char* name) {
+  if (n < 0 || d < 0) return fail(RGBX_E_ARG, "%s: negative size", name);
+  if (n == 0 || d == 0) return RGBX_OK;
+  if (!src || !idx || !dst) return fail(RGBX_E_ARG, "%s: null pointer", name);
+  if (n >= INT32_MAX || d >= INT32_MAX) return fail(RGBX_E_RANGE, "%s: size exceeds int32", name);
+  if (lds < d || ldd < d) return fail(RGBX_E_ARG, "%s: leading dimension < d", name);
+  int64_t blocks = cdiv(n, 4);
+  if (blocks > kMaxGrid) blocks = kMaxGrid;
+  const bool v4 = d % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && aligned16(src) && aligned16(dst);
+  if (v4)
+    rows_kernel<4, SCATTER_ADD><<<(int)blocks, 256, 0, s>>>(src, lds, idx, (int)n, (int)d, dst, ldd);
+  else
+    rows_kernel<1, SCATTER_ADD><<<(int)blocks, 256, 0, s>>>(src, lds, idx, (int)n, (int)d, dst, ldd);
+  RGBX_CHECK_LAUNCH(name);
+  return RGBX_OK;
+}
+
+}  // namespace
+}  // namespace rgbx
+
+extern "C" int rgbx_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, int64_t n,
+                                    int64_t d, float* dst, int64_t ldd, rgbx_stream_t stream) {
+  return rgbx::run<false>(src, lds, idx, n, d, dst, ldd, (hipStream_t)stream, "gather_rows");
+}
+
+extern "C" int rgbx_scatter_add_rows_f32(const float* src, int64_t lds, const int32_t* idx, int64_t n,
+                                         int64_t d, float* dst, int64_t ldd, rgbx_stream_t stream) {
+  return rgbx::run<true>(src, lds, idx, n, d, dst, ldd, (hipStream_t)stream, "scatter_add_rows");
+}

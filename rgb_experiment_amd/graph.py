@@ -1,0 +1,155 @@
+"""Device-resident graph structures for the message-passing kernels.
+
+The reference recomputes the self-loop rewrite and ``gcn_norm`` inside every conv call
+(models/gcn.py:27 -> GCNConv.forward [PyG]; models/graphsage.py:53-56; restated at
+models/dagnn.py:12-31). ``edge_index`` is constant inside ``experiment()``
+(itexperiments.py:332), so here the int64 edge list is turned ONCE into a CSR grouped by target
+(forward) and one grouped by source (backward), by ``rgbx_csr_build``; results are cached per
+``edge_index`` tensor.
+
+HBM layout per graph (E' = edges after the rewrite):
+  rowptr  int32 [N+1]   |  col  int32 [E']  |  perm int32 [E'] (slot -> input edge id)
+  dis     f32   [N]     deg^-1/2 over the target index           (GCN / APPNP)
+  w       f32   [E']    dis[src]*dis[tgt] per forward slot; w_t the same per transposed slot
+  inv_deg f32   [N]     1/max(deg,1) (mean);  w_mean_t f32 [E'] = inv_deg[tgt] per transposed slot
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+
+LOOPS_KEEP = 0
+LOOPS_ADD_REMAINING = 1
+LOOPS_REMOVE_ADD = 2
+
+
+class CSR:
+    """CSR over `N` aggregation rows: rowptr [N+1], col / perm [E'] (int32, device)."""
+
+    __slots__ = ("rowptr", "col", "perm", "N", "nnz")
+
+    def __init__(self, rowptr, col, perm, N, nnz):
+        self.rowptr, self.col, self.perm, self.N, self.nnz = rowptr, col, perm, N, nnz
+
+
+def build_csr(agg_row, other_row, N, loops_mode):
+    """int64 device vectors (aggregate-into index, gather-from index) -> CSR via the HIP library."""
+    _lib.require_device(agg_row, other_row)
+    lib = _lib.load()
+    E = agg_row.numel()
+    dev = agg_row.device
+    agg_row = agg_row.contiguous()
+    other_row = other_row.contiguous()
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.rgbx_csr_workspace_bytes(E, N, ctypes.byref(nbytes)), "rgbx_csr_workspace_bytes")
+    cap = max(E + N, 1)
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(cap, dtype=torch.int32, device=dev)
+    perm = torch.empty(cap, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=dev)
+    _lib.check(
+        lib.rgbx_csr_build(_lib.ptr(agg_row), _lib.ptr(other_row), E, N, loops_mode, _lib.ptr(rowptr),
+                           _lib.ptr(col), _lib.ptr(perm), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+        "rgbx_csr_build")
+    nnz = int(rowptr[N].item())  # one sync per graph; also orders `ws` lifetime after the kernels
+    return CSR(rowptr, col[:max(nnz, 1)], perm[:max(nnz, 1)], N, nnz)
+
+
+class Graph:
+    """All cached structures of one (edge_index, N, loops_mode)."""
+
+    def __init__(self, edge_index, num_nodes, loops_mode):
+        if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.int64:
+            raise RuntimeError(f"edge_index must be int64 [2, E], got {edge_index.dtype} {tuple(edge_index.shape)}")
+        _lib.require_device(edge_index)
+        self.N = int(num_nodes)
+        self.E = int(edge_index.size(1))
+        self.loops_mode = loops_mode
+        if self.E > 0:
+            lo, hi = int(edge_index.min().item()), int(edge_index.max().item())
+            if lo < 0 or hi >= self.N:
+                raise RuntimeError(f"edge_index values [{lo}, {hi}] outside [0, {self.N})")
+        self._src = edge_index[0]
+        self._dst = edge_index[1]
+        self.fwd = build_csr(self._dst, self._src, self.N, loops_mode)
+        self._bwd = None
+        self._dis = self._w = self._w_t = self._inv_deg = self._w_mean_t = None
+
+    # transposed CSR (rows = sources) for backward
+    @property
+    def bwd(self):
+        if self._bwd is None:
+            self._bwd = build_csr(self._src, self._dst, self.N, self.loops_mode)
+        return self._bwd
+
+    def _f32(self, n):
+        return torch.empty(max(n, 1), dtype=torch.float32, device=self.fwd.rowptr.device)
+
+    @property
+    def dis(self):
+        if self._dis is None:
+            self._dis = self._f32(self.N)
+            _lib.check(_lib.load().rgbx_deg_inv_sqrt_f32(_lib.ptr(self.fwd.rowptr), self.N, _lib.ptr(self._dis),
+                                                         _lib.stream_ptr()), "rgbx_deg_inv_sqrt_f32")
+        return self._dis
+
+    def _norm(self, csr):
+        w = self._f32(csr.nnz)
+        _lib.check(_lib.load().rgbx_gcn_norm_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), self.N,
+                                                 _lib.ptr(self.dis), _lib.ptr(w), _lib.stream_ptr()),
+                   "rgbx_gcn_norm_f32")
+        return w
+
+    @property
+    def w(self):
+        if self._w is None:
+            self._w = self._norm(self.fwd)
+        return self._w
+
+    @property
+    def w_t(self):
+        if self._w_t is None:
+            self._w_t = self._norm(self.bwd)
+        return self._w_t
+
+    @property
+    def inv_deg(self):
+        if self._inv_deg is None:
+            self._inv_deg = self._f32(self.N)
+            _lib.check(_lib.load().rgbx_inv_degree_f32(_lib.ptr(self.fwd.rowptr), self.N,
+                                                       _lib.ptr(self._inv_deg), _lib.stream_ptr()),
+                       "rgbx_inv_degree_f32")
+        return self._inv_deg
+
+    @property
+    def w_mean_t(self):
+        """Per transposed slot (j -> i): 1/deg(i), the weight of dY[i] in dX[j] for aggr='mean'."""
+        if self._w_mean_t is None:
+            self._w_mean_t = self.inv_deg[self.bwd.col.long()].contiguous() if self.bwd.nnz else self._f32(0)
+        return self._w_mean_t
+
+
+_CACHE = OrderedDict()
+_CACHE_MAX = 16
+
+
+def get_graph(edge_index, num_nodes, loops_mode):
+    """Cached Graph for this edge_index tensor (identity + in-place version), N and rewrite mode."""
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device),
+           int(num_nodes), int(loops_mode))
+    g = _CACHE.get(key)
+    if g is None:
+        g = Graph(edge_index, num_nodes, loops_mode)
+        g._keepalive = edge_index  # the key holds data_ptr: keep the storage alive while cached
+        _CACHE[key] = g
+        while len(_CACHE) > _CACHE_MAX:
+            _CACHE.popitem(last=False)
+    else:
+        _CACHE.move_to_end(key)
+    return g
+
+
+def clear_cache():
+    _CACHE.clear()

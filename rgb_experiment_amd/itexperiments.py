@@ -1,0 +1,286 @@
+"""experiment() — the reference's single entry point (itexperiments.py:42-605), re-provided with the
+same keyword surface so that examples/simple_example.py-style calls run unchanged, with the model
+forward/backward executing in the HIP message-passing kernels.
+
+Scope: data loading / mask remake / feature normalisation / model dispatch by
+lower-cased ``model_name`` / full-batch Adam + NLLLoss loop with early stopping / metrics dict.
+Out of scope and rejected with ``NotImplementedError``: the PTA branch, C&S post-processing, plots,
+PCA (reference :351-374, :514-601) and the non-hot-path zoo members.
+
+Deliberate deviations from reference quirks:
+  * ``compare_pred_label(need_all_metrics=False)`` returns zeros instead of raising
+    ``UnboundLocalError`` (reference :658-664).
+  * the mask-validity test is ``not (valid_list or valid_tensor)``; the reference's
+    ``(not valid_list) or (not valid_tensor)`` (:210) is always true, so it remade masks always.
+    Pass ``remake_data_mask=True`` for the reference behaviour.
+"""
+import random
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .data import Data
+from .initial_params import InitialParameters
+from .models import REGISTRY
+from .rd2pd import RD2PD
+from .utils import get_classification_mask, get_random_mask, get_whole_mask, to_undirected
+
+_OUT_OF_SCOPE = ("ggnn", "dagnn", "pta", "supergat", "sgc", "gin", "fagcn")
+
+
+def _macro_prf(label, pred):
+    """Macro precision / recall / F1 and micro F1 with zero_division=0, over the labels present in
+    either vector (what sklearn.metrics computes at reference :653-657)."""
+    try:
+        from sklearn import metrics
+        return (metrics.precision_score(label, pred, average="macro", zero_division=0),
+                metrics.recall_score(label, pred, average="macro", zero_division=0),
+                metrics.f1_score(label, pred, average="macro", zero_division=0),
+                metrics.f1_score(label, pred, average="micro", zero_division=0))
+    except ImportError:  # same arithmetic without sklearn
+        label, pred = np.asarray(label), np.asarray(pred)
+        classes = np.union1d(label, pred)
+        p, r, f = [], [], []
+        for c in classes:
+            tp = float(np.sum((pred == c) & (label == c)))
+            pp, ap = float(np.sum(pred == c)), float(np.sum(label == c))
+            pc = tp / pp if pp else 0.0
+            rc = tp / ap if ap else 0.0
+            p.append(pc)
+            r.append(rc)
+            f.append(2 * pc * rc / (pc + rc) if pc + rc else 0.0)
+        micro = float(np.mean(pred == label)) if len(label) else 0.0
+        return float(np.mean(p)), float(np.mean(r)), float(np.mean(f)), micro
+
+
+def compare_pred_label(pred, label, need_all_metrics):
+    """Accuracy (+ macro precision/recall/F1, micro F1) of two label vectors (reference :639-664)."""
+    total = pred.size(0)
+    accuracy = pred.eq(label).sum().item() / total
+    precision = recall = f1_macro = f1_micro = 0
+    if need_all_metrics:
+        p = pred.cpu() if isinstance(pred, Tensor) else pred
+        l = label.cpu() if isinstance(label, Tensor) else label
+        precision, recall, f1_macro, f1_micro = _macro_prf(l, p)
+    return {"ACC": accuracy, "precision_score": precision, "recall_score": recall,
+            "f1_macro": f1_macro, "f1_micro": f1_micro}
+
+
+def test(model, x, y, mask, need_all_metrics):
+    """Eval-mode forward + metrics on `mask` (reference :611-634). `x` = forward kwargs dict."""
+    model.eval()
+    with torch.no_grad():
+        pure_out = model(**x)
+    out = pure_out["out"]
+    pred = out.max(dim=1)[1][mask]
+    label = y[mask]
+    res = compare_pred_label(pred, label, need_all_metrics)
+    res.update({"test_op": out, "pred": pred, "label": label, "emb": pure_out["emb"], "pure_out": pure_out})
+    return res
+
+
+def _normalize_features(features, how, method):
+    """reference :261-299: 'row' / 'col' / 'all' x MinMaxScalar / StandardScalar / sum."""
+    dim = {"row": 1, "col": 0, "all": [0, 1]}[how]
+    if method == "MinMaxScalar":
+        if isinstance(dim, int):
+            lo, hi = torch.min(features, dim)[0], torch.max(features, dim)[0]
+        else:
+            lo, hi = torch.min(features), torch.max(features)
+        den = (hi - lo).clamp(min=1e-12)
+        return ((features.T - lo) / den).T if dim == 1 else (features - lo) / den
+    if method == "StandardScalar":
+        mean, std = torch.mean(features, dim), torch.std(features, dim)
+        den = std.clamp(min=1e-12)
+        return ((features.T - mean) / den).T if dim == 1 else (features - mean) / den
+    return features / features.sum(dim, keepdim=True).clamp(min=1)
+
+
+def _masks_usable(data):
+    """Masks exist and are index lists or 1-D tensors no longer than the node count (reference
+    :196-209)."""
+    names = ("train_mask", "val_mask", "test_mask")
+    if not all(getattr(data, n, None) is not None for n in names):
+        return False
+    n = data.num_nodes
+    ms = [getattr(data, k) for k in names]
+    if all(isinstance(m, list) for m in ms):
+        return all(len(m) <= n for m in ms)
+    if all(isinstance(m, Tensor) for m in ms):
+        return all(m.dim() == 1 and m.size(0) <= n for m in ms)
+    return False
+
+
+def _make_masks(y, mode, ratio, num_train_per_class, num_val, num_test, seed):
+    if mode == "ratio":
+        return get_whole_mask(y, ratio, seed)
+    if mode == "classification":
+        return get_classification_mask(y, ratio, seed)
+    if mode == "random":
+        return get_random_mask(y, num_train_per_class, num_val, num_test, seed)
+    raise ValueError(f"dataset_split_mode {mode!r} not in ratio/classification/random")
+
+
+def experiment(model_init_param: dict, *,
+               task: str = "node_prediction",
+               dataset_name: str = "Github",
+               dataset_root: str = InitialParameters.default_data_path,
+               dataset_split_mode: str = "ratio",
+               dataset_split_ratio: str = "6-2-2",
+               num_train_per_class: int = 20, num_val: int = 500, num_test: int = 1000,
+               dataset_split_seed: int = 123456789,
+               specify_data: bool = False, data: Data = None, remake_data_mask: bool = False,
+               to_undirected_graph: bool = False,
+               normalize_feature: str = None, normalize_feature_method: str = None,
+               pta_loss_decay: float = 0.05,
+               pta_weight_decay: float = 0.005,
+               supergat_graph_lambda: float = 4,
+               cuda_index: int = 0, use_cpu: bool = False,
+               need_to_reappear: bool = False, reappear_seed: int = 14530529,
+               model_name: str = "MLP",
+               learning_rate: float = 0.1, weight_decay: float = 0,
+               epoch: int = 50,
+               early_stopping: int = 10,
+               early_stopping_criterion: str = "acc",
+               implement_early_stopping: bool = True,
+               post_cs: bool = False,
+               cs_param: dict = None,
+               print_pics: bool = False,
+               pics_root: str = InitialParameters.default_pics_path,
+               pics_name: str = "pic1.png",
+               print_confusion_matrix: bool = False,
+               check_data_valid: bool = False,
+               vis_feat: bool = False,
+               feat_pic_names_prefix: str = None,
+               total_seed: int = 12345678,
+               ini_seed: int = 1234567,
+               need_all_metrics: bool = True,
+               f1_average: str = "macro",
+               loss_func_hp: dict = None, print_print: bool = True,
+               specify_model: bool = True, model: nn.Module = None,
+               begin_early_stopping: int = 20,
+               return_model: bool = False):
+    """Train + evaluate one model on one graph; returns {'ACC', 'precision_score', 'recall_score',
+    'f1_macro', 'f1_micro'} (reference :603-605). ``return_model=True`` (an addition) also returns
+    the trained module and the per-epoch curves under 'model' / 'history'."""
+    say = print if print_print else (lambda *a, **k: None)
+    say(f"running node classification: {'custom' if specify_data else dataset_name} data, model {model_name}")
+
+    name = model_name.lower()
+    if name in _OUT_OF_SCOPE:
+        raise NotImplementedError(f"model_name={model_name!r} is outside the MI355X hot-path scope "
+                                  f"(supported: {sorted(REGISTRY)})")
+    if name not in REGISTRY:
+        raise ValueError(f"unknown model_name {model_name!r}")
+    if post_cs or print_pics or vis_feat:
+        raise NotImplementedError("post_cs / print_pics / vis_feat are reporting features outside the "
+                                  "hot-path scope")
+
+    # ---- data (reference :179-229) ----------------------------------------------------------
+    if not specify_data:
+        data = RD2PD(dataset_root=dataset_root, dataset_name=dataset_name, split_method=dataset_split_mode,
+                     split_ratio=dataset_split_ratio, split_seed=dataset_split_seed,
+                     num_train_per_class=num_train_per_class, num_val=num_val, num_test=num_test).data
+    else:
+        data = data.clone()
+        if remake_data_mask or not _masks_usable(data):
+            say("re-splitting the dataset (train/val/test masks)")
+            data.train_mask, data.val_mask, data.test_mask = _make_masks(
+                data.y.cpu(), dataset_split_mode, dataset_split_ratio, num_train_per_class, num_val, num_test,
+                dataset_split_seed)
+
+    if to_undirected_graph:  # reference :235-238
+        data.edge_index = to_undirected(data.edge_index, num_nodes=data.num_nodes)
+
+    # ---- device (reference :246-258): the message-passing path is HIP-only -------------------
+    if name != "mlp" and (use_cpu or not torch.cuda.is_available()):
+        raise RuntimeError("rgb_experiment_amd runs message passing in HIP kernels on an MI355X device; "
+                           "use_cpu=True / no visible GPU is not supported (no CPU fallback)")
+    device = torch.device(f"cuda:{cuda_index}" if (torch.cuda.is_available() and not use_cpu) else "cpu")
+    data = data.to(device)
+    features = data.x
+    if normalize_feature in ("row", "col", "all"):
+        features = _normalize_features(features, normalize_feature, normalize_feature_method)
+
+    if need_to_reappear:  # reference :305-310
+        random.seed(reappear_seed)
+        np.random.seed(reappear_seed)
+        torch.manual_seed(reappear_seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(reappear_seed)
+
+    # ---- model (reference :315-391) ----------------------------------------------------------
+    input_dim = data.num_node_features
+    output_dim = int(data.y.max().item()) + 1
+    net = REGISTRY[name](input_dim=input_dim, output_dim=output_dim, **model_init_param)
+    fwd = {"x": features} if name == "mlp" else {"x": features, "edge_index": data.edge_index}
+    net.to(device)
+    optimizer = torch.optim.Adam(net.parameters(), lr=learning_rate, weight_decay=weight_decay)
+    criterion = nn.NLLLoss()
+    y, train_mask, val_mask, test_mask = data.y, data.train_mask, data.val_mask, data.test_mask
+
+    hist = {k: [] for k in ("train_acc", "train_loss", "val_acc", "val_loss", "test_acc", "test_loss")}
+    best_state, best_val_loss, best_val_acc, patience = {}, 0, 0, 0
+
+    # ---- full-batch loop (reference :417-504): 1 train forward+backward, 2 eval forwards ------
+    for i in range(epoch):
+        net.train()
+        optimizer.zero_grad()
+        out = net(**fwd)["out"]
+        loss = criterion(out[train_mask], y[train_mask])
+        hist["train_acc"].append(compare_pred_label(out[train_mask].max(dim=1)[1], y[train_mask],
+                                                    need_all_metrics)["ACC"])
+        hist["train_loss"].append(loss.item())
+        loss.backward()
+        optimizer.step()
+
+        val = test(net, fwd, y, val_mask, need_all_metrics)
+        val_acc = val["ACC"]
+        val_loss = criterion(val["test_op"][val_mask], y[val_mask]).item()
+        hist["val_acc"].append(val_acc)
+        hist["val_loss"].append(val_loss)
+        tst = test(net, fwd, y, test_mask, need_all_metrics)
+        hist["test_acc"].append(tst["ACC"])
+        hist["test_loss"].append(criterion(tst["test_op"][test_mask], y[test_mask]).item())
+
+        if i == 0:
+            best_val_loss, best_val_acc = val_loss, val_acc
+        if early_stopping_criterion == "loss":
+            improved = val_loss <= best_val_loss
+        elif early_stopping_criterion == "acc":
+            improved = val_acc >= best_val_acc
+        else:
+            raise ValueError(f"early_stopping_criterion {early_stopping_criterion!r} not in loss/acc")
+        if improved:
+            patience = 0
+            best_val_loss, best_val_acc = min(val_loss, best_val_loss), max(val_acc, best_val_acc)
+            best_state = deepcopy(net.state_dict())
+        elif implement_early_stopping and i > begin_early_stopping:
+            patience += 1
+            if patience > early_stopping:
+                break
+
+    if best_state:
+        net.load_state_dict(best_state)
+    final = test(net, fwd, y, test_mask, need_all_metrics)
+
+    if print_confusion_matrix:
+        k = output_dim
+        cm = torch.zeros(k, k, dtype=torch.long)
+        for t, p in zip(final["label"].cpu().tolist(), final["pred"].cpu().tolist()):
+            cm[t, p] += 1
+        print(cm.numpy())
+    if check_data_valid:  # reference :575-584
+        print("train/val/test sizes:", int(train_mask.sum()), int(val_mask.sum()), int(test_mask.sum()))
+        print("overlaps train&val, train&test, val&test:", int((train_mask & val_mask).sum()),
+              int((train_mask & test_mask).sum()), int((val_mask & test_mask).sum()))
+
+    result = {k: final[k] for k in ("ACC", "precision_score", "recall_score", "f1_macro", "f1_micro")}
+    if return_model:
+        result["model"] = net
+        result["history"] = hist
+        result["emb"] = final["emb"]
+    return result

@@ -1,0 +1,20 @@
+"""APPNPStack — reference models/appnp_stack.py:8-31: lin1 -> BatchNorm1d -> lin2 -> APPNP(K, alpha);
+the propagation runs at width output_dim."""
+import torch.nn as nn
+
+from ..nn import APPNP
+from ._stack import model_output
+
+
+class APPNPStack(nn.Module):
+    def __init__(self, hidden_unit, input_dim, output_dim, K, alpha, dropout_rate):
+        super().__init__()
+        self.dropout_rate = dropout_rate
+        self.lin1 = nn.Linear(input_dim, hidden_unit)
+        self.lin2 = nn.Linear(hidden_unit, output_dim)
+        self.bn = nn.BatchNorm1d(hidden_unit)
+        self.conv = APPNP(K, alpha)
+
+    def forward(self, x, edge_index):
+        h = self.lin2(self.bn(self.lin1(x)))
+        return model_output(self.conv(h, edge_index))

@@ -1,0 +1,128 @@
+"""Conv layers with the parameter names and semantics of the PyG layers the reference imports,
+computing their ``propagate`` in HIP kernels (rgb_experiment_amd.ops).
+
+  GCNConv    <- torch_geometric.nn.conv.GCNConv   (reference models/gcn.py:3,18-21)
+  SAGEConv   <- torch_geometric.nn.conv.SAGEConv  (reference models/graphsage2.py:5,20-23)
+  MySAGEConv <- my_SAGEConv                       (reference models/graphsage.py:36-62)
+  GATConv    <- torch_geometric.nn.conv.GATConv   (reference models/gat.py:3,18-21)
+  APPNP      <- torch_geometric.nn.conv.APPNP     (reference models/appnp_stack.py:3,22)
+
+Dense X·W^T products go through torch.mm (hipBLASLt); everything indexed by edge_index goes through
+librgbx_hip.so.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..graph import LOOPS_ADD_REMAINING, LOOPS_KEEP, LOOPS_REMOVE_ADD, get_graph
+
+
+def glorot_(t):
+    """PyG's glorot: U(-a, a), a = sqrt(6 / (size(-2) + size(-1)))."""
+    a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        t.uniform_(-a, a)
+    return t
+
+
+class GCNConv(nn.Module):
+    """out = A_hat (x W^T) + b, A_hat = D^-1/2 (A ∪ I) D^-1/2 with in-degree over the target index
+    (gcn_norm restated at reference models/dagnn.py:12-31; message norm*x_j at dagnn.py:57-59).
+    Parameters: ``lin.weight`` [out, in] (glorot, no bias), ``bias`` [out] (zeros)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot_(self.lin.weight)
+        nn.init.zeros_(self.bias)
+
+    def forward(self, x, edge_index):
+        graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
+        return ops.propagate_gcn(self.lin(x), graph) + self.bias
+
+
+class SAGEConv(nn.Module):
+    """out = lin_l(mean_{j in N(i)} x_j) + lin_r(x_i); no self-loops; nodes without in-edges
+    aggregate 0 [PyG SAGEConv defaults: aggr='mean', root_weight=True, lin_l bias, lin_r no bias]."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x, edge_index):
+        graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
+        return self.lin_l(ops.propagate_mean(x, graph)) + self.lin_r(x)
+
+
+class MySAGEConv(nn.Module):
+    """reference models/graphsage.py:36-62: x_l = lin_l(x), x_r = lin_r(x) (both with bias),
+    remove_self_loops + add_self_loops, mean over N(i) ∪ {i} of x_l, then += x_r."""
+
+    def __init__(self, in_channels, out_channels, add_self_loops=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.add_self_loops = add_self_loops
+        self.lin_l = nn.Linear(in_channels, out_channels)
+        self.lin_r = nn.Linear(in_channels, out_channels)
+
+    def forward(self, x, edge_index):
+        mode = LOOPS_REMOVE_ADD if self.add_self_loops else LOOPS_KEEP
+        graph = get_graph(edge_index, x.size(0), mode)
+        return ops.propagate_mean(self.lin_l(x), graph) + self.lin_r(x)
+
+
+class GATConv(nn.Module):
+    """h = x W^T viewed [N,H,C]; e_ij = LeakyReLU(<h_j,att_src> + <h_i,att_dst>, 0.2); softmax over
+    the in-edges of i (self-loops removed then re-added); out_i = sum_j alpha_ij h_j; heads
+    concatenated (or averaged when concat=False); + bias [PyG GATConv defaults; dropout 0 as the
+    reference never sets it, models/gat.py:18-21]."""
+
+    def __init__(self, in_channels, out_channels, heads=1, concat=True, negative_slope=0.2):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.heads, self.concat, self.negative_slope = heads, concat, negative_slope
+        self.lin_src = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.lin_dst = self.lin_src  # shared, as PyG does for a single feature matrix
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels if concat else out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot_(self.lin_src.weight)
+        glorot_(self.att_src)
+        glorot_(self.att_dst)
+        nn.init.zeros_(self.bias)
+
+    def forward(self, x, edge_index):
+        H, C = self.heads, self.out_channels
+        graph = get_graph(edge_index, x.size(0), LOOPS_REMOVE_ADD)
+        h = self.lin_src(x)
+        a_src, a_dst = ops.gat_scores(h, self.att_src, self.att_dst, H, C)
+        out = ops.gat_aggregate(h, a_src, a_dst, graph, H, C, self.negative_slope)
+        if not self.concat:
+            out = out.view(-1, H, C).mean(dim=1)
+        return out + self.bias
+
+
+class APPNP(nn.Module):
+    """z^0 = x; z^{k+1} = (1-alpha) A_hat z^k + alpha x, K times (in-repo twin of the recurrence:
+    reference models/pta.py:79-84); gcn_norm computed once per graph."""
+
+    def __init__(self, K, alpha):
+        super().__init__()
+        self.K, self.alpha = K, alpha
+
+    def forward(self, x, edge_index):
+        graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
+        return ops.appnp_propagate(x, graph, self.K, self.alpha)

@@ -1,0 +1,262 @@
+"""Autograd wrappers around the HIP aggregation kernels (C ABI: include/rgbx_hip.h).
+
+Each Function is one ``MessagePassing.propagate`` of the reference: forward runs on the
+target-grouped CSR, backward runs the SAME kernel on the source-grouped (transposed) CSR, so no
+[E', d] tensor is ever materialised (cf. the gather -> multiply -> scatter temporaries of the
+PyG path the reference uses, models/gcn.py:27).
+"""
+import torch
+
+from . import _lib
+
+# Optional per-launch timing hook used by bench.py: when set to a list, every aggregation launch
+# appends (kind, start_event, end_event) recorded on the launch stream.
+_EVENT_SINK = None
+
+
+def set_event_sink(sink):
+    global _EVENT_SINK
+    _EVENT_SINK = sink
+
+
+class _Timed:
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        if _EVENT_SINK is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _EVENT_SINK is not None:
+            self.e.record()
+            _EVENT_SINK.append((self.kind, self.s, self.e))
+        return False
+
+
+def spmm_raw(csr, w, rs, x, y=None, a=1.0, b=0.0, out=None, kind="spmm"):
+    """out[i] = a*rs[i]*sum_p w[p]*x[col[p]] + b*y[i] over `csr` (no autograd)."""
+    _lib.require_device(x, y)
+    x = x if x.stride(-1) == 1 else x.contiguous()
+    px, ldx = _lib.mat(x, "x")
+    N, d = csr.N, x.size(1)
+    if out is None:
+        out = torch.empty((N, d), dtype=torch.float32, device=x.device)
+    po, ldo = _lib.mat(out, "out")
+    py, ldy = (0, 0) if y is None else _lib.mat(y, "y")
+    with _Timed(kind):
+        _lib.check(
+            _lib.load().rgbx_spmm_csr_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
+                                          px, ldx, py, ldy, po, ldo, N, d, float(a), float(b),
+                                          _lib.stream_ptr()), "rgbx_spmm_csr_f32")
+    return out
+
+
+class _PropagateGCN(torch.autograd.Function):
+    """A_hat x with A_hat = D^-1/2 (A + I) D^-1/2 (dagnn.py:12-31, message dagnn.py:57-59)."""
+
+    @staticmethod
+    def forward(ctx, x, graph):
+        ctx.graph = graph
+        return spmm_raw(graph.fwd, graph.w, None, x, kind="gcn_fwd")
+
+    @staticmethod
+    def backward(ctx, gy):
+        g = ctx.graph
+        return spmm_raw(g.bwd, g.w_t, None, gy.contiguous(), kind="gcn_bwd"), None
+
+
+class _PropagateMean(torch.autograd.Function):
+    """mean_{j in N(i)} x_j with sum/max(count,1) (aggr='mean', graphsage.py:39,58)."""
+
+    @staticmethod
+    def forward(ctx, x, graph):
+        ctx.graph = graph
+        return spmm_raw(graph.fwd, None, graph.inv_deg, x, kind="mean_fwd")
+
+    @staticmethod
+    def backward(ctx, gy):
+        g = ctx.graph
+        return spmm_raw(g.bwd, g.w_mean_t, None, gy.contiguous(), kind="mean_bwd"), None
+
+
+class _PropagateSum(torch.autograd.Function):
+    """Unweighted sum over incoming edges (aggr='add', no norm)."""
+
+    @staticmethod
+    def forward(ctx, x, graph):
+        ctx.graph = graph
+        return spmm_raw(graph.fwd, None, None, x, kind="sum_fwd")
+
+    @staticmethod
+    def backward(ctx, gy):
+        return spmm_raw(ctx.graph.bwd, None, None, gy.contiguous(), kind="sum_bwd"), None
+
+
+def propagate_gcn(x, graph):
+    return _PropagateGCN.apply(x, graph)
+
+
+def propagate_mean(x, graph):
+    return _PropagateMean.apply(x, graph)
+
+
+def propagate_sum(x, graph):
+    return _PropagateSum.apply(x, graph)
+
+
+def appnp_raw(csr, w, h, K, alpha, kind="appnp"):
+    _lib.require_device(h)
+    h = h.contiguous()
+    ph, ldh = _lib.mat(h, "h")
+    out = torch.empty_like(h)
+    tmp = torch.empty_like(h) if K > 1 else None
+    po, ldo = _lib.mat(out, "out")
+    with _Timed(kind):
+        _lib.check(
+            _lib.load().rgbx_appnp_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), ph, ldh, po,
+                                       _lib.ptr(tmp), ldo, csr.N, h.size(1), int(K), float(alpha),
+                                       _lib.stream_ptr()), "rgbx_appnp_f32")
+    return out
+
+
+class _APPNP(torch.autograd.Function):
+    """z <- (1-alpha) A_hat z + alpha h, K times (appnp_stack.py:29; twin pta.py:79-84).
+
+    Backward is the same recurrence on the transposed graph applied to the incoming gradient:
+    dL/dh = M^K g + alpha * sum_{j<K} M^j g with M = (1-alpha) A_hat^T (Horner form)."""
+
+    @staticmethod
+    def forward(ctx, h, graph, K, alpha):
+        ctx.graph, ctx.K, ctx.alpha = graph, K, alpha
+        return appnp_raw(graph.fwd, graph.w, h, K, alpha, kind="appnp_fwd")
+
+    @staticmethod
+    def backward(ctx, gy):
+        g = ctx.graph
+        return appnp_raw(g.bwd, g.w_t, gy, ctx.K, ctx.alpha, kind="appnp_bwd"), None, None, None
+
+
+def appnp_propagate(h, graph, K, alpha):
+    return _APPNP.apply(h, graph, K, alpha)
+
+
+class _GATScores(torch.autograd.Function):
+    """a_src[n,h] = <hfeat[n,h,:], att_src[h,:]> and a_dst likewise (GATConv.forward [PyG])."""
+
+    @staticmethod
+    def forward(ctx, hfeat, att_src, att_dst, H, C):
+        _lib.require_device(hfeat, att_src, att_dst)
+        hfeat = hfeat.contiguous()
+        n = hfeat.size(0)
+        a_src = torch.empty((n, H), dtype=torch.float32, device=hfeat.device)
+        a_dst = torch.empty_like(a_src)
+        ph, ldh = _lib.mat(hfeat, "hfeat")
+        att_s = att_src.reshape(H, C).contiguous()
+        att_d = att_dst.reshape(H, C).contiguous()
+        _lib.check(
+            _lib.load().rgbx_gat_scores_f32(ph, ldh, _lib.ptr(att_s), _lib.ptr(att_d), _lib.ptr(a_src),
+                                            _lib.ptr(a_dst), n, H, C, _lib.stream_ptr()), "rgbx_gat_scores_f32")
+        ctx.save_for_backward(hfeat, att_s, att_d)
+        ctx.H, ctx.C, ctx.att_shape = H, C, att_src.shape
+        return a_src, a_dst
+
+    @staticmethod
+    def backward(ctx, g_as, g_ad):
+        hfeat, att_s, att_d = ctx.saved_tensors
+        H, C = ctx.H, ctx.C
+        h3 = hfeat.view(-1, H, C)
+        g_h = (g_as.unsqueeze(-1) * att_s + g_ad.unsqueeze(-1) * att_d).reshape(hfeat.shape)
+        g_att_s = torch.einsum("nh,nhc->hc", g_as, h3).reshape(ctx.att_shape)
+        g_att_d = torch.einsum("nh,nhc->hc", g_ad, h3).reshape(ctx.att_shape)
+        return g_h, g_att_s, g_att_d, None, None
+
+
+class _GATAggregate(torch.autograd.Function):
+    """out[i,h,:] = sum_j softmax_j(leaky_relu(a_src[j,h] + a_dst[i,h])) * hfeat[j,h,:]."""
+
+    @staticmethod
+    def forward(ctx, hfeat, a_src, a_dst, graph, H, C, slope):
+        _lib.require_device(hfeat, a_src, a_dst)
+        hfeat, a_src, a_dst = hfeat.contiguous(), a_src.contiguous(), a_dst.contiguous()
+        N = graph.N
+        dev = hfeat.device
+        out = torch.empty((N, H * C), dtype=torch.float32, device=dev)
+        m = torch.empty((N, H), dtype=torch.float32, device=dev)
+        rden = torch.empty_like(m)
+        ph, ldh = _lib.mat(hfeat, "hfeat")
+        po, ldo = _lib.mat(out, "out")
+        csr = graph.fwd
+        with _Timed("gat_fwd"):
+            _lib.check(
+                _lib.load().rgbx_gat_aggregate_fwd_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), ph, ldh,
+                                                       _lib.ptr(a_src), _lib.ptr(a_dst), po, ldo, _lib.ptr(m),
+                                                       _lib.ptr(rden), N, H, C, float(slope),
+                                                       _lib.stream_ptr()), "rgbx_gat_aggregate_fwd_f32")
+        ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out)
+        ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, slope
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        hfeat, a_src, a_dst, m, rden, out = ctx.saved_tensors
+        g, H, C, slope = ctx.graph, ctx.H, ctx.C, ctx.slope
+        gout = gout.contiguous()
+        N, dev = g.N, gout.device
+        lib = _lib.load()
+        dsum = torch.empty((N, H), dtype=torch.float32, device=dev)
+        g_ad = torch.empty_like(dsum)
+        g_as = torch.empty_like(dsum)
+        g_h = torch.empty_like(hfeat)
+        ph, ldh = _lib.mat(hfeat, "hfeat")
+        po, ldo = _lib.mat(out, "out")
+        pg, ldg = _lib.mat(gout, "gout")
+        pgh, ldgh = _lib.mat(g_h, "g_hfeat")
+        with _Timed("gat_bwd_dst"):
+            _lib.check(
+                lib.rgbx_gat_bwd_dst_f32(_lib.ptr(g.fwd.rowptr), _lib.ptr(g.fwd.col), ph, ldh, _lib.ptr(a_src),
+                                         _lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, pg, ldg,
+                                         _lib.ptr(dsum), _lib.ptr(g_ad), N, H, C, float(slope),
+                                         _lib.stream_ptr()), "rgbx_gat_bwd_dst_f32")
+        with _Timed("gat_bwd_src"):
+            _lib.check(
+                lib.rgbx_gat_bwd_src_f32(_lib.ptr(g.bwd.rowptr), _lib.ptr(g.bwd.col), ph, ldh, _lib.ptr(a_src),
+                                         _lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), _lib.ptr(dsum), pg, ldg,
+                                         pgh, ldgh, _lib.ptr(g_as), N, H, C, float(slope),
+                                         _lib.stream_ptr()), "rgbx_gat_bwd_src_f32")
+        return g_h, g_as, g_ad, None, None, None, None
+
+
+def gat_scores(hfeat, att_src, att_dst, H, C):
+    return _GATScores.apply(hfeat, att_src, att_dst, H, C)
+
+
+def gat_aggregate(hfeat, a_src, a_dst, graph, H, C, slope=0.2):
+    return _GATAggregate.apply(hfeat, a_src, a_dst, graph, H, C, slope)
+
+
+def gather_rows(src, idx, out=None):
+    """out[r] = src[idx[r]] (idx int32, device)."""
+    _lib.require_device(src, idx)
+    ps, lds = _lib.mat(src, "src")
+    n, d = idx.numel(), src.size(1)
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=src.device)
+    po, ldo = _lib.mat(out, "dst")
+    _lib.check(_lib.load().rgbx_gather_rows_f32(ps, lds, _lib.ptr(idx), n, d, po, ldo, _lib.stream_ptr()),
+               "rgbx_gather_rows_f32")
+    return out
+
+
+def scatter_add_rows(src, idx, dst):
+    """dst[idx[r]] += src[r]; idx entries unique."""
+    _lib.require_device(src, idx, dst)
+    ps, lds = _lib.mat(src, "src")
+    pd, ldd = _lib.mat(dst, "dst")
+    _lib.check(
+        _lib.load().rgbx_scatter_add_rows_f32(ps, lds, _lib.ptr(idx), idx.numel(), src.size(1), pd, ldd,
+                                              _lib.stream_ptr()), "rgbx_scatter_add_rows_f32")
+    return dst

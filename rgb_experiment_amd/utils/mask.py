@@ -1,0 +1,79 @@
+"""Train/val/test split masks, bit-exact with the reference (utils/mask.py) for a given seed —
+the masks select the loss rows, so they are part of the path's inputs (golden fixture G4).
+Labels equal to -1 mean "unlabelled" and never enter a split."""
+import random
+
+import torch
+
+
+def _split_sizes(ratio, n):
+    parts = [int(p) for p in ratio.split("-")]
+    total = sum(parts)
+    n_train = int(parts[0] / total * n)
+    n_val = int(parts[1] / total * n)
+    return n_train, n_val
+
+
+def _to_mask(index, total):
+    mask = torch.zeros(total, dtype=torch.bool)
+    mask[index] = True
+    return mask
+
+
+def get_order(ratio, masked_index, total_node_num, seed=1234567):
+    """Shuffle positions 0..len-1 with Python's `random` seeded by `seed`, cut at the ratio
+    boundaries (floor), map back through `masked_index` (reference utils/mask.py:66-102)."""
+    random.seed(seed)
+    order = list(range(len(masked_index)))
+    random.shuffle(order)
+    n_train, n_val = _split_sizes(ratio, len(order))
+    pieces = (order[:n_train], order[n_train:n_train + n_val], order[n_train + n_val:])
+    return tuple(_to_mask(masked_index[p], total_node_num) for p in pieces)
+
+
+def check_train_containing(train_mask, y):
+    """True iff every label other than -1 occurs under train_mask (reference utils/mask.py:24-32)."""
+    present = set(y[train_mask].tolist())
+    return all(lbl in present for lbl in y.unique().tolist() if lbl != -1)
+
+
+def get_whole_mask(y, ratio, seed=1234567):
+    """Ratio split over all labelled nodes; the seed is bumped by one until the train part holds
+    every class (reference utils/mask.py:10-22)."""
+    labelled = torch.arange(len(y), dtype=torch.int64)[y != -1]
+    while True:
+        masks = get_order(ratio, labelled, len(y), seed)
+        if check_train_containing(masks[0], y):
+            return masks
+        seed += 1
+
+
+def get_classification_mask(y, ratio, seed=1234567):
+    """Ratio split inside every class, unioned (reference utils/mask.py:37-62)."""
+    total = len(y)
+    out = [torch.zeros(total, dtype=torch.bool) for _ in range(3)]
+    for lbl in y.unique().tolist():
+        if lbl == -1:
+            continue
+        members = (y == lbl).nonzero(as_tuple=True)[0]
+        for acc, part in zip(out, get_order(ratio, members, total, seed)):
+            acc |= part
+    return tuple(out)
+
+
+def get_random_mask(y, num_train_per_class, num_val, num_test, seed):
+    """Planetoid-style split (reference utils/mask.py:106-138): per class a seeded randperm picks
+    the train nodes; val/test come from an UNSEEDED (global RNG) permutation of the remaining
+    labelled nodes, exactly as the reference does (mask.py:133)."""
+    gen = torch.Generator()
+    gen.manual_seed(seed)
+    total = len(y)
+    train = torch.zeros(total, dtype=torch.bool)
+    for lbl in y.unique().tolist():
+        if lbl == -1:
+            continue
+        members = (y == lbl).nonzero(as_tuple=False).view(-1)
+        train[members[torch.randperm(members.size(0), generator=gen)[:num_train_per_class]]] = True
+    rest = ((~train) & (y != -1)).nonzero(as_tuple=False).view(-1)
+    rest = rest[torch.randperm(rest.size(0))]
+    return train, _to_mask(rest[:num_val], total), _to_mask(rest[num_val:num_val + num_test], total)

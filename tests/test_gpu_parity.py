@@ -1,0 +1,448 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle, on a real MI355X.
+
+Tolerances: index work (CSR rowptr / col / perm) bit-exact; fp32 aggregation outputs |diff| <= 1e-4
+absolute on O(1) data (the north-star bound on logits), tighter where stated. Summation order inside a
+row differs from the oracle's edge order, so bit-equality of floats is not expected."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_GRAPHS
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def rand_graph(n, e, seed, loops=0, dups=0):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    if loops:
+        k = torch.randint(0, n, (loops,), generator=g)
+        ei = torch.cat([ei, torch.stack([k, k])], dim=1)
+    if dups and e:
+        ei = torch.cat([ei, ei[:, :dups]], dim=1)
+    return ei[:, torch.randperm(ei.size(1), generator=g)]
+
+
+# ---- runtime sanity ---------------------------------------------------------------------------------
+
+def test_one_hip_runtime_in_process(dev):
+    """librgbx_hip.so must bind to the libamdhip64 torch already loaded (same SONAME), otherwise
+    streams and device pointers would cross two runtimes."""
+    from rgb_experiment_amd import _lib
+    _lib.load()
+    torch.zeros(1, device=dev)
+    paths = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}
+    assert len(paths) == 1, paths
+    assert any("librgbx_hip.so" in line for line in open("/proc/self/maps"))
+
+
+# ---- graph preparation: bit-exact ----------------------------------------------------------------------
+
+CSR_CASES = [
+    (1, 0, 0, 0), (5, 0, 0, 0), (7, 20, 3, 4), (64, 64 * 70, 5, 50), (1000, 20000, 30, 100),
+    (50000, 800000, 100, 1000), (3, 500, 10, 100),
+]
+
+
+@pytest.mark.parametrize("n,e,loops,dups", CSR_CASES)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_csr_build_bit_exact(dev, n, e, loops, dups, mode):
+    from rgb_experiment_amd.graph import Graph
+    ei = rand_graph(n, e, seed=n + e, loops=loops, dups=dups)
+    g = Graph(ei.to(dev), n, mode)
+    rei, ids = O.rewrite_edges(ei, n, mode)
+    for csr, agg, other in ((g.fwd, rei[1], rei[0]), (g.bwd, rei[0], rei[1])):
+        rowptr, col, perm = O.csr_from_edges(agg, other, ids, n)
+        assert csr.nnz == rei.size(1)
+        assert torch.equal(csr.rowptr.cpu(), rowptr)
+        assert torch.equal(csr.col.cpu()[:csr.nnz], col)
+        assert torch.equal(csr.perm.cpu()[:csr.nnz], perm)
+
+
+@pytest.mark.parametrize("name", GOLDEN_GRAPHS)
+def test_gcn_norm_on_golden_graphs(dev, golden, name):
+    """The HIP A_hat, densified, equals the reference's normalize_adj matrix (golden G1)."""
+    from rgb_experiment_amd.graph import Graph
+    ei = torch.from_numpy(golden[f"g1/{name}/edge_index"]).flip(0)  # see test_oracle_golden G1
+    n = int(golden[f"g1/{name}/num_nodes"])
+    g = Graph(ei.to(dev), n, 1)
+    rowptr, col, w = g.fwd.rowptr.cpu().long(), g.fwd.col.cpu().long(), g.w.cpu()
+    dense = torch.zeros(n, n)
+    for i in range(n):
+        for p in range(rowptr[i], rowptr[i + 1]):
+            dense[i, col[p]] += w[p]
+    assert torch.allclose(dense, torch.from_numpy(golden[f"g1/{name}/adj_ref"]).float(), atol=1e-6)
+
+
+def test_norm_vectors(dev):
+    from rgb_experiment_amd.graph import Graph
+    n = 3000
+    ei = rand_graph(n, 30000, 5, loops=20, dups=50)
+    g = Graph(ei.to(dev), n, 1)
+    rei, w = O.gcn_norm(ei, None, n)
+    _, _, perm = O.csr_from_edges(rei[1], rei[0], torch.arange(rei.size(1)), n)
+    assert torch.allclose(g.w.cpu()[:g.fwd.nnz], w[perm.long()], atol=1e-7)
+    _, _, perm_t = O.csr_from_edges(rei[0], rei[1], torch.arange(rei.size(1)), n)
+    assert torch.allclose(g.w_t.cpu()[:g.bwd.nnz], w[perm_t.long()], atol=1e-7)
+    g0 = Graph(ei.to(dev), n, 0)
+    cnt = torch.bincount(ei[1], minlength=n).clamp(min=1).float()
+    assert torch.equal(g0.inv_deg.cpu()[:n], 1.0 / cnt)
+
+
+def test_out_of_range_edge_index_is_rejected(dev):
+    from rgb_experiment_amd.graph import Graph
+    with pytest.raises(RuntimeError, match="outside"):
+        Graph(torch.tensor([[0, 5], [1, 2]], device=dev), 4, 1)
+    with pytest.raises(RuntimeError, match="int64"):
+        Graph(torch.tensor([[0, 1], [1, 2]], device=dev, dtype=torch.int32), 4, 1)
+
+
+# ---- SpMM -------------------------------------------------------------------------------------------
+
+WIDTHS = [1, 2, 3, 4, 7, 8, 12, 16, 30, 32, 64, 100, 128, 130, 256, 260, 512, 1433]
+
+
+@pytest.mark.parametrize("d", WIDTHS)
+def test_spmm_gcn_widths(dev, d):
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n = 1500
+    ei = rand_graph(n, 12000, d, loops=10, dups=30)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(d))
+    g = Graph(ei.to(dev), n, 1)
+    got = ops.propagate_gcn(x.to(dev), g).cpu()
+    rei, w = O.gcn_norm(ei, None, n)
+    want = O.propagate(rei, x, n, w, "add")
+    assert (got - want).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("d", [5, 64, 128])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_spmm_mean_and_sum(dev, d, mode):
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n = 2000
+    ei = rand_graph(n, 9000, 77 + d, loops=15, dups=15)  # sparse enough to leave isolated nodes in mode 0
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(1))
+    g = Graph(ei.to(dev), n, mode)
+    rei, _ = O.rewrite_edges(ei, n, mode)
+    assert (ops.propagate_mean(x.to(dev), g).cpu() - O.propagate(rei, x, n, None, "mean")).abs().max() < TOL
+    assert (ops.propagate_sum(x.to(dev), g).cpu() - O.propagate(rei, x, n, None, "add")).abs().max() < 5e-4
+
+
+def test_spmm_heavy_rows_and_exact_wave_multiples(dev):
+    """Rows with 0, 1, 63, 64, 65, 128, 129 and 5000 in-edges (chunk loop + tail predicates)."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    degs = [0, 1, 63, 64, 65, 128, 129, 5000, 0, 7]
+    n = 6000
+    g = torch.Generator().manual_seed(9)
+    src = torch.cat([torch.randint(len(degs), n, (k,), generator=g) for k in degs])
+    dst = torch.cat([torch.full((k,), i, dtype=torch.int64) for i, k in enumerate(degs)])
+    ei = torch.stack([src, dst])
+    x = torch.randn(n, 128, generator=g)
+    gr = Graph(ei.to(dev), n, 0)
+    got = ops.propagate_sum(x.to(dev), gr).cpu()
+    want = O.propagate(ei, x, n, None, "add")
+    assert (got - want).abs().max().item() < 1e-3  # 5000-term sums of N(0,1)
+    assert torch.equal(got[len(degs):], torch.zeros(n - len(degs), 128))
+
+
+def test_spmm_epilogue_and_strides(dev):
+    """a, b, y, row scale, and non-contiguous leading dimensions (column slices of wider matrices)."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n, d = 900, 64
+    ei = rand_graph(n, 7000, 3)
+    gr = Graph(ei.to(dev), n, 1)
+    gen = torch.Generator().manual_seed(2)
+    big = torch.randn(n, 3 * d + 1, generator=gen).to(dev)
+    x = big[:, 1:1 + d]        # misaligned for float4 -> scalar path
+    x4 = big[:, 64:64 + d]     # 16-byte aligned slice, ld = 193 -> not a multiple of 4 -> scalar path
+    y = torch.randn(n, d, generator=gen).to(dev)
+    rs = torch.rand(n, generator=gen).to(dev)
+    rei, w = O.gcn_norm(ei, None, n)
+    for xs in (x, x4):
+        got = ops.spmm_raw(gr.fwd, gr.w, rs, xs, y=y, a=0.7, b=-1.3).cpu()
+        want = 0.7 * rs.cpu().view(-1, 1) * O.propagate(rei, xs.cpu(), n, w, "add") - 1.3 * y.cpu()
+        assert (got - want).abs().max().item() < TOL
+    out = torch.zeros(n, 2 * d, device=dev)
+    ops.spmm_raw(gr.fwd, gr.w, None, y, out=out[:, d:])
+    assert (out[:, d:].cpu() - O.propagate(rei, y.cpu(), n, w, "add")).abs().max() < TOL
+    assert torch.equal(out[:, :d].cpu(), torch.zeros(n, d))
+
+
+def test_spmm_empty_graph_and_single_node(dev):
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    ei = torch.zeros(2, 0, dtype=torch.int64)
+    x = torch.randn(5, 8)
+    g0 = Graph(ei.to(dev), 5, 0)
+    assert torch.equal(ops.propagate_sum(x.to(dev), g0).cpu(), torch.zeros(5, 8))
+    g1 = Graph(ei.to(dev), 5, 1)  # only the added self-loops: A_hat = I
+    assert torch.allclose(ops.propagate_gcn(x.to(dev), g1).cpu(), x, atol=1e-7)
+    g2 = Graph(torch.tensor([[0], [0]], device=dev), 1, 1)
+    assert torch.allclose(ops.propagate_gcn(x[:1].to(dev), g2).cpu(), x[:1], atol=1e-7)
+
+
+@pytest.mark.parametrize("K", [0, 1, 2, 10])
+@pytest.mark.parametrize("d", [7, 128])
+def test_appnp(dev, K, d):
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n = 2500
+    ei = rand_graph(n, 20000, 11, loops=5, dups=5)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(K))
+    gr = Graph(ei.to(dev), n, 1)
+    got = ops.appnp_propagate(x.to(dev), gr, K, 0.1).cpu()
+    assert (got - O.appnp(x, ei, K, 0.1)).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("name", GOLDEN_GRAPHS)
+def test_appnp_against_reference_golden(dev, golden, name):
+    """HIP APPNP == the reference's PTA.inference output (golden G3), not only the oracle."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    ei = torch.from_numpy(golden[f"g1/{name}/edge_index"]).flip(0)
+    n = int(golden[f"g1/{name}/num_nodes"])
+    h = torch.softmax(torch.from_numpy(golden[f"g3/{name}/h"]), dim=-1)
+    gr = Graph(ei.to(dev), n, 1)
+    for K, alpha in ((1, 0.1), (10, 0.1), (4, 0.35)):
+        got = ops.appnp_propagate(h.to(dev), gr, K, alpha).cpu()
+        assert torch.allclose(got, torch.from_numpy(golden[f"g3/{name}/K{K}_a{alpha}/out"]), atol=1e-6)
+
+
+# ---- autograd of the aggregation ops ----------------------------------------------------------------------
+
+def _grad_pair(fn_gpu, fn_cpu, x, dev):
+    xg = x.to(dev).requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    og, oc = fn_gpu(xg), fn_cpu(xc)
+    go = torch.randn(oc.shape, generator=torch.Generator().manual_seed(5))
+    og.backward(go.to(dev))
+    oc.backward(go)
+    return (og.detach().cpu() - oc.detach()).abs().max().item(), (xg.grad.cpu() - xc.grad).abs().max().item()
+
+
+@pytest.mark.parametrize("d", [7, 128])
+def test_backward_gcn_mean_appnp(dev, d):
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n = 1800
+    ei = rand_graph(n, 15000, 21, loops=8, dups=8)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(3))
+    g1, g2, g0 = Graph(ei.to(dev), n, 1), Graph(ei.to(dev), n, 2), Graph(ei.to(dev), n, 0)
+    rei, w = O.gcn_norm(ei, None, n)
+    r2, _ = O.rewrite_edges(ei, n, 2)
+    cases = [
+        (lambda t: ops.propagate_gcn(t, g1), lambda t: O.propagate(rei, t, n, w, "add")),
+        (lambda t: ops.propagate_mean(t, g2), lambda t: O.propagate(r2, t, n, None, "mean")),
+        (lambda t: ops.propagate_mean(t, g0), lambda t: O.propagate(ei, t, n, None, "mean")),
+        (lambda t: ops.appnp_propagate(t, g1, 10, 0.1), lambda t: O.appnp(t, ei, 10, 0.1)),
+        (lambda t: ops.appnp_propagate(t, g1, 1, 0.3), lambda t: O.appnp(t, ei, 1, 0.3)),
+    ]
+    for fg, fc in cases:
+        e_out, e_grad = _grad_pair(fg, fc, x, dev)
+        assert e_out < TOL and e_grad < TOL, (e_out, e_grad)
+
+
+# ---- GAT -----------------------------------------------------------------------------------------------
+
+GAT_SHAPES = [(8, 16), (1, 128), (8, 8), (1, 7), (3, 5), (8, 64), (2, 96), (1, 1), (5, 2), (1, 256), (16, 4)]
+
+
+@pytest.mark.parametrize("H,C", GAT_SHAPES)
+def test_gat_conv_forward_backward(dev, H, C):
+    from rgb_experiment_amd.nn import GATConv
+    n, f = 700, 24
+    ei = rand_graph(n, 6000, H * 100 + C, loops=10, dups=10)
+    gen = torch.Generator().manual_seed(H + C)
+    x = torch.randn(n, f, generator=gen)
+    for concat in (True, False):
+        torch.manual_seed(7)
+        conv = GATConv(f, C, H, concat=concat)
+        with torch.no_grad():
+            conv.bias.uniform_(-1, 1)
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in conv.state_dict().items() if "lin_dst" not in k}
+        conv.to(dev)
+        xg = x.to(dev).requires_grad_(True)
+        xc = x.clone().requires_grad_(True)
+        og = conv(xg, ei.to(dev))
+        oc = O.gat_conv(xc, ei, sd["lin_src.weight"], sd["att_src"], sd["att_dst"], sd["bias"], H, concat)
+        assert (og.detach().cpu() - oc.detach()).abs().max().item() < TOL
+        go = torch.randn(oc.shape, generator=gen)
+        og.backward(go.to(dev))
+        oc.backward(go)
+        assert (xg.grad.cpu() - xc.grad).abs().max().item() < 2e-4
+        for name, p in (("lin_src.weight", conv.lin_src.weight), ("att_src", conv.att_src),
+                        ("att_dst", conv.att_dst), ("bias", conv.bias)):
+            ref = sd[name].grad
+            assert (p.grad.cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), name
+
+
+def test_gat_rescale_branch_with_spiked_scores(dev):
+    """Force the online-softmax running max to jump late in a row and across neighbour groups: one
+    source has a huge attention logit and is the LAST in-edge of a 200-edge row."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n, H, C = 300, 2, 8
+    gen = torch.Generator().manual_seed(0)
+    src = torch.cat([torch.randint(1, n - 1, (199,), generator=gen), torch.tensor([n - 1])])
+    ei = torch.stack([src, torch.zeros(200, dtype=torch.int64)])
+    h = torch.randn(n, H * C, generator=gen)
+    a_s = torch.randn(n, H, generator=gen)
+    a_s[n - 1] = 60.0   # exp(60) would overflow a non-rescaled fp32 sum of exp(e - m_old)
+    a_s[5] = -80.0
+    a_d = torch.randn(n, H, generator=gen)
+    gr = Graph(ei.to(dev), n, 0)
+    got = ops.gat_aggregate(h.to(dev), a_s.to(dev), a_d.to(dev), gr, H, C, 0.2).cpu()
+    e = torch.nn.functional.leaky_relu(a_s[ei[0]] + a_d[ei[1]], 0.2)
+    al = O.segment_softmax(e, ei[1], n)
+    want = torch.zeros(n, H, C).index_add_(0, ei[1], h.view(n, H, C)[ei[0]] * al.unsqueeze(-1)).reshape(n, H * C)
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() < TOL
+    assert torch.equal(got[1:], torch.zeros(n - 1, H * C))  # rows without in-edges
+
+
+# ---- whole models: logits within 1e-4 of the oracle with identical weights --------------------------------
+
+def _model_case(name):
+    from rgb_experiment_amd import models as M
+    if name == "gcn":
+        return M.GCN, dict(num_layers=3, hidden_unit=64, dropout_rate=0.5), lambda sd, x, ei, tr: O.gcn_forward(sd, x, ei, 3, tr)
+    if name == "graphsage":
+        return M.GraphSAGE, dict(num_layers=2, hidden_unit=64, dropout_rate=0.5), lambda sd, x, ei, tr: O.graphsage_forward(sd, x, ei, 2, tr)
+    if name == "graphsage2":
+        return M.GraphSAGE2, dict(num_layers=2, hidden_unit=64, dropout_rate=0.5), lambda sd, x, ei, tr: O.graphsage2_forward(sd, x, ei, 2, tr)
+    if name == "gat":
+        return M.GAT, dict(num_layers=2, hidden_unit=8, dropout_rate=0.5, heads=8), lambda sd, x, ei, tr: O.gat_forward(sd, x, ei, 2, 8, tr)
+    if name == "appnpstack":
+        return M.APPNPStack, dict(hidden_unit=64, K=10, alpha=0.1, dropout_rate=0.5), lambda sd, x, ei, tr: O.appnp_stack_forward(sd, x, ei, 10, 0.1, tr)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack"])
+def test_model_logits_and_gradients(dev, name):
+    cls, kw, oracle_fwd = _model_case(name)
+    n, f, c = 2708, 200, 7
+    gen = torch.Generator().manual_seed(42)
+    ei = rand_graph(n, 10556, 42, loops=5, dups=5)
+    x = torch.rand(n, f, generator=gen)
+    x = x / x.sum(1, keepdim=True)
+    y = torch.randint(0, c, (n,), generator=gen)
+    torch.manual_seed(14530529)
+    model = cls(input_dim=f, output_dim=c, **kw)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(dev)
+
+    model.eval()
+    with torch.no_grad():
+        out = model(x.to(dev), ei.to(dev))
+    ref = oracle_fwd(sd, x, ei, False)
+    assert set(out) == {"out", "emb", "x"}
+    assert (out["emb"].cpu() - ref["emb"]).abs().max().item() < TOL
+    assert (out["out"].cpu() - ref["out"]).abs().max().item() < TOL
+
+    model.train()
+    out = model(x.to(dev), ei.to(dev))
+    loss = torch.nn.functional.nll_loss(out["out"][:1500], y[:1500].to(dev))
+    loss.backward()
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    ref = oracle_fwd(ref_sd, x, ei, True)
+    ref_loss = torch.nn.functional.nll_loss(ref["out"][:1500], y[:1500])
+    ref_loss.backward()
+    assert (out["emb"].detach().cpu() - ref["emb"].detach()).abs().max().item() < TOL
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    for pname, p in model.named_parameters():
+        rg = ref_sd[pname].grad
+        assert rg is not None, pname
+        assert (p.grad.cpu() - rg).abs().max().item() < 1e-4 * max(1.0, rg.abs().max().item()), pname
+
+
+def test_experiment_cora_shaped_gcn(dev):
+    """BASELINE config 1: Cora-shaped synthetic Data through experiment(); the trained model's logits
+    equal the oracle's forward with the trained weights."""
+    import rgb_experiment_amd as R
+    n, pairs, f, c = 2708, 5278, 1433, 7
+    gen = torch.Generator().manual_seed(1234567)
+    a = torch.randint(0, n, (pairs,), generator=gen)
+    b = (a + 1 + torch.randint(0, n - 1, (pairs,), generator=gen)) % n  # no self-loops
+    ei = torch.cat([torch.stack([a, b]), torch.stack([b, a])], dim=1)
+    x = torch.zeros(n, f)
+    x.scatter_(1, torch.randint(0, f, (n, 18), generator=gen), 1.0)
+    y = torch.randint(0, c, (n,), generator=gen)
+    data = R.Data(x=x, y=y, edge_index=ei)
+    res = R.experiment({"num_layers": 2, "hidden_unit": 64, "dropout_rate": 0.5}, specify_data=True, data=data,
+                       model_name="GCN", learning_rate=0.01, epoch=12, normalize_feature="row",
+                       need_to_reappear=True, print_print=False, return_model=True)
+    assert 0.0 <= res["ACC"] <= 1.0 and len(res["history"]["train_loss"]) == 12
+    assert res["history"]["train_loss"][-1] < res["history"]["train_loss"][0]
+    model = res["model"].eval()
+    xn = x / x.sum(1, keepdim=True).clamp(min=1)
+    with torch.no_grad():
+        emb = model(xn.to(dev), ei.to(dev))["emb"].cpu()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    assert (emb - O.gcn_forward(sd, xn, ei, 2, False)["emb"]).abs().max().item() < TOL
+
+
+# ---- halo pack / unpack -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("d", [1, 7, 128, 132])
+def test_gather_and_scatter_rows(dev, d):
+    from rgb_experiment_amd import ops
+    gen = torch.Generator().manual_seed(d)
+    src = torch.randn(500, d, generator=gen)
+    idx = torch.randperm(500, generator=gen)[:300].to(torch.int32)
+    got = ops.gather_rows(src.to(dev), idx.to(dev)).cpu()
+    assert torch.equal(got, src[idx.long()])
+    dst = torch.randn(500, d, generator=gen)
+    add = torch.randn(300, d, generator=gen)
+    want = dst.clone()
+    want[idx.long()] += add
+    got = ops.scatter_add_rows(add.to(dev), idx.to(dev), dst.to(dev)).cpu()
+    assert torch.equal(got, want)
+
+
+# ---- BASELINE sizes: size-independent properties -------------------------------------------------------
+
+@pytest.mark.parametrize("n,e", [(200_000, 4_000_000), (2_000_000, 60_000_000)])
+def test_full_size_properties(dev, n, e):
+    """At the benchmark sizes the oracle would need tens of GB, so check exact properties instead:
+    (1) CSR row counts == bincount of the rewritten targets and perm is a permutation (bit-exact);
+    (2) unweighted sum of an all-ones matrix == in-degree exactly (integers are exact in fp32);
+    (3) linearity: A(ax + by) == a*Ax + b*Ay; (4) mean of a constant vector is that constant;
+    (5) <A x, y> == <x, A^T y> ties the forward and the transposed (backward) CSR together."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    gen = torch.Generator().manual_seed(1234567)
+    ei = torch.randint(0, n, (2, e), generator=gen, dtype=torch.int64).to(dev)
+    g = Graph(ei, n, 1)
+    nonloop = ei[0] != ei[1]
+    indeg = torch.bincount(ei[1][nonloop], minlength=n) + 1
+    assert g.fwd.nnz == int(nonloop.sum()) + n
+    assert torch.equal((g.fwd.rowptr[1:] - g.fwd.rowptr[:-1]).long(), indeg)
+    seen = torch.zeros(e + n, dtype=torch.bool, device=dev)
+    seen[g.fwd.perm.long()] = True
+    assert int(seen.sum()) == g.fwd.nnz and not bool(seen[:e][~nonloop].any())
+    d = 128
+    ones = torch.ones(n, d, device=dev)
+    deg_out = ops.propagate_sum(ones, g)
+    assert torch.equal(deg_out[:, 0].long(), indeg) and torch.equal(deg_out[:, 0], deg_out[:, d - 1])
+    assert torch.allclose(ops.propagate_mean(3.25 * ones, g), 3.25 * ones, atol=1e-5)
+    x = torch.randn(n, d, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    y = torch.randn(n, d, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    ax, ay = ops.propagate_gcn(x, g), ops.propagate_gcn(y, g)
+    lin = ops.propagate_gcn(0.5 * x - 2.0 * y, g)
+    assert (lin - (0.5 * ax - 2.0 * ay)).abs().max().item() < 1e-4
+    aty = ops.spmm_raw(g.bwd, g.w_t, None, y)
+    lhs, rhs = (ax.double() * y.double()).sum().item(), (x.double() * aty.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))

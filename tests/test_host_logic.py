@@ -1,0 +1,176 @@
+"""Host-side pieces either side of the hot path: split masks (bit-exact vs the reference, golden G4),
+subgraph relabelling (G5), metrics (G6), edge utilities, Data container, experiment() argument handling."""
+import numpy as np
+import pytest
+import torch
+
+import rgb_experiment_amd as R
+from rgb_experiment_amd import utils as U
+from rgb_experiment_amd.models import REGISTRY
+
+
+@pytest.mark.parametrize("case", ["small", "cora_shaped"])
+@pytest.mark.parametrize("ratio,seed", [("6-2-2", 123456789), ("5-2-3", 14530529), ("1-1-3", 1234567)])
+def test_g4_masks_bit_exact(golden, case, ratio, seed):
+    y = torch.from_numpy(golden[f"g4/{case}/y"])
+    got = torch.stack(U.get_whole_mask(y, ratio, seed)).numpy()
+    assert np.array_equal(got, golden[f"g4/{case}/whole/{ratio}/{seed}"])
+    got = torch.stack(U.get_classification_mask(y, ratio, seed)).numpy()
+    assert np.array_equal(got, golden[f"g4/{case}/classification/{ratio}/{seed}"])
+
+
+@pytest.mark.parametrize("case", ["small", "cora_shaped"])
+def test_g4_random_mask_train_part(golden, case):
+    y = torch.from_numpy(golden[f"g4/{case}/y"])
+    train, val, test = U.get_random_mask(y, 5, 10, 20, 1234567)
+    assert np.array_equal(train.numpy(), golden[f"g4/{case}/random_train/5/1234567"])
+    assert int(val.sum()) == 10 and int(test.sum()) == 20
+    assert not (train & val).any() and not (train & test).any() and not (val & test).any()
+    assert not (y[train | val | test] == -1).any()
+
+
+def test_g5_node_induced_subgraph(golden):
+    ei = torch.from_numpy(golden["g5/edge_index"])
+    n = int(golden["g5/num_nodes"])
+    picked = golden["g5/nodes_list"].tolist()
+    assert np.array_equal(U.node_induced_subgraph(n, picked, ei, True).numpy(), golden["g5/list_reorder"])
+    assert np.array_equal(U.node_induced_subgraph(n, picked, ei, False).numpy(), golden["g5/list_keep"])
+    m = torch.from_numpy(golden["g5/nodes_mask"])
+    assert np.array_equal(U.node_induced_subgraph(n, m, ei, True).numpy(), golden["g5/mask_reorder"])
+
+
+def test_g6_compare_pred_label(golden):
+    pred, label = torch.from_numpy(golden["g6/pred"]), torch.from_numpy(golden["g6/label"])
+    res = R.compare_pred_label(pred, label, True)
+    got = [res[k] for k in ("ACC", "precision_score", "recall_score", "f1_macro", "f1_micro")]
+    assert np.allclose(got, golden["g6/metrics"], atol=1e-12)
+    res0 = R.compare_pred_label(pred, label, False)  # reference raises UnboundLocalError here
+    assert res0["ACC"] == res["ACC"] and res0["f1_macro"] == 0 and res0["f1_micro"] == 0
+
+
+def test_metrics_without_sklearn_agree(golden, monkeypatch):
+    import builtins
+    from rgb_experiment_amd import itexperiments as it
+    pred, label = golden["g6/pred"], golden["g6/label"]
+    with_sk = it._macro_prf(label, pred)
+    real_import = builtins.__import__
+
+    def no_sklearn(name, *a, **k):
+        if name.startswith("sklearn"):
+            raise ImportError(name)
+        return real_import(name, *a, **k)
+
+    monkeypatch.setattr(builtins, "__import__", no_sklearn)
+    assert np.allclose(it._macro_prf(label, pred), with_sk, atol=1e-12)
+
+
+def test_edge_utils():
+    ei = torch.tensor([[2, 0, 0, 1, 1], [0, 1, 1, 1, 2]])
+    und = U.to_undirected(ei, 3)
+    assert und.tolist() == [[0, 0, 1, 1, 1, 2, 2], [1, 2, 0, 1, 2, 0, 1]]
+    assert U.coalesce(ei, 3).tolist() == [[0, 1, 1, 2], [1, 1, 2, 0]]
+    assert U.remove_self_loops(ei).tolist() == [[2, 0, 0, 1], [0, 1, 1, 2]]
+    assert U.add_remaining_self_loops(ei, 3).tolist() == [[2, 0, 0, 1, 0, 1, 2], [0, 1, 1, 2, 0, 1, 2]]
+    assert U.to_undirected(torch.zeros(2, 0, dtype=torch.long), 3).shape == (2, 0)
+
+
+def test_data_container():
+    d = R.Data(x=torch.randn(4, 3), y=torch.tensor([0, 1, 0, 1]), edge_index=torch.tensor([[0], [1]]))
+    assert d.num_nodes == 4 and d.num_node_features == 3 and d.num_edges == 1
+    c = d.clone()
+    c.x[0, 0] = 99.0
+    assert d.x[0, 0] != 99.0
+    d.train_mask = torch.tensor([True, False, False, False])
+    assert d.to("cpu").train_mask.tolist() == [True, False, False, False]
+    assert "edge_index" in repr(d)
+
+
+def test_registry_and_constructor_signatures():
+    assert sorted(REGISTRY) == ["appnpstack", "gat", "gcn", "graphsage", "graphsage2", "mlp"]
+    m = REGISTRY["gcn"](input_dim=5, output_dim=3, **R.InitialParameters.defaults_for("GCN"))
+    assert [k for k in m.state_dict() if k.startswith("convs.0")] == ["convs.0.bias", "convs.0.lin.weight"]
+    assert m.state_dict()["convs.0.lin.weight"].shape == (64, 5)
+    g = REGISTRY["gat"](input_dim=5, output_dim=3, **R.InitialParameters.defaults_for("gat"))
+    sd = g.state_dict()
+    assert sd["convs.0.att_src"].shape == (1, 8, 8) and sd["convs.0.lin_src.weight"].shape == (64, 5)
+    assert sd["convs.1.att_dst"].shape == (1, 1, 3) and sd["convs.1.bias"].shape == (3,)
+    assert sd["bns.0.weight"].shape == (64,)
+    s = REGISTRY["graphsage"](input_dim=5, output_dim=3, **R.InitialParameters.defaults_for("graphsage"))
+    assert {"convs.0.lin_l.bias", "convs.0.lin_r.bias"} <= set(s.state_dict())
+    s2 = REGISTRY["graphsage2"](input_dim=5, output_dim=3, **R.InitialParameters.defaults_for("graphsage2"))
+    assert "convs.0.lin_l.bias" in s2.state_dict() and "convs.0.lin_r.bias" not in s2.state_dict()
+    a = REGISTRY["appnpstack"](input_dim=5, output_dim=3, **R.InitialParameters.defaults_for("appnpstack"))
+    assert a.conv.K == 10 and a.conv.alpha == 0.1 and "lin1.weight" in a.state_dict()
+
+
+def _toy(n=60, f=6, c=3, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return R.Data(x=torch.randn(n, f, generator=g), y=torch.randint(0, c, (n,), generator=g),
+                  edge_index=torch.randint(0, n, (2, 200), generator=g))
+
+
+def test_experiment_mlp_runs_on_cpu_and_returns_metric_dict():
+    """MLP has no message passing, so the harness itself can be exercised without a GPU."""
+    res = R.experiment({"num_layers": 2, "hidden_unit": 8, "dropout_rate": 0.5}, specify_data=True, data=_toy(),
+                       model_name="MLP", epoch=5, learning_rate=0.01, use_cpu=True, print_print=False,
+                       need_to_reappear=True, return_model=True)
+    assert set(res) >= {"ACC", "precision_score", "recall_score", "f1_macro", "f1_micro"}
+    assert 0.0 <= res["ACC"] <= 1.0 and len(res["history"]["val_acc"]) == 5
+    out = res["model"](_toy().x)
+    assert set(out) == {"out", "emb", "x"} and torch.allclose(out["out"].exp().sum(1), torch.ones(60), atol=1e-5)
+
+
+def test_experiment_early_stopping_and_seeding_are_deterministic():
+    kw = dict(specify_data=True, data=_toy(), model_name="mlp", epoch=60, learning_rate=0.05, use_cpu=True,
+              print_print=False, need_to_reappear=True, early_stopping=2, begin_early_stopping=3,
+              return_model=True, need_all_metrics=False)
+    a = R.experiment({"num_layers": 2, "hidden_unit": 8, "dropout_rate": 0.5}, **kw)
+    b = R.experiment({"num_layers": 2, "hidden_unit": 8, "dropout_rate": 0.5}, **kw)
+    assert a["ACC"] == b["ACC"] and a["history"]["train_loss"] == b["history"]["train_loss"]
+    assert len(a["history"]["train_loss"]) < 60  # stopped early
+
+
+def test_experiment_rejects_cpu_for_graph_models_and_out_of_scope_names():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        R.experiment(R.InitialParameters.defaults_for("gcn"), specify_data=True, data=_toy(), model_name="GCN",
+                     use_cpu=True, print_print=False)
+    with pytest.raises(NotImplementedError):
+        R.experiment({}, specify_data=True, data=_toy(), model_name="DAGNN", print_print=False)
+    with pytest.raises(ValueError):
+        R.experiment({}, specify_data=True, data=_toy(), model_name="nope", print_print=False)
+
+
+def test_experiment_mask_remake_rules():
+    d = _toy()
+    m = torch.zeros(60, dtype=torch.bool)
+    d.train_mask, d.val_mask, d.test_mask = m.clone(), m.clone(), m.clone()
+    d.train_mask[:30], d.val_mask[30:45], d.test_mask[45:] = True, True, True
+    from rgb_experiment_amd.itexperiments import _masks_usable
+    assert _masks_usable(d)
+    d.val_mask = None
+    assert not _masks_usable(d)
+
+
+def test_rd2pd_roundtrip(tmp_path):
+    d = _toy()
+    folder = tmp_path / "toy"
+    folder.mkdir()
+    np.save(folder / "x.npy", d.x.numpy())
+    np.save(folder / "y.npy", d.y.numpy())
+    np.save(folder / "edge_index.npy", d.edge_index.numpy())
+    ds = R.RD2PD("toy", str(tmp_path), split_ratio="6-2-2", split_seed=7, remove_self_loop=True,
+                 remove_duplicate_edges=True)
+    want = U.get_whole_mask(d.y, "6-2-2", 7)
+    assert torch.equal(ds.data.train_mask, want[0]) and ds.num_nodes == 60
+    ei = ds.data.edge_index
+    assert (ei[0] != ei[1]).all() and torch.unique(ei[0] * 60 + ei[1]).numel() == ei.size(1)
+
+
+def test_feature_normalisation_modes():
+    from rgb_experiment_amd.itexperiments import _normalize_features
+    x = torch.tensor([[1., 3.], [2., 2.], [0., 0.]])
+    assert torch.allclose(_normalize_features(x, "row", None), torch.tensor([[.25, .75], [.5, .5], [0., 0.]]))
+    mm = _normalize_features(x, "col", "MinMaxScalar")
+    assert torch.allclose(mm, torch.tensor([[.5, 1.], [1., 2 / 3], [0., 0.]]))
+    st = _normalize_features(x, "col", "StandardScalar")
+    assert torch.allclose(st.mean(0), torch.zeros(2), atol=1e-6)
