@@ -133,12 +133,27 @@ class Graph:
 
 _CACHE = OrderedDict()
 _CACHE_MAX = 16
+_PINNED = {}
+
+
+def _key(edge_index, num_nodes, loops_mode):
+    return (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device),
+            int(num_nodes), int(loops_mode))
+
+
+def register_graph(edge_index, num_nodes, loops_mode, graph):
+    """Bind a prepared graph object (e.g. a dist.DistGraph) to an edge_index tensor; pinned entries
+    are not evicted."""
+    graph._keepalive = edge_index
+    _PINNED[_key(edge_index, num_nodes, loops_mode)] = graph
 
 
 def get_graph(edge_index, num_nodes, loops_mode):
     """Cached Graph for this edge_index tensor (identity + in-place version), N and rewrite mode."""
-    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device),
-           int(num_nodes), int(loops_mode))
+    key = _key(edge_index, num_nodes, loops_mode)
+    g = _PINNED.get(key)
+    if g is not None:
+        return g
     g = _CACHE.get(key)
     if g is None:
         g = Graph(edge_index, num_nodes, loops_mode)
@@ -153,3 +168,4 @@ def get_graph(edge_index, num_nodes, loops_mode):
 
 def clear_cache():
     _CACHE.clear()
+    _PINNED.clear()

@@ -96,15 +96,25 @@ class _PropagateSum(torch.autograd.Function):
         return spmm_raw(ctx.graph.bwd, None, None, gy.contiguous(), kind="sum_bwd"), None
 
 
+def _is_dist(graph):
+    return getattr(graph, "is_distributed", False)
+
+
 def propagate_gcn(x, graph):
+    if _is_dist(graph):
+        return graph.propagate(x, "gcn")
     return _PropagateGCN.apply(x, graph)
 
 
 def propagate_mean(x, graph):
+    if _is_dist(graph):
+        return graph.propagate(x, "mean")
     return _PropagateMean.apply(x, graph)
 
 
 def propagate_sum(x, graph):
+    if _is_dist(graph):
+        return graph.propagate(x, "sum")
     return _PropagateSum.apply(x, graph)
 
 
@@ -141,6 +151,11 @@ class _APPNP(torch.autograd.Function):
 
 
 def appnp_propagate(h, graph, K, alpha):
+    if _is_dist(graph):  # one halo exchange per iteration; autograd chains the K distributed propagates
+        z = h
+        for _ in range(K):
+            z = (1.0 - alpha) * graph.propagate(z, "gcn") + alpha * h
+        return z
     return _APPNP.apply(h, graph, K, alpha)
 
 

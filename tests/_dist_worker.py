@@ -1,0 +1,119 @@
+"""Worker processes for the world_size>1 tests (gloo, CPU). The distributed HOST logic under test is
+the product's (plan, halo exchange, DistBatchNorm, gradient all-reduce, runner); the per-rank
+aggregation arithmetic is injected from the oracle because there is no GPU here."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import ref_cpu as O  # noqa: E402
+
+
+class OracleAggregator:
+    """Same interface as rgb_experiment_amd.dist.HipAggregator, computed by oracle.propagate."""
+
+    def prepare(self, agg, gather, n_rows, w):
+        return torch.stack([gather, agg]), n_rows, w
+
+    def run(self, handle, x, y=None, kind=None):
+        ei, n_rows, w = handle
+        out = O.propagate(ei, x, n_rows, w, "add")
+        return out if y is None else y.add_(out)
+
+    def gather(self, x, idx):
+        return x[idx.long()]
+
+
+def make_problem(n=97, e=900, f=12, c=5, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    loops = torch.randint(0, n, (9,), generator=g)
+    ei = torch.cat([ei, torch.stack([loops, loops]), ei[:, :7]], dim=1)
+    x = torch.randn(n, f, generator=g)
+    y = torch.randint(0, c, (n,), generator=g)
+    perm = torch.randperm(n, generator=g)
+    masks = []
+    a, b = int(0.6 * n), int(0.8 * n)
+    for part in (perm[:a], perm[a:b], perm[b:]):
+        m = torch.zeros(n, dtype=torch.bool)
+        m[part] = True
+        masks.append(m)
+    return ei, x, y, masks
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+
+
+def propagate_worker(rank, world, port, out_dir):
+    """Forward + backward of the distributed propagate for every (loops_mode, kind)."""
+    _init(rank, world, port)
+    from rgb_experiment_amd.dist import Comm, DistGraph, partition_bounds
+    ei, x, _, _ = make_problem()
+    n = x.size(0)
+    lo, hi = partition_bounds(n, world)[rank:rank + 2]
+    go = torch.randn(n, x.size(1), generator=torch.Generator().manual_seed(5))
+    res = {}
+    for mode, kind in ((1, "gcn"), (2, "mean"), (0, "mean"), (0, "sum")):
+        dg = DistGraph(ei, n, mode, Comm(), OracleAggregator())
+        xl = x[lo:hi].clone().requires_grad_(True)
+        out = dg.propagate(xl, kind)
+        out.backward(go[lo:hi])
+        res[f"{mode}_{kind}"] = (out.detach(), xl.grad)
+    torch.save(res, os.path.join(out_dir, f"prop_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def runner_worker(rank, world, port, out_dir, model_name):
+    """Three epochs of DistRunner (train + evals) — compared by the test with single-process training."""
+    _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import Comm, DistRunner
+    ei, x, y, masks = make_problem()
+    torch.manual_seed(14530529)
+    model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
+    r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
+                   backend=OracleAggregator())
+    hist = [r.epoch() for _ in range(3)]
+    torch.save({"hist": hist, "logits_eval": r.logits(False), "lo": r.lo, "hi": r.hi,
+                "state": {k: v.clone() for k, v in r.model.state_dict().items()}},
+               os.path.join(out_dir, f"run_{model_name}_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def build_model(M, name, f, c):
+    if name == "gcn":
+        return M.GCN(num_layers=3, hidden_unit=16, input_dim=f, output_dim=c, dropout_rate=0.5)
+    if name == "graphsage":
+        return M.GraphSAGE(num_layers=2, hidden_unit=16, input_dim=f, output_dim=c, dropout_rate=0.5)
+    if name == "graphsage2":
+        return M.GraphSAGE2(num_layers=2, hidden_unit=16, input_dim=f, output_dim=c, dropout_rate=0.5)
+    if name == "appnpstack":
+        return M.APPNPStack(hidden_unit=16, input_dim=f, output_dim=c, K=4, alpha=0.1, dropout_rate=0.5)
+    raise KeyError(name)
+
+
+def gpu_runner_worker(rank, world, port, out_dir, model_name):
+    """Rehearsal of the real per-rank HIP path: `world` ranks share cuda:0, collectives go through gloo
+    with host staging (RCCL cannot put two ranks on one device)."""
+    _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import Comm, DistRunner
+    dev = torch.device("cuda:0")
+    ei, x, y, masks = make_problem(n=5000, e=60000, f=32, c=8)
+    torch.manual_seed(14530529)
+    model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
+    r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm())
+    hist = [r.epoch() for _ in range(2)]
+    torch.cuda.synchronize()
+    torch.save({"hist": hist, "logits_eval": r.logits(False).cpu(), "lo": r.lo, "hi": r.hi},
+               os.path.join(out_dir, f"gpu_{model_name}_{rank}.pt"))
+    dist.destroy_process_group()

@@ -1,0 +1,157 @@
+"""world_size 2 and 3 on CPU (gloo): the 1-D node partition, the all-to-all halo exchange, global
+BatchNorm statistics and gradient all-reduce reproduce single-process results."""
+import copy
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import _dist_worker as W
+from oracle import ref_cpu as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_plan_is_consistent_and_covers_every_edge():
+    from rgb_experiment_amd.dist import PartitionPlan, partition_bounds
+    ei, x, _, _ = W.make_problem()
+    n = x.size(0)
+    for world in (1, 2, 3, 5):
+        plans = [PartitionPlan(ei, n, world, r, 1, "gcn") for r in range(world)]
+        assert sum(p.nnz_local for p in plans) == plans[0].nnz_total
+        b = partition_bounds(n, world)
+        assert b[0] == 0 and b[-1] == n
+        for p in range(world):
+            for half in ("fwd", "bwd"):
+                hp = getattr(plans[p], half)
+                assert sum(hp.recv_counts) == hp.n_halo and hp.recv_counts[p] == 0
+                assert sum(hp.send_counts) == hp.n_send and hp.send_counts[p] == 0
+                off = 0
+                for q in range(world):
+                    hq = getattr(plans[q], half)
+                    assert hp.send_counts[q] == hq.recv_counts[p]
+                    # the rows p sends to q are exactly the rows q expects from p, in the same order
+                    q_off = sum(hq.recv_counts[:p])
+                    want = hq.halo_ids[q_off:q_off + hq.recv_counts[p]]
+                    got = hp.send_idx[off:off + hp.send_counts[q]].long() + hp.lo
+                    assert torch.equal(got, want)
+                    off += hp.send_counts[q]
+                if hp.rem_gather.numel():
+                    assert int(hp.rem_gather.max()) < hp.n_halo
+                if hp.loc_gather.numel():
+                    assert int(hp.loc_gather.max()) < hp.n_local
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_propagate_matches_single_process(world, tmp_path):
+    mp.spawn(W.propagate_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ei, x, _, _ = W.make_problem()
+    n = x.size(0)
+    go = torch.randn(n, x.size(1), generator=torch.Generator().manual_seed(5))
+    parts = [torch.load(os.path.join(tmp_path, f"prop_{r}.pt")) for r in range(world)]
+    for mode, kind in ((1, "gcn"), (2, "mean"), (0, "mean"), (0, "sum")):
+        rei, _ = O.rewrite_edges(ei, n, mode)
+        xr = x.clone().requires_grad_(True)
+        if kind == "gcn":
+            _, w = O.gcn_norm(ei, None, n)
+            want = O.propagate(rei, xr, n, w, "add")
+        else:
+            want = O.propagate(rei, xr, n, None, "add" if kind == "sum" else "mean")
+        want.backward(go)
+        out = torch.cat([p[f"{mode}_{kind}"][0] for p in parts])
+        grad = torch.cat([p[f"{mode}_{kind}"][1] for p in parts])
+        assert torch.allclose(out, want.detach(), atol=1e-5), (mode, kind)
+        assert torch.allclose(grad, xr.grad, atol=1e-5), (mode, kind)
+
+
+def _single_process_reference(model_name):
+    """The same three epochs, one process, whole graph, with the oracle's forward under autograd."""
+    from rgb_experiment_amd import models as M
+    ei, x, y, masks = W.make_problem()
+    torch.manual_seed(14530529)
+    model = W.build_model(M, model_name, x.size(1), int(y.max()) + 1)
+    params = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()
+              if "lin_dst" not in k}
+    trainable = [k for k, _ in model.named_parameters()]
+    opt = torch.optim.Adam([params[k] for k in trainable], lr=0.01)
+
+    def fwd(training):
+        if model_name == "gcn":
+            return O.gcn_forward(params, x, ei, 3, training)
+        if model_name == "graphsage":
+            return O.graphsage_forward(params, x, ei, 2, training)
+        if model_name == "graphsage2":
+            return O.graphsage2_forward(params, x, ei, 2, training)
+        return O.appnp_stack_forward(params, x, ei, 4, 0.1, training)
+
+    hist = []
+    for _ in range(3):
+        opt.zero_grad()
+        bn_inputs = {}
+        out = fwd(True)["out"]
+        loss = torch.nn.functional.nll_loss(out[masks[0]], y[masks[0]])
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            ev = fwd(False)["out"]
+            vl = torch.nn.functional.nll_loss(ev[masks[1]], y[masks[1]]).item()
+            sl = torch.nn.functional.nll_loss(ev[masks[2]], y[masks[2]]).item()
+        hist.append((loss.item(), vl, sl))
+    return hist, params
+
+
+@pytest.mark.parametrize("model_name,world", [("gcn", 2), ("gcn", 3), ("graphsage", 2), ("graphsage2", 2),
+                                               ("appnpstack", 2)])
+def test_dist_runner_training_matches_single_process(model_name, world, tmp_path):
+    """Train-mode BatchNorm uses batch statistics in the oracle and reduced statistics in the runner, so
+    train losses and trained WEIGHTS must agree; eval losses use running statistics, which the
+    oracle's functional BN does not update, so they are compared in a separate running-stat-free way:
+    every rank's trained parameters are identical and equal to the single-process ones."""
+    mp.spawn(W.runner_worker, args=(world, _free_port(), str(tmp_path), model_name), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"run_{model_name}_{r}.pt")) for r in range(world)]
+    hist, params = _single_process_reference(model_name)
+    for r in range(1, world):  # replicated parameters stay bit-identical across ranks
+        for k, v in parts[0]["state"].items():
+            assert torch.equal(v, parts[r]["state"][k]), k
+        assert parts[0]["hist"] == parts[r]["hist"]
+    for step in range(3):
+        assert abs(parts[0]["hist"][step][0] - hist[step][0]) < 2e-5, (step, parts[0]["hist"][step], hist[step])
+    # A bias added right before a BatchNorm has an exactly-zero true gradient (BN removes constant
+    # shifts); Adam turns its rounding noise into +-lr steps, so those entries are not comparable.
+    last = {"gcn": "convs.2.", "graphsage": "convs.1.", "graphsage2": "convs.1.", "appnpstack": "lin2."}[model_name]
+    for k, v in params.items():
+        pre_bn_bias = k.endswith("bias") and not k.startswith(("bns.", "bn.", last))
+        if v.is_floating_point() and "running" not in k and not pre_bn_bias:
+            assert torch.allclose(parts[0]["state"][k], v.detach(), atol=2e-5), k
+    assert parts[0]["lo"] == 0 and parts[-1]["hi"] == 97
+
+
+def test_dist_batchnorm_matches_full_batch_bn():
+    """world = 1 (no process group): DistBatchNorm1d == nn.BatchNorm1d incl. running stats and grads."""
+    from rgb_experiment_amd.dist import Comm, DistBatchNorm1d
+    torch.manual_seed(0)
+    ref = torch.nn.BatchNorm1d(6)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 2)
+        ref.bias.uniform_(-1, 1)
+    mine = DistBatchNorm1d.convert(torch.nn.Sequential(copy.deepcopy(ref)), Comm())[0]
+    assert isinstance(mine, DistBatchNorm1d) and list(mine.state_dict()) == list(ref.state_dict())
+    x = torch.randn(40, 6) * 3 + 1
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = ref(xa), mine(xb)
+    go = torch.randn(40, 6)
+    ya.backward(go)
+    yb.backward(go)
+    assert torch.allclose(ya, yb, atol=1e-5) and torch.allclose(xa.grad, xb.grad, atol=1e-5)
+    assert torch.allclose(ref.weight.grad, mine.weight.grad, atol=1e-5)
+    assert torch.allclose(ref.bias.grad, mine.bias.grad, atol=1e-5)
+    assert torch.allclose(ref.running_mean, mine.running_mean, atol=1e-6)
+    assert torch.allclose(ref.running_var, mine.running_var, atol=1e-5)
+    ref.eval(), mine.eval()
+    assert torch.allclose(ref(x), mine(x), atol=1e-6)
