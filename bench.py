@@ -102,11 +102,18 @@ def main():
     if args.gpus > 1 and world == 1:
         sys.exit("bench.py: --gpus N > 1 must be launched with `python -m torch.distributed.run "
                  "--nproc-per-node N ...` (one rank per GPU)")
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        # RGBX_DIST_BACKEND=gloo rehearses the N>1 code path with several ranks on ONE GPU (host-staged
+        # collectives); the real runs use RCCL ("nccl").
+        backend = os.environ.get("RGBX_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from rgb_experiment_amd import ops
     from rgb_experiment_amd.models import GCN
@@ -121,10 +128,16 @@ def main():
 
     if world > 1:
         from rgb_experiment_amd.dist import DistGCNRunner
+        from rgb_experiment_amd.graph import LOOPS_ADD_REMAINING
         runner = DistGCNRunner(model, ei, x, y, (train_mask, val_mask, test_mask), rank, world, dev, lr=0.01)
-        nnz_total = runner.nnz_total
+        plan = runner.plan(LOOPS_ADD_REMAINING, "gcn")  # partition + per-rank CSRs built here, once
+        nnz_total = plan.nnz_total
         step = runner.epoch
-        spmm_rows, spmm_nnz = runner.local_rows, runner.local_nnz
+        n_loc = plan.n_local
+        nnz_loc, nnz_rem = int(plan.fwd.loc_agg.numel()), int(plan.fwd.rem_agg.numel())
+        # one propagate on a rank = local-source SpMM + remote-source SpMM accumulating into the same rows
+        alg = spmm_alg_bytes(n_loc, nnz_loc, d) + spmm_alg_bytes(n_loc, nnz_rem, d) + n_loc * 4 * d
+        halo_mb = plan.fwd.n_halo * d * 4 / 1e6
     else:
         from rgb_experiment_amd.graph import get_graph, LOOPS_ADD_REMAINING
         model.to(dev)
@@ -134,7 +147,8 @@ def main():
         graph = get_graph(ei_d, N, LOOPS_ADD_REMAINING)
         _ = graph.w, graph.w_t  # graph preparation happens once per edge_index, outside the loop
         nnz_total = graph.fwd.nnz
-        spmm_rows, spmm_nnz = N, nnz_total
+        alg = spmm_alg_bytes(N, nnz_total, d)
+        halo_mb = 0.0
         nll = torch.nn.functional.nll_loss
 
         def evaluate(mask):
@@ -175,10 +189,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    spmm_ms = [s.elapsed_time(e) for kind, s, e in events if kind in ("gcn_fwd", "gcn_bwd")]
-    spmm_avg_s = (sum(spmm_ms) / len(spmm_ms)) * 1e-3 if spmm_ms else float("nan")
     n_prop = 8  # 6 forward + 2 transposed propagates per epoch (2-layer GCN)
-    alg = spmm_alg_bytes(spmm_rows, spmm_nnz, d)
+    kinds = ("gcn_fwd", "gcn_bwd") if world == 1 else ("dist_fwd_local", "dist_fwd_remote", "dist_bwd_local",
+                                                       "dist_bwd_remote")
+    spmm_total_ms = sum(s.elapsed_time(e) for kind, s, e in events if kind in kinds)
+    spmm_avg_s = spmm_total_ms * 1e-3 / (n_prop * args.steps)  # kernel time per propagate (on this rank)
     achieved = alg / spmm_avg_s / 1e9
 
     result = {
@@ -198,14 +213,14 @@ def main():
                    "width": d, "propagates_per_step": n_prop,
                    "parallelism": "single GPU" if world == 1 else f"1-D node partition x{world}, RCCL all-to-all halo"},
         "epochs_per_s": args.steps / elapsed,
-        "spmm_edges_per_s": spmm_nnz * world / spmm_avg_s if world == 1 else None,
+        "spmm_edges_per_s": nnz_total / spmm_avg_s if world == 1 else None,
         "spmm_ms": spmm_avg_s * 1e3,
-        "spmm_launches_timed": len(spmm_ms),
+        "halo_mb_per_rank_per_propagate": halo_mb,
         "final_losses": {"train": last[0], "val": last[1], "test": last[3]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "spmm_csr_kernel<32,4,true>", "algorithmic_bytes_per_launch": alg,
-                     "note": "per rank" if world > 1 else "whole graph"},
+                     "note": "rank 0's share (local + remote SpMM)" if world > 1 else "whole graph"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ei, x, N)

@@ -114,6 +114,6 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name):
     r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm())
     hist = [r.epoch() for _ in range(2)]
     torch.cuda.synchronize()
-    torch.save({"hist": hist, "logits_eval": r.logits(False).cpu(), "lo": r.lo, "hi": r.hi},
+    torch.save({"hist": hist, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi},
                os.path.join(out_dir, f"gpu_{model_name}_{rank}.pt"))
     dist.destroy_process_group()
