@@ -18,7 +18,11 @@
  *   rgbx_appnp_f32        APPNP.forward's K-step recurrence (models/appnp_stack.py:29),
  *                         restated in-repo by models/pta.py:79-84.
  *   rgbx_gat_*            GATConv.forward/message + segment softmax (models/gat.py:28,30) [PyG].
- *   rgbx_gather_rows_f32 / rgbx_scatter_rows_f32
+ *   rgbx_gemm_tn_f32      dW = dY^T X of the nn.Linear / conv.lin layers under loss.backward()
+ *                         (itexperiments.py:439; layers at models/gcn.py:18-21, appnp_stack.py:19-20).
+ *   rgbx_masked_nll_*     nn.NLLLoss on out[mask] and the arg-max accuracy (itexperiments.py:400,
+ *                         429,434,624-626,643).
+ *   rgbx_gather_rows_f32 / rgbx_scatter_add_rows_f32
  *                         halo pack / unpack for the 1-D node partition (new capability; the
  *                         reference is single-device, itexperiments.py:246).
  *
@@ -99,13 +103,15 @@ int rgbx_inv_degree_f32(const int32_t* rowptr, int64_t N, float* inv, rgbx_strea
 
 /* ---- aggregation ------------------------------------------------------------------------- */
 
-/* out[i,:] = a * rs[i] * sum_{p in row i} w[p] * x[col[p],:]  +  b * y[i,:]
+/* out[i,:] = a * rs[i] * sum_{p in row i} w[p] * x[col[p],:]  +  b * y[i,:]  +  bias[:]
  *   w  == NULL -> every weight is 1;  rs == NULL -> every row scale is 1;
- *   y  == NULL -> no additive term (b ignored).  `out` may alias `y` but not `x`.
+ *   y  == NULL -> no additive term (b ignored);  bias == NULL -> no per-column term (the conv
+ *   layer's `out += bias`, fused into the store).  `out` may alias `y` but not `x`.
  * N rows, d columns; x has n_src rows (col[] < n_src is the caller's contract). */
 int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
-                      const float* x, int64_t ldx, const float* y, int64_t ldy, float* out,
-                      int64_t ldo, int64_t N, int64_t d, float a, float b, rgbx_stream_t stream);
+                      const float* x, int64_t ldx, const float* y, int64_t ldy, const float* bias,
+                      float* out, int64_t ldo, int64_t N, int64_t d, float a, float b,
+                      rgbx_stream_t stream);
 
 /* z_0 = h;  z_{k+1} = (1-alpha) * A_hat z_k + alpha * h, k = 0..K-1; result in `out`.
  * `tmp` is an [N, d] scratch (ld = ldo); h, out, tmp must not alias. K >= 0. */
@@ -150,6 +156,33 @@ int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const fl
                          const float* rden, const float* dsum, const float* gout, int64_t ldg,
                          float* g_hfeat, int64_t ldgh, float* g_a_src, int64_t N, int H, int C,
                          float slope, rgbx_stream_t stream);
+
+/* ---- dense weight gradient on the MFMA units ---------------------------------------------- */
+
+/* Scratch bytes for rgbx_gemm_tn_f32 (split-K partial tiles). */
+int rgbx_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N, size_t* bytes);
+
+/* C[M,N] = alpha * A^T B, A [K,M] (lda), B [K,N] (ldb), fp32 row-major, K = node count (huge),
+ * M,N = feature widths. Split-K over the whole chip on v_mfma_f32_32x32x2_f32 (exact fp32), partials
+ * reduced in slab order (bitwise reproducible). This is dW = dY^T X of every Linear on the path. */
+int rgbx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                     int64_t K, int64_t M, int64_t N, float alpha, void* workspace,
+                     size_t workspace_bytes, rgbx_stream_t stream);
+
+/* ---- loss / metrics on masked rows ---------------------------------------------------------- */
+
+/* stats[0] = sum over selected rows of -logp[i, y[i]]; stats[1] = number of selected rows;
+ * stats[2] = number of selected rows whose first arg-max equals y[i] (only if want_accuracy).
+ * A row is selected when mask == NULL or mask[i] != 0, and 0 <= y[i] < C. `stats` (3 doubles, device)
+ * is zeroed by the call. logp is [N, C] (ld). */
+int rgbx_masked_nll_fwd_f32(const float* logp, int64_t ld, const int64_t* y, const uint8_t* mask,
+                            int64_t N, int64_t C, double* stats, int want_accuracy,
+                            rgbx_stream_t stream);
+
+/* grad[i,c] = -scale[0] if row i is selected and c == y[i], else 0, for every (i, c): the gradient
+ * of scale * stats[0] w.r.t. logp. `scale` is a device scalar (no host sync). */
+int rgbx_masked_nll_bwd_f32(const int64_t* y, const uint8_t* mask, int64_t N, int64_t C,
+                            const float* scale, float* grad, int64_t ldg, rgbx_stream_t stream);
 
 /* ---- halo pack / unpack (multi-GPU node partition) ----------------------------------------- */
 

@@ -1,0 +1,179 @@
+// Tall-skinny fp32 GEMM on the MFMA units: C[M,N] = A^T B with A [K,M], B [K,N] row-major and
+// K (= number of nodes) in the millions, M, N (= feature widths) in the hundreds. This is the weight
+// gradient dW = dY^T X of every dense layer on the path (reference: the nn.Linear / GCNConv.lin /
+// GATConv.lin_src inside models/gcn.py:18-21, graphsage.py:46-47, gat.py:18-21, appnp_stack.py:19-20,
+// differentiated by loss.backward(), itexperiments.py:439). A generic GEMM library tiles M x N only,
+// which leaves 16 workgroups for a 128 x 128 output; here K is split across the whole chip.
+//
+// Kernel 1: grid (S, ceil(M/128), ceil(N/128)); a workgroup (4 waves) owns one 128x128 output tile over
+// one K-slab, stages [32 x 128] tiles of A and B through LDS with 16-byte loads, and every wave
+// accumulates a 64x64 quadrant with v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain). Both operands are
+// read along their contiguous dimension: lane l of a fragment holds row k0 + (l >> 5), column
+// c0 + (l & 31) — no transposes anywhere. Partial tiles go to a workspace with plain stores.
+// Kernel 2: sums the S partials in slab order (bitwise reproducible, no float atomics).
+#include "rgbx_common.h"
+
+namespace rgbx {
+namespace {
+
+constexpr int BM = 128, BN = 128, KT = 32;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <bool VEC4>
+__device__ __forceinline__ void stage_tile(float* __restrict__ lds, const float* __restrict__ src,
+                                           int64_t ld, int64_t k0, int64_t k_end, int c0, int ncols) {
+  // [KT x 128] tile, row-major in LDS; rows >= k_end and columns >= ncols are zero-filled
+  const int tid = threadIdx.x;
+  if constexpr (VEC4) {
+#pragma unroll
+    for (int p = 0; p < KT * 32 / 256; ++p) {
+      const int idx = p * 256 + tid;  // float4 index
+      const int r = idx >> 5, c = (idx & 31) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int64_t k = k0 + r;
+      if (k < k_end && c0 + c < ncols) {  // ncols % 4 == 0 on this path
+        v = *reinterpret_cast<const float4*>(src + k * ld + c0 + c);
+      }
+      *reinterpret_cast<float4*>(lds + r * 128 + c) = v;
+    }
+  } else {
+#pragma unroll 4
+    for (int p = 0; p < KT * 128 / 256; ++p) {
+      const int idx = p * 256 + tid;
+      const int r = idx >> 7, c = idx & 127;
+      const int64_t k = k0 + r;
+      lds[r * 128 + c] = (k < k_end && c0 + c < ncols) ? src[k * ld + c0 + c] : 0.f;
+    }
+  }
+}
+
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+gemm_tn_partial_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                       float* __restrict__ part, int64_t K, int M, int N, int64_t slab) {
+  __shared__ float lds[2 * KT * 128];
+  float* la = lds;
+  float* lb = lds + KT * 128;
+  const int split = blockIdx.x;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.z * BN;
+  const int64_t k_begin = (int64_t)split * slab;
+  const int64_t k_end = k_begin + slab < K ? k_begin + slab : K;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int kr = lane >> 5, cc = lane & 31;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += KT) {
+    __syncthreads();
+    stage_tile<VEC4>(la, A, lda, k0, k_end, m0, M);
+    stage_tile<VEC4>(lb, B, ldb, k0, k_end, n0, N);
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < KT; kk += 2) {
+      const float a0 = la[(kk + kr) * 128 + wm + cc];
+      const float a1 = la[(kk + kr) * 128 + wm + 32 + cc];
+      const float b0 = lb[(kk + kr) * 128 + wn + cc];
+      const float b1 = lb[(kk + kr) * 128 + wn + 32 + cc];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  float* out = part + (int64_t)split * M * N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kr;
+        const int n = n0 + wn + j * 32 + cc;
+        if (m < M && n < N) out[(int64_t)m * N + n] = acc[i][j][r];
+      }
+}
+
+// 32 consecutive output elements per block; 8 split-lanes per element stride the S partials, then the
+// 8 sub-sums are added in lane order: the summation order is fixed, so results are reproducible.
+__global__ void __launch_bounds__(256)
+gemm_tn_reduce_kernel(const float* __restrict__ part, int S, int64_t MN, float* __restrict__ C, int N,
+                      int64_t ldc, float alpha) {
+  __shared__ float sh[8][32];
+  const int j = threadIdx.x & 31, q = threadIdx.x >> 5;
+  for (int64_t base = (int64_t)blockIdx.x * 32; base < MN; base += (int64_t)gridDim.x * 32) {
+    const int64_t i = base + j;
+    float s = 0.f;
+    if (i < MN)
+      for (int p = q; p < S; p += 8) s += part[(int64_t)p * MN + i];
+    __syncthreads();
+    sh[q][j] = s;
+    __syncthreads();
+    if (q == 0 && i < MN) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += sh[k][j];
+      C[(i / N) * ldc + (i % N)] = alpha * t;
+    }
+  }
+}
+
+int choose_splits(int64_t K, int M, int N) {
+  const int64_t tiles = cdiv(M, BM) * cdiv(N, BN);
+  int64_t s = cdiv(1024, tiles);            // ~4 workgroups per CU over the whole grid
+  const int64_t max_s = cdiv(K, 4 * KT);    // keep at least 4 staged tiles per slab
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+}  // namespace
+}  // namespace rgbx
+
+using namespace rgbx;
+
+extern "C" int rgbx_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N, size_t* bytes) {
+  if (!bytes || K < 0 || M < 0 || N < 0) return fail(RGBX_E_ARG, "gemm_tn_workspace_bytes: bad argument");
+  if (M >= INT32_MAX || N >= INT32_MAX) return fail(RGBX_E_RANGE, "gemm_tn: M or N exceeds int32");
+  *bytes = (size_t)choose_splits(K, (int)M, (int)N) * (size_t)M * (size_t)N * sizeof(float);
+  return RGBX_OK;
+}
+
+extern "C" int rgbx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                                int64_t ldc, int64_t K, int64_t M, int64_t N, float alpha, void* workspace,
+                                size_t workspace_bytes, rgbx_stream_t stream) {
+  if (K < 0 || M < 0 || N < 0) return fail(RGBX_E_ARG, "gemm_tn: negative size");
+  if (M == 0 || N == 0) return RGBX_OK;
+  if (!C || (K > 0 && (!A || !B))) return fail(RGBX_E_ARG, "gemm_tn: null pointer");
+  if (M >= INT32_MAX || N >= INT32_MAX) return fail(RGBX_E_RANGE, "gemm_tn: M or N exceeds int32");
+  if (lda < M || ldb < N || ldc < N) return fail(RGBX_E_ARG, "gemm_tn: leading dimension too small");
+  size_t need = 0;
+  if (int rc = rgbx_gemm_tn_workspace_bytes(K, M, N, &need)) return rc;
+  if (!workspace || workspace_bytes < need)
+    return fail(RGBX_E_WS, "gemm_tn: workspace %zu < %zu bytes", workspace_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  const int S = choose_splits(K, (int)M, (int)N);
+  const int64_t slab = cdiv(cdiv(K > 0 ? K : 1, S), KT) * KT;
+  float* part = static_cast<float*>(workspace);
+  dim3 grid(S, (unsigned)cdiv(M, BM), (unsigned)cdiv(N, BN));
+  const bool v4 = aligned16(A) && aligned16(B) && lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0;
+  if (v4)
+    gemm_tn_partial_kernel<true><<<grid, 256, 0, s>>>(A, lda, B, ldb, part, K, (int)M, (int)N, slab);
+  else
+    gemm_tn_partial_kernel<false><<<grid, 256, 0, s>>>(A, lda, B, ldb, part, K, (int)M, (int)N, slab);
+  RGBX_CHECK_LAUNCH("gemm_tn_partial_kernel");
+  const int64_t MN = M * N;
+  int64_t rb = cdiv(MN, 32);
+  if (rb > kMaxGrid) rb = kMaxGrid;
+  gemm_tn_reduce_kernel<<<(int)rb, 256, 0, s>>>(part, S, MN, C, (int)N, ldc, alpha);
+  RGBX_CHECK_LAUNCH("gemm_tn_reduce_kernel");
+  return RGBX_OK;
+}

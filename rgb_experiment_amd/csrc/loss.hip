@@ -1,0 +1,150 @@
+// Masked NLL over log-probabilities + accuracy, forward and backward: the reference's
+// `criterion(out[mask], y[mask])` with nn.NLLLoss() and `out[mask].max(dim=1)[1].eq(y[mask])`
+// (itexperiments.py:400,429,434,467,472,624-626,643) without materialising out[mask]: one pass over
+// the mask, one gathered element (or one row, for the arg-max) per selected node.
+#include "rgbx_common.h"
+
+namespace rgbx {
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+  return t;
+}
+
+// stats[0] += sum of -logp[i, y_i], stats[1] += number of selected rows (mask set, label in range)
+__global__ void __launch_bounds__(256)
+nll_sum_kernel(const float* __restrict__ logp, int64_t ld, const int64_t* __restrict__ y,
+               const uint8_t* __restrict__ mask, int64_t N, int C, double* __restrict__ stats) {
+  __shared__ double sh[4];
+  double loss = 0.0, cnt = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (mask && !mask[i]) continue;
+    const int64_t t = y[i];
+    if (t < 0 || t >= C) continue;
+    loss -= (double)logp[i * ld + t];
+    cnt += 1.0;
+  }
+  loss = block_sum(loss, sh);
+  cnt = block_sum(cnt, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[0], loss);
+    atomicAdd(&stats[1], cnt);
+  }
+}
+
+// One wave per selected row: additionally stats[2] += (first arg-max of the row == y_i)
+__global__ void __launch_bounds__(256)
+nll_acc_kernel(const float* __restrict__ logp, int64_t ld, const int64_t* __restrict__ y,
+               const uint8_t* __restrict__ mask, int64_t N, int C, double* __restrict__ stats) {
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  double loss = 0.0, cnt = 0.0, hit = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); i < N; i += (int64_t)gridDim.x * wpb) {
+    if (mask && !mask[i]) continue;  // wave-uniform
+    const int64_t t = y[i];
+    if (t < 0 || t >= C) continue;
+    const float* row = logp + i * ld;
+    float best = -INFINITY;
+    int arg = INT32_MAX;
+    for (int c = lane; c < C; c += 64) {
+      const float v = row[c];
+      if (v > best) { best = v; arg = c; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(best, off);
+      const int oa = __shfl_xor(arg, off);
+      if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    if (lane == 0) {
+      loss -= (double)row[t];
+      cnt += 1.0;
+      hit += arg == (int)t ? 1.0 : 0.0;
+    }
+  }
+  loss = block_sum(loss, sh);
+  cnt = block_sum(cnt, sh);
+  hit = block_sum(hit, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[0], loss);
+    atomicAdd(&stats[1], cnt);
+    atomicAdd(&stats[2], hit);
+  }
+}
+
+// grad[i, :] = 0 except grad[i, y_i] = -scale for selected rows; scale read from device memory
+template <int VEC>
+__global__ void __launch_bounds__(256)
+nll_bwd_kernel(const int64_t* __restrict__ y, const uint8_t* __restrict__ mask, int64_t N, int C,
+               const float* __restrict__ scale, float* __restrict__ grad, int64_t ldg) {
+  const float s = -scale[0];
+  const int per_row = (C + VEC - 1) / VEC;
+  const int64_t total = N * per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / per_row;
+    const int c = (int)(idx % per_row) * VEC;
+    int64_t t = -1;
+    if (!mask || mask[i]) t = y[i];
+    float v[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = (c + k == t) ? s : 0.f;
+    if constexpr (VEC == 1) {
+      grad[i * ldg + c] = v[0];
+    } else {
+      store_vec<VEC>(grad + i * ldg + c, v);
+    }
+  }
+}
+
+}  // namespace
+}  // namespace rgbx
+
+using namespace rgbx;
+
+extern "C" int rgbx_masked_nll_fwd_f32(const float* logp, int64_t ld, const int64_t* y, const uint8_t* mask,
+                                       int64_t N, int64_t C, double* stats, int want_accuracy,
+                                       rgbx_stream_t stream) {
+  if (N < 0 || C <= 0 || !stats) return fail(RGBX_E_ARG, "masked_nll_fwd: bad argument");
+  if (C >= INT32_MAX) return fail(RGBX_E_RANGE, "masked_nll_fwd: C exceeds int32");
+  hipStream_t s = (hipStream_t)stream;
+  RGBX_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(double), s));
+  if (N == 0) return RGBX_OK;
+  if (!logp || !y || ld < C) return fail(RGBX_E_ARG, "masked_nll_fwd: null pointer or ld < C");
+  if (want_accuracy) {
+    int64_t b = cdiv(N, 4);
+    nll_acc_kernel<<<(int)(b < kMaxGrid ? b : kMaxGrid), 256, 0, s>>>(logp, ld, y, mask, N, (int)C, stats);
+  } else {
+    int64_t b = cdiv(N, 256);
+    nll_sum_kernel<<<(int)(b < 2048 ? b : 2048), 256, 0, s>>>(logp, ld, y, mask, N, (int)C, stats);
+  }
+  RGBX_CHECK_LAUNCH("masked_nll_fwd");
+  return RGBX_OK;
+}
+
+extern "C" int rgbx_masked_nll_bwd_f32(const int64_t* y, const uint8_t* mask, int64_t N, int64_t C,
+                                       const float* scale, float* grad, int64_t ldg, rgbx_stream_t stream) {
+  if (N < 0 || C <= 0) return fail(RGBX_E_ARG, "masked_nll_bwd: bad size");
+  if (N == 0) return RGBX_OK;
+  if (!y || !scale || !grad || ldg < C) return fail(RGBX_E_ARG, "masked_nll_bwd: null pointer or ld < C");
+  if (C >= INT32_MAX) return fail(RGBX_E_RANGE, "masked_nll_bwd: C exceeds int32");
+  hipStream_t s = (hipStream_t)stream;
+  const bool v4 = C % 4 == 0 && ldg % 4 == 0 && aligned16(grad);
+  const int64_t total = N * (v4 ? C / 4 : C);
+  int64_t b = cdiv(total, 256);
+  const int grid = (int)(b < kMaxGrid ? b : kMaxGrid);
+  if (v4)
+    nll_bwd_kernel<4><<<grid, 256, 0, s>>>(y, mask, N, (int)C, scale, grad, ldg);
+  else
+    nll_bwd_kernel<1><<<grid, 256, 0, s>>>(y, mask, N, (int)C, scale, grad, ldg);
+  RGBX_CHECK_LAUNCH("nll_bwd_kernel");
+  return RGBX_OK;
+}

@@ -1,4 +1,4 @@
-// CSR row-gather SpMM for gfx950: out[i,:] = a*rs[i]*sum_p w[p]*x[col[p],:] + b*y[i,:].
+// CSR row-gather SpMM for gfx950: out[i,:] = a*rs[i]*sum_p w[p]*x[col[p],:] + b*y[i,:] + bias[:].
 // Replaces MessagePassing.propagate(aggr='add'|'mean', message = norm * x_j): reference
 // models/dagnn.py:34-36,46,57-59 (in-repo twin of what GCNConv / APPNP run, models/gcn.py:27,
 // models/appnp_stack.py:29) and models/graphsage.py:58 (mean). No [E', d] temporary exists:
@@ -22,6 +22,7 @@ struct SpmmArgs {
   const float* rs;
   const float* x;
   const float* y;
+  const float* bias;
   float* out;
   int64_t ldx, ldy, ldo;
   int N, d;
@@ -101,6 +102,12 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const SpmmArgs A) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) r[i] = fmaf(A.b, yv[i], r[i]);
         }
+        if (A.bias) {
+          float bv[VEC];
+          load_vec<VEC>(bv, A.bias + c);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) r[i] += bv[i];
+        }
         store_vec<VEC>(A.out + (int64_t)row * A.ldo + c, r);
       }
     }
@@ -140,7 +147,7 @@ int spmm_dispatch(const SpmmArgs& A, hipStream_t s) {
     auto okp = [&](const void* p, int64_t ld) {
       return !p || (((reinterpret_cast<uintptr_t>(p) & mask) == 0) && (ld % v == 0));
     };
-    return A.d % v == 0 && okp(A.x, A.ldx) && okp(A.y, A.ldy) && okp(A.out, A.ldo);
+    return A.d % v == 0 && okp(A.x, A.ldx) && okp(A.y, A.ldy) && okp(A.out, A.ldo) && okp(A.bias, v);
   };
   if (vec_ok(4)) return dispatch_groups<4>(A, s);
   if (vec_ok(2)) return dispatch_groups<2>(A, s);
@@ -153,15 +160,15 @@ using namespace rgbx;
 
 extern "C" int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w,
                                  const float* rs, const float* x, int64_t ldx, const float* y,
-                                 int64_t ldy, float* out, int64_t ldo, int64_t N, int64_t d, float a,
-                                 float b, rgbx_stream_t stream) {
+                                 int64_t ldy, const float* bias, float* out, int64_t ldo, int64_t N,
+                                 int64_t d, float a, float b, rgbx_stream_t stream) {
   if (N < 0 || d < 0) return fail(RGBX_E_ARG, "spmm: negative size");
   if (N == 0 || d == 0) return RGBX_OK;
   if (!rowptr || !col || !x || !out) return fail(RGBX_E_ARG, "spmm: null pointer");
   if (N >= INT32_MAX || d >= INT32_MAX) return fail(RGBX_E_RANGE, "spmm: N or d exceeds int32");
   if (ldx < d || ldo < d || (y && ldy < d)) return fail(RGBX_E_ARG, "spmm: leading dimension < d");
   if (out == x) return fail(RGBX_E_ARG, "spmm: out must not alias x");
-  SpmmArgs A{rowptr, col, w, rs, x, y, out, ldx, ldy, ldo, (int)N, (int)d, a, b};
+  SpmmArgs A{rowptr, col, w, rs, x, y, bias, out, ldx, ldy, ldo, (int)N, (int)d, a, b};
   return spmm_dispatch(A, (hipStream_t)stream);
 }
 
@@ -186,7 +193,7 @@ extern "C" int rgbx_appnp_f32(const int32_t* rowptr, const int32_t* col, const f
   int64_t lds = ldh;
   for (int k = 0; k < K; ++k) {
     float* dst = ((K - 1 - k) % 2 == 0) ? out : tmp;
-    SpmmArgs A{rowptr, col, w, nullptr, src, h, dst, lds, ldh, ldo, (int)N, (int)d, 1.0f - alpha, alpha};
+    SpmmArgs A{rowptr, col, w, nullptr, src, h, nullptr, dst, lds, ldh, ldo, (int)N, (int)d, 1.0f - alpha, alpha};
     if (int rc = spmm_dispatch(A, s)) return rc;
     src = dst;
     lds = ldo;

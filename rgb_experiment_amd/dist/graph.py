@@ -4,7 +4,7 @@ import torch
 
 from .. import graph as _graph
 from .comm import Comm
-from .plan import PartitionPlan
+from .plan import PartitionPlan, edge_weights, partition_bounds, rewrite_global
 
 
 class HipAggregator:
@@ -42,16 +42,31 @@ class _DistPropagate(torch.autograd.Function):
 
 class DistGraph:
     """What `get_graph` returns on a rank of a partitioned run. `edge_index` is the GLOBAL int64 edge
-    list (every rank holds it at set-up; only index arithmetic touches it), `num_nodes` the global N."""
+    list (every rank holds it at set-up; only index arithmetic touches it), `num_nodes` the global N.
+
+    Two exchange schemes, chosen per (kind, width) by the bytes a rank must receive per propagate:
+      * "halo"    — ship the boundary rows a rank's edges gather from (n_halo * d * 4 B), overlap with
+                    the local-edge SpMM. Wins when the partition has a small boundary.
+      * "reshard" — all-to-all transpose the row-sharded [n_local, d] activations into column shards
+                    [N, d/P], run the WHOLE graph's SpMM on d/P columns with no halo, transpose back
+                    (2 * n_local * d * 4 * (P-1)/P B). Wins on expander-like graphs (the benchmark's
+                    uniform random graph: every remote row is a boundary row).
+    """
 
     is_distributed = True
 
-    def __init__(self, edge_index, num_nodes, loops_mode, comm=None, backend=None):
+    def __init__(self, edge_index, num_nodes, loops_mode, comm=None, backend=None, exchange="auto"):
         self.edge_index, self.N_global, self.loops_mode = edge_index, int(num_nodes), loops_mode
         self.comm = comm or Comm()
         self.backend = backend or HipAggregator()
-        self._kinds = {}
+        self.exchange = exchange
+        self._kinds, self._full, self._choice = {}, {}, {}
+        b = partition_bounds(self.N_global, self.comm.world)
+        self.bounds = b
+        self.n_local = b[self.comm.rank + 1] - b[self.comm.rank]
+        self.row_counts = [b[q + 1] - b[q] for q in range(self.comm.world)]
 
+    # ---- halo scheme ---------------------------------------------------------------------------
     def _get(self, kind):
         st = self._kinds.get(kind)
         if st is None:
@@ -71,7 +86,7 @@ class DistGraph:
     def plan(self, kind):
         return self._get(kind)["plan"]
 
-    def _run(self, kind, direction, x):
+    def _run_halo(self, kind, direction, x):
         d = self._get(kind)[direction]
         half = d["half"]
         work = recv = None
@@ -85,16 +100,73 @@ class DistGraph:
                 out = self.backend.run(d["rem"], recv, y=out, kind=f"dist_{direction}_remote")
         return out
 
+    # ---- reshard scheme ------------------------------------------------------------------------
+    def _get_full(self, kind):
+        st = self._full.get(kind)
+        if st is None:
+            src, dst = rewrite_global(self.edge_index, self.N_global, self.loops_mode)
+            w = edge_weights(src, dst, self.N_global, kind)
+            st = {"nnz": int(src.numel()),
+                  "fwd": self.backend.prepare(dst, src, self.N_global, w),
+                  "bwd": self.backend.prepare(src, dst, self.N_global, w)}
+            self._full[kind] = st
+        return st
+
+    def _run_reshard(self, kind, direction, x):
+        P, n_loc, d = self.comm.world, self.n_local, x.size(1)
+        dc = d // P
+        # rows -> columns: peer q receives my rows restricted to its column slice
+        send = x.view(n_loc, P, dc).permute(1, 0, 2).reshape(P * n_loc, dc)
+        cols, work = self.comm.all_to_all_rows(send, [n_loc] * P, self.row_counts)
+        work.wait()
+        y = self.backend.run(self._get_full(kind)[direction], cols, kind=f"dist_{direction}_colshard")
+        # columns -> rows
+        back, work = self.comm.all_to_all_rows(y, self.row_counts, [n_loc] * P)
+        work.wait()
+        return back.view(P, n_loc, dc).permute(1, 0, 2).reshape(n_loc, d)
+
+    # ---- choice --------------------------------------------------------------------------------
+    def halo_rows(self):
+        """Rows this rank would receive per forward propagate under the halo scheme."""
+        if "halo_rows" not in self._choice:
+            src, dst = rewrite_global(self.edge_index, self.N_global, self.loops_mode)
+            lo, hi = self.bounds[self.comm.rank], self.bounds[self.comm.rank + 1]
+            remote = (dst >= lo) & (dst < hi) & ((src < lo) | (src >= hi))
+            self._choice["halo_rows"] = int(torch.unique(src[remote]).numel())
+        return self._choice["halo_rows"]
+
+    def scheme(self, d):
+        """'halo' or 'reshard' for feature width d (all ranks reach the same answer). Reshard needs
+        d divisible by the world size."""
+        P = self.comm.world
+        if P == 1 or d % P != 0 or self.exchange == "halo":
+            return "halo"
+        if self.exchange == "reshard":
+            return "reshard"
+        key = ("scheme", d)
+        if key not in self._choice:
+            halo_bytes = torch.tensor([float(self.halo_rows()) * d * 4], dtype=torch.float64,
+                                      device=self.edge_index.device)
+            halo_bytes = self.comm.all_reduce_sum_(halo_bytes).item() / P  # mean over ranks
+            reshard_bytes = 2.0 * (self.N_global / P) * d * 4 * (P - 1) / P
+            self._choice[key] = "reshard" if reshard_bytes < halo_bytes else "halo"
+        return self._choice[key]
+
+    def _run(self, kind, direction, x):
+        if self.comm.world > 1 and self.scheme(x.size(1)) == "reshard":
+            return self._run_reshard(kind, direction, x.contiguous())
+        return self._run_halo(kind, direction, x)
+
     def propagate(self, x, kind):
         return _DistPropagate.apply(x, self, kind)
 
 
-def install(token_edge_index, n_local, edge_index, num_nodes, comm=None, backend=None):
+def install(token_edge_index, n_local, edge_index, num_nodes, comm=None, backend=None, exchange="auto"):
     """Register DistGraphs so that conv layers called with (x_local, token_edge_index) aggregate over
     the partitioned global graph. Returns {loops_mode: DistGraph}."""
     graphs = {}
     for mode in (_graph.LOOPS_KEEP, _graph.LOOPS_ADD_REMAINING, _graph.LOOPS_REMOVE_ADD):
-        g = DistGraph(edge_index, num_nodes, mode, comm, backend)
+        g = DistGraph(edge_index, num_nodes, mode, comm, backend, exchange)
         _graph.register_graph(token_edge_index, n_local, mode, g)
         graphs[mode] = g
     return graphs

@@ -16,7 +16,7 @@ class DistRunner:
     rank keeps its node slice of x / y / masks and the whole edge list for index arithmetic."""
 
     def __init__(self, model, edge_index, x, y, masks, rank, world, device, lr=0.01, weight_decay=0.0,
-                 comm=None, backend=None):
+                 comm=None, backend=None, exchange="auto"):
         self.comm = comm or Comm()
         self.rank, self.world, self.device = rank, world, device
         N = x.size(0)
@@ -28,7 +28,7 @@ class DistRunner:
         self.edge_index = edge_index.to(device)
         # the conv layers see (x_local, token): the token's cache entries are the DistGraphs
         self.token = torch.zeros((2, 1), dtype=torch.int64, device=device)
-        self.graphs = install(self.token, hi - lo, self.edge_index, N, self.comm, backend)
+        self.graphs = install(self.token, hi - lo, self.edge_index, N, self.comm, backend, exchange)
         self.model = DistBatchNorm1d.convert(model.to(device), self.comm)
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
         cnt = torch.tensor([float(m.sum()) for m in self.masks], dtype=torch.float64, device=device)
@@ -47,12 +47,18 @@ class DistRunner:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
 
+    def _nll_sum(self, out, m):
+        if out.is_cuda:
+            from .. import ops
+            return ops.masked_nll_loss(out, self.y, m, reduction="sum")
+        return F.nll_loss(out[m], self.y[m], reduction="sum")
+
     def train_step(self):
         self.model.train()
         self.opt.zero_grad()
         out = self.model(self.x, self.token)["out"]
         m = self.masks[0]
-        loss = F.nll_loss(out[m], self.y[m], reduction="sum") / self.mask_counts[0]
+        loss = self._nll_sum(out, m) / self.mask_counts[0]
         loss.backward()
         self._sync_grads()
         self.opt.step()
@@ -63,10 +69,14 @@ class DistRunner:
         with torch.no_grad():
             res = self.model(self.x, self.token)
         out, m = res["out"], self.masks[which]
-        stats = torch.stack([F.nll_loss(out[m], self.y[m], reduction="sum"),
-                             (out[m].max(dim=1)[1] == self.y[m]).sum().float()])
-        stats = self.comm.all_reduce_sum_(stats) / self.mask_counts[which]
-        return stats[0].item(), stats[1].item(), res
+        if out.is_cuda:
+            from .. import ops
+            stats = ops.masked_nll_accuracy(out, self.y, m)[[0, 2]]
+        else:  # gloo/CPU tests
+            stats = torch.stack([F.nll_loss(out[m], self.y[m], reduction="sum"),
+                                 (out[m].max(dim=1)[1] == self.y[m]).sum().float()]).double()
+        stats = (self.comm.all_reduce_sum_(stats) / self.mask_counts[which]).tolist()
+        return stats[0], stats[1], res
 
     def epoch(self):
         """1 train forward+backward+Adam, then val and test forwards, as the reference loop body."""

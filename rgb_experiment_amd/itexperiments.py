@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from . import ops
 from .data import Data
 from .initial_params import InitialParameters
 from .models import REGISTRY
@@ -230,7 +231,10 @@ def experiment(model_init_param: dict, *,
         net.train()
         optimizer.zero_grad()
         out = net(**fwd)["out"]
-        loss = criterion(out[train_mask], y[train_mask])
+        if out.is_cuda:  # NLLLoss on out[train_mask] (reference :429) in one masked pass
+            loss = ops.masked_nll_loss(out, y, train_mask)
+        else:
+            loss = criterion(out[train_mask], y[train_mask])
         hist["train_acc"].append(compare_pred_label(out[train_mask].max(dim=1)[1], y[train_mask],
                                                     need_all_metrics)["ACC"])
         hist["train_loss"].append(loss.item())

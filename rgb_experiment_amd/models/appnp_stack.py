@@ -2,6 +2,7 @@
 the propagation runs at width output_dim."""
 import torch.nn as nn
 
+from .. import ops
 from ..nn import APPNP
 from ._stack import model_output
 
@@ -16,5 +17,6 @@ class APPNPStack(nn.Module):
         self.conv = APPNP(K, alpha)
 
     def forward(self, x, edge_index):
-        h = self.lin2(self.bn(self.lin1(x)))
+        h = ops.linear(x, self.lin1.weight, self.lin1.bias)
+        h = ops.linear(self.bn(h), self.lin2.weight, self.lin2.bias)
         return model_output(self.conv(h, edge_index))

@@ -7,8 +7,8 @@ computing their ``propagate`` in HIP kernels (rgb_experiment_amd.ops).
   GATConv    <- torch_geometric.nn.conv.GATConv   (reference models/gat.py:3,18-21)
   APPNP      <- torch_geometric.nn.conv.APPNP     (reference models/appnp_stack.py:3,22)
 
-Dense X·W^T products go through torch.mm (hipBLASLt); everything indexed by edge_index goes through
-librgbx_hip.so.
+Dense X·W^T products go through hipBLASLt (forward, input gradient) and rgbx_gemm_tn_f32 (weight
+gradient, split-K fp32 MFMA); everything indexed by edge_index goes through librgbx_hip.so.
 """
 import math
 
@@ -46,7 +46,7 @@ class GCNConv(nn.Module):
 
     def forward(self, x, edge_index):
         graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
-        return ops.propagate_gcn(self.lin(x), graph) + self.bias
+        return ops.propagate_gcn(ops.linear(x, self.lin.weight), graph, bias=self.bias)
 
 
 class SAGEConv(nn.Module):
@@ -61,7 +61,8 @@ class SAGEConv(nn.Module):
 
     def forward(self, x, edge_index):
         graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
-        return self.lin_l(ops.propagate_mean(x, graph)) + self.lin_r(x)
+        agg = ops.propagate_mean(x, graph)
+        return ops.linear(agg, self.lin_l.weight, self.lin_l.bias) + ops.linear(x, self.lin_r.weight)
 
 
 class MySAGEConv(nn.Module):
@@ -78,7 +79,8 @@ class MySAGEConv(nn.Module):
     def forward(self, x, edge_index):
         mode = LOOPS_REMOVE_ADD if self.add_self_loops else LOOPS_KEEP
         graph = get_graph(edge_index, x.size(0), mode)
-        return ops.propagate_mean(self.lin_l(x), graph) + self.lin_r(x)
+        x_l = ops.linear(x, self.lin_l.weight, self.lin_l.bias)
+        return ops.propagate_mean(x_l, graph) + ops.linear(x, self.lin_r.weight, self.lin_r.bias)
 
 
 class GATConv(nn.Module):
@@ -107,7 +109,7 @@ class GATConv(nn.Module):
     def forward(self, x, edge_index):
         H, C = self.heads, self.out_channels
         graph = get_graph(edge_index, x.size(0), LOOPS_REMOVE_ADD)
-        h = self.lin_src(x)
+        h = ops.linear(x, self.lin_src.weight)
         a_src, a_dst = ops.gat_scores(h, self.att_src, self.att_dst, H, C)
         out = ops.gat_aggregate(h, a_src, a_dst, graph, H, C, self.negative_slope)
         if not self.concat:

@@ -37,9 +37,9 @@ class _Timed:
         return False
 
 
-def spmm_raw(csr, w, rs, x, y=None, a=1.0, b=0.0, out=None, kind="spmm"):
-    """out[i] = a*rs[i]*sum_p w[p]*x[col[p]] + b*y[i] over `csr` (no autograd)."""
-    _lib.require_device(x, y)
+def spmm_raw(csr, w, rs, x, y=None, a=1.0, b=0.0, out=None, kind="spmm", bias=None):
+    """out[i] = a*rs[i]*sum_p w[p]*x[col[p]] + b*y[i] + bias over `csr` (no autograd)."""
+    _lib.require_device(x, y, bias)
     x = x if x.stride(-1) == 1 else x.contiguous()
     px, ldx = _lib.mat(x, "x")
     N, d = csr.N, x.size(1)
@@ -50,7 +50,7 @@ def spmm_raw(csr, w, rs, x, y=None, a=1.0, b=0.0, out=None, kind="spmm"):
     with _Timed(kind):
         _lib.check(
             _lib.load().rgbx_spmm_csr_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
-                                          px, ldx, py, ldy, po, ldo, N, d, float(a), float(b),
+                                          px, ldx, py, ldy, _lib.ptr(bias), po, ldo, N, d, float(a), float(b),
                                           _lib.stream_ptr()), "rgbx_spmm_csr_f32")
     return out
 
@@ -59,14 +59,18 @@ class _PropagateGCN(torch.autograd.Function):
     """A_hat x with A_hat = D^-1/2 (A + I) D^-1/2 (dagnn.py:12-31, message dagnn.py:57-59)."""
 
     @staticmethod
-    def forward(ctx, x, graph):
-        ctx.graph = graph
-        return spmm_raw(graph.fwd, graph.w, None, x, kind="gcn_fwd")
+    def forward(ctx, x, graph, bias):
+        ctx.graph, ctx.has_bias = graph, bias is not None
+        b = None if bias is None else bias.detach().contiguous()
+        return spmm_raw(graph.fwd, graph.w, None, x, kind="gcn_fwd", bias=b)
 
     @staticmethod
     def backward(ctx, gy):
         g = ctx.graph
-        return spmm_raw(g.bwd, g.w_t, None, gy.contiguous(), kind="gcn_bwd"), None
+        gy = gy.contiguous()
+        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        gx = spmm_raw(g.bwd, g.w_t, None, gy, kind="gcn_bwd") if ctx.needs_input_grad[0] else None
+        return gx, None, gb
 
 
 class _PropagateMean(torch.autograd.Function):
@@ -100,10 +104,12 @@ def _is_dist(graph):
     return getattr(graph, "is_distributed", False)
 
 
-def propagate_gcn(x, graph):
+def propagate_gcn(x, graph, bias=None):
+    """A_hat x (+ bias, fused into the kernel's store)."""
     if _is_dist(graph):
-        return graph.propagate(x, "gcn")
-    return _PropagateGCN.apply(x, graph)
+        out = graph.propagate(x, "gcn")
+        return out if bias is None else out + bias
+    return _PropagateGCN.apply(x, graph, bias)
 
 
 def propagate_mean(x, graph):
@@ -275,3 +281,102 @@ def scatter_add_rows(src, idx, dst):
         _lib.load().rgbx_scatter_add_rows_f32(ps, lds, _lib.ptr(idx), idx.numel(), src.size(1), pd, ldd,
                                               _lib.stream_ptr()), "rgbx_scatter_add_rows_f32")
     return dst
+
+
+# ---- dense layers: forward through hipBLASLt, weight gradient through the split-K MFMA kernel --------
+
+def gemm_tn(a, b, alpha=1.0):
+    """a^T b for a [K,M], b [K,N] (fp32, device): rgbx_gemm_tn_f32."""
+    _lib.require_device(a, b)
+    a = a if a.stride(-1) == 1 else a.contiguous()
+    b = b if b.stride(-1) == 1 else b.contiguous()
+    pa, lda = _lib.mat(a, "a")
+    pb, ldb = _lib.mat(b, "b")
+    K, M, N = a.size(0), a.size(1), b.size(1)
+    lib = _lib.load()
+    import ctypes
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.rgbx_gemm_tn_workspace_bytes(K, M, N, ctypes.byref(nbytes)), "rgbx_gemm_tn_workspace_bytes")
+    ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=a.device)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with _Timed("gemm_tn"):
+        _lib.check(lib.rgbx_gemm_tn_f32(pa, lda, pb, ldb, _lib.ptr(out), N, K, M, N, float(alpha), _lib.ptr(ws),
+                                        ws.numel(), _lib.stream_ptr()), "rgbx_gemm_tn_f32")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T (+ b). dW = dy^T x runs on rgbx_gemm_tn_f32 when the tensors are on the GPU."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = gemm_tn(gy, x) if gy.is_cuda else gy.t() @ x
+        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    return _Linear.apply(x, weight, bias)
+
+
+# ---- masked NLL + accuracy ------------------------------------------------------------------------
+
+def _nll_stats(logp, y, mask, want_acc):
+    _lib.require_device(logp, y, mask)
+    if y.dtype != torch.int64:
+        raise RuntimeError(f"labels must be int64, got {y.dtype}")
+    if mask is not None and mask.dtype not in (torch.bool, torch.uint8):
+        raise RuntimeError(f"mask must be bool, got {mask.dtype}")
+    pl, ld = _lib.mat(logp, "logp")
+    stats = torch.empty(3, dtype=torch.float64, device=logp.device)
+    y = y.contiguous()
+    mask = None if mask is None else mask.contiguous()
+    _lib.check(_lib.load().rgbx_masked_nll_fwd_f32(pl, ld, _lib.ptr(y), _lib.ptr(mask), logp.size(0), logp.size(1),
+                                                   _lib.ptr(stats), int(want_acc), _lib.stream_ptr()),
+               "rgbx_masked_nll_fwd_f32")
+    return stats, y, mask
+
+
+class _MaskedNLL(torch.autograd.Function):
+    """nn.NLLLoss()(logp[mask], y[mask]) without materialising the selection (itexperiments.py:400,429).
+    reduction 'mean' divides by the number of selected rows, 'sum' does not."""
+
+    @staticmethod
+    def forward(ctx, logp, y, mask, reduction):
+        logp = logp if logp.stride(-1) == 1 else logp.contiguous()
+        stats, y, mask = _nll_stats(logp, y, mask, False)
+        ctx.y, ctx.mask, ctx.shape, ctx.reduction = y, mask, logp.shape, reduction
+        ctx.count = stats[1]
+        return (stats[0] / stats[1] if reduction == "mean" else stats[0]).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        scale = (g.double() / ctx.count if ctx.reduction == "mean" else g.double()).float().reshape(1).contiguous()
+        N, C = ctx.shape
+        grad = torch.empty((N, C), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.load().rgbx_masked_nll_bwd_f32(_lib.ptr(ctx.y), _lib.ptr(ctx.mask), N, C, _lib.ptr(scale),
+                                                       _lib.ptr(grad), C, _lib.stream_ptr()),
+                   "rgbx_masked_nll_bwd_f32")
+        return grad, None, None, None
+
+
+def masked_nll_loss(logp, y, mask=None, reduction="mean"):
+    return _MaskedNLL.apply(logp, y, mask, reduction)
+
+
+def masked_nll_accuracy(logp, y, mask=None):
+    """(sum of -logp[i,y_i], selected-row count, correct arg-max count) as a float64 device tensor [3]."""
+    logp = logp.detach()
+    logp = logp if logp.stride(-1) == 1 else logp.contiguous()
+    return _nll_stats(logp, y, mask, True)[0]

@@ -53,7 +53,7 @@ def _init(rank, world, port):
     torch.set_num_threads(1)
 
 
-def propagate_worker(rank, world, port, out_dir):
+def propagate_worker(rank, world, port, out_dir, exchange="halo"):
     """Forward + backward of the distributed propagate for every (loops_mode, kind)."""
     _init(rank, world, port)
     from rgb_experiment_amd.dist import Comm, DistGraph, partition_bounds
@@ -63,7 +63,8 @@ def propagate_worker(rank, world, port, out_dir):
     go = torch.randn(n, x.size(1), generator=torch.Generator().manual_seed(5))
     res = {}
     for mode, kind in ((1, "gcn"), (2, "mean"), (0, "mean"), (0, "sum")):
-        dg = DistGraph(ei, n, mode, Comm(), OracleAggregator())
+        dg = DistGraph(ei, n, mode, Comm(), OracleAggregator(), exchange)
+        res.setdefault("schemes", []).append(dg.scheme(x.size(1)))
         xl = x[lo:hi].clone().requires_grad_(True)
         out = dg.propagate(xl, kind)
         out.backward(go[lo:hi])
@@ -72,7 +73,7 @@ def propagate_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def runner_worker(rank, world, port, out_dir, model_name):
+def runner_worker(rank, world, port, out_dir, model_name, exchange="halo"):
     """Three epochs of DistRunner (train + evals) — compared by the test with single-process training."""
     _init(rank, world, port)
     from rgb_experiment_amd import models as M
@@ -81,7 +82,7 @@ def runner_worker(rank, world, port, out_dir, model_name):
     torch.manual_seed(14530529)
     model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
     r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
-                   backend=OracleAggregator())
+                   backend=OracleAggregator(), exchange=exchange)
     hist = [r.epoch() for _ in range(3)]
     torch.save({"hist": hist, "logits_eval": r.logits(False), "lo": r.lo, "hi": r.hi,
                 "state": {k: v.clone() for k, v in r.model.state_dict().items()}},
@@ -101,7 +102,7 @@ def build_model(M, name, f, c):
     raise KeyError(name)
 
 
-def gpu_runner_worker(rank, world, port, out_dir, model_name):
+def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo"):
     """Rehearsal of the real per-rank HIP path: `world` ranks share cuda:0, collectives go through gloo
     with host staging (RCCL cannot put two ranks on one device)."""
     _init(rank, world, port)
@@ -111,7 +112,7 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name):
     ei, x, y, masks = make_problem(n=5000, e=60000, f=32, c=8)
     torch.manual_seed(14530529)
     model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
-    r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm())
+    r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm(), exchange=exchange)
     hist = [r.epoch() for _ in range(2)]
     torch.cuda.synchronize()
     torch.save({"hist": hist, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi},

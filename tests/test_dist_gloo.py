@@ -48,13 +48,19 @@ def test_plan_is_consistent_and_covers_every_edge():
                     assert int(hp.loc_gather.max()) < hp.n_local
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_distributed_propagate_matches_single_process(world, tmp_path):
-    mp.spawn(W.propagate_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,exchange", [(2, "halo"), (3, "halo"), (2, "reshard"), (3, "reshard"), (3, "auto")])
+def test_distributed_propagate_matches_single_process(world, exchange, tmp_path):
+    mp.spawn(W.propagate_worker, args=(world, _free_port(), str(tmp_path), exchange), nprocs=world, join=True)
     ei, x, _, _ = W.make_problem()
     n = x.size(0)
     go = torch.randn(n, x.size(1), generator=torch.Generator().manual_seed(5))
     parts = [torch.load(os.path.join(tmp_path, f"prop_{r}.pt")) for r in range(world)]
+    schemes = parts[0]["schemes"]
+    assert all(p["schemes"] == schemes for p in parts)  # every rank takes the same branch
+    if exchange != "auto":
+        assert set(schemes) == {exchange}  # feature width 12 is divisible by 2 and 3
+    else:  # dense random graph: every remote row is a boundary row, so the transpose is cheaper
+        assert set(schemes) == {"reshard"}
     for mode, kind in ((1, "gcn"), (2, "mean"), (0, "mean"), (0, "sum")):
         rei, _ = O.rewrite_edges(ei, n, mode)
         xr = x.clone().requires_grad_(True)
@@ -106,14 +112,16 @@ def _single_process_reference(model_name):
     return hist, params
 
 
-@pytest.mark.parametrize("model_name,world", [("gcn", 2), ("gcn", 3), ("graphsage", 2), ("graphsage2", 2),
-                                               ("appnpstack", 2)])
-def test_dist_runner_training_matches_single_process(model_name, world, tmp_path):
+@pytest.mark.parametrize("model_name,world,exchange", [("gcn", 2, "halo"), ("gcn", 3, "halo"), ("graphsage", 2, "halo"),
+                                                        ("graphsage2", 2, "halo"), ("appnpstack", 2, "halo"),
+                                                        ("gcn", 2, "reshard"), ("graphsage2", 2, "auto")])
+def test_dist_runner_training_matches_single_process(model_name, world, exchange, tmp_path):
     """Train-mode BatchNorm uses batch statistics in the oracle and reduced statistics in the runner, so
     train losses and trained WEIGHTS must agree; eval losses use running statistics, which the
     oracle's functional BN does not update, so they are compared in a separate running-stat-free way:
     every rank's trained parameters are identical and equal to the single-process ones."""
-    mp.spawn(W.runner_worker, args=(world, _free_port(), str(tmp_path), model_name), nprocs=world, join=True)
+    mp.spawn(W.runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange), nprocs=world,
+             join=True)
     parts = [torch.load(os.path.join(tmp_path, f"run_{model_name}_{r}.pt")) for r in range(world)]
     hist, params = _single_process_reference(model_name)
     for r in range(1, world):  # replicated parameters stay bit-identical across ranks

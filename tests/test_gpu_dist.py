@@ -45,9 +45,12 @@ def _single_gpu(model_name):
         return hist, model(x, ei)["emb"].cpu()
 
 
-@pytest.mark.parametrize("model_name,world", [("gcn", 2), ("gcn", 3), ("graphsage", 2), ("appnpstack", 2)])
-def test_partitioned_hip_run_matches_single_gpu(model_name, world, tmp_path):
-    mp.spawn(W.gpu_runner_worker, args=(world, _free_port(), str(tmp_path), model_name), nprocs=world, join=True)
+@pytest.mark.parametrize("model_name,world,exchange", [("gcn", 2, "halo"), ("gcn", 3, "halo"), ("graphsage", 2, "halo"),
+                                                        ("appnpstack", 2, "halo"), ("gcn", 2, "reshard"),
+                                                        ("appnpstack", 2, "reshard"), ("gcn", 4, "auto")])
+def test_partitioned_hip_run_matches_single_gpu(model_name, world, exchange, tmp_path):
+    mp.spawn(W.gpu_runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange), nprocs=world,
+             join=True)
     parts = [torch.load(os.path.join(tmp_path, f"gpu_{model_name}_{r}.pt")) for r in range(world)]
     hist, emb = _single_gpu(model_name)
     # Train-mode quantities (batch statistics) are well conditioned: compare tightly. Eval-mode ones

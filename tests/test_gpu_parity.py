@@ -394,6 +394,83 @@ def test_experiment_cora_shaped_gcn(dev):
     assert (emb - O.gcn_forward(sd, xn, ei, 2, False)["emb"]).abs().max().item() < TOL
 
 
+# ---- dense weight gradient (split-K MFMA) and masked NLL ----------------------------------------------
+
+@pytest.mark.parametrize("K,M,N", [(1, 1, 1), (7, 3, 5), (33, 128, 128), (2708, 64, 1433), (2708, 7, 64),
+                                   (5000, 130, 260), (100000, 128, 128), (300001, 128, 16)])
+def test_gemm_tn(dev, K, M, N):
+    from rgb_experiment_amd import ops
+    gen = torch.Generator().manual_seed(K + M + N)
+    a = torch.randn(K, M, generator=gen)
+    b = torch.randn(K, N, generator=gen)
+    got = ops.gemm_tn(a.to(dev), b.to(dev)).cpu()
+    want = (a.double().t() @ b.double())
+    tol = 1e-5 + 2e-6 * K ** 0.5 * 4
+    assert got.shape == (M, N)
+    assert (got.double() - want).abs().max().item() < tol
+    again = ops.gemm_tn(a.to(dev), b.to(dev)).cpu()
+    assert torch.equal(got, again)  # fixed-order split-K reduction: bitwise reproducible
+
+
+def test_gemm_tn_strided_inputs(dev):
+    from rgb_experiment_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    big_a = torch.randn(4000, 200, generator=gen).to(dev)
+    big_b = torch.randn(4000, 300, generator=gen).to(dev)
+    for a, b in ((big_a[:, 8:136], big_b[:, 4:132]), (big_a[:, 3:70], big_b[:, 1:100])):
+        got = ops.gemm_tn(a, b).cpu().double()
+        want = a.cpu().double().t() @ b.cpu().double()
+        assert (got - want).abs().max().item() < 1e-3
+
+
+def test_linear_autograd_uses_mfma_wgrad(dev):
+    from rgb_experiment_amd import ops
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(5000, 96, generator=gen)
+    w = torch.randn(40, 96, generator=gen)
+    b = torch.randn(40, generator=gen)
+    go = torch.randn(5000, 40, generator=gen)
+    outs = []
+    for d in ("cpu", dev):
+        xd, wd, bd = (t.detach().clone().to(d).requires_grad_(True) for t in (x, w, b))
+        y = ops.linear(xd, wd, bd) if d != "cpu" else torch.nn.functional.linear(xd, wd, bd)
+        y.backward(go.to(d))
+        outs.append([t.detach().cpu() for t in (y, xd.grad, wd.grad, bd.grad)])
+    for got, want in zip(outs[1], outs[0]):
+        assert (got - want).abs().max().item() < 1e-3 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("N,C", [(1, 1), (1000, 7), (200003, 128), (5000, 130)])
+def test_masked_nll_and_accuracy(dev, N, C):
+    from rgb_experiment_amd import ops
+    gen = torch.Generator().manual_seed(N + C)
+    logits = torch.randn(N, C, generator=gen)
+    y = torch.randint(0, C, (N,), generator=gen)
+    mask = torch.rand(N, generator=gen) < 0.6
+    mask[0] = True
+    y_with_unlabelled = y.clone()
+    y_with_unlabelled[~mask] = -1  # unlabelled nodes are never selected (reference rd2pd.py note 2)
+    for m in (mask, None):
+        yy = y if m is None else y_with_unlabelled
+        lc = logits.clone().requires_grad_(True)
+        lp_c = torch.log_softmax(lc, 1)
+        sel = slice(None) if m is None else m
+        want = torch.nn.functional.nll_loss(lp_c[sel], y[sel])
+        want.backward()
+        lg = logits.to(dev).requires_grad_(True)
+        lp_g = torch.log_softmax(lg, 1)
+        got = ops.masked_nll_loss(lp_g, yy.to(dev), None if m is None else m.to(dev))
+        got.backward()
+        assert abs(got.item() - want.item()) < 1e-5
+        assert (lg.grad.cpu() - lc.grad).abs().max().item() < 1e-6
+        stats = ops.masked_nll_accuracy(lp_g, yy.to(dev), None if m is None else m.to(dev)).cpu()
+        acc = (lp_c[sel].max(dim=1)[1] == y[sel]).sum().item()
+        assert int(stats[1]) == (N if m is None else int(mask.sum())) and int(stats[2]) == acc
+        assert abs(stats[0].item() / stats[1].item() - want.item()) < 1e-5
+    s = ops.masked_nll_loss(torch.log_softmax(logits.to(dev), 1), y.to(dev), mask.to(dev), reduction="sum")
+    assert abs(s.item() - torch.nn.functional.nll_loss(lp_c.detach()[mask], y[mask], reduction="sum").item()) < 1e-2
+
+
 # ---- halo pack / unpack -------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("d", [1, 7, 128, 132])
