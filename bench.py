@@ -59,6 +59,17 @@ def split_masks(N):
     return masks
 
 
+def pmc_traffic(workload, world):
+    """HBM-side bytes per SpMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
+    WRITE_SIZE, gfx950 correction; profiles/pmc_traffic_<workload>.json). PMC counters cannot be read
+    from inside this process, so this is the last profiled value for the same kernel and workload, or None."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["traffic_bytes_per_launch"]
+
+
 def spmm_alg_bytes(n_rows, nnz, d):
     """gathered rows + col + weight per edge, output row + rowptr per node."""
     return nnz * (4 * d + 8) + n_rows * 4 * d + 4 * (n_rows + 1)
@@ -222,7 +233,7 @@ def main():
         "kernel_ms_by_kind": by_kind,
         "final_losses": {"train": last[0], "val": last[1], "test": last[3]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),
                      "kernel": "spmm_csr_kernel<32,4,true>", "algorithmic_bytes_per_launch": alg,
                      "note": "rank 0's share (local + remote SpMM)" if world > 1 else "whole graph"},
     }
