@@ -250,3 +250,79 @@ def appnp_stack_forward(sd, x, edge_index, K, alpha, training=False):
     h = batch_norm(h, sd, "bn.", training)
     h = h @ sd["lin2.weight"].t() + sd["lin2.bias"]
     return _finish(appnp(h, edge_index, K, alpha))
+
+
+# ---- "next" rows: models that reuse the same propagate --------------------------------
+
+def pta_norm_adj_dense(edge_index, num_nodes):
+    """Dense D^-1/2 (A + I) D^-1/2 exactly as itexperiments.py:354-356,671-684: A[src, dst] += 1 per edge
+    (coo_matrix sums duplicates), + identity (an existing self-loop ends up with 2), D = row sums."""
+    a = torch.zeros(num_nodes, num_nodes, dtype=torch.float64)
+    a.index_put_((edge_index[0], edge_index[1]), torch.ones(edge_index.size(1), dtype=torch.float64), accumulate=True)
+    a = a + torch.eye(num_nodes, dtype=torch.float64)
+    r = a.sum(1).pow(-0.5)
+    r[torch.isinf(r)] = 0
+    return (r.view(-1, 1) * a * r.view(1, -1)).float()
+
+
+def label_propagation(adj, labels, idx, K, alpha):
+    """itexperiments.py:698-719 with a dense adj."""
+    c = int(labels.max()) + 1
+    y0 = torch.zeros(labels.size(0), c)
+    y0[idx, labels[idx]] = 1.0
+    onehot = torch.nn.functional.one_hot(labels.clamp(min=0), c).float()
+    y = y0
+    for _ in range(K):
+        y = adj @ y
+        y[idx] = onehot[idx]
+        y = (1 - alpha) * y + alpha * y0
+    return y
+
+
+def pta_inference(h, adj, K, alpha):
+    """models/pta.py:79-84 with a dense adj."""
+    y0 = torch.softmax(h, dim=-1)
+    y = y0
+    for _ in range(K):
+        y = (1 - alpha) * (adj @ y) + alpha * y0
+    return y
+
+
+def sgc_forward(sd, x, edge_index, K, add_loops=True):
+    """models/sgc.py:12-14 -> SGConv [PyG]: lin(A_hat^K x), gcn_norm with or without added self-loops."""
+    n = x.size(0)
+    ei, w = gcn_norm(edge_index, None, n, add_loops=add_loops)
+    for _ in range(K):
+        x = propagate(ei, x, n, w, "add")
+    return _finish(x @ sd["conv1.lin.weight"].t() + sd["conv1.lin.bias"])
+
+
+def _gin_block(sd, prefix, x, training):
+    h = torch.relu(x @ sd[prefix + "0.weight"].t() + sd[prefix + "0.bias"])
+    h = torch.relu(h @ sd[prefix + "2.weight"].t() + sd[prefix + "2.bias"])
+    return batch_norm(h, sd, prefix + "4.", training)
+
+
+def gin_forward(sd, x, edge_index, num_layers, training=False):
+    """models/gin.py:48-54 -> GINConv [PyG]: nn((1 + eps) x_i + sum_j x_j); dropout omitted (p = 0 / eval)."""
+    n = x.size(0)
+    for prefix in ["conv1."] + [f"convs.{i}." for i in range(num_layers - 1)]:
+        agg = propagate(edge_index, x, n, None, "add") + (1 + sd[prefix + "eps"]) * x
+        x = _gin_block(sd, prefix + "nn.", agg, training)
+    x = torch.relu(x @ sd["lin1.weight"].t() + sd["lin1.bias"])
+    return _finish(x @ sd["lin2.weight"].t() + sd["lin2.bias"])
+
+
+def dagnn_forward(sd, x, edge_index, K):
+    """models/dagnn.py:41-55,79-86 (dropout omitted: p = 0 / eval)."""
+    n = x.size(0)
+    x = torch.relu(x @ sd["lin1.weight"].t() + sd["lin1.bias"])
+    x = x @ sd["lin2.weight"].t() + sd["lin2.bias"]
+    ei, w = gcn_norm(edge_index, None, n)
+    preds = [x]
+    for _ in range(K):
+        x = propagate(ei, x, n, w, "add")
+        preds.append(x)
+    pps = torch.stack(preds, dim=1)
+    retain = torch.sigmoid(pps @ sd["prop.proj.weight"].t() + sd["prop.proj.bias"]).squeeze(-1)
+    return _finish(torch.matmul(retain.unsqueeze(1), pps).squeeze(1))

@@ -2,8 +2,9 @@
 surface (reference rgb_experiment/__init__.py:1-4)."""
 from .data import Data
 from .initial_params import InitialParameters
-from .itexperiments import compare_pred_label, experiment, test
+from .itexperiments import compare_pred_label, experiment, label_propagation, normalized_adjacency, test
 from .rd2pd import RD2PD
 
 __version__ = "0.1.0"
-__all__ = ["experiment", "test", "compare_pred_label", "InitialParameters", "RD2PD", "Data"]
+__all__ = ["experiment", "test", "compare_pred_label", "label_propagation", "normalized_adjacency",
+           "InitialParameters", "RD2PD", "Data"]

@@ -8,14 +8,18 @@ class InitialParameters:
     default_data_path = os.environ.get("RGB_DATA_ROOT", os.path.join(os.path.dirname(_PKG), "data"))
     default_pics_path = os.path.join(os.path.dirname(_PKG), "pics")
 
-    model_names = ["MLP", "GCN", "GraphSAGE", "GAT", "APPNPStack", "GraphSAGE2"]
-    # reference initial_params.py:24-30
+    model_names = ["MLP", "GCN", "GraphSAGE", "GAT", "APPNPStack", "GraphSAGE2", "PTA", "DAGNN", "SGC", "GIN"]
+    # reference initial_params.py:24-35
     default_init_params = [
         {"num_layers": 3, "hidden_unit": 64, "dropout_rate": 0.5},
         {"num_layers": 2, "hidden_unit": 64, "dropout_rate": 0.5},
         {"num_layers": 2, "hidden_unit": 64, "dropout_rate": 0.5},
         {"num_layers": 2, "hidden_unit": 8, "dropout_rate": 0.5, "heads": 8},
         {"hidden_unit": 64, "dropout_rate": 0.5, "alpha": 0.1, "K": 10},
+        {"num_layers": 2, "hidden_unit": 64, "dropout_rate": 0.5},
+        {"nhid": 64, "dropout": 0, "epsilon": 100, "mode": 2, "K": 10, "alpha": 0.1},
+        {"hidden_dim": 64, "K": 10, "dropout_rate": 0.5},
+        {"K": 2},
         {"num_layers": 2, "hidden_unit": 64, "dropout_rate": 0.5},
     ]
 

@@ -2,10 +2,11 @@
 same keyword surface so that examples/simple_example.py-style calls run unchanged, with the model
 forward/backward executing in the HIP message-passing kernels.
 
-Scope (SURVEY §8b): data loading / mask remake / feature normalisation / model dispatch by
-lower-cased ``model_name`` / full-batch Adam + NLLLoss loop with early stopping / metrics dict.
-Out of scope and rejected with ``NotImplementedError``: the PTA branch, C&S post-processing, plots,
-PCA (reference :351-374, :514-601) and the non-hot-path zoo members.
+Scope (SURVEY §8b, §8f): data loading / mask remake / feature normalisation / model dispatch by
+lower-cased ``model_name`` / full-batch Adam + NLLLoss loop with early stopping / the PTA branch
+(label propagation + soft-label loss + propagated inference, reference :351-374, :422-462) / metrics
+dict. Out of scope and rejected with ``NotImplementedError``: C&S post-processing, plots, PCA
+(reference :514-601) and the GGNN / SuperGAT / FAGCN zoo members.
 
 Deliberate deviations from reference quirks:
   * ``compare_pred_label(need_all_metrics=False)`` returns zeros instead of raising
@@ -29,7 +30,7 @@ from .models import REGISTRY
 from .rd2pd import RD2PD
 from .utils import get_classification_mask, get_random_mask, get_whole_mask, to_undirected
 
-_OUT_OF_SCOPE = ("ggnn", "dagnn", "pta", "supergat", "sgc", "gin", "fagcn")
+_OUT_OF_SCOPE = ("ggnn", "supergat", "fagcn")
 
 
 def _macro_prf(label, pred):
@@ -125,6 +126,28 @@ def _make_masks(y, mode, ratio, num_train_per_class, num_val, num_test, seed):
     raise ValueError(f"dataset_split_mode {mode!r} not in ratio/classification/random")
 
 
+def normalized_adjacency(edge_index, num_nodes):
+    """reference :354-357 (edge_index2sparse_matrix + I, normalize_adj): D^-1/2 (A + I) D^-1/2 with
+    adj[src, dst], as a device-resident CSR (models.pta.NormAdj) instead of a torch sparse tensor."""
+    from .models.pta import NormAdj
+    return NormAdj(edge_index, num_nodes)
+
+
+def label_propagation(adj, labels, idx, K, alpha, device=None):
+    """reference :698-719: K rounds of y <- adj @ y, clamp the rows in `idx` to their one-hot labels,
+    y <- (1-alpha) y + alpha y0."""
+    n_class = int(labels.max().item()) + 1
+    y0 = torch.zeros((labels.shape[0], n_class), dtype=torch.float32, device=labels.device)
+    y0[idx, labels[idx]] = 1.0
+    onehot = torch.nn.functional.one_hot(labels.clamp(min=0), n_class).to(torch.float32)
+    y = y0
+    for _ in range(K):
+        y = adj.matmul(y)
+        y[idx] = onehot[idx]
+        y = (1 - alpha) * y + alpha * y0
+    return y
+
+
 def experiment(model_init_param: dict, *,
                task: str = "node_prediction",
                dataset_name: str = "Github",
@@ -216,18 +239,34 @@ def experiment(model_init_param: dict, *,
     # ---- model (reference :315-391) ----------------------------------------------------------
     input_dim = data.num_node_features
     output_dim = int(data.y.max().item()) + 1
-    net = REGISTRY[name](input_dim=input_dim, output_dim=output_dim, **model_init_param)
-    fwd = {"x": features} if name == "mlp" else {"x": features, "edge_index": data.edge_index}
+    y, train_mask, val_mask, test_mask = data.y, data.train_mask, data.val_mask, data.test_mask
+    is_pta = name == "pta"
+    if is_pta:  # reference :351-374
+        adj = normalized_adjacency(data.edge_index, data.num_nodes)
+        idx = [m.nonzero(as_tuple=True)[0] for m in (train_mask, val_mask, test_mask)]
+        K, alpha = model_init_param["K"], model_init_param["alpha"]
+        y_soft = [label_propagation(adj, y, i, K, alpha) for i in idx]
+        net = REGISTRY[name](nfeat=input_dim, nclass=output_dim, **model_init_param)
+        fwd = {"x": features}
+    else:
+        net = REGISTRY[name](input_dim=input_dim, output_dim=output_dim, **model_init_param)
+        fwd = {"x": features} if name == "mlp" else {"x": features, "edge_index": data.edge_index}
     net.to(device)
     optimizer = torch.optim.Adam(net.parameters(), lr=learning_rate, weight_decay=weight_decay)
     criterion = nn.NLLLoss()
-    y, train_mask, val_mask, test_mask = data.y, data.train_mask, data.val_mask, data.test_mask
 
     hist = {k: [] for k in ("train_acc", "train_loss", "val_acc", "val_loss", "test_acc", "test_loss")}
     best_state, best_val_loss, best_val_acc, patience = {}, 0, 0, 0
+    best_pta_metrics = None
 
-    # ---- full-batch loop (reference :417-504): 1 train forward+backward, 2 eval forwards ------
-    for i in range(epoch):
+    # Inside the loop the reference computes sklearn precision/recall/F1 on the CPU for train, val and
+    # test every epoch (:434,:464,:470) and then uses only 'ACC' of each; the returned dict comes from
+    # the final test() (:512). Accuracy alone is therefore computed in the loop (no host copies of the
+    # prediction vectors), the full metrics once at the end: same return values, fewer syncs.
+    loop_metrics = False
+
+    def generic_epoch(i):
+        """reference :427-440, :464-473: 1 train forward+backward, 2 eval forwards."""
         net.train()
         optimizer.zero_grad()
         out = net(**fwd)["out"]
@@ -236,20 +275,47 @@ def experiment(model_init_param: dict, *,
         else:
             loss = criterion(out[train_mask], y[train_mask])
         hist["train_acc"].append(compare_pred_label(out[train_mask].max(dim=1)[1], y[train_mask],
-                                                    need_all_metrics)["ACC"])
+                                                    loop_metrics)["ACC"])
         hist["train_loss"].append(loss.item())
         loss.backward()
         optimizer.step()
-
-        val = test(net, fwd, y, val_mask, need_all_metrics)
-        val_acc = val["ACC"]
+        val = test(net, fwd, y, val_mask, loop_metrics)
         val_loss = criterion(val["test_op"][val_mask], y[val_mask]).item()
-        hist["val_acc"].append(val_acc)
-        hist["val_loss"].append(val_loss)
-        tst = test(net, fwd, y, test_mask, need_all_metrics)
+        tst = test(net, fwd, y, test_mask, loop_metrics)
         hist["test_acc"].append(tst["ACC"])
         hist["test_loss"].append(criterion(tst["test_op"][test_mask], y[test_mask]).item())
+        return val["ACC"], val_loss, None
 
+    def pta_epoch(i):
+        """reference :422-425, :442-462 (including its quirk: the test loss is taken on the propagated
+        probabilities, not on the logits)."""
+        net.train()
+        optimizer.zero_grad()
+        output = net(features)
+        loss = pta_loss_decay * net.loss_function(y_hat=output, y_soft=y_soft[0], epoch=i) \
+            + pta_weight_decay * torch.sum(net.Linear1.weight ** 2) / 2
+        hist["train_loss"].append(loss.item())
+        loss.backward()
+        optimizer.step()
+        with torch.no_grad():
+            prob = net.inference(output.detach(), adj)
+            hist["train_acc"].append(compare_pred_label(prob[idx[0]].max(dim=1)[1], y[idx[0]], loop_metrics)["ACC"])
+            net.eval()
+            output = net(features)
+            val_loss = (pta_loss_decay * net.loss_function(y_hat=output, y_soft=y_soft[1])).item()
+            prob = net.inference(output, adj)
+            val_acc = compare_pred_label(prob[idx[1]].max(dim=1)[1], y[idx[1]], loop_metrics)["ACC"]
+            hist["test_loss"].append((pta_loss_decay * net.loss_function(y_hat=prob, y_soft=y_soft[2])).item())
+            metrics = compare_pred_label(prob[idx[2]].max(dim=1)[1], y[idx[2]], need_all_metrics)
+            metrics["emb"] = prob
+        hist["test_acc"].append(metrics["ACC"])
+        return val_acc, val_loss, metrics
+
+    # ---- full-batch loop with early stopping (reference :417-504) -------------------------------
+    for i in range(epoch):
+        val_acc, val_loss, pta_metrics = (pta_epoch if is_pta else generic_epoch)(i)
+        hist["val_acc"].append(val_acc)
+        hist["val_loss"].append(val_loss)
         if i == 0:
             best_val_loss, best_val_acc = val_loss, val_acc
         if early_stopping_criterion == "loss":
@@ -262,6 +328,7 @@ def experiment(model_init_param: dict, *,
             patience = 0
             best_val_loss, best_val_acc = min(val_loss, best_val_loss), max(val_acc, best_val_acc)
             best_state = deepcopy(net.state_dict())
+            best_pta_metrics = pta_metrics
         elif implement_early_stopping and i > begin_early_stopping:
             patience += 1
             if patience > early_stopping:
@@ -269,7 +336,12 @@ def experiment(model_init_param: dict, *,
 
     if best_state:
         net.load_state_dict(best_state)
-    final = test(net, fwd, y, test_mask, need_all_metrics)
+    if is_pta:  # reference :509-510
+        final = dict(best_pta_metrics)
+        final.setdefault("label", y[idx[2]])
+        final.setdefault("pred", final["emb"][idx[2]].max(dim=1)[1])
+    else:
+        final = test(net, fwd, y, test_mask, need_all_metrics)
 
     if print_confusion_matrix:
         k = output_dim

@@ -1,3 +1,3 @@
-from .conv import GCNConv, SAGEConv, MySAGEConv, GATConv, APPNP
+from .conv import GCNConv, SAGEConv, MySAGEConv, GATConv, APPNP, SGConv, GINConv
 
-__all__ = ["GCNConv", "SAGEConv", "MySAGEConv", "GATConv", "APPNP"]
+__all__ = ["GCNConv", "SAGEConv", "MySAGEConv", "GATConv", "APPNP", "SGConv", "GINConv"]

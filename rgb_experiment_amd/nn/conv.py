@@ -128,3 +128,44 @@ class APPNP(nn.Module):
     def forward(self, x, edge_index):
         graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
         return ops.appnp_propagate(x, graph, self.K, self.alpha)
+
+
+class SGConv(nn.Module):
+    """x' = lin(A_hat^K x) with gcn_norm (self-loops added unless add_self_loops=False) and the
+    propagated features cached after the first call when cached=True [PyG SGConv, as built at reference
+    models/sgc.py:9-10]. The K propagates run as one rgbx_appnp_f32 call with alpha = 0."""
+
+    def __init__(self, in_channels, out_channels, K=1, cached=False, add_self_loops=True, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.K = in_channels, out_channels, K
+        self.cached, self.add_self_loops = cached, add_self_loops
+        self.lin = nn.Linear(in_channels, out_channels, bias=bias)
+        self._cached_x = None
+
+    def forward(self, x, edge_index):
+        h = self._cached_x
+        if h is None:
+            mode = LOOPS_ADD_REMAINING if self.add_self_loops else LOOPS_KEEP
+            graph = get_graph(edge_index, x.size(0), mode)
+            h = ops.appnp_propagate(x, graph, self.K, 0.0)
+            if self.cached:
+                self._cached_x = h if h.requires_grad else h.detach()
+        return ops.linear(h, self.lin.weight, self.lin.bias)
+
+
+class GINConv(nn.Module):
+    """out = nn((1 + eps) * x_i + sum_{j in N(i)} x_j), edges as given, eps learnable when train_eps
+    [PyG GINConv, as built at reference models/gin.py:14-34]."""
+
+    def __init__(self, nn_module, eps=0.0, train_eps=False):
+        super().__init__()
+        self.nn = nn_module
+        self.initial_eps = eps
+        if train_eps:
+            self.eps = nn.Parameter(torch.tensor([float(eps)]))
+        else:
+            self.register_buffer("eps", torch.tensor([float(eps)]))
+
+    def forward(self, x, edge_index):
+        graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
+        return self.nn(ops.propagate_sum(x, graph) + (1 + self.eps) * x)

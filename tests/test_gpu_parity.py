@@ -471,6 +471,93 @@ def test_masked_nll_and_accuracy(dev, N, C):
     assert abs(s.item() - torch.nn.functional.nll_loss(lp_c.detach()[mask], y[mask], reduction="sum").item()) < 1e-2
 
 
+# ---- "next" rows: PTA propagation pinned by the reference goldens, SGC / GIN / DAGNN ----------
+
+@pytest.mark.parametrize("name", GOLDEN_GRAPHS)
+def test_pta_propagation_against_reference_goldens(dev, golden, name):
+    """HIP label_propagation == reference label_propagation output (G2); HIP PTA.inference == reference
+    PTA.inference output (G3); the CSR-held adjacency densifies to the reference's normalize_adj (G1)."""
+    import rgb_experiment_amd as R
+    from rgb_experiment_amd.models import PTA
+    ei = torch.from_numpy(golden[f"g1/{name}/edge_index"])
+    n = int(golden[f"g1/{name}/num_nodes"])
+    adj = R.normalized_adjacency(ei.to(dev), n)
+    eye = torch.eye(n, device=dev)
+    assert torch.allclose(adj.matmul(eye).cpu(), torch.from_numpy(golden[f"g1/{name}/adj_ref"]).float(), atol=1e-6)
+    labels = torch.from_numpy(golden[f"g2/{name}/labels"]).to(dev)
+    idx = torch.from_numpy(golden[f"g2/{name}/idx"]).to(dev)
+    for K in (3, 10):
+        got = R.label_propagation(adj, labels, idx, K, 0.1).cpu()
+        assert torch.allclose(got, torch.from_numpy(golden[f"g2/{name}/K{K}/out"]), atol=1e-6)
+    h = torch.from_numpy(golden[f"g3/{name}/h"]).to(dev)
+    for K, alpha in ((1, 0.1), (10, 0.1), (4, 0.35)):
+        model = PTA(nfeat=3, nhid=4, nclass=5, dropout=0.0, epsilon=100, K=K, alpha=alpha)
+        got = model.inference(h, adj).cpu()
+        assert torch.allclose(got, torch.from_numpy(golden[f"g3/{name}/K{K}_a{alpha}/out"]), atol=1e-6)
+
+
+def test_pta_adjacency_with_loops_and_duplicates(dev):
+    """The reference's A + I counts an existing self-loop twice and duplicate edges separately."""
+    import rgb_experiment_amd as R
+    ei = rand_graph(300, 2500, 8, loops=25, dups=40)
+    adj = R.normalized_adjacency(ei.to(dev), 300)
+    x = torch.randn(300, 9, generator=torch.Generator().manual_seed(0))
+    assert (adj.matmul(x.to(dev)).cpu() - O.pta_norm_adj_dense(ei, 300) @ x).abs().max().item() < 1e-5
+
+
+def test_next_row_models(dev):
+    from rgb_experiment_amd import models as M
+    n, f, c = 1200, 20, 6
+    ei = rand_graph(n, 9000, 4, loops=6, dups=6)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(n, f, generator=gen)
+    y = torch.randint(0, c, (n,), generator=gen)
+    cases = [
+        (M.SGC(input_dim=f, output_dim=c, K=2), lambda sd, tr: O.sgc_forward(sd, x, ei, 2)),
+        (M.SGC(input_dim=f, output_dim=c, K=3, cached=False, add_self_loops=False),
+         lambda sd, tr: O.sgc_forward(sd, x, ei, 3, add_loops=False)),
+        (M.GIN(input_dim=f, output_dim=c, hidden_unit=16, num_layers=2, dropout_rate=0.0),
+         lambda sd, tr: O.gin_forward(sd, x, ei, 2, tr)),
+        (M.DAGNN(input_dim=f, hidden_dim=16, output_dim=c, K=5, dropout_rate=0.0),
+         lambda sd, tr: O.dagnn_forward(sd, x, ei, 5)),
+    ]
+    for model, oracle_fwd in cases:
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.to(dev).train()
+        out = model(x.to(dev), ei.to(dev))
+        loss = torch.nn.functional.nll_loss(out["out"], y.to(dev))
+        loss.backward()
+        ref_sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        ref = oracle_fwd(ref_sd, True)
+        ref_loss = torch.nn.functional.nll_loss(ref["out"], y)
+        ref_loss.backward()
+        assert (out["emb"].detach().cpu() - ref["emb"].detach()).abs().max().item() < 2e-4, type(model).__name__
+        for pname, p in model.named_parameters():
+            rg = ref_sd[pname].grad
+            assert (p.grad.cpu() - rg).abs().max().item() < 2e-4 * max(1.0, rg.abs().max().item()), pname
+    sgc = cases[0][0]
+    assert sgc.conv1._cached_x is not None  # cached=True keeps A_hat^K x after the first call
+
+
+def test_experiment_pta_and_sgc_run(dev):
+    import rgb_experiment_amd as R
+    n, f, c = 800, 16, 4
+    gen = torch.Generator().manual_seed(5)
+    centers = torch.randn(c, f, generator=gen) * 2
+    y = torch.randint(0, c, (n,), generator=gen)
+    x = centers[y] + torch.randn(n, f, generator=gen)
+    same = (y.view(-1, 1) == y.view(1, -1)) & (torch.rand(n, n, generator=gen) < 0.02)
+    ei = same.nonzero().t().contiguous()
+    data = R.Data(x=x, y=y, edge_index=ei)
+    for name, params in (("PTA", R.InitialParameters.defaults_for("pta")), ("SGC", {"K": 2}),
+                         ("DAGNN", {"hidden_dim": 16, "K": 4, "dropout_rate": 0.5}),
+                         ("GIN", {"num_layers": 2, "hidden_unit": 16, "dropout_rate": 0.5})):
+        res = R.experiment(params, specify_data=True, data=data, model_name=name, learning_rate=0.01, epoch=25,
+                           need_to_reappear=True, print_print=False, return_model=True)
+        assert res["ACC"] > 0.6, (name, res["ACC"])  # separable clusters on a homophilous graph
+        assert len(res["history"]["val_acc"]) == 25
+
+
 # ---- halo pack / unpack -------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("d", [1, 7, 128, 132])

@@ -86,7 +86,8 @@ def test_data_container():
 
 
 def test_registry_and_constructor_signatures():
-    assert sorted(REGISTRY) == ["appnpstack", "gat", "gcn", "graphsage", "graphsage2", "mlp"]
+    assert sorted(REGISTRY) == ["appnpstack", "dagnn", "gat", "gcn", "gin", "graphsage", "graphsage2", "mlp", "pta",
+                                "sgc"]
     m = REGISTRY["gcn"](input_dim=5, output_dim=3, **R.InitialParameters.defaults_for("GCN"))
     assert [k for k in m.state_dict() if k.startswith("convs.0")] == ["convs.0.bias", "convs.0.lin.weight"]
     assert m.state_dict()["convs.0.lin.weight"].shape == (64, 5)
@@ -135,7 +136,7 @@ def test_experiment_rejects_cpu_for_graph_models_and_out_of_scope_names():
         R.experiment(R.InitialParameters.defaults_for("gcn"), specify_data=True, data=_toy(), model_name="GCN",
                      use_cpu=True, print_print=False)
     with pytest.raises(NotImplementedError):
-        R.experiment({}, specify_data=True, data=_toy(), model_name="DAGNN", print_print=False)
+        R.experiment({}, specify_data=True, data=_toy(), model_name="FAGCN", print_print=False)
     with pytest.raises(ValueError):
         R.experiment({}, specify_data=True, data=_toy(), model_name="nope", print_print=False)
 

@@ -66,6 +66,24 @@ def test_g3_appnp_matches_pta_inference(golden, name, K, alpha):
     assert torch.allclose(got, ref, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", GOLDEN_GRAPHS)
+def test_next_row_oracles_against_reference_goldens(golden, name):
+    """pta_norm_adj_dense == G1, label_propagation == G2, pta_inference == G3 (dense restatements used as
+    the oracle of the PTA path)."""
+    n, ei = _graph(golden, name)
+    adj = O.pta_norm_adj_dense(ei, n)
+    assert torch.allclose(adj, torch.from_numpy(golden[f"g1/{name}/adj_ref"]).float(), atol=1e-6)
+    labels = torch.from_numpy(golden[f"g2/{name}/labels"])
+    idx = torch.from_numpy(golden[f"g2/{name}/idx"])
+    for K in (3, 10):
+        assert torch.allclose(O.label_propagation(adj, labels, idx, K, 0.1),
+                              torch.from_numpy(golden[f"g2/{name}/K{K}/out"]), atol=1e-6)
+    h = torch.from_numpy(golden[f"g3/{name}/h"])
+    for K, alpha in ((1, 0.1), (10, 0.1), (4, 0.35)):
+        assert torch.allclose(O.pta_inference(h, adj, K, alpha),
+                              torch.from_numpy(golden[f"g3/{name}/K{K}_a{alpha}/out"]), atol=1e-6)
+
+
 # ---- hand-derived known answers (independent of the reference) -----------------------------------
 
 def test_kat_gcn_norm_duplicates_and_existing_loops():
