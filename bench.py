@@ -98,12 +98,28 @@ def cpu_baseline(ei, x, N, budget_s=20.0):
             "seconds_per_run": med}
 
 
+MODELS = {
+    # name: (constructor kwargs, propagates per epoch = 3 forwards + 1 backward, loops_mode, weighting kind)
+    "gcn": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 8, 1, "gcn"),
+    "graphsage": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 8, 2, "mean"),
+    "graphsage2": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 7, 0, "mean"),
+    "gat": (dict(num_layers=2, hidden_unit=16, heads=8, dropout_rate=0.5), 8, 2, "gat"),
+    "appnpstack": (dict(hidden_unit=64, K=10, alpha=0.1, dropout_rate=0.5), 40, 1, "gcn"),
+}
+AGG_KINDS = ("gcn_fwd", "gcn_bwd", "mean_fwd", "mean_bwd", "appnp_fwd", "appnp_bwd", "gat_fwd", "gat_bwd_dst",
+             "gat_bwd_src", "dist_fwd_local", "dist_fwd_remote", "dist_bwd_local", "dist_bwd_remote",
+             "dist_fwd_colshard", "dist_bwd_colshard")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="L")
+    ap.add_argument("--model", choices=sorted(MODELS), default="gcn",
+                    help="gcn is the BASELINE.json headline; the others are its configs 3-5")
+    ap.add_argument("--exchange", choices=["auto", "halo", "reshard"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -126,40 +142,58 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    from rgb_experiment_amd import models as M
     from rgb_experiment_amd import ops
-    from rgb_experiment_amd.models import GCN
 
     wl = WORKLOADS[args.workload]
     N, E, d = wl["N"], wl["E"], wl["d"]
     ei, x, y = synth(N, E, d)
     train_mask, val_mask, test_mask = split_masks(N)
+    kwargs, n_prop, loops_mode, kind = MODELS[args.model]
+    cls = {"gcn": M.GCN, "graphsage": M.GraphSAGE, "graphsage2": M.GraphSAGE2, "gat": M.GAT,
+           "appnpstack": M.APPNPStack}[args.model]
 
     torch.manual_seed(14530529)  # the reference's reappear_seed (itexperiments.py:57)
-    model = GCN(num_layers=2, hidden_unit=d, input_dim=d, output_dim=d, dropout_rate=0.5)
+    model = cls(input_dim=d, output_dim=d, **kwargs)
+    wl_name = wl["name"].replace("GCN", {"gcn": "GCN", "graphsage": "GraphSAGE", "graphsage2": "GraphSAGE2",
+                                         "gat": "GAT 8 heads", "appnpstack": "APPNP K=10"}[args.model])
 
+    comm_mb, scheme = 0.0, "single GPU"
     if world > 1:
-        from rgb_experiment_amd.dist import DistGCNRunner
-        from rgb_experiment_amd.graph import LOOPS_ADD_REMAINING
-        runner = DistGCNRunner(model, ei, x, y, (train_mask, val_mask, test_mask), rank, world, dev, lr=0.01)
-        plan = runner.plan(LOOPS_ADD_REMAINING, "gcn")  # partition + per-rank CSRs built here, once
-        nnz_total = plan.nnz_total
+        if args.model == "gat":
+            sys.exit("bench.py: GAT is not distributed yet (DESIGN.md section 4)")
+        from rgb_experiment_amd.dist import DistRunner
+        runner = DistRunner(model, ei, x, y, (train_mask, val_mask, test_mask), rank, world, dev, lr=0.01,
+                            exchange=args.exchange)
+        dgraph = runner.graphs[loops_mode]
         step = runner.epoch
-        n_loc = plan.n_local
-        nnz_loc, nnz_rem = int(plan.fwd.loc_agg.numel()), int(plan.fwd.rem_agg.numel())
-        # one propagate on a rank = local-source SpMM + remote-source SpMM accumulating into the same rows
-        alg = spmm_alg_bytes(n_loc, nnz_loc, d) + spmm_alg_bytes(n_loc, nnz_rem, d) + n_loc * 4 * d
-        halo_mb = plan.fwd.n_halo * d * 4 / 1e6
+        n_loc = runner.hi - runner.lo
+        scheme = dgraph.scheme(d)
+        if scheme == "reshard":  # whole graph at width d / P on every rank, two all-to-all transposes
+            nnz_total = dgraph._get_full(kind)["nnz"]
+            alg = spmm_alg_bytes(N, nnz_total, d // world)
+            comm_mb = 2 * n_loc * d * 4 * (world - 1) / world / 1e6
+        else:  # local-source SpMM + remote-source SpMM accumulating into the same rows
+            plan = dgraph.plan(kind)
+            nnz_total = plan.nnz_total
+            nnz_loc, nnz_rem = int(plan.fwd.loc_agg.numel()), int(plan.fwd.rem_agg.numel())
+            alg = spmm_alg_bytes(n_loc, nnz_loc, d) + spmm_alg_bytes(n_loc, nnz_rem, d) + n_loc * 4 * d
+            comm_mb = plan.fwd.n_halo * d * 4 / 1e6
     else:
-        from rgb_experiment_amd.graph import get_graph, LOOPS_ADD_REMAINING
+        from rgb_experiment_amd.graph import get_graph
         model.to(dev)
         ei_d, x_d, y_d = ei.to(dev), x.to(dev), y.to(dev)
         tm, vm, sm = train_mask.to(dev), val_mask.to(dev), test_mask.to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=0.01)
-        graph = get_graph(ei_d, N, LOOPS_ADD_REMAINING)
-        _ = graph.w, graph.w_t  # graph preparation happens once per edge_index, outside the loop
+        graph = get_graph(ei_d, N, loops_mode)  # graph preparation happens once per edge_index, outside the loop
+        _ = graph.bwd
+        if kind == "gcn":
+            _ = graph.w, graph.w_t
         nnz_total = graph.fwd.nnz
-        alg = spmm_alg_bytes(N, nnz_total, d)
-        halo_mb = 0.0
+        if kind == "gat":  # scores + rows per edge, out + saved max / 1/sum per node
+            alg = nnz_total * (4 + 4 * 8 + 4 * d) + N * (8 * d + 12 * 8) + 4 * (N + 1)
+        else:
+            alg = spmm_alg_bytes(N, nnz_total, d)
 
         def evaluate(mask):
             model.eval()
@@ -199,19 +233,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    n_prop = 8  # 6 forward + 2 transposed propagates per epoch (2-layer GCN)
-    kinds = ("gcn_fwd", "gcn_bwd") if world == 1 else ("dist_fwd_local", "dist_fwd_remote", "dist_bwd_local",
-                                                       "dist_bwd_remote")
-    spmm_total_ms = sum(s.elapsed_time(e) for kind, s, e in events if kind in kinds)
-    spmm_avg_s = spmm_total_ms * 1e-3 / (n_prop * args.steps)  # kernel time per propagate (on this rank)
-    achieved = alg / spmm_avg_s / 1e9
+    agg_total_ms = sum(s.elapsed_time(e) for k, s, e in events if k in AGG_KINDS)
+    agg_avg_s = agg_total_ms * 1e-3 / (n_prop * args.steps)  # aggregation kernel time per propagate (this rank)
+    achieved = alg / agg_avg_s / 1e9
     by_kind = {}
-    for kind, s, e in events:
-        by_kind.setdefault(kind, []).append(s.elapsed_time(e))
+    for k, s, e in events:
+        by_kind.setdefault(k, []).append(s.elapsed_time(e))
     by_kind = {k: {"n": len(v), "avg_ms": sum(v) / len(v)} for k, v in sorted(by_kind.items())}
+    kernel = {"gat": "gat_fwd_kernel<4> / gat_bwd_dst_kernel<4> / gat_bwd_src_kernel<4>"}.get(
+        args.model, "spmm_csr_kernel<32,4,*>" if scheme != "reshard" else f"spmm_csr_kernel at width {d // world}")
 
     result = {
-        "metric": "aggregated edges/sec (full-graph GCN d=128, reference epoch = train fwd+bwd+Adam + 2 eval fwd)",
+        "metric": "aggregated edges/sec (full-graph GCN d=128, reference epoch = train fwd+bwd+Adam + 2 eval fwd)"
+                  if args.model == "gcn" else f"aggregated edges/sec (full-graph {args.model} d=128, reference epoch)",
         "value": n_prop * nnz_total * args.steps / elapsed,
         "unit": "edges/s",
         "n_gpus": world,
@@ -223,19 +257,21 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": wl["name"], "nodes": N, "edges_in": E, "edges_aggregated_per_propagate": nnz_total,
+        "config": {"workload": wl_name, "nodes": N, "edges_in": E, "edges_aggregated_per_propagate": nnz_total,
                    "width": d, "propagates_per_step": n_prop,
-                   "parallelism": "single GPU" if world == 1 else f"1-D node partition x{world}, RCCL all-to-all halo"},
+                   "parallelism": "single GPU" if world == 1 else
+                   f"1-D node partition x{world}, RCCL all-to-all ({scheme} exchange)"},
         "epochs_per_s": args.steps / elapsed,
-        "spmm_edges_per_s": nnz_total / spmm_avg_s if world == 1 else None,
-        "spmm_ms": spmm_avg_s * 1e3,
-        "halo_mb_per_rank_per_propagate": halo_mb,
+        "spmm_edges_per_s": nnz_total / agg_avg_s if world == 1 else None,
+        "spmm_ms": agg_avg_s * 1e3,
+        "exchange_mb_per_rank_per_propagate": comm_mb,
         "kernel_ms_by_kind": by_kind,
         "final_losses": {"train": last[0], "val": last[1], "test": last[3]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),
-                     "kernel": "spmm_csr_kernel<32,4,true>", "algorithmic_bytes_per_launch": alg,
-                     "note": "rank 0's share (local + remote SpMM)" if world > 1 else "whole graph"},
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic(args.workload, world) if args.model == "gcn" else None,
+                     "kernel": kernel, "algorithmic_bytes_per_launch": alg,
+                     "note": "rank 0's share of one propagate" if world > 1 else "whole graph, one propagate"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ei, x, N)
