@@ -138,24 +138,25 @@ int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const 
                                float slope, rgbx_stream_t stream);
 
 /* Backward, target side (same CSR as forward). Per target i, head h:
- *   dsum[i,h]   = <gout[i,h,:], out[i,h,:]>
+ *   dsum[i,h]    = <gout[i,h,:], out[i,h,:]>
  *   g_a_dst[i,h] = sum_p alpha_p * (<gout[i,h,:], hfeat[col[p],h,:]> - dsum[i,h]) * lrelu'(s_p)
- * `dsum` ([N,H]) is an output consumed by the source-side pass. */
+ * `nodeq` ([N,H,4] floats, 16-byte aligned) is an output consumed by the source-side pass: the record
+ * (a_dst, m, rden, dsum) of every (target, head), so that pass needs one 16-byte gather per edge and
+ * head instead of four 4-byte ones. */
 int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                          int64_t ldh, const float* a_src, const float* a_dst, const float* m,
                          const float* rden, const float* out, int64_t ldo, const float* gout,
-                         int64_t ldg, float* dsum, float* g_a_dst, int64_t N, int H, int C,
+                         int64_t ldg, float* nodeq, float* g_a_dst, int64_t N, int H, int C,
                          float slope, rgbx_stream_t stream);
 
 /* Backward, source side, over the TRANSPOSED CSR (rows = sources j, col = targets i):
  *   g_hfeat[j,h,:] = sum_{p: j->i} alpha_p * gout[i,h,:]
  *   g_a_src[j,h]   = sum_{p: j->i} alpha_p * (<gout[i,h,:], hfeat[j,h,:]> - dsum[i,h]) * lrelu'(s_p)
- * alpha is recomputed from a_src, a_dst, m, rden; no edge-sized tensor is kept. */
+ * alpha is recomputed from a_src[j] and nodeq[i]; no edge-sized tensor is kept. */
 int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const float* hfeat,
-                         int64_t ldh, const float* a_src, const float* a_dst, const float* m,
-                         const float* rden, const float* dsum, const float* gout, int64_t ldg,
-                         float* g_hfeat, int64_t ldgh, float* g_a_src, int64_t N, int H, int C,
-                         float slope, rgbx_stream_t stream);
+                         int64_t ldh, const float* a_src, const float* nodeq, const float* gout,
+                         int64_t ldg, float* g_hfeat, int64_t ldgh, float* g_a_src, int64_t N, int H,
+                         int C, float slope, rgbx_stream_t stream);
 
 /* ---- dense weight gradient on the MFMA units ---------------------------------------------- */
 

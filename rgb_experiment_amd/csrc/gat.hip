@@ -167,7 +167,7 @@ gat_bwd_dst_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                    const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
                    const float* __restrict__ a_dst, const float* __restrict__ m_in,
                    const float* __restrict__ rden_in, const float* __restrict__ out, int64_t ldo,
-                   const float* __restrict__ gout, int64_t ldg, float* __restrict__ dsum_out,
+                   const float* __restrict__ gout, int64_t ldg, float4* __restrict__ nodeq_out,
                    float* __restrict__ g_a_dst, int N, float slope, const GatLayout L) {
   const int lane = threadIdx.x & 63;
   const int NG = kWave / L.G;
@@ -230,7 +230,8 @@ gat_bwd_dst_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
       }
       for (int off = 32; off >= L.G; off >>= 1) acc += __shfl_xor(acc, off);
       if (g == 0 && active && ch == 0) {
-        dsum_out[(int64_t)row * L.H + head] = dsum;
+        // everything the source-side pass needs about target (row, head), in ONE 16-byte record
+        nodeq_out[(int64_t)row * L.H + head] = make_float4(ad, mi, rd, dsum);
         g_a_dst[(int64_t)row * L.H + head] = acc;
       }
     }
@@ -243,9 +244,8 @@ template <int VEC>
 __global__ void __launch_bounds__(256)
 gat_bwd_src_kernel(const int* __restrict__ rowptr_t, const int* __restrict__ col_t,
                    const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
-                   const float* __restrict__ a_dst, const float* __restrict__ m_in,
-                   const float* __restrict__ rden_in, const float* __restrict__ dsum_in,
-                   const float* __restrict__ gout, int64_t ldg, float* __restrict__ g_hfeat,
+                   const float4* __restrict__ nodeq, const float* __restrict__ gout, int64_t ldg,
+                   float* __restrict__ g_hfeat,
                    int64_t ldgh, float* __restrict__ g_a_src, int N, float slope,
                    const GatLayout L) {
   const int lane = threadIdx.x & 63;
@@ -289,11 +289,11 @@ gat_bwd_src_kernel(const int* __restrict__ rowptr_t, const int* __restrict__ col
 #pragma unroll
             for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
             if (ok[u]) {
-              const int64_t q = (int64_t)tgt * L.H + head;
-              ad[u] = a_dst[q];
-              mi[u] = m_in[q];
-              rd[u] = rden_in[q];
-              dsm[u] = dsum_in[q];
+              const float4 q = nodeq[(int64_t)tgt * L.H + head];  // (a_dst, max, 1/sum, dsum)
+              ad[u] = q.x;
+              mi[u] = q.y;
+              rd[u] = q.z;
+              dsm[u] = q.w;
               load_vec<VEC>(v[u], gout + (int64_t)tgt * ldg + cofs);
             }
           }
@@ -409,14 +409,15 @@ extern "C" int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* 
 extern "C" int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                                     int64_t ldh, const float* a_src, const float* a_dst, const float* m,
                                     const float* rden, const float* out, int64_t ldo, const float* gout,
-                                    int64_t ldg, float* dsum, float* g_a_dst, int64_t N, int H, int C,
+                                    int64_t ldg, float* nodeq, float* g_a_dst, int64_t N, int H, int C,
                                     float slope, rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_bwd_dst")) return rc;
   if (N == 0) return RGBX_OK;
-  if (!rowptr || !col || !hfeat || !a_src || !a_dst || !m || !rden || !out || !gout || !dsum || !g_a_dst)
+  if (!rowptr || !col || !hfeat || !a_src || !a_dst || !m || !rden || !out || !gout || !nodeq || !g_a_dst)
     return fail(RGBX_E_ARG, "gat_bwd_dst: null pointer");
   const int64_t F = (int64_t)H * C;
   if (ldh < F || ldo < F || ldg < F) return fail(RGBX_E_ARG, "gat_bwd_dst: leading dimension < H*C");
+  if (!aligned16(nodeq)) return fail(RGBX_E_ALIGN, "gat_bwd_dst: nodeq must be 16-byte aligned");
   const int vec = pick_vec(C, {hfeat, out, gout}, {ldh, ldo, ldg});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_bwd_dst")) return rc;
@@ -424,7 +425,7 @@ extern "C" int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, c
   const int grid = gat_grid(N);
 #define RGBX_GAT_BD(V)                                                                              \
   gat_bwd_dst_kernel<V><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, a_dst, m, rden, out, ldo, \
-                                             gout, ldg, dsum, g_a_dst, (int)N, slope, L)
+                                             gout, ldg, reinterpret_cast<float4*>(nodeq), g_a_dst, (int)N, slope, L)
   if (vec == 4) RGBX_GAT_BD(4);
   else if (vec == 2) RGBX_GAT_BD(2);
   else RGBX_GAT_BD(1);
@@ -434,15 +435,14 @@ extern "C" int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, c
 }
 
 extern "C" int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const float* hfeat,
-                                    int64_t ldh, const float* a_src, const float* a_dst, const float* m,
-                                    const float* rden, const float* dsum, const float* gout, int64_t ldg,
-                                    float* g_hfeat, int64_t ldgh, float* g_a_src, int64_t N, int H, int C,
-                                    float slope, rgbx_stream_t stream) {
+                                    int64_t ldh, const float* a_src, const float* nodeq, const float* gout,
+                                    int64_t ldg, float* g_hfeat, int64_t ldgh, float* g_a_src, int64_t N, int H,
+                                    int C, float slope, rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_bwd_src")) return rc;
   if (N == 0) return RGBX_OK;
-  if (!rowptr_t || !col_t || !hfeat || !a_src || !a_dst || !m || !rden || !dsum || !gout || !g_hfeat ||
-      !g_a_src)
+  if (!rowptr_t || !col_t || !hfeat || !a_src || !nodeq || !gout || !g_hfeat || !g_a_src)
     return fail(RGBX_E_ARG, "gat_bwd_src: null pointer");
+  if (!aligned16(nodeq)) return fail(RGBX_E_ALIGN, "gat_bwd_src: nodeq must be 16-byte aligned");
   const int64_t F = (int64_t)H * C;
   if (ldh < F || ldg < F || ldgh < F) return fail(RGBX_E_ARG, "gat_bwd_src: leading dimension < H*C");
   const int vec = pick_vec(C, {hfeat, gout, g_hfeat}, {ldh, ldg, ldgh});
@@ -451,8 +451,9 @@ extern "C" int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_
   hipStream_t s = (hipStream_t)stream;
   const int grid = gat_grid(N);
 #define RGBX_GAT_BS(V)                                                                                \
-  gat_bwd_src_kernel<V><<<grid, 256, 0, s>>>(rowptr_t, col_t, hfeat, ldh, a_src, a_dst, m, rden, dsum,  \
-                                             gout, ldg, g_hfeat, ldgh, g_a_src, (int)N, slope, L)
+  gat_bwd_src_kernel<V><<<grid, 256, 0, s>>>(rowptr_t, col_t, hfeat, ldh, a_src,                          \
+                                             reinterpret_cast<const float4*>(nodeq), gout, ldg, g_hfeat, ldgh, \
+                                             g_a_src, (int)N, slope, L)
   if (vec == 4) RGBX_GAT_BS(4);
   else if (vec == 2) RGBX_GAT_BS(2);
   else RGBX_GAT_BS(1);

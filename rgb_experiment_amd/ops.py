@@ -228,9 +228,9 @@ class _GATAggregate(torch.autograd.Function):
         gout = gout.contiguous()
         N, dev = g.N, gout.device
         lib = _lib.load()
-        dsum = torch.empty((N, H), dtype=torch.float32, device=dev)
-        g_ad = torch.empty_like(dsum)
-        g_as = torch.empty_like(dsum)
+        nodeq = torch.empty((N, H, 4), dtype=torch.float32, device=dev)  # (a_dst, max, 1/sum, dsum) records
+        g_ad = torch.empty((N, H), dtype=torch.float32, device=dev)
+        g_as = torch.empty_like(g_ad)
         g_h = torch.empty_like(hfeat)
         ph, ldh = _lib.mat(hfeat, "hfeat")
         po, ldo = _lib.mat(out, "out")
@@ -240,13 +240,12 @@ class _GATAggregate(torch.autograd.Function):
             _lib.check(
                 lib.rgbx_gat_bwd_dst_f32(_lib.ptr(g.fwd.rowptr), _lib.ptr(g.fwd.col), ph, ldh, _lib.ptr(a_src),
                                          _lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, pg, ldg,
-                                         _lib.ptr(dsum), _lib.ptr(g_ad), N, H, C, float(slope),
+                                         _lib.ptr(nodeq), _lib.ptr(g_ad), N, H, C, float(slope),
                                          _lib.stream_ptr()), "rgbx_gat_bwd_dst_f32")
         with _Timed("gat_bwd_src"):
             _lib.check(
                 lib.rgbx_gat_bwd_src_f32(_lib.ptr(g.bwd.rowptr), _lib.ptr(g.bwd.col), ph, ldh, _lib.ptr(a_src),
-                                         _lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), _lib.ptr(dsum), pg, ldg,
-                                         pgh, ldgh, _lib.ptr(g_as), N, H, C, float(slope),
+                                         _lib.ptr(nodeq), pg, ldg, pgh, ldgh, _lib.ptr(g_as), N, H, C, float(slope),
                                          _lib.stream_ptr()), "rgbx_gat_bwd_src_f32")
         return g_h, g_as, g_ad, None, None, None, None
 
