@@ -160,16 +160,22 @@ def main():
 
     comm_mb, scheme = 0.0, "single GPU"
     if world > 1:
-        if args.model == "gat":
-            sys.exit("bench.py: GAT is not distributed yet (DESIGN.md section 4)")
         from rgb_experiment_amd.dist import DistRunner
         runner = DistRunner(model, ei, x, y, (train_mask, val_mask, test_mask), rank, world, dev, lr=0.01,
                             exchange=args.exchange)
         dgraph = runner.graphs[loops_mode]
         step = runner.epoch
         n_loc = runner.hi - runner.lo
-        scheme = dgraph.scheme(d)
-        if scheme == "reshard":  # whole graph at width d / P on every rank, two all-to-all transposes
+        scheme = dgraph.scheme(d) if kind != "gat" else "halo"
+        if kind == "gat":  # halo rows appended to the local rows, one rectangular CSR
+            model.eval()
+            with torch.no_grad():
+                model(runner.x, runner.token)  # builds the plan + rectangular CSRs once, outside the timing
+            plan = dgraph._kinds["gat"]["plan"]
+            nnz_total = plan.nnz_total
+            alg = plan.nnz_local * (4 + 4 * 8 + 4 * d) + n_loc * (8 * d + 12 * 8) + 4 * (n_loc + 1)
+            comm_mb = plan.fwd.n_halo * d * 4 / 1e6
+        elif scheme == "reshard":  # whole graph at width d / P on every rank, two all-to-all transposes
             nnz_total = dgraph._get_full(kind)["nnz"]
             alg = spmm_alg_bytes(N, nnz_total, d // world)
             comm_mb = 2 * n_loc * d * 4 * (world - 1) / world / 1e6

@@ -28,6 +28,54 @@ class HipAggregator:
         from .. import ops
         return ops.gather_rows(x, idx)
 
+    def scatter_add(self, src, idx, dst):
+        from .. import ops
+        return ops.scatter_add_rows(src, idx, dst)
+
+    def prepare_rect(self, agg, gather, n_tgt, n_src):
+        """Rectangular graph: targets [0, n_tgt) aggregate from sources [0, n_src) (local rows + halo)."""
+        return _RectGraph(_graph.build_csr(agg, gather, n_tgt, _graph.LOOPS_KEEP),
+                          _graph.build_csr(gather, agg, n_src, _graph.LOOPS_KEEP))
+
+    def gat(self, rect, x_ext, att_src, att_dst, n_tgt, H, C, slope):
+        from .. import ops
+        a_src, a_dst = ops.gat_scores(x_ext, att_src, att_dst, H, C)
+        return ops.gat_aggregate(x_ext, a_src, a_dst[:n_tgt], rect, H, C, slope)
+
+
+class _RectGraph:
+    def __init__(self, fwd, bwd):
+        self.fwd, self.bwd = fwd, bwd
+
+
+class _HaloGather(torch.autograd.Function):
+    """x_local [n_local, d] -> [x_local; halo rows] with the boundary rows fetched by one all-to-all.
+    Backward sends the halo part of the gradient home and adds it to the owners' rows (one
+    unique-index scatter-add per peer, in rank order: deterministic)."""
+
+    @staticmethod
+    def forward(ctx, x, dgraph, half):
+        ctx.dgraph, ctx.half = dgraph, half
+        x = x.contiguous()
+        send = dgraph.backend.gather(x, half.send_idx) if half.n_send else x.new_empty((0, x.size(1)))
+        recv, work = dgraph.comm.all_to_all_rows(send, half.send_counts, half.recv_counts)
+        work.wait()
+        return torch.cat([x, recv], dim=0)
+
+    @staticmethod
+    def backward(ctx, g_ext):
+        dgraph, half = ctx.dgraph, ctx.half
+        n = half.n_local
+        g_loc = g_ext[:n].clone()
+        back, work = dgraph.comm.all_to_all_rows(g_ext[n:].contiguous(), half.recv_counts, half.send_counts)
+        work.wait()
+        off = 0
+        for cnt in half.send_counts:
+            if cnt:
+                dgraph.backend.scatter_add(back[off:off + cnt], half.send_idx[off:off + cnt], g_loc)
+            off += cnt
+        return g_loc, None, None
+
 
 class _DistPropagate(torch.autograd.Function):
     @staticmethod
@@ -159,6 +207,23 @@ class DistGraph:
 
     def propagate(self, x, kind):
         return _DistPropagate.apply(x, self, kind)
+
+    # ---- GAT: attention needs every in-edge of a target in one softmax, so the halo rows are appended to
+    # the local rows and ONE rectangular CSR (local targets x [local; halo] sources) feeds the same fused
+    # kernels as the single-GPU path. a_src of halo rows is recomputed locally from the received rows.
+    def gat(self, h, att_src, att_dst, H, C, slope):
+        st = self._kinds.get("gat")
+        if st is None:
+            plan = PartitionPlan(self.edge_index, self.N_global, self.comm.world, self.comm.rank,
+                                 self.loops_mode, "sum")
+            f = plan.fwd
+            agg = torch.cat([f.loc_agg, f.rem_agg])
+            gather = torch.cat([f.loc_gather, f.n_local + f.rem_gather])
+            st = {"plan": plan, "rect": self.backend.prepare_rect(agg, gather, f.n_local, f.n_local + f.n_halo)}
+            self._kinds["gat"] = st
+        half = st["plan"].fwd
+        x_ext = _HaloGather.apply(h, self, half) if self.comm.world > 1 else h
+        return self.backend.gat(st["rect"], x_ext, att_src, att_dst, half.n_local, H, C, slope)
 
 
 def install(token_edge_index, n_local, edge_index, num_nodes, comm=None, backend=None, exchange="auto"):

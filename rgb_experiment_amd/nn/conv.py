@@ -110,8 +110,7 @@ class GATConv(nn.Module):
         H, C = self.heads, self.out_channels
         graph = get_graph(edge_index, x.size(0), LOOPS_REMOVE_ADD)
         h = ops.linear(x, self.lin_src.weight)
-        a_src, a_dst = ops.gat_scores(h, self.att_src, self.att_dst, H, C)
-        out = ops.gat_aggregate(h, a_src, a_dst, graph, H, C, self.negative_slope)
+        out = ops.gat_attend(h, self.att_src, self.att_dst, graph, H, C, self.negative_slope)
         if not self.concat:
             out = out.view(-1, H, C).mean(dim=1)
         return out + self.bias

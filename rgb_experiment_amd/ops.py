@@ -203,7 +203,7 @@ class _GATAggregate(torch.autograd.Function):
     def forward(ctx, hfeat, a_src, a_dst, graph, H, C, slope):
         _lib.require_device(hfeat, a_src, a_dst)
         hfeat, a_src, a_dst = hfeat.contiguous(), a_src.contiguous(), a_dst.contiguous()
-        N = graph.N
+        N = graph.fwd.N  # targets; hfeat / a_src may have more rows (sources incl. a halo) than targets
         dev = hfeat.device
         out = torch.empty((N, H * C), dtype=torch.float32, device=dev)
         m = torch.empty((N, H), dtype=torch.float32, device=dev)
@@ -226,11 +226,11 @@ class _GATAggregate(torch.autograd.Function):
         hfeat, a_src, a_dst, m, rden, out = ctx.saved_tensors
         g, H, C, slope = ctx.graph, ctx.H, ctx.C, ctx.slope
         gout = gout.contiguous()
-        N, dev = g.N, gout.device
+        N, n_src, dev = g.fwd.N, g.bwd.N, gout.device
         lib = _lib.load()
         nodeq = torch.empty((N, H, 4), dtype=torch.float32, device=dev)  # (a_dst, max, 1/sum, dsum) records
         g_ad = torch.empty((N, H), dtype=torch.float32, device=dev)
-        g_as = torch.empty_like(g_ad)
+        g_as = torch.empty((n_src, H), dtype=torch.float32, device=dev)
         g_h = torch.empty_like(hfeat)
         ph, ldh = _lib.mat(hfeat, "hfeat")
         po, ldo = _lib.mat(out, "out")
@@ -245,7 +245,8 @@ class _GATAggregate(torch.autograd.Function):
         with _Timed("gat_bwd_src"):
             _lib.check(
                 lib.rgbx_gat_bwd_src_f32(_lib.ptr(g.bwd.rowptr), _lib.ptr(g.bwd.col), ph, ldh, _lib.ptr(a_src),
-                                         _lib.ptr(nodeq), pg, ldg, pgh, ldgh, _lib.ptr(g_as), N, H, C, float(slope),
+                                         _lib.ptr(nodeq), pg, ldg, pgh, ldgh, _lib.ptr(g_as), n_src, H, C,
+                                         float(slope),
                                          _lib.stream_ptr()), "rgbx_gat_bwd_src_f32")
         return g_h, g_as, g_ad, None, None, None, None
 
@@ -256,6 +257,14 @@ def gat_scores(hfeat, att_src, att_dst, H, C):
 
 def gat_aggregate(hfeat, a_src, a_dst, graph, H, C, slope=0.2):
     return _GATAggregate.apply(hfeat, a_src, a_dst, graph, H, C, slope)
+
+
+def gat_attend(h, att_src, att_dst, graph, H, C, slope=0.2):
+    """Scores + edge-softmax + aggregation of one GATConv; dispatches to the partitioned graph."""
+    if _is_dist(graph):
+        return graph.gat(h, att_src, att_dst, H, C, slope)
+    a_src, a_dst = gat_scores(h, att_src, att_dst, H, C)
+    return gat_aggregate(h, a_src, a_dst, graph, H, C, slope)
 
 
 def gather_rows(src, idx, out=None):

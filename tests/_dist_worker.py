@@ -28,6 +28,24 @@ class OracleAggregator:
     def gather(self, x, idx):
         return x[idx.long()]
 
+    def scatter_add(self, src, idx, dst):
+        return dst.index_add_(0, idx.long(), src)
+
+    def prepare_rect(self, agg, gather, n_tgt, n_src):
+        return torch.stack([gather, agg]), n_tgt
+
+    def gat(self, rect, x_ext, att_src, att_dst, n_tgt, H, C, slope):
+        """GATConv attention on a rectangular graph (targets = the first n_tgt rows), plain torch ops."""
+        ei, _ = rect
+        h = x_ext.view(-1, H, C)
+        a_s = (h * att_src.view(1, H, C)).sum(-1)
+        a_d = (h[:n_tgt] * att_dst.view(1, H, C)).sum(-1)
+        src, dst = ei[0], ei[1]
+        e = torch.nn.functional.leaky_relu(a_s[src] + a_d[dst], slope)
+        alpha = O.segment_softmax(e, dst, n_tgt)
+        out = torch.zeros((n_tgt, H, C), dtype=x_ext.dtype).index_add_(0, dst, h[src] * alpha.unsqueeze(-1))
+        return out.reshape(n_tgt, H * C)
+
 
 def make_problem(n=97, e=900, f=12, c=5, seed=0):
     g = torch.Generator().manual_seed(seed)
@@ -99,6 +117,8 @@ def build_model(M, name, f, c):
         return M.GraphSAGE2(num_layers=2, hidden_unit=16, input_dim=f, output_dim=c, dropout_rate=0.5)
     if name == "appnpstack":
         return M.APPNPStack(hidden_unit=16, input_dim=f, output_dim=c, K=4, alpha=0.1, dropout_rate=0.5)
+    if name == "gat":
+        return M.GAT(num_layers=2, hidden_unit=4, heads=3, input_dim=f, output_dim=c, dropout_rate=0.5)
     raise KeyError(name)
 
 

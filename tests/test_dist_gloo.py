@@ -94,6 +94,8 @@ def _single_process_reference(model_name):
             return O.graphsage_forward(params, x, ei, 2, training)
         if model_name == "graphsage2":
             return O.graphsage2_forward(params, x, ei, 2, training)
+        if model_name == "gat":
+            return O.gat_forward(params, x, ei, 2, 3, training)
         return O.appnp_stack_forward(params, x, ei, 4, 0.1, training)
 
     hist = []
@@ -114,7 +116,8 @@ def _single_process_reference(model_name):
 
 @pytest.mark.parametrize("model_name,world,exchange", [("gcn", 2, "halo"), ("gcn", 3, "halo"), ("graphsage", 2, "halo"),
                                                         ("graphsage2", 2, "halo"), ("appnpstack", 2, "halo"),
-                                                        ("gcn", 2, "reshard"), ("graphsage2", 2, "auto")])
+                                                        ("gcn", 2, "reshard"), ("graphsage2", 2, "auto"), ("gat", 2, "halo"),
+                                                        ("gat", 3, "auto")])
 def test_dist_runner_training_matches_single_process(model_name, world, exchange, tmp_path):
     """Train-mode BatchNorm uses batch statistics in the oracle and reduced statistics in the runner, so
     train losses and trained WEIGHTS must agree; eval losses use running statistics, which the
@@ -132,7 +135,8 @@ def test_dist_runner_training_matches_single_process(model_name, world, exchange
         assert abs(parts[0]["hist"][step][0] - hist[step][0]) < 2e-5, (step, parts[0]["hist"][step], hist[step])
     # A bias added right before a BatchNorm has an exactly-zero true gradient (BN removes constant
     # shifts); Adam turns its rounding noise into +-lr steps, so those entries are not comparable.
-    last = {"gcn": "convs.2.", "graphsage": "convs.1.", "graphsage2": "convs.1.", "appnpstack": "lin2."}[model_name]
+    last = {"gcn": "convs.2.", "graphsage": "convs.1.", "graphsage2": "convs.1.", "appnpstack": "lin2.",
+            "gat": "convs.1."}[model_name]
     for k, v in params.items():
         pre_bn_bias = k.endswith("bias") and not k.startswith(("bns.", "bn.", last))
         if v.is_floating_point() and "running" not in k and not pre_bn_bias:
