@@ -103,6 +103,23 @@ int rgbx_inv_degree_f32(const int32_t* rowptr, int64_t N, float* inv, rgbx_strea
 
 /* ---- aggregation ------------------------------------------------------------------------- */
 
+/* Optional plan for rows with very many slots (hub nodes). Rows with more than `threshold` slots are
+ * skipped by the row-per-wave kernel; each is cut into consecutive chunks (chunk c covers slots
+ * [chunk_begin[c], chunk_end[c]) of the CSR), one wave sums one chunk into partial[c, :], and the
+ * partials of long row r (chunks long_chunk_ptr[r] .. long_chunk_ptr[r+1]) are added in chunk order
+ * before the epilogue — bitwise reproducible, no atomics. All arrays are device memory owned by the
+ * caller; `partial` is an [n_chunks, d] fp32 scratch. NULL (or threshold 0) = no splitting. */
+typedef struct rgbx_row_split {
+  int32_t threshold;
+  int32_t n_chunks;
+  int32_t n_long;
+  const int32_t* chunk_begin;    /* [n_chunks] */
+  const int32_t* chunk_end;      /* [n_chunks] */
+  const int32_t* long_row;       /* [n_long] row ids, ascending */
+  const int32_t* long_chunk_ptr; /* [n_long + 1] */
+  float* partial;                /* [n_chunks, d] */
+} rgbx_row_split_t;
+
 /* out[i,:] = a * rs[i] * sum_{p in row i} w[p] * x[col[p],:]  +  b * y[i,:]  +  bias[:]
  *   w  == NULL -> every weight is 1;  rs == NULL -> every row scale is 1;
  *   y  == NULL -> no additive term (b ignored);  bias == NULL -> no per-column term (the conv
@@ -111,13 +128,13 @@ int rgbx_inv_degree_f32(const int32_t* rowptr, int64_t N, float* inv, rgbx_strea
 int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
                       const float* x, int64_t ldx, const float* y, int64_t ldy, const float* bias,
                       float* out, int64_t ldo, int64_t N, int64_t d, float a, float b,
-                      rgbx_stream_t stream);
+                      const rgbx_row_split_t* split, rgbx_stream_t stream);
 
 /* z_0 = h;  z_{k+1} = (1-alpha) * A_hat z_k + alpha * h, k = 0..K-1; result in `out`.
  * `tmp` is an [N, d] scratch (ld = ldo); h, out, tmp must not alias. K >= 0. */
 int rgbx_appnp_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* h,
                    int64_t ldh, float* out, float* tmp, int64_t ldo, int64_t N, int64_t d, int K,
-                   float alpha, rgbx_stream_t stream);
+                   float alpha, const rgbx_row_split_t* split, rgbx_stream_t stream);
 
 /* ---- GAT: fused score + edge-softmax + aggregate ------------------------------------------ */
 

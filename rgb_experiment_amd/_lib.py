@@ -17,6 +17,13 @@ _I64 = ctypes.c_int64
 _I = ctypes.c_int
 _F = ctypes.c_float
 
+class RowSplit(ctypes.Structure):
+    """rgbx_row_split_t"""
+    _fields_ = [("threshold", ctypes.c_int32), ("n_chunks", ctypes.c_int32), ("n_long", ctypes.c_int32),
+                ("chunk_begin", ctypes.c_void_p), ("chunk_end", ctypes.c_void_p), ("long_row", ctypes.c_void_p),
+                ("long_chunk_ptr", ctypes.c_void_p), ("partial", ctypes.c_void_p)]
+
+
 # name -> argtypes, exactly the declarations of include/rgbx_hip.h
 SIGNATURES = {
     "rgbx_csr_workspace_bytes": [_I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
@@ -24,8 +31,8 @@ SIGNATURES = {
     "rgbx_deg_inv_sqrt_f32": [_P, _I64, _P, _P],
     "rgbx_gcn_norm_f32": [_P, _P, _I64, _P, _P, _P],
     "rgbx_inv_degree_f32": [_P, _I64, _P, _P],
-    "rgbx_spmm_csr_f32": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _F, _F, _P],
-    "rgbx_appnp_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _F, _P],
+    "rgbx_spmm_csr_f32": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _F, _F, _P, _P],
+    "rgbx_appnp_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _F, _P, _P],
     "rgbx_gat_scores_f32": [_P, _I64, _P, _P, _P, _P, _I64, _I, _I, _P],
     "rgbx_gat_aggregate_fwd_f32": [_P, _P, _P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I, _I, _F, _P],
     "rgbx_gat_bwd_dst_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I,

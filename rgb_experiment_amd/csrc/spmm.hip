@@ -10,6 +10,12 @@
 // 1 KiB per wave-instruction, two neighbours per instruction). U steps are issued back to back
 // so 8 neighbour rows are in flight per wave. The 64 column indices (and weights) of a row
 // chunk are read once, coalesced, and handed to the groups with ds_bpermute.
+//
+// Degree skew: a row owned by one wave runs as long as its slot list, so hub rows (thousands of
+// in-edges against a median of tens) would set the kernel time. With a row-split plan
+// (rgbx_row_split_t) the main kernel skips rows longer than the threshold; their slot lists are cut
+// into fixed chunks summed by separate waves into a partial buffer, and a last pass adds each
+// row's partials in chunk order (bitwise reproducible) and applies the epilogue.
 #include "rgbx_common.h"
 
 namespace rgbx {
@@ -27,14 +33,80 @@ struct SpmmArgs {
   int64_t ldx, ldy, ldo;
   int N, d;
   float a, b;
+  int skip_longer;  // > 0: rows with more slots than this are left to the split-row kernels
 };
+
+// Weighted sum of the gathered rows of slots [start, end) into acc (this lane's VEC columns, base
+// pointer xc). On return the NG groups' partial sums are folded: every lane of a column holds the total.
+template <int G, int VEC, bool HAS_W>
+__device__ __forceinline__ void accumulate_slots(const SpmmArgs& A, int start, int end, const float* xc,
+                                                 bool active, int lane, int g, float (&acc)[VEC]) {
+  constexpr int NG = kWave / G;
+  constexpr int U = 4;
+  for (int base = start; base < end; base += kWave) {
+    const int n = min(kWave, end - base);
+    int mycol = 0;
+    float myw = 0.f;
+    if (lane < n) {
+      mycol = A.col[base + lane];
+      if constexpr (HAS_W) myw = A.w[base + lane];
+    }
+    for (int k = 0; k < n; k += NG * U) {
+      float v[U][VEC];
+      float ww[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = k + u * NG + g;
+        const int src = __shfl(mycol, idx & 63);
+        if constexpr (HAS_W) ww[u] = __shfl(myw, idx & 63);
+        const bool ok = active && idx < n;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+        if (ok) load_vec<VEC>(v[u], xc + (int64_t)src * A.ldx);
+        if constexpr (HAS_W) { if (!ok) ww[u] = 0.f; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          if constexpr (HAS_W) acc[i] = fmaf(ww[u], v[u][i], acc[i]);
+          else acc[i] += v[u][i];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= G; off >>= 1) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void spmm_epilogue(const SpmmArgs& A, int row, int c, const float (&acc)[VEC]) {
+  const float scale = A.rs ? A.a * A.rs[row] : A.a;
+  float r[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) r[i] = scale * acc[i];
+  if (A.y) {
+    float yv[VEC];
+    load_vec<VEC>(yv, A.y + (int64_t)row * A.ldy + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] = fmaf(A.b, yv[i], r[i]);
+  }
+  if (A.bias) {
+    float bv[VEC];
+    load_vec<VEC>(bv, A.bias + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] += bv[i];
+  }
+  store_vec<VEC>(A.out + (int64_t)row * A.ldo + c, r);
+}
 
 // G lanes per neighbour row, VEC floats per lane; columns beyond G*VEC are covered by an outer
 // chunk loop (only taken for d > G*VEC, i.e. d > 256 on the float4 path).
 template <int G, int VEC, bool HAS_W>
 __global__ void __launch_bounds__(256) spmm_csr_kernel(const SpmmArgs A) {
-  constexpr int NG = kWave / G;
-  constexpr int U = 4;
   const int lane = threadIdx.x & 63;
   const int g = lane / G;
   const int t = lane % G;
@@ -45,77 +117,70 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const SpmmArgs A) {
   for (int row = wave0; row < A.N; row += wstride) {
     const int start = __builtin_amdgcn_readfirstlane(A.rowptr[row]);
     const int end = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
+    if (A.skip_longer > 0 && end - start > A.skip_longer) continue;  // split-row kernels own it
     for (int cbase = 0; cbase < A.d; cbase += G * VEC) {
       const int c = cbase + t * VEC;
       const bool active = c < A.d;
-      const float* xc = A.x + c;
       float acc[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      accumulate_slots<G, VEC, HAS_W>(A, start, end, A.x + c, active, lane, g, acc);
+      if (g == 0 && active) spmm_epilogue<VEC>(A, row, c, acc);
+    }
+  }
+}
 
-      for (int base = start; base < end; base += kWave) {
-        const int n = min(kWave, end - base);
-        int mycol = 0;
-        float myw = 0.f;
-        if (lane < n) {
-          mycol = A.col[base + lane];
-          if constexpr (HAS_W) myw = A.w[base + lane];
-        }
-        for (int k = 0; k < n; k += NG * U) {
-          float v[U][VEC];
-          float ww[U];
+// One wave per chunk of a long row: raw weighted sums (no epilogue) into partial[chunk, d].
+template <int G, int VEC, bool HAS_W>
+__global__ void __launch_bounds__(256)
+spmm_chunk_kernel(const SpmmArgs A, int n_chunks, const int* __restrict__ chunk_begin,
+                  const int* __restrict__ chunk_end, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane / G;
+  const int t = lane % G;
+  const int wpb = blockDim.x >> 6;
+  for (int ch = blockIdx.x * wpb + (threadIdx.x >> 6); ch < n_chunks; ch += gridDim.x * wpb) {
+    const int start = __builtin_amdgcn_readfirstlane(chunk_begin[ch]);
+    const int end = __builtin_amdgcn_readfirstlane(chunk_end[ch]);
+    for (int cbase = 0; cbase < A.d; cbase += G * VEC) {
+      const int c = cbase + t * VEC;
+      const bool active = c < A.d;
+      float acc[VEC];
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int idx = k + u * NG + g;
-            const int src = __shfl(mycol, idx & 63);
-            if constexpr (HAS_W) ww[u] = __shfl(myw, idx & 63);
-            const bool ok = active && idx < n;
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      accumulate_slots<G, VEC, HAS_W>(A, start, end, A.x + c, active, lane, g, acc);
+      if (g == 0 && active) store_vec<VEC>(partial + (int64_t)ch * A.d + c, acc);
+    }
+  }
+}
+
+// One wave per long row: partials added in chunk order, then the normal epilogue.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+spmm_combine_kernel(const SpmmArgs A, int n_long, const int* __restrict__ long_row,
+                    const int* __restrict__ long_chunk_ptr, const float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < n_long; r += gridDim.x * wpb) {
+    const int row = long_row[r];
+    const int c0 = long_chunk_ptr[r], c1 = long_chunk_ptr[r + 1];
+    for (int c = lane * VEC; c < A.d; c += kWave * VEC) {
+      float acc[VEC];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
-            if (ok) load_vec<VEC>(v[u], xc + (int64_t)src * A.ldx);
-            if constexpr (HAS_W) { if (!ok) ww[u] = 0.f; }
-          }
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      for (int ch = c0; ch < c1; ++ch) {
+        float p[VEC];
+        load_vec<VEC>(p, partial + (int64_t)ch * A.d + c);
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-              if constexpr (HAS_W) acc[i] = fmaf(ww[u], v[u][i], acc[i]);
-              else acc[i] += v[u][i];
-            }
-          }
-        }
+        for (int i = 0; i < VEC; ++i) acc[i] += p[i];
       }
-      // fold the NG neighbour groups together
-#pragma unroll
-      for (int off = 32; off >= G; off >>= 1) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
-      }
-      if (g == 0 && active) {
-        const float scale = A.rs ? A.a * A.rs[row] : A.a;
-        float r[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) r[i] = scale * acc[i];
-        if (A.y) {
-          float yv[VEC];
-          load_vec<VEC>(yv, A.y + (int64_t)row * A.ldy + c);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) r[i] = fmaf(A.b, yv[i], r[i]);
-        }
-        if (A.bias) {
-          float bv[VEC];
-          load_vec<VEC>(bv, A.bias + c);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) r[i] += bv[i];
-        }
-        store_vec<VEC>(A.out + (int64_t)row * A.ldo + c, r);
-      }
+      spmm_epilogue<VEC>(A, row, c, acc);
     }
   }
 }
 
 template <int G, int VEC>
-int launch(const SpmmArgs& A, hipStream_t s) {
+int launch(const SpmmArgs& A, const rgbx_row_split_t* sp, hipStream_t s) {
   constexpr int kWavesPerBlock = 4;
   int64_t blocks = cdiv(A.N, kWavesPerBlock);
   if (blocks > kMaxGrid) blocks = kMaxGrid;
@@ -124,36 +189,59 @@ int launch(const SpmmArgs& A, hipStream_t s) {
   else
     spmm_csr_kernel<G, VEC, false><<<(int)blocks, 256, 0, s>>>(A);
   RGBX_CHECK_LAUNCH("spmm_csr_kernel");
+  if (sp) {
+    int64_t cb = cdiv(sp->n_chunks, kWavesPerBlock);
+    if (cb > kMaxGrid) cb = kMaxGrid;
+    if (A.w)
+      spmm_chunk_kernel<G, VEC, true><<<(int)cb, 256, 0, s>>>(A, sp->n_chunks, sp->chunk_begin, sp->chunk_end,
+                                                             sp->partial);
+    else
+      spmm_chunk_kernel<G, VEC, false><<<(int)cb, 256, 0, s>>>(A, sp->n_chunks, sp->chunk_begin, sp->chunk_end,
+                                                              sp->partial);
+    RGBX_CHECK_LAUNCH("spmm_chunk_kernel");
+    int64_t lb = cdiv(sp->n_long, kWavesPerBlock);
+    if (lb > kMaxGrid) lb = kMaxGrid;
+    spmm_combine_kernel<VEC><<<(int)lb, 256, 0, s>>>(A, sp->n_long, sp->long_row, sp->long_chunk_ptr, sp->partial);
+    RGBX_CHECK_LAUNCH("spmm_combine_kernel");
+  }
   return RGBX_OK;
 }
 
 template <int VEC>
-int dispatch_groups(const SpmmArgs& A, hipStream_t s) {
+int dispatch_groups(const SpmmArgs& A, const rgbx_row_split_t* sp, hipStream_t s) {
   const int lanes = (A.d + VEC - 1) / VEC;  // lanes needed to cover one row
-  if (lanes <= 1) return launch<1, VEC>(A, s);
-  if (lanes <= 2) return launch<2, VEC>(A, s);
-  if (lanes <= 4) return launch<4, VEC>(A, s);
-  if (lanes <= 8) return launch<8, VEC>(A, s);
-  if (lanes <= 16) return launch<16, VEC>(A, s);
-  if (lanes <= 32) return launch<32, VEC>(A, s);
-  return launch<64, VEC>(A, s);
+  if (lanes <= 1) return launch<1, VEC>(A, sp, s);
+  if (lanes <= 2) return launch<2, VEC>(A, sp, s);
+  if (lanes <= 4) return launch<4, VEC>(A, sp, s);
+  if (lanes <= 8) return launch<8, VEC>(A, sp, s);
+  if (lanes <= 16) return launch<16, VEC>(A, sp, s);
+  if (lanes <= 32) return launch<32, VEC>(A, sp, s);
+  return launch<64, VEC>(A, sp, s);
 }
 
-}  // namespace
-
-int spmm_dispatch(const SpmmArgs& A, hipStream_t s) {
+int spmm_dispatch(SpmmArgs A, const rgbx_row_split_t* split, hipStream_t s) {
+  const rgbx_row_split_t* sp = nullptr;
+  if (split && split->threshold > 0 && split->n_chunks > 0) {
+    if (split->n_long <= 0 || !split->chunk_begin || !split->chunk_end || !split->long_row ||
+        !split->long_chunk_ptr || !split->partial)
+      return fail(RGBX_E_ARG, "spmm: incomplete row-split plan");
+    sp = split;
+    A.skip_longer = split->threshold;
+  }
   auto vec_ok = [&](int v) {
     const uintptr_t mask = (uintptr_t)v * 4 - 1;
     auto okp = [&](const void* p, int64_t ld) {
       return !p || (((reinterpret_cast<uintptr_t>(p) & mask) == 0) && (ld % v == 0));
     };
-    return A.d % v == 0 && okp(A.x, A.ldx) && okp(A.y, A.ldy) && okp(A.out, A.ldo) && okp(A.bias, v);
+    return A.d % v == 0 && okp(A.x, A.ldx) && okp(A.y, A.ldy) && okp(A.out, A.ldo) && okp(A.bias, v) &&
+           (!sp || okp(sp->partial, v));
   };
-  if (vec_ok(4)) return dispatch_groups<4>(A, s);
-  if (vec_ok(2)) return dispatch_groups<2>(A, s);
-  return dispatch_groups<1>(A, s);
+  if (vec_ok(4)) return dispatch_groups<4>(A, sp, s);
+  if (vec_ok(2)) return dispatch_groups<2>(A, sp, s);
+  return dispatch_groups<1>(A, sp, s);
 }
 
+}  // namespace
 }  // namespace rgbx
 
 using namespace rgbx;
@@ -161,20 +249,22 @@ using namespace rgbx;
 extern "C" int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w,
                                  const float* rs, const float* x, int64_t ldx, const float* y,
                                  int64_t ldy, const float* bias, float* out, int64_t ldo, int64_t N,
-                                 int64_t d, float a, float b, rgbx_stream_t stream) {
+                                 int64_t d, float a, float b, const rgbx_row_split_t* split,
+                                 rgbx_stream_t stream) {
   if (N < 0 || d < 0) return fail(RGBX_E_ARG, "spmm: negative size");
   if (N == 0 || d == 0) return RGBX_OK;
   if (!rowptr || !col || !x || !out) return fail(RGBX_E_ARG, "spmm: null pointer");
   if (N >= INT32_MAX || d >= INT32_MAX) return fail(RGBX_E_RANGE, "spmm: N or d exceeds int32");
   if (ldx < d || ldo < d || (y && ldy < d)) return fail(RGBX_E_ARG, "spmm: leading dimension < d");
   if (out == x) return fail(RGBX_E_ARG, "spmm: out must not alias x");
-  SpmmArgs A{rowptr, col, w, rs, x, y, bias, out, ldx, ldy, ldo, (int)N, (int)d, a, b};
-  return spmm_dispatch(A, (hipStream_t)stream);
+  SpmmArgs A{rowptr, col, w, rs, x, y, bias, out, ldx, ldy, ldo, (int)N, (int)d, a, b, 0};
+  return spmm_dispatch(A, split, (hipStream_t)stream);
 }
 
 extern "C" int rgbx_appnp_f32(const int32_t* rowptr, const int32_t* col, const float* w,
                               const float* h, int64_t ldh, float* out, float* tmp, int64_t ldo,
-                              int64_t N, int64_t d, int K, float alpha, rgbx_stream_t stream) {
+                              int64_t N, int64_t d, int K, float alpha, const rgbx_row_split_t* split,
+                              rgbx_stream_t stream) {
   if (N < 0 || d < 0 || K < 0) return fail(RGBX_E_ARG, "appnp: negative size");
   if (N == 0 || d == 0) return RGBX_OK;
   if (!rowptr || !col || !h || !out || (K > 1 && !tmp)) return fail(RGBX_E_ARG, "appnp: null pointer");
@@ -193,8 +283,8 @@ extern "C" int rgbx_appnp_f32(const int32_t* rowptr, const int32_t* col, const f
   int64_t lds = ldh;
   for (int k = 0; k < K; ++k) {
     float* dst = ((K - 1 - k) % 2 == 0) ? out : tmp;
-    SpmmArgs A{rowptr, col, w, nullptr, src, h, nullptr, dst, lds, ldh, ldo, (int)N, (int)d, 1.0f - alpha, alpha};
-    if (int rc = spmm_dispatch(A, s)) return rc;
+    SpmmArgs A{rowptr, col, w, nullptr, src, h, nullptr, dst, lds, ldh, ldo, (int)N, (int)d, 1.0f - alpha, alpha, 0};
+    if (int rc = spmm_dispatch(A, split, s)) return rc;
     src = dst;
     lds = ldo;
   }

@@ -25,13 +25,48 @@ LOOPS_ADD_REMAINING = 1
 LOOPS_REMOVE_ADD = 2
 
 
+LONG_ROW_SLOTS = 1024  # rows with more slots are cut into chunks of this many, summed by separate waves
+
+
 class CSR:
-    """CSR over `N` aggregation rows: rowptr [N+1], col / perm [E'] (int32, device)."""
+    """CSR over `N` aggregation rows: rowptr [N+1], col / perm [E'] (int32, device); `split` is the
+    hub-row plan (None when no row exceeds LONG_ROW_SLOTS)."""
 
-    __slots__ = ("rowptr", "col", "perm", "N", "nnz")
+    __slots__ = ("rowptr", "col", "perm", "N", "nnz", "split")
 
-    def __init__(self, rowptr, col, perm, N, nnz):
-        self.rowptr, self.col, self.perm, self.N, self.nnz = rowptr, col, perm, N, nnz
+    def __init__(self, rowptr, col, perm, N, nnz, split=None):
+        self.rowptr, self.col, self.perm, self.N, self.nnz, self.split = rowptr, col, perm, N, nnz, split
+
+    def split_arg(self, d, device):
+        """ctypes rgbx_row_split_t for one launch at width d (allocates the partial scratch), or None."""
+        if self.split is None:
+            return None, None
+        sp = self.split
+        partial = torch.empty((sp["n_chunks"], d), dtype=torch.float32, device=device)
+        st = _lib.RowSplit(sp["threshold"], sp["n_chunks"], sp["n_long"], sp["chunk_begin"].data_ptr(),
+                           sp["chunk_end"].data_ptr(), sp["long_row"].data_ptr(), sp["long_chunk_ptr"].data_ptr(),
+                           partial.data_ptr())
+        return st, partial
+
+
+def make_row_split(rowptr, threshold=None):
+    """Chunk plan for rows with more than `threshold` slots (index arithmetic on the device, once)."""
+    threshold = LONG_ROW_SLOTS if threshold is None else threshold
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    if deg.numel() == 0 or int(deg.max().item()) <= threshold:
+        return None
+    long_row = (deg > threshold).nonzero(as_tuple=True)[0]
+    nch = (deg[long_row] + threshold - 1) // threshold
+    ptr = torch.zeros(long_row.numel() + 1, dtype=torch.int64, device=rowptr.device)
+    ptr[1:] = torch.cumsum(nch, 0)
+    n_chunks = int(ptr[-1].item())
+    owner = torch.repeat_interleave(torch.arange(long_row.numel(), device=rowptr.device), nch)
+    k = torch.arange(n_chunks, device=rowptr.device) - ptr[:-1][owner]
+    begin = rowptr[long_row].long()[owner] + k * threshold
+    end = torch.minimum(begin + threshold, rowptr[long_row + 1].long()[owner])
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    return {"threshold": int(threshold), "n_chunks": n_chunks, "n_long": int(long_row.numel()),
+            "chunk_begin": i32(begin), "chunk_end": i32(end), "long_row": i32(long_row), "long_chunk_ptr": i32(ptr)}
 
 
 def build_csr(agg_row, other_row, N, loops_mode):
@@ -54,7 +89,7 @@ def build_csr(agg_row, other_row, N, loops_mode):
                            _lib.ptr(col), _lib.ptr(perm), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
         "rgbx_csr_build")
     nnz = int(rowptr[N].item())  # one sync per graph; also orders `ws` lifetime after the kernels
-    return CSR(rowptr, col[:max(nnz, 1)], perm[:max(nnz, 1)], N, nnz)
+    return CSR(rowptr, col[:max(nnz, 1)], perm[:max(nnz, 1)], N, nnz, make_row_split(rowptr))
 
 
 class Graph:

@@ -5,6 +5,8 @@ target-grouped CSR, backward runs the SAME kernel on the source-grouped (transpo
 [E', d] tensor is ever materialised (cf. the gather -> multiply -> scatter temporaries of the
 PyG path the reference uses, models/gcn.py:27).
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -47,11 +49,13 @@ def spmm_raw(csr, w, rs, x, y=None, a=1.0, b=0.0, out=None, kind="spmm", bias=No
         out = torch.empty((N, d), dtype=torch.float32, device=x.device)
     po, ldo = _lib.mat(out, "out")
     py, ldy = (0, 0) if y is None else _lib.mat(y, "y")
+    split, _scratch = csr.split_arg(d, x.device)
     with _Timed(kind):
         _lib.check(
             _lib.load().rgbx_spmm_csr_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
                                           px, ldx, py, ldy, _lib.ptr(bias), po, ldo, N, d, float(a), float(b),
-                                          _lib.stream_ptr()), "rgbx_spmm_csr_f32")
+                                          None if split is None else ctypes.byref(split), _lib.stream_ptr()),
+            "rgbx_spmm_csr_f32")
     return out
 
 
@@ -131,11 +135,13 @@ def appnp_raw(csr, w, h, K, alpha, kind="appnp"):
     out = torch.empty_like(h)
     tmp = torch.empty_like(h) if K > 1 else None
     po, ldo = _lib.mat(out, "out")
+    split, _scratch = csr.split_arg(h.size(1), h.device)
     with _Timed(kind):
         _lib.check(
             _lib.load().rgbx_appnp_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), ph, ldh, po,
                                        _lib.ptr(tmp), ldo, csr.N, h.size(1), int(K), float(alpha),
-                                       _lib.stream_ptr()), "rgbx_appnp_f32")
+                                       None if split is None else ctypes.byref(split), _lib.stream_ptr()),
+            "rgbx_appnp_f32")
     return out
 
 

@@ -40,7 +40,7 @@ def test_argument_errors_do_not_need_a_gpu():
     """Negative return codes come from host-side validation, before any launch."""
     from rgb_experiment_amd import _lib
     lib = _lib.load()
-    rc = lib.rgbx_spmm_csr_f32(None, None, None, None, None, 4, None, 0, None, None, 4, 8, 4, 1.0, 0.0, None)
+    rc = lib.rgbx_spmm_csr_f32(None, None, None, None, None, 4, None, 0, None, None, 4, 8, 4, 1.0, 0.0, None, None)
     assert rc == -1
     assert b"null" in lib.rgbx_last_error_string()
     n = ctypes.c_size_t(0)

@@ -175,3 +175,20 @@ def test_feature_normalisation_modes():
     assert torch.allclose(mm, torch.tensor([[.5, 1.], [1., 2 / 3], [0., 0.]]))
     st = _normalize_features(x, "col", "StandardScalar")
     assert torch.allclose(st.mean(0), torch.zeros(2), atol=1e-6)
+
+
+def test_row_split_plan_covers_long_rows_exactly():
+    """Hub-row chunk plan (graph.make_row_split): pure index arithmetic, checked on CPU tensors."""
+    from rgb_experiment_amd.graph import make_row_split
+    deg = torch.tensor([3, 0, 2500, 1024, 1025, 7, 4096, 1])
+    rowptr = torch.zeros(len(deg) + 1, dtype=torch.int32)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    assert make_row_split(rowptr, threshold=5000) is None
+    sp = make_row_split(rowptr, threshold=1024)
+    assert sp["long_row"].tolist() == [2, 4, 6] and sp["n_long"] == 3
+    assert sp["long_chunk_ptr"].tolist() == [0, 3, 5, 9] and sp["n_chunks"] == 9
+    for r, row in enumerate(sp["long_row"].tolist()):
+        c0, c1 = sp["long_chunk_ptr"][r].item(), sp["long_chunk_ptr"][r + 1].item()
+        b, e = sp["chunk_begin"][c0:c1].tolist(), sp["chunk_end"][c0:c1].tolist()
+        assert b[0] == rowptr[row].item() and e[-1] == rowptr[row + 1].item()
+        assert all(x == y for x, y in zip(e[:-1], b[1:])) and all(0 < y - x <= 1024 for x, y in zip(b, e))
