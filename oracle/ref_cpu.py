@@ -326,3 +326,43 @@ def dagnn_forward(sd, x, edge_index, K):
     pps = torch.stack(preds, dim=1)
     retain = torch.sigmoid(pps @ sd["prop.proj.weight"].t() + sd["prop.proj.bias"]).squeeze(-1)
     return _finish(torch.matmul(retain.unsqueeze(1), pps).squeeze(1))
+
+
+def label_propagation_pyg(y, edge_index, num_layers, alpha, post_step=None):
+    """torch_geometric.nn.LabelPropagation.forward [PyG] as used by CorrectAndSmooth: gcn_norm WITHOUT
+    added self-loops, out <- alpha * propagate(out) + (1 - alpha) * y, then post_step (default clamp to
+    [0, 1]). PARITY UNPINNED (no in-repo statement)."""
+    post_step = post_step or (lambda t: t.clamp_(0.0, 1.0))
+    n = y.size(0)
+    ei, w = gcn_norm(edge_index, None, n, add_loops=False)
+    out = y
+    res = (1 - alpha) * out
+    for _ in range(num_layers):
+        out = propagate(ei, out, n, w, "add")
+        out = post_step(out * alpha + res)
+    return out
+
+
+def correct_and_smooth(y_soft, y_train, mask, edge_index, num_correction_layers, correction_alpha,
+                       num_smoothing_layers, smoothing_alpha, autoscale=True, scale=1.0):
+    """CorrectAndSmooth.correct + .smooth [PyG] behind itexperiments.py:520-526. PARITY UNPINNED."""
+    c = y_soft.size(1)
+    onehot = torch.nn.functional.one_hot(y_train, c).to(y_soft.dtype)
+    numel = int(mask.sum())
+    error = torch.zeros_like(y_soft)
+    error[mask] = onehot - y_soft[mask]
+    if autoscale:
+        sm = label_propagation_pyg(error, edge_index, num_correction_layers, correction_alpha,
+                                   lambda t: t.clamp_(-1.0, 1.0))
+        sigma = error[mask].abs().sum() / numel
+        sc = sigma / sm.abs().sum(dim=1, keepdim=True)
+        sc[sc.isinf() | (sc > 1000)] = 1.0
+        y = y_soft + sc * sm
+    else:
+        def fix(t):
+            t[mask] = error[mask]
+            return t
+        y = y_soft + scale * label_propagation_pyg(error, edge_index, num_correction_layers, correction_alpha, fix)
+    y = y.clone()
+    y[mask] = onehot
+    return label_propagation_pyg(y, edge_index, num_smoothing_layers, smoothing_alpha)

@@ -23,6 +23,10 @@ class InitialParameters:
         {"num_layers": 2, "hidden_unit": 64, "dropout_rate": 0.5},
     ]
 
+    # reference initial_params.py:42
+    default_cs_param = {"num_correction_layers": 50, "correction_alpha": 0.8, "num_smoothing_layers": 50,
+                        "smoothing_alpha": 0.8, "autoscale": True}
+
     @classmethod
     def defaults_for(cls, model_name):
         for name, params in zip(cls.model_names, cls.default_init_params):

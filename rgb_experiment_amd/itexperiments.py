@@ -5,8 +5,8 @@ forward/backward executing in the HIP message-passing kernels.
 Scope: data loading / mask remake / feature normalisation / model dispatch by
 lower-cased ``model_name`` / full-batch Adam + NLLLoss loop with early stopping / the PTA branch
 (label propagation + soft-label loss + propagated inference, reference :351-374, :422-462) / metrics
-dict. Out of scope and rejected with ``NotImplementedError``: C&S post-processing, plots, PCA
-(reference :514-601) and the GGNN / SuperGAT / FAGCN zoo members.
+dict / Correct & Smooth post-processing (reference :514-534). Out of scope and rejected with
+``NotImplementedError``: plots, PCA (reference :536-601) and the GGNN / SuperGAT / FAGCN zoo members.
 
 Deliberate deviations from reference quirks:
   * ``compare_pred_label(need_all_metrics=False)`` returns zeros instead of raising
@@ -199,9 +199,10 @@ def experiment(model_init_param: dict, *,
                                   f"(supported: {sorted(REGISTRY)})")
     if name not in REGISTRY:
         raise ValueError(f"unknown model_name {model_name!r}")
-    if post_cs or print_pics or vis_feat:
-        raise NotImplementedError("post_cs / print_pics / vis_feat are reporting features outside the "
-                                  "hot-path scope")
+    if print_pics or vis_feat:
+        raise NotImplementedError("print_pics / vis_feat are reporting features outside the hot-path scope")
+    if post_cs and name == "pta":
+        raise ValueError("post_cs cannot be combined with PTA (reference :517)")
 
     # ---- data (reference :179-229) ----------------------------------------------------------
     if not specify_data:
@@ -342,6 +343,19 @@ def experiment(model_init_param: dict, *,
         final.setdefault("pred", final["emb"][idx[2]].max(dim=1)[1])
     else:
         final = test(net, fwd, y, test_mask, need_all_metrics)
+
+    if post_cs:  # reference :516-534: C&S on exp(log-probs) of the best model, metrics on the test rows
+        from .nn import CorrectAndSmooth
+        if data.edge_index.device.type != "cuda":
+            raise RuntimeError("post_cs runs its propagation in HIP kernels; a GPU is required (no CPU fallback)")
+        post = CorrectAndSmooth(**(cs_param or InitialParameters.default_cs_param))
+        y_soft = final["test_op"].exp()
+        y_soft = post.correct(y_soft, y[train_mask], train_mask, data.edge_index)
+        y_soft = post.smooth(y_soft, y[train_mask], train_mask, data.edge_index)
+        pred = y_soft.max(dim=1)[1][test_mask]
+        cs = compare_pred_label(pred, y[test_mask], need_all_metrics)
+        final.update(cs)
+        final["pred"], final["label"] = pred, y[test_mask]
 
     if print_confusion_matrix:
         k = output_dim

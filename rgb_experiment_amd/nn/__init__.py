@@ -1,3 +1,5 @@
 from .conv import GCNConv, SAGEConv, MySAGEConv, GATConv, APPNP, SGConv, GINConv
+from .correct_and_smooth import CorrectAndSmooth, LabelPropagation
 
-__all__ = ["GCNConv", "SAGEConv", "MySAGEConv", "GATConv", "APPNP", "SGConv", "GINConv"]
+__all__ = ["GCNConv", "SAGEConv", "MySAGEConv", "GATConv", "APPNP", "SGConv", "GINConv",
+           "CorrectAndSmooth", "LabelPropagation"]

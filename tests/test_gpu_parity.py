@@ -581,6 +581,23 @@ def test_next_row_models(dev):
     assert sgc.conv1._cached_x is not None  # cached=True keeps A_hat^K x after the first call
 
 
+@pytest.mark.parametrize("autoscale", [True, False])
+def test_correct_and_smooth(dev, autoscale):
+    from rgb_experiment_amd.nn import CorrectAndSmooth
+    n, c = 1500, 5
+    ei = rand_graph(n, 9000, 12, loops=5, dups=5)
+    gen = torch.Generator().manual_seed(1)
+    y = torch.randint(0, c, (n,), generator=gen)
+    y_soft = torch.softmax(torch.randn(n, c, generator=gen), dim=1)
+    mask = torch.rand(n, generator=gen) < 0.5
+    want = O.correct_and_smooth(y_soft, y[mask], mask, ei, 20, 0.8, 15, 0.7, autoscale=autoscale)
+    post = CorrectAndSmooth(20, 0.8, 15, 0.7, autoscale=autoscale)
+    got = post.correct(y_soft.to(dev), y[mask].to(dev), mask.to(dev), ei.to(dev))
+    got = post.smooth(got, y[mask].to(dev), mask.to(dev), ei.to(dev)).cpu()
+    assert (got - want).abs().max().item() < 1e-5
+    assert (got.max(dim=1)[1] == want.max(dim=1)[1]).float().mean().item() > 0.999
+
+
 def test_experiment_pta_and_sgc_run(dev):
     import rgb_experiment_amd as R
     n, f, c = 800, 16, 4
@@ -598,6 +615,12 @@ def test_experiment_pta_and_sgc_run(dev):
                            need_to_reappear=True, print_print=False, return_model=True)
         assert res["ACC"] > 0.6, (name, res["ACC"])  # separable clusters on a homophilous graph
         assert len(res["history"]["val_acc"]) == 25
+    plain = R.experiment({"num_layers": 2, "hidden_unit": 16, "dropout_rate": 0.5}, specify_data=True, data=data,
+                         model_name="MLP", learning_rate=0.01, epoch=15, need_to_reappear=True, print_print=False)
+    with_cs = R.experiment({"num_layers": 2, "hidden_unit": 16, "dropout_rate": 0.5}, specify_data=True, data=data,
+                           model_name="MLP", learning_rate=0.01, epoch=15, need_to_reappear=True, print_print=False,
+                           post_cs=True, cs_param=R.InitialParameters.default_cs_param)
+    assert with_cs["ACC"] >= plain["ACC"] - 0.02  # homophilous graph: C&S does not hurt the MLP
 
 
 # ---- halo pack / unpack -------------------------------------------------------------------------------
