@@ -165,7 +165,33 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
         opt.step()
         return (train_loss,) + evaluate(vm) + evaluate(sm)
 
+    def graphed():
+        """The same epoch captured once as a hipGraph and replayed (rgb_experiment_amd.epoch_graph): needs a
+        fresh capturable Adam; returns a run() callable."""
+        from rgb_experiment_amd.epoch_graph import GraphedEpoch
+        gopt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+        return GraphedEpoch(model, gopt, {"x": x_d, "edge_index": ei_d}, y_d, (tm, vm, sm)).capture().run
+
+    step.graphed = graphed
     return step, nnz_total, alg
+
+
+def time_graphed(step, steps, warmup):
+    """ms per epoch of the hipGraph replay of the same epoch (secondary number; `value` stays on the eager
+    loop, whose launches carry the per-kernel HIP events the roofline needs)."""
+    try:
+        run = step.graphed()
+        for _ in range(warmup):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"ms_per_step": dt / steps * 1e3, "epochs_per_s": steps / dt}
+    except Exception as exc:
+        return {"error": repr(exc)}
 
 
 def secondary_config(dev, steps, warmup):
@@ -194,9 +220,11 @@ def secondary_config(dev, steps, warmup):
     elapsed = time.perf_counter() - t0
     ops.set_event_sink(None)
     spmm_s = sum(s.elapsed_time(e) for k, s, e in events if k in ("gcn_fwd", "gcn_bwd")) * 1e-3 / (8 * steps)
+    replay = time_graphed(step, steps, warmup)
     clear_cache()
     return {"workload": wl["name"], "value": 8 * nnz * steps / elapsed, "unit": "edges/s",
             "ms_per_step": elapsed / steps * 1e3, "epochs_per_s": steps / elapsed, "spmm_ms": spmm_s * 1e3,
+            "hip_graph_replay": replay,
             "roofline_frac_algorithmic": alg / spmm_s / 1e9 / HBM_PEAK_GBS,
             "note": "X fits the Infinity Cache at this size: the fraction is cache-served, not HBM"}
 
@@ -342,6 +370,8 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ei, x, N)
+    if world == 1:
+        result["hip_graph_replay"] = time_graphed(step, args.steps, args.warmup)
     if world == 1 and args.workload == "L" and args.model == "gcn":
         del step, model
         from rgb_experiment_amd.graph import clear_cache

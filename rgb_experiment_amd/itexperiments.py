@@ -186,10 +186,13 @@ def experiment(model_init_param: dict, *,
                loss_func_hp: dict = None, print_print: bool = True,
                specify_model: bool = True, model: nn.Module = None,
                begin_early_stopping: int = 20,
-               return_model: bool = False):
+               return_model: bool = False,
+               use_hip_graph: bool = True):
     """Train + evaluate one model on one graph; returns {'ACC', 'precision_score', 'recall_score',
     'f1_macro', 'f1_micro'} (reference :603-605). ``return_model=True`` (an addition) also returns
-    the trained module and the per-epoch curves under 'model' / 'history'."""
+    the trained module and the per-epoch curves under 'model' / 'history'. ``use_hip_graph=True`` (an
+    addition) captures one epoch of the loop into a hipGraph and replays it (epoch_graph.py); the
+    arithmetic is unchanged, only launch latency and host round-trips go away."""
     say = print if print_print else (lambda *a, **k: None)
     say(f"running node classification: {'custom' if specify_data else dataset_name} data, model {model_name}")
 
@@ -253,7 +256,21 @@ def experiment(model_init_param: dict, *,
         net = REGISTRY[name](input_dim=input_dim, output_dim=output_dim, **model_init_param)
         fwd = {"x": features} if name == "mlp" else {"x": features, "edge_index": data.edge_index}
     net.to(device)
-    optimizer = torch.optim.Adam(net.parameters(), lr=learning_rate, weight_decay=weight_decay)
+    graphed = None
+    # capturable Adam keeps its step count on the device: required for graph capture, and used for the
+    # eager GPU loop too so that both loops run the very same update kernels
+    optimizer = torch.optim.Adam(net.parameters(), lr=learning_rate, weight_decay=weight_decay,
+                                 capturable=device.type == "cuda")
+    if use_hip_graph and device.type == "cuda" and not is_pta:
+        from .epoch_graph import GraphedEpoch
+        try:
+            graphed = GraphedEpoch(net, optimizer, fwd, y, (train_mask, val_mask, test_mask)).capture()
+        except Exception as exc:  # stay on the (GPU) eager loop; never a CPU path
+            say(f"hipGraph capture failed ({exc!r}); running the eager loop")
+            torch.cuda.synchronize()
+            graphed = None
+            optimizer = torch.optim.Adam(net.parameters(), lr=learning_rate, weight_decay=weight_decay,
+                                         capturable=True)
     criterion = nn.NLLLoss()
 
     hist = {k: [] for k in ("train_acc", "train_loss", "val_acc", "val_loss", "test_acc", "test_loss")}
@@ -268,6 +285,13 @@ def experiment(model_init_param: dict, *,
 
     def generic_epoch(i):
         """reference :427-440, :464-473: 1 train forward+backward, 2 eval forwards."""
+        if graphed is not None:
+            tl, ta, vl, va, sl, sa = graphed.run()
+            hist["train_loss"].append(tl)
+            hist["train_acc"].append(ta)
+            hist["test_loss"].append(sl)
+            hist["test_acc"].append(sa)
+            return va, vl, None
         net.train()
         optimizer.zero_grad()
         out = net(**fwd)["out"]

@@ -598,6 +598,31 @@ def test_correct_and_smooth(dev, autoscale):
     assert (got.max(dim=1)[1] == want.max(dim=1)[1]).float().mean().item() > 0.999
 
 
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack", "gin"])
+def test_hip_graph_epoch_equals_eager_loop(dev, name):
+    """The captured-and-replayed epoch reproduces the eager loop: same losses, same trained weights."""
+    import rgb_experiment_amd as R
+    n, f, c = 1500, 40, 5
+    gen = torch.Generator().manual_seed(11)
+    ei = rand_graph(n, 9000, 13, loops=4, dups=4)
+    data = R.Data(x=torch.randn(n, f, generator=gen), y=torch.randint(0, c, (n,), generator=gen), edge_index=ei)
+    params = R.InitialParameters.defaults_for(name)
+    params["dropout_rate"] = 0.0 if name == "gin" else params["dropout_rate"]
+    runs = []
+    for graphed in (False, True):
+        res = R.experiment(params, specify_data=True, data=data, model_name=name, learning_rate=0.01, epoch=8,
+                           need_to_reappear=True, print_print=False, return_model=True, use_hip_graph=graphed,
+                           need_all_metrics=False)
+        runs.append(res)
+    a, b = runs
+    assert len(b["history"]["train_loss"]) == 8
+    for key in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_acc"):
+        assert np.allclose(a["history"][key], b["history"][key], rtol=0, atol=2e-6), key
+    for (ka, va), (kb, vb) in zip(a["model"].state_dict().items(), b["model"].state_dict().items()):
+        assert ka == kb and torch.allclose(va.float(), vb.float(), atol=1e-6), ka
+    assert abs(a["ACC"] - b["ACC"]) < 1e-9
+
+
 def test_experiment_pta_and_sgc_run(dev):
     import rgb_experiment_amd as R
     n, f, c = 800, 16, 4
