@@ -366,3 +366,49 @@ def correct_and_smooth(y_soft, y_train, mask, edge_index, num_correction_layers,
     y = y.clone()
     y[mask] = onehot
     return label_propagation_pyg(y, edge_index, num_smoothing_layers, smoothing_alpha)
+
+
+# ---- C restatement (oracle/propagate_ref.c) ------------------------------------------------------------
+
+def _c_lib():
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "liboracle_ref.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is not built (make -C oracle)")
+    lib = ctypes.CDLL(path)
+    P, I64, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    lib.oracle_propagate_coo_f32.restype = None
+    lib.oracle_propagate_coo_f32.argtypes = [P, P, P, I64, P, I64, P, I64, I64, I64, I]
+    lib.oracle_propagate_csr_f32.restype = None
+    lib.oracle_propagate_csr_f32.argtypes = [P, P, P, P, I64, P, I64, I64, I64, I, I]
+    lib.oracle_max_threads.restype = I
+    return lib
+
+
+def propagate_c_coo(edge_index, x, num_nodes, edge_weight=None, aggr="add"):
+    """oracle_propagate_coo_f32: edge-order scatter-add in C (same arithmetic as `propagate`)."""
+    lib = _c_lib()
+    src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()
+    x = x.contiguous().float()
+    w = None if edge_weight is None else edge_weight.contiguous().float()
+    out = torch.empty((num_nodes, x.size(1)), dtype=torch.float32)
+    lib.oracle_propagate_coo_f32(src.data_ptr(), dst.data_ptr(), 0 if w is None else w.data_ptr(), src.numel(),
+                                 x.data_ptr(), x.size(1), out.data_ptr(), x.size(1), num_nodes, x.size(1),
+                                 int(aggr == "mean"))
+    return out
+
+
+def propagate_c_csr(rowptr, col, w, x, aggr="add", threads=0):
+    """oracle_propagate_csr_f32: per-target sums over a CSR (int32 rowptr / col), OpenMP over rows."""
+    lib = _c_lib()
+    x = x.contiguous().float()
+    n = rowptr.numel() - 1
+    out = torch.empty((n, x.size(1)), dtype=torch.float32)
+    lib.oracle_propagate_csr_f32(rowptr.data_ptr(), col.data_ptr(), 0 if w is None else w.data_ptr(), x.data_ptr(),
+                                 x.size(1), out.data_ptr(), x.size(1), n, x.size(1), int(aggr == "mean"), threads)
+    return out
+
+
+def c_threads():
+    return _c_lib().oracle_max_threads()

@@ -198,3 +198,30 @@ def test_batch_norm_matches_torch():
     assert torch.allclose(O.batch_norm(x, sd, "p.", True), want, atol=1e-5)
     bn.eval()
     assert torch.allclose(O.batch_norm(x, sd, "p.", False), bn(x), atol=1e-5)
+
+
+@pytest.mark.parametrize("aggr", ["add", "mean"])
+def test_c_restatement_matches_python_oracle(aggr):
+    """oracle/propagate_ref.c (edge-order COO and OpenMP CSR forms) == oracle.propagate."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    g = torch.Generator().manual_seed(5)
+    n, e, d = 700, 9000, 37
+    ei = torch.randint(0, n, (2, e), generator=g)
+    x = torch.randn(n, d, generator=g)
+    rei, w = O.gcn_norm(ei, None, n)
+    w = w if aggr == "add" else None
+    want = O.propagate(rei, x, n, w, aggr)
+    assert torch.allclose(O.propagate_c_coo(rei, x, n, w, aggr), want, atol=1e-6)
+    rowptr, col, perm = O.csr_from_edges(rei[1], rei[0], torch.arange(rei.size(1)), n)
+    ws = None if w is None else w[perm.long()].contiguous()
+    for threads in (1, 3):
+        assert torch.allclose(O.propagate_c_csr(rowptr, col, ws, x, aggr, threads), want, atol=1e-6)
+    # golden G1: the C form reproduces the reference's normalize_adj rows too
+    z = np.load(os.path.join(root, "tests", "golden", "reference_pygfree.npz"))
+    ei4 = torch.from_numpy(z["g1__survey4__edge_index"]).flip(0)
+    r4, w4 = O.gcn_norm(ei4, None, 4)
+    dense = O.propagate_c_coo(r4, torch.eye(4), 4, w4, "add")
+    assert torch.allclose(dense, torch.from_numpy(z["g1__survey4__adj_ref"]).float(), atol=1e-6)
