@@ -14,7 +14,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..graph import LOOPS_ADD_REMAINING, LOOPS_KEEP, LOOPS_REMOVE_ADD, get_graph

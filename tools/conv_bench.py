@@ -10,7 +10,7 @@ import torch
 
 from bench import WORKLOADS, synth
 from rgb_experiment_amd import ops
-from rgb_experiment_amd.graph import LOOPS_ADD_REMAINING, LOOPS_KEEP, LOOPS_REMOVE_ADD, get_graph
+from rgb_experiment_amd.graph import LOOPS_ADD_REMAINING, LOOPS_REMOVE_ADD, get_graph
 
 
 def timed(fn, reps=10):

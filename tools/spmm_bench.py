@@ -3,7 +3,6 @@
 process, HIP events on the launch stream). Usage: python tools/spmm_bench.py [S|L] [rounds]"""
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
