@@ -70,6 +70,15 @@ def pmc_traffic(workload, world):
         return json.load(f)["traffic_bytes_per_launch"]
 
 
+def gat_alg_bytes(n_rows, nnz, d, H=8):
+    """Forward: col + a_src[H] + feature row per edge, out + max + 1/sum per node. Backward: the source
+    pass (col + 16H-byte record + gout row per edge, ds store), the width-H segment sum, the streaming prep.
+    Returned: the mean over the 6 forward and 2 backward propagates of an epoch."""
+    fwd = nnz * (4 + 4 * H + 4 * d) + n_rows * (8 * d + 12 * H) + 4 * (n_rows + 1)
+    bwd = nnz * (4 + 16 * H + 4 * d) + nnz * 4 * H + nnz * (4 + 4 * H) + n_rows * (16 * d + 24 * H)
+    return (6 * fwd + 2 * bwd) / 8
+
+
 def spmm_alg_bytes(n_rows, nnz, d):
     """gathered rows + col + weight per edge, output row + rowptr per node."""
     return nnz * (4 * d + 8) + n_rows * 4 * d + 4 * (n_rows + 1)
@@ -142,8 +151,8 @@ MODELS = {
     "gat": (dict(num_layers=2, hidden_unit=16, heads=8, dropout_rate=0.5), 8, 2, "gat"),
     "appnpstack": (dict(hidden_unit=64, K=10, alpha=0.1, dropout_rate=0.5), 40, 1, "gcn"),
 }
-AGG_KINDS = ("gcn_fwd", "gcn_bwd", "mean_fwd", "mean_bwd", "appnp_fwd", "appnp_bwd", "gat_fwd", "gat_bwd_dst",
-             "gat_bwd_src", "dist_fwd_local", "dist_fwd_remote", "dist_bwd_local", "dist_bwd_remote",
+AGG_KINDS = ("gcn_fwd", "gcn_bwd", "mean_fwd", "mean_bwd", "appnp_fwd", "appnp_bwd", "gat_fwd", "gat_bwd_prep",
+             "gat_bwd_src", "gat_bwd_segsum", "dist_fwd_local", "dist_fwd_remote", "dist_bwd_local", "dist_bwd_remote",
              "dist_fwd_colshard", "dist_bwd_colshard")
 
 
@@ -162,8 +171,8 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
     if kind == "gcn":
         _ = graph.w, graph.w_t
     nnz_total = graph.fwd.nnz
-    if kind == "gat":  # scores + rows per edge, out + saved max / 1/sum per node
-        alg = nnz_total * (4 + 4 * 8 + 4 * d) + N * (8 * d + 12 * 8) + 4 * (N + 1)
+    if kind == "gat":  # SURVEY §8d per-launch bytes, averaged over the 6 forward + 2 backward propagates
+        alg = gat_alg_bytes(N, nnz_total, d)
     else:
         alg = spmm_alg_bytes(N, nnz_total, d)
 
@@ -310,7 +319,7 @@ def main():
                 model(runner.x, runner.token)  # builds the plan + rectangular CSRs once, outside the timing
             plan = dgraph._kinds["gat"]["plan"]
             nnz_total = plan.nnz_total
-            alg = plan.nnz_local * (4 + 4 * 8 + 4 * d) + n_loc * (8 * d + 12 * 8) + 4 * (n_loc + 1)
+            alg = gat_alg_bytes(n_loc, plan.nnz_local, d)
             comm_mb = plan.fwd.n_halo * d * 4 / 1e6
         elif scheme == "reshard":  # whole graph at width d / P on every rank, two all-to-all transposes
             nnz_total = dgraph._get_full(kind)["nnz"]
@@ -354,7 +363,7 @@ def main():
     for k, s, e in events:
         by_kind.setdefault(k, []).append(s.elapsed_time(e))
     by_kind = {k: {"n": len(v), "avg_ms": sum(v) / len(v)} for k, v in sorted(by_kind.items())}
-    kernel = {"gat": "gat_fwd_kernel<4> / gat_bwd_dst_kernel<4> / gat_bwd_src_kernel<4>"}.get(
+    kernel = {"gat": "gat_fwd_kernel<4> / gat_bwd_src_kernel<4> (+ prep, segment sum)"}.get(
         args.model, "spmm_csr_kernel<32,4,*>" if scheme != "reshard" else f"spmm_csr_kernel at width {d // world}")
 
     result = {

@@ -166,14 +166,24 @@ int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, const float*
                          int64_t ldg, float* nodeq, float* g_a_dst, int64_t N, int H, int C,
                          float slope, rgbx_stream_t stream);
 
+/* The per-target record alone (no neighbour loop, one streaming pass over out / gout):
+ *   nodeq[i,h] = (a_dst[i,h], m[i,h], rden[i,h], <gout[i,h,:], out[i,h,:]>). */
+int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const float* rden, const float* out,
+                          int64_t ldo, const float* gout, int64_t ldg, float* nodeq, int64_t N, int H,
+                          int C, rgbx_stream_t stream);
+
 /* Backward, source side, over the TRANSPOSED CSR (rows = sources j, col = targets i):
  *   g_hfeat[j,h,:] = sum_{p: j->i} alpha_p * gout[i,h,:]
- *   g_a_src[j,h]   = sum_{p: j->i} alpha_p * (<gout[i,h,:], hfeat[j,h,:]> - dsum[i,h]) * lrelu'(s_p)
- * alpha is recomputed from a_src[j] and nodeq[i]; no edge-sized tensor is kept. */
+ *   ds_p[h]        = alpha_p * (<gout[i,h,:], hfeat[j,h,:]> - dsum[i,h]) * lrelu'(s_p)
+ *   g_a_src[j,h]   = sum_{p: j->i} ds_p[h]
+ * alpha is recomputed from a_src[j] and nodeq[i]. If `ds` is not NULL, ds_p is also stored at
+ * ds[p, :] ([E', H] in transposed-slot order): g_a_dst[i,h] = sum of ds over the in-edges of i is then a
+ * width-H segment sum (rgbx_spmm_csr_f32 over the forward rowptr with col = the forward-slot ->
+ * transposed-slot map), which replaces the second full gather pass of rgbx_gat_bwd_dst_f32. */
 int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const float* hfeat,
                          int64_t ldh, const float* a_src, const float* nodeq, const float* gout,
-                         int64_t ldg, float* g_hfeat, int64_t ldgh, float* g_a_src, int64_t N, int H,
-                         int C, float slope, rgbx_stream_t stream);
+                         int64_t ldg, float* g_hfeat, int64_t ldgh, float* g_a_src, float* ds, int64_t N,
+                         int H, int C, float slope, rgbx_stream_t stream);
 
 /* ---- dense weight gradient on the MFMA units ---------------------------------------------- */
 

@@ -239,6 +239,44 @@ gat_bwd_dst_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward, per-target record only (no neighbour loop): nodeq[i,h] = (a_dst, m, rden, <gout_i, out_i>_h).
+template <int VEC>
+__global__ void __launch_bounds__(256)
+gat_bwd_prep_kernel(const float* __restrict__ a_dst, const float* __restrict__ m_in,
+                    const float* __restrict__ rden_in, const float* __restrict__ out, int64_t ldo,
+                    const float* __restrict__ gout, int64_t ldg, float4* __restrict__ nodeq_out, int N,
+                    const GatLayout L) {
+  const int lane = threadIdx.x & 63;
+  const int t = lane % L.G;
+  const int g = lane / L.G;
+  const int hl = t / L.LPH;
+  const int ch = (t % L.LPH) * VEC;
+  const int NG = kWave / L.G;
+  const int wpb = blockDim.x >> 6;
+  // NG rows per wave step: group g of the wave takes row (base + g)
+  for (int row0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * NG; row0 < N; row0 += gridDim.x * wpb * NG) {
+    const int row = row0 + g;
+    for (int hbase = 0; hbase < L.H; hbase += L.HPC) {
+      const int head = hbase + hl;
+      const bool active = row < N && hl < L.HPC && head < L.H && ch < L.C;
+      const int cofs = head * L.C + ch;
+      float go[VEC], o[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) go[i] = o[i] = 0.f;
+      if (active) {
+        load_vec<VEC>(go, gout + (int64_t)row * ldg + cofs);
+        load_vec<VEC>(o, out + (int64_t)row * ldo + cofs);
+      }
+      const float dsum = head_sum(dot_vec<VEC>(go, o), L.LPH);
+      if (active && ch == 0) {
+        const int64_t q = (int64_t)row * L.H + head;
+        nodeq_out[q] = make_float4(a_dst[q], m_in[q], rden_in[q], dsum);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Backward, source side, over the transposed CSR: row = source j, col_t[p] = target i.
 template <int VEC>
 __global__ void __launch_bounds__(256)
@@ -246,7 +284,7 @@ gat_bwd_src_kernel(const int* __restrict__ rowptr_t, const int* __restrict__ col
                    const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
                    const float4* __restrict__ nodeq, const float* __restrict__ gout, int64_t ldg,
                    float* __restrict__ g_hfeat,
-                   int64_t ldgh, float* __restrict__ g_a_src, int N, float slope,
+                   int64_t ldgh, float* __restrict__ g_a_src, float* __restrict__ ds_out, int N, float slope,
                    const GatLayout L) {
   const int lane = threadIdx.x & 63;
   const int NG = kWave / L.G;
@@ -305,7 +343,11 @@ gat_bwd_src_kernel(const int* __restrict__ rowptr_t, const int* __restrict__ col
             const float alpha = ok[u] ? expf(e - mi[u]) * rd[u] : 0.f;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = fmaf(alpha, v[u][i], acc[i]);
-            acc_as = fmaf(alpha * (dal - dsm[u]), s > 0.f ? 1.f : slope, acc_as);
+            const float dsv = alpha * (dal - dsm[u]) * (s > 0.f ? 1.f : slope);
+            acc_as += dsv;
+            // d loss / d score of this edge and head, in transposed-slot order: the target side sums it
+            // per target afterwards (a width-H segment sum) instead of re-gathering every source row
+            if (ds_out && ok[u] && ch == 0) ds_out[(int64_t)(base + k + u * NG + g) * L.H + head] = dsv;
           }
         }
       }
@@ -434,10 +476,35 @@ extern "C" int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, c
   return RGBX_OK;
 }
 
+extern "C" int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const float* rden, const float* out,
+                                     int64_t ldo, const float* gout, int64_t ldg, float* nodeq, int64_t N, int H,
+                                     int C, rgbx_stream_t stream) {
+  if (int rc = check_common(N, H, C, "gat_bwd_prep")) return rc;
+  if (N == 0) return RGBX_OK;
+  if (!a_dst || !m || !rden || !out || !gout || !nodeq) return fail(RGBX_E_ARG, "gat_bwd_prep: null pointer");
+  const int64_t F = (int64_t)H * C;
+  if (ldo < F || ldg < F) return fail(RGBX_E_ARG, "gat_bwd_prep: leading dimension < H*C");
+  if (!aligned16(nodeq)) return fail(RGBX_E_ALIGN, "gat_bwd_prep: nodeq must be 16-byte aligned");
+  const int vec = pick_vec(C, {out, gout}, {ldo, ldg});
+  GatLayout L;
+  if (int rc = make_layout(H, C, vec, &L, "gat_bwd_prep")) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t b = cdiv(N, 4 * (kWave / L.G));
+  const int grid = (int)(b < kMaxGrid ? b : kMaxGrid);
+#define RGBX_GAT_BP(V) \
+  gat_bwd_prep_kernel<V><<<grid, 256, 0, s>>>(a_dst, m, rden, out, ldo, gout, ldg, reinterpret_cast<float4*>(nodeq), (int)N, L)
+  if (vec == 4) RGBX_GAT_BP(4);
+  else if (vec == 2) RGBX_GAT_BP(2);
+  else RGBX_GAT_BP(1);
+#undef RGBX_GAT_BP
+  RGBX_CHECK_LAUNCH("gat_bwd_prep_kernel");
+  return RGBX_OK;
+}
+
 extern "C" int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const float* hfeat,
                                     int64_t ldh, const float* a_src, const float* nodeq, const float* gout,
-                                    int64_t ldg, float* g_hfeat, int64_t ldgh, float* g_a_src, int64_t N, int H,
-                                    int C, float slope, rgbx_stream_t stream) {
+                                    int64_t ldg, float* g_hfeat, int64_t ldgh, float* g_a_src, float* ds,
+                                    int64_t N, int H, int C, float slope, rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_bwd_src")) return rc;
   if (N == 0) return RGBX_OK;
   if (!rowptr_t || !col_t || !hfeat || !a_src || !nodeq || !gout || !g_hfeat || !g_a_src)
@@ -453,7 +520,7 @@ extern "C" int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_
 #define RGBX_GAT_BS(V)                                                                                \
   gat_bwd_src_kernel<V><<<grid, 256, 0, s>>>(rowptr_t, col_t, hfeat, ldh, a_src,                          \
                                              reinterpret_cast<const float4*>(nodeq), gout, ldg, g_hfeat, ldgh, \
-                                             g_a_src, (int)N, slope, L)
+                                             g_a_src, ds, (int)N, slope, L)
   if (vec == 4) RGBX_GAT_BS(4);
   else if (vec == 2) RGBX_GAT_BS(2);
   else RGBX_GAT_BS(1);

@@ -229,32 +229,55 @@ class _GATAggregate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        """Three launches, one full gather pass: (1) per-target records nodeq = (a_dst, max, 1/sum,
+        <gout, out>) in a streaming pass; (2) the source-side pass over the transposed CSR gathers gout
+        rows + records, produces g_hfeat, g_a_src and the per-edge score gradient ds; (3) g_a_dst is the
+        width-H segment sum of ds over each target's in-edges (the SpMM kernel over the slot map)."""
         hfeat, a_src, a_dst, m, rden, out = ctx.saved_tensors
         g, H, C, slope = ctx.graph, ctx.H, ctx.C, ctx.slope
         gout = gout.contiguous()
         N, n_src, dev = g.fwd.N, g.bwd.N, gout.device
         lib = _lib.load()
         nodeq = torch.empty((N, H, 4), dtype=torch.float32, device=dev)  # (a_dst, max, 1/sum, dsum) records
-        g_ad = torch.empty((N, H), dtype=torch.float32, device=dev)
         g_as = torch.empty((n_src, H), dtype=torch.float32, device=dev)
         g_h = torch.empty_like(hfeat)
         ph, ldh = _lib.mat(hfeat, "hfeat")
         po, ldo = _lib.mat(out, "out")
         pg, ldg = _lib.mat(gout, "gout")
         pgh, ldgh = _lib.mat(g_h, "g_hfeat")
-        with _Timed("gat_bwd_dst"):
+        seg = gat_segment_csr(g)
+        ds = torch.empty((max(g.bwd.nnz, 1), H), dtype=torch.float32, device=dev)
+        with _Timed("gat_bwd_prep"):
             _lib.check(
-                lib.rgbx_gat_bwd_dst_f32(_lib.ptr(g.fwd.rowptr), _lib.ptr(g.fwd.col), ph, ldh, _lib.ptr(a_src),
-                                         _lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, pg, ldg,
-                                         _lib.ptr(nodeq), _lib.ptr(g_ad), N, H, C, float(slope),
-                                         _lib.stream_ptr()), "rgbx_gat_bwd_dst_f32")
+                lib.rgbx_gat_bwd_prep_f32(_lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, pg, ldg,
+                                          _lib.ptr(nodeq), N, H, C, _lib.stream_ptr()), "rgbx_gat_bwd_prep_f32")
         with _Timed("gat_bwd_src"):
             _lib.check(
                 lib.rgbx_gat_bwd_src_f32(_lib.ptr(g.bwd.rowptr), _lib.ptr(g.bwd.col), ph, ldh, _lib.ptr(a_src),
-                                         _lib.ptr(nodeq), pg, ldg, pgh, ldgh, _lib.ptr(g_as), n_src, H, C,
-                                         float(slope),
-                                         _lib.stream_ptr()), "rgbx_gat_bwd_src_f32")
+                                         _lib.ptr(nodeq), pg, ldg, pgh, ldgh, _lib.ptr(g_as), _lib.ptr(ds), n_src, H,
+                                         C, float(slope), _lib.stream_ptr()), "rgbx_gat_bwd_src_f32")
+        g_ad = spmm_raw(seg, None, None, ds, kind="gat_bwd_segsum")
         return g_h, g_as, g_ad, None, None, None, None
+
+
+def gat_segment_csr(graph):
+    """CSR over the targets whose `col` is, per forward slot, the TRANSPOSED slot of the same edge: summing
+    rows of the per-edge tensor `ds` (stored in transposed-slot order) through it gives per-target totals.
+    Built once per graph from the two slot -> edge-id permutations."""
+    seg = getattr(graph, "_gat_seg", None)
+    if seg is None:
+        from .graph import CSR
+        f, b = graph.fwd, graph.bwd
+        if f.nnz:
+            inv = torch.empty(int(max(f.perm[:f.nnz].max(), b.perm[:b.nnz].max()).item()) + 1, dtype=torch.int32,
+                              device=f.perm.device)
+            inv[b.perm[:b.nnz].long()] = torch.arange(b.nnz, dtype=torch.int32, device=inv.device)
+            col = inv[f.perm[:f.nnz].long()].contiguous()
+        else:
+            col = f.col
+        seg = CSR(f.rowptr, col, f.perm, f.N, f.nnz, f.split)
+        graph._gat_seg = seg
+    return seg
 
 
 def gat_scores(hfeat, att_src, att_dst, H, C):

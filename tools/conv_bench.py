@@ -53,7 +53,9 @@ def main():
         rows.append((f"gat fwd H={H} C={C}",
                      timed(lambda: ops.gat_aggregate(x, a_s.detach(), a_d.detach(), g2, H, C, 0.2)), b_fwd))
         t_bwd = timed(lambda: torch.autograd.grad(out, (hx, a_s, a_d), gy, retain_graph=True))
-        rows.append((f"gat bwd (dst+src) H={H} C={C}", t_bwd, 2 * b_fwd + 2 * N * 4 * H * C))
+        # prep (stream out, gout) + source pass (col, 16H-byte record, gout row per edge; ds store) + segment sum
+        b_bwd = nnz * (4 + 16 * H + 4 * H * C) + nnz * 4 * H + nnz * (4 + 4 * H) + N * (16 * H * C + 24 * H)
+        rows.append((f"gat bwd (prep+src+segsum) H={H} C={C}", t_bwd, b_bwd))
     print(f"workload {wl['name']}  E'={nnz}")
     for name, ms, b in rows:
         print(f"{name:34s} {ms:9.3f} ms   {b / 1e9:8.2f} GB alg -> {b / ms / 1e6:8.1f} GB/s = {b / ms / 1e6 / 8000:5.3f} of 8 TB/s"
