@@ -331,6 +331,39 @@ def test_gat_conv_forward_backward(dev, H, C):
             assert (p.grad.cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), name
 
 
+def test_gat_backward_two_implementations_agree(dev):
+    """g_a_dst from the segment-sum path (ops) equals the direct target-side gather kernel
+    rgbx_gat_bwd_dst_f32 (the first implementation, still exported)."""
+    from rgb_experiment_amd import _lib, ops
+    from rgb_experiment_amd.graph import Graph
+    n, H, C = 900, 4, 8
+    ei = rand_graph(n, 8000, 31, loops=5, dups=5)
+    gen = torch.Generator().manual_seed(2)
+    g = Graph(ei.to(dev), n, 2)
+    h = torch.randn(n, H * C, generator=gen).to(dev).requires_grad_(True)
+    a_s = torch.randn(n, H, generator=gen).to(dev).requires_grad_(True)
+    a_d = torch.randn(n, H, generator=gen).to(dev).requires_grad_(True)
+    out = ops.gat_aggregate(h, a_s, a_d, g, H, C, 0.2)
+    go = torch.randn(n, H * C, generator=gen).to(dev)
+    _, _, g_ad = torch.autograd.grad(out, (h, a_s, a_d), go)
+    m = torch.empty(n, H, device=dev)
+    rden = torch.empty(n, H, device=dev)
+    out2 = torch.empty(n, H * C, device=dev)
+    lib = _lib.load()
+    hd, asd, add = h.detach().contiguous(), a_s.detach().contiguous(), a_d.detach().contiguous()
+    _lib.check(lib.rgbx_gat_aggregate_fwd_f32(g.fwd.rowptr.data_ptr(), g.fwd.col.data_ptr(), hd.data_ptr(), H * C,
+                                              asd.data_ptr(), add.data_ptr(), out2.data_ptr(), H * C, m.data_ptr(),
+                                              rden.data_ptr(), n, H, C, 0.2, _lib.stream_ptr()), "fwd")
+    nodeq = torch.empty(n, H, 4, device=dev)
+    ref = torch.empty(n, H, device=dev)
+    _lib.check(lib.rgbx_gat_bwd_dst_f32(g.fwd.rowptr.data_ptr(), g.fwd.col.data_ptr(), hd.data_ptr(), H * C,
+                                        asd.data_ptr(), add.data_ptr(), m.data_ptr(), rden.data_ptr(), out2.data_ptr(),
+                                        H * C, go.data_ptr(), H * C, nodeq.data_ptr(), ref.data_ptr(), n, H, C, 0.2,
+                                        _lib.stream_ptr()), "bwd_dst")
+    assert torch.equal(out2, out.detach())
+    assert (g_ad - ref).abs().max().item() < 1e-5
+
+
 def test_gat_rescale_branch_with_spiked_scores(dev):
     """Force the online-softmax running max to jump late in a row and across neighbour groups: one
     source has a huge attention logit and is the LAST in-edge of a 200-edge row."""
