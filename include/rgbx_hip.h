@@ -148,11 +148,14 @@ int rgbx_gat_scores_f32(const float* hfeat, int64_t ldh, const float* att_src,
  *   alpha = exp(e_p - max_p e_p) / (sum_p exp(e_p - max) + 1e-16)
  *   out[i,h,:] = sum_p alpha_p * hfeat[col[p],h,:]
  * Saves m[i,h] = max and rden[i,h] = 1/(sum + 1e-16) for backward (both [N,H]).
- * Rows without edges produce 0 (m = 0, rden = 0). */
+ * Rows without edges produce 0 (m = 0, rden = 0).
+ * Source scores: either `a_src` ([n_src, H], gathered per edge) or, when `att_src` ([H, C]) is not
+ * NULL, recomputed inside the kernel from each gathered row as <hfeat[col[p],h,:], att_src[h,:]>
+ * (saves one cache-line request per edge; `a_src` is then ignored and may be NULL). */
 int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
-                               int64_t ldh, const float* a_src, const float* a_dst, float* out,
-                               int64_t ldo, float* m, float* rden, int64_t N, int H, int C,
-                               float slope, rgbx_stream_t stream);
+                               int64_t ldh, const float* a_src, const float* att_src,
+                               const float* a_dst, float* out, int64_t ldo, float* m, float* rden,
+                               int64_t N, int H, int C, float slope, rgbx_stream_t stream);
 
 /* Backward, target side (same CSR as forward). Per target i, head h:
  *   dsum[i,h]    = <gout[i,h,:], out[i,h,:]>

@@ -34,7 +34,7 @@ SIGNATURES = {
     "rgbx_spmm_csr_f32": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _F, _F, _P, _P],
     "rgbx_appnp_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _F, _P, _P],
     "rgbx_gat_scores_f32": [_P, _I64, _P, _P, _P, _P, _I64, _I, _I, _P],
-    "rgbx_gat_aggregate_fwd_f32": [_P, _P, _P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I, _I, _F, _P],
+    "rgbx_gat_aggregate_fwd_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _I64, _P, _P, _I64, _I, _I, _F, _P],
     "rgbx_gat_bwd_dst_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I,
                              _F, _P],
     "rgbx_gat_bwd_prep_f32": [_P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _I, _P],

@@ -72,7 +72,8 @@ template <int VEC>
 __global__ void __launch_bounds__(256)
 gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
-               const float* __restrict__ a_dst, float* __restrict__ out, int64_t ldo,
+               const float* __restrict__ att_src, const float* __restrict__ a_dst, float* __restrict__ out,
+               int64_t ldo,
                float* __restrict__ m_out, float* __restrict__ rden_out, int N, float slope,
                const GatLayout L) {
   const int lane = threadIdx.x & 63;
@@ -91,6 +92,12 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
       const bool active = hl < L.HPC && head < L.H && ch < L.C;
       const int cofs = head * L.C + ch;
       const float ad = active ? a_dst[(int64_t)row * L.H + head] : 0.f;
+      // With att_src given, the source score <h_j, att_src> is formed from the gathered row itself (a few
+      // cross-lane adds) instead of a fifth cache-line request per edge for a_src[j].
+      float att[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) att[i] = 0.f;
+      if (att_src && active) load_vec<VEC>(att, att_src + cofs);
       float m = kNegBig, l = 0.f;
       float acc[VEC];
 #pragma unroll
@@ -112,9 +119,13 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
 #pragma unroll
             for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
             if (ok[u]) {
-              as[u] = a_src[(int64_t)src * L.H + head];
+              if (!att_src) as[u] = a_src[(int64_t)src * L.H + head];
               load_vec<VEC>(v[u], hfeat + (int64_t)src * ldh + cofs);
             }
+          }
+          if (att_src) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) as[u] = head_sum(dot_vec<VEC>(v[u], att), L.LPH);
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
@@ -425,21 +436,21 @@ extern "C" int rgbx_gat_scores_f32(const float* hfeat, int64_t ldh, const float*
 }
 
 extern "C" int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
-                                          int64_t ldh, const float* a_src, const float* a_dst,
-                                          float* out, int64_t ldo, float* m, float* rden, int64_t N,
-                                          int H, int C, float slope, rgbx_stream_t stream) {
+                                          int64_t ldh, const float* a_src, const float* att_src,
+                                          const float* a_dst, float* out, int64_t ldo, float* m, float* rden,
+                                          int64_t N, int H, int C, float slope, rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_fwd")) return rc;
   if (N == 0) return RGBX_OK;
-  if (!rowptr || !col || !hfeat || !a_src || !a_dst || !out || !m || !rden)
+  if (!rowptr || !col || !hfeat || (!a_src && !att_src) || !a_dst || !out || !m || !rden)
     return fail(RGBX_E_ARG, "gat_fwd: null pointer");
   if (ldh < (int64_t)H * C || ldo < (int64_t)H * C) return fail(RGBX_E_ARG, "gat_fwd: leading dimension < H*C");
-  const int vec = pick_vec(C, {hfeat, out}, {ldh, ldo});
+  const int vec = pick_vec(C, {hfeat, out, att_src}, {ldh, ldo});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_fwd")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int grid = gat_grid(N);
 #define RGBX_GAT_FWD(V) \
-  gat_fwd_kernel<V><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, a_dst, out, ldo, m, rden, (int)N, slope, L)
+  gat_fwd_kernel<V><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out, ldo, m, rden, (int)N, slope, L)
   if (vec == 4) RGBX_GAT_FWD(4);
   else if (vec == 2) RGBX_GAT_FWD(2);
   else RGBX_GAT_FWD(1);

@@ -352,7 +352,7 @@ def test_gat_backward_two_implementations_agree(dev):
     lib = _lib.load()
     hd, asd, add = h.detach().contiguous(), a_s.detach().contiguous(), a_d.detach().contiguous()
     _lib.check(lib.rgbx_gat_aggregate_fwd_f32(g.fwd.rowptr.data_ptr(), g.fwd.col.data_ptr(), hd.data_ptr(), H * C,
-                                              asd.data_ptr(), add.data_ptr(), out2.data_ptr(), H * C, m.data_ptr(),
+                                              asd.data_ptr(), None, add.data_ptr(), out2.data_ptr(), H * C, m.data_ptr(),
                                               rden.data_ptr(), n, H, C, 0.2, _lib.stream_ptr()), "fwd")
     nodeq = torch.empty(n, H, 4, device=dev)
     ref = torch.empty(n, H, device=dev)

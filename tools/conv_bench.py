@@ -50,8 +50,12 @@ def main():
         hx = x.clone().requires_grad_(True)
         out = ops.gat_aggregate(hx, a_s.requires_grad_(True), a_d.requires_grad_(True), g2, H, C, 0.2)
         b_fwd = nnz * (4 + 4 * H + 4 * H * C) + N * (4 * H * C + 4 * H) + N * (4 * H * C + 8 * H) + 4 * (N + 1)
-        rows.append((f"gat fwd H={H} C={C}",
+        att = torch.randn(1, H, C, device=dev)
+        rows.append((f"gat fwd H={H} C={C} (a_src gathered)",
                      timed(lambda: ops.gat_aggregate(x, a_s.detach(), a_d.detach(), g2, H, C, 0.2)), b_fwd))
+        rows.append((f"gat fwd H={H} C={C} (a_src in-kernel)",
+                     timed(lambda: ops.gat_aggregate(x, a_s.detach(), a_d.detach(), g2, H, C, 0.2, att_src=att)),
+                     b_fwd - nnz * 4 * H))
         t_bwd = timed(lambda: torch.autograd.grad(out, (hx, a_s, a_d), gy, retain_graph=True))
         # prep (stream out, gout) + source pass (col, 16H-byte record, gout row per edge; ds store) + segment sum
         b_bwd = nnz * (4 + 16 * H + 4 * H * C) + nnz * 4 * H + nnz * (4 + 4 * H) + N * (16 * H * C + 24 * H)
