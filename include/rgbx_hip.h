@@ -143,6 +143,19 @@ int rgbx_gat_scores_f32(const float* hfeat, int64_t ldh, const float* att_src,
                         const float* att_dst, float* a_src, float* a_dst, int64_t n, int H, int C,
                         rgbx_stream_t stream);
 
+/* Floats of device scratch rgbx_gat_scores_bwd_f32 needs (per-workgroup partial sums). */
+int rgbx_gat_scores_bwd_scratch_floats(int64_t n, int H, int C, int64_t* count);
+
+/* Backward of rgbx_gat_scores_f32, fused with the accumulation into the feature gradient:
+ *   g_hfeat[r,h,:] += g_a_src[r,h] * att_src[h,:] + g_a_dst[r,h] * att_dst[h,:]   (in place)
+ *   g_att_src[h,:]  = sum_r g_a_src[r,h] * hfeat[r,h,:],   g_att_dst likewise
+ * over rows r in [0, n); g_a_dst has n_dst <= n rows (rows beyond are zero: halo rows of a partitioned
+ * run have no target role). Partial sums per workgroup are added in workgroup order (reproducible). */
+int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const float* g_a_src, const float* g_a_dst,
+                            int64_t n_dst, const float* att_src, const float* att_dst, float* g_hfeat,
+                            int64_t ldgh, float* g_att_src, float* g_att_dst, float* scratch,
+                            int64_t scratch_floats, int64_t n, int H, int C, rgbx_stream_t stream);
+
 /* Forward over the target-grouped CSR. For every target i and head h:
  *   e_p   = leaky_relu(a_src[col[p],h] + a_dst[i,h], slope)
  *   alpha = exp(e_p - max_p e_p) / (sum_p exp(e_p - max) + 1e-16)
@@ -202,13 +215,17 @@ int rgbx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, f
 
 /* ---- loss / metrics on masked rows ---------------------------------------------------------- */
 
+/* Doubles of device scratch rgbx_masked_nll_fwd_f32 needs (3 per workgroup). */
+int rgbx_masked_nll_scratch_doubles(int64_t N, int want_accuracy, int64_t* count);
+
 /* stats[0] = sum over selected rows of -logp[i, y[i]]; stats[1] = number of selected rows;
  * stats[2] = number of selected rows whose first arg-max equals y[i] (only if want_accuracy).
- * A row is selected when mask == NULL or mask[i] != 0, and 0 <= y[i] < C. `stats` (3 doubles, device)
- * is zeroed by the call. logp is [N, C] (ld). */
+ * A row is selected when mask == NULL or mask[i] != 0, and 0 <= y[i] < C. `stats` = 3 doubles (device).
+ * Per-workgroup sums go to `scratch` and are added in workgroup order (reproducible; no atomics).
+ * logp is [N, C] (ld). */
 int rgbx_masked_nll_fwd_f32(const float* logp, int64_t ld, const int64_t* y, const uint8_t* mask,
-                            int64_t N, int64_t C, double* stats, int want_accuracy,
-                            rgbx_stream_t stream);
+                            int64_t N, int64_t C, double* stats, double* scratch,
+                            int64_t scratch_doubles, int want_accuracy, rgbx_stream_t stream);
 
 /* grad[i,c] = -scale[0] if row i is selected and c == y[i], else 0, for every (i, c): the gradient
  * of scale * stats[0] w.r.t. logp. `scale` is a device scalar (no host sync). */

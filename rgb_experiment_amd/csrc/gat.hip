@@ -39,31 +39,137 @@ __device__ __forceinline__ float head_sum(float v, int LPH) {
 }
 
 // ------------------------------------------------------------------------------------------
-// scores: a_src[n,h] = <hfeat[n,h,:], att_src[h,:]>, a_dst likewise. One wave per node.
+// scores: a_src[n,h] = <hfeat[n,h,:], att_src[h,:]>, a_dst likewise. Same lane layout as the aggregate
+// kernels; the NG groups of a wave take NG consecutive rows per step.
+template <int VEC>
 __global__ void __launch_bounds__(256)
 gat_scores_kernel(const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ att_src,
                   const float* __restrict__ att_dst, float* __restrict__ a_src,
-                  float* __restrict__ a_dst, int n, int H, int C) {
+                  float* __restrict__ a_dst, int n, const GatLayout L) {
   const int lane = threadIdx.x & 63;
+  const int NG = kWave / L.G;
+  const int g = lane / L.G;
+  const int t = lane % L.G;
+  const int hl = t / L.LPH;
+  const int ch = (t % L.LPH) * VEC;
   const int wpb = blockDim.x >> 6;
-  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += gridDim.x * wpb) {
-    const float* x = hfeat + (int64_t)row * ldh;
-    for (int h = 0; h < H; ++h) {
-      float ss = 0.f, sd = 0.f;
-      for (int c = lane; c < C; c += 64) {
-        const float v = x[h * C + c];
-        ss = fmaf(v, att_src[h * C + c], ss);
-        sd = fmaf(v, att_dst[h * C + c], sd);
-      }
-      for (int off = 32; off > 0; off >>= 1) {
-        ss += __shfl_xor(ss, off);
-        sd += __shfl_xor(sd, off);
-      }
-      if (lane == 0) {
-        a_src[(int64_t)row * H + h] = ss;
-        a_dst[(int64_t)row * H + h] = sd;
+  for (int hbase = 0; hbase < L.H; hbase += L.HPC) {
+    const int head = hbase + hl;
+    const bool lane_ok = hl < L.HPC && head < L.H && ch < L.C;
+    const int cofs = head * L.C + ch;
+    float as[VEC], ad[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) as[i] = ad[i] = 0.f;
+    if (lane_ok) {
+      load_vec<VEC>(as, att_src + cofs);
+      load_vec<VEC>(ad, att_dst + cofs);
+    }
+    for (int row0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * NG; row0 < n; row0 += gridDim.x * wpb * NG) {
+      const int row = row0 + g;
+      const bool active = lane_ok && row < n;
+      float h[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) h[i] = 0.f;
+      if (active) load_vec<VEC>(h, hfeat + (int64_t)row * ldh + cofs);
+      const float ss = head_sum(dot_vec<VEC>(h, as), L.LPH);
+      const float sd = head_sum(dot_vec<VEC>(h, ad), L.LPH);
+      if (active && ch == 0) {
+        a_src[(int64_t)row * L.H + head] = ss;
+        a_dst[(int64_t)row * L.H + head] = sd;
       }
     }
+  }
+}
+
+// Backward of the scores, fused with the accumulation into the feature gradient:
+//   g_hfeat[n,h,:] += g_a_src[n,h] * att_src[h,:] + g_a_dst[n,h] * att_dst[h,:]     (g_a_dst rows >= n_dst are 0)
+//   part[block, 0, h, c] = sum over the block's rows of g_a_src[n,h] * hfeat[n,h,c];  part[block, 1, ...] with g_a_dst
+// A second kernel adds the per-block partials in block order into g_att_src / g_att_dst (reproducible).
+template <int VEC>
+__global__ void __launch_bounds__(256)
+gat_scores_bwd_kernel(const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ g_a_src,
+                      const float* __restrict__ g_a_dst, int n_dst, const float* __restrict__ att_src,
+                      const float* __restrict__ att_dst, float* __restrict__ g_hfeat, int64_t ldgh,
+                      float* __restrict__ part, int n, const GatLayout L) {
+  extern __shared__ float red[];  // [waves][2][G * VEC]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int NG = kWave / L.G;
+  const int g = lane / L.G;
+  const int t = lane % L.G;
+  const int hl = t / L.LPH;
+  const int ch = (t % L.LPH) * VEC;
+  const int wpb = blockDim.x >> 6;
+  const int F = L.H * L.C;
+  for (int hbase = 0; hbase < L.H; hbase += L.HPC) {
+    const int head = hbase + hl;
+    const bool lane_ok = hl < L.HPC && head < L.H && ch < L.C;
+    const int cofs = head * L.C + ch;
+    float as[VEC], ad[VEC], ps[VEC], pd[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) as[i] = ad[i] = ps[i] = pd[i] = 0.f;
+    if (lane_ok) {
+      load_vec<VEC>(as, att_src + cofs);
+      load_vec<VEC>(ad, att_dst + cofs);
+    }
+    for (int row0 = (blockIdx.x * wpb + wave) * NG; row0 < n; row0 += gridDim.x * wpb * NG) {
+      const int row = row0 + g;
+      if (lane_ok && row < n) {
+        float h[VEC], gh[VEC];
+        load_vec<VEC>(h, hfeat + (int64_t)row * ldh + cofs);
+        load_vec<VEC>(gh, g_hfeat + (int64_t)row * ldgh + cofs);
+        const float gs = g_a_src[(int64_t)row * L.H + head];
+        const float gd = row < n_dst ? g_a_dst[(int64_t)row * L.H + head] : 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          gh[i] = fmaf(gs, as[i], fmaf(gd, ad[i], gh[i]));
+          ps[i] = fmaf(gs, h[i], ps[i]);
+          pd[i] = fmaf(gd, h[i], pd[i]);
+        }
+        store_vec<VEC>(g_hfeat + (int64_t)row * ldgh + cofs, gh);
+      }
+    }
+    // fold the NG row groups, then the block's waves (fixed order), then one partial record per block
+    for (int off = 32; off >= L.G; off >>= 1) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        ps[i] += __shfl_xor(ps[i], off);
+        pd[i] += __shfl_xor(pd[i], off);
+      }
+    }
+    const int width = L.G * VEC;
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        red[(wave * 2 + 0) * width + t * VEC + i] = ps[i];
+        red[(wave * 2 + 1) * width + t * VEC + i] = pd[i];
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && g == 0 && lane_ok) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int w = 0; w < wpb; ++w) {
+          s0 += red[(w * 2 + 0) * width + t * VEC + i];
+          s1 += red[(w * 2 + 1) * width + t * VEC + i];
+        }
+        part[((int64_t)blockIdx.x * 2 + 0) * F + cofs + i] = s0;
+        part[((int64_t)blockIdx.x * 2 + 1) * F + cofs + i] = s1;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gat_scores_bwd_finish_kernel(const float* __restrict__ part, int n_blocks, int F, float* __restrict__ g_att_src,
+                             float* __restrict__ g_att_dst) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < 2 * F; c += gridDim.x * blockDim.x) {
+    const int which = c / F, col = c % F;
+    float s = 0.f;
+    for (int b = 0; b < n_blocks; ++b) s += part[((int64_t)b * 2 + which) * F + col];
+    (which == 0 ? g_att_src : g_att_dst)[col] = s;
   }
 }
 
@@ -429,9 +535,72 @@ extern "C" int rgbx_gat_scores_f32(const float* hfeat, int64_t ldh, const float*
   if (n == 0) return RGBX_OK;
   if (!hfeat || !att_src || !att_dst || !a_src || !a_dst) return fail(RGBX_E_ARG, "gat_scores: null pointer");
   if (ldh < (int64_t)H * C) return fail(RGBX_E_ARG, "gat_scores: leading dimension < H*C");
-  gat_scores_kernel<<<gat_grid(n), 256, 0, (hipStream_t)stream>>>(hfeat, ldh, att_src, att_dst, a_src,
-                                                                 a_dst, (int)n, H, C);
+  const int vec = pick_vec(C, {hfeat, att_src, att_dst}, {ldh});
+  GatLayout L;
+  if (int rc = make_layout(H, C, vec, &L, "gat_scores")) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t b = cdiv(n, 4 * (kWave / L.G));
+  const int grid = (int)(b < kMaxGrid ? b : kMaxGrid);
+#define RGBX_GAT_SC(V) gat_scores_kernel<V><<<grid, 256, 0, s>>>(hfeat, ldh, att_src, att_dst, a_src, a_dst, (int)n, L)
+  if (vec == 4) RGBX_GAT_SC(4);
+  else if (vec == 2) RGBX_GAT_SC(2);
+  else RGBX_GAT_SC(1);
+#undef RGBX_GAT_SC
   RGBX_CHECK_LAUNCH("gat_scores_kernel");
+  return RGBX_OK;
+}
+
+namespace {
+int scores_bwd_grid(int64_t n, const GatLayout& L) {
+  int64_t b = cdiv(n, 4 * (kWave / L.G) * 8);  // >= 8 row steps per wave so that partial records stay few
+  if (b > 1024) b = 1024;
+  return (int)(b < 1 ? 1 : b);
+}
+}  // namespace
+
+extern "C" int rgbx_gat_scores_bwd_scratch_floats(int64_t n, int H, int C, int64_t* count) {
+  if (!count) return fail(RGBX_E_ARG, "gat_scores_bwd_scratch_floats: null pointer");
+  if (int rc = check_common(n, H, C, "gat_scores_bwd")) return rc;
+  *count = (int64_t)1024 * 2 * H * C;  // upper bound over every layout's grid
+  return RGBX_OK;
+}
+
+extern "C" int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const float* g_a_src,
+                                       const float* g_a_dst, int64_t n_dst, const float* att_src,
+                                       const float* att_dst, float* g_hfeat, int64_t ldgh, float* g_att_src,
+                                       float* g_att_dst, float* scratch, int64_t scratch_floats, int64_t n, int H,
+                                       int C, rgbx_stream_t stream) {
+  if (int rc = check_common(n, H, C, "gat_scores_bwd")) return rc;
+  if (!g_att_src || !g_att_dst) return fail(RGBX_E_ARG, "gat_scores_bwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int F = H * C;
+  if (n == 0) {
+    RGBX_HIP(hipMemsetAsync(g_att_src, 0, F * sizeof(float), s));
+    RGBX_HIP(hipMemsetAsync(g_att_dst, 0, F * sizeof(float), s));
+    return RGBX_OK;
+  }
+  if (!hfeat || !g_a_src || !g_a_dst || !att_src || !att_dst || !g_hfeat || !scratch)
+    return fail(RGBX_E_ARG, "gat_scores_bwd: null pointer");
+  if (n_dst < 0 || n_dst > n) return fail(RGBX_E_ARG, "gat_scores_bwd: n_dst outside [0, n]");
+  if (ldh < F || ldgh < F) return fail(RGBX_E_ARG, "gat_scores_bwd: leading dimension < H*C");
+  const int vec = pick_vec(C, {hfeat, g_hfeat, att_src, att_dst}, {ldh, ldgh});
+  GatLayout L;
+  if (int rc = make_layout(H, C, vec, &L, "gat_scores_bwd")) return rc;
+  const int grid = scores_bwd_grid(n, L);
+  if (scratch_floats < (int64_t)grid * 2 * F)
+    return fail(RGBX_E_WS, "gat_scores_bwd: scratch %lld < %lld floats", (long long)scratch_floats,
+                (long long)grid * 2 * F);
+  const size_t lds = (size_t)4 * 2 * L.G * vec * sizeof(float);
+#define RGBX_GAT_SB(V)                                                                                       \
+  gat_scores_bwd_kernel<V><<<grid, 256, lds, s>>>(hfeat, ldh, g_a_src, g_a_dst, (int)n_dst, att_src, att_dst, \
+                                                  g_hfeat, ldgh, scratch, (int)n, L)
+  if (vec == 4) RGBX_GAT_SB(4);
+  else if (vec == 2) RGBX_GAT_SB(2);
+  else RGBX_GAT_SB(1);
+#undef RGBX_GAT_SB
+  RGBX_CHECK_LAUNCH("gat_scores_bwd_kernel");
+  gat_scores_bwd_finish_kernel<<<(int)cdiv(2 * F, 256), 256, 0, s>>>(scratch, grid, F, g_att_src, g_att_dst);
+  RGBX_CHECK_LAUNCH("gat_scores_bwd_finish_kernel");
   return RGBX_OK;
 }
 

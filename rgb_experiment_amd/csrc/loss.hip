@@ -18,10 +18,10 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return t;
 }
 
-// stats[0] += sum of -logp[i, y_i], stats[1] += number of selected rows (mask set, label in range)
+// per block: sum of -logp[i, y_i] and number of selected rows (mask set, label in range)
 __global__ void __launch_bounds__(256)
 nll_sum_kernel(const float* __restrict__ logp, int64_t ld, const int64_t* __restrict__ y,
-               const uint8_t* __restrict__ mask, int64_t N, int C, double* __restrict__ stats) {
+               const uint8_t* __restrict__ mask, int64_t N, int C, double* __restrict__ partials) {
   __shared__ double sh[4];
   double loss = 0.0, cnt = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N;
@@ -34,16 +34,17 @@ nll_sum_kernel(const float* __restrict__ logp, int64_t ld, const int64_t* __rest
   }
   loss = block_sum(loss, sh);
   cnt = block_sum(cnt, sh);
-  if (threadIdx.x == 0) {
-    atomicAdd(&stats[0], loss);
-    atomicAdd(&stats[1], cnt);
+  if (threadIdx.x == 0) {  // one record per block; summed in block order by nll_finish_kernel
+    partials[3 * blockIdx.x + 0] = loss;
+    partials[3 * blockIdx.x + 1] = cnt;
+    partials[3 * blockIdx.x + 2] = 0.0;
   }
 }
 
-// One wave per selected row: additionally stats[2] += (first arg-max of the row == y_i)
+// One wave per selected row: additionally the number of rows whose first arg-max equals y_i
 __global__ void __launch_bounds__(256)
 nll_acc_kernel(const float* __restrict__ logp, int64_t ld, const int64_t* __restrict__ y,
-               const uint8_t* __restrict__ mask, int64_t N, int C, double* __restrict__ stats) {
+               const uint8_t* __restrict__ mask, int64_t N, int C, double* __restrict__ partials) {
   __shared__ double sh[4];
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -74,9 +75,21 @@ nll_acc_kernel(const float* __restrict__ logp, int64_t ld, const int64_t* __rest
   cnt = block_sum(cnt, sh);
   hit = block_sum(hit, sh);
   if (threadIdx.x == 0) {
-    atomicAdd(&stats[0], loss);
-    atomicAdd(&stats[1], cnt);
-    atomicAdd(&stats[2], hit);
+    partials[3 * blockIdx.x + 0] = loss;
+    partials[3 * blockIdx.x + 1] = cnt;
+    partials[3 * blockIdx.x + 2] = hit;
+  }
+}
+
+// stats[k] = sum over blocks of partials[b, k], in block order (one block; reproducible, no atomics)
+__global__ void __launch_bounds__(256)
+nll_finish_kernel(const double* __restrict__ partials, int n_blocks, double* __restrict__ stats) {
+  __shared__ double sh[4];
+  for (int k = 0; k < 3; ++k) {
+    double v = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) v += partials[3 * b + k];
+    v = block_sum(v, sh);
+    if (threadIdx.x == 0) stats[k] = v;
   }
 }
 
@@ -110,23 +123,39 @@ nll_bwd_kernel(const int64_t* __restrict__ y, const uint8_t* __restrict__ mask, 
 
 using namespace rgbx;
 
+extern "C" int rgbx_masked_nll_scratch_doubles(int64_t N, int want_accuracy, int64_t* count) {
+  if (!count || N < 0) return fail(RGBX_E_ARG, "masked_nll_scratch_doubles: bad argument");
+  int64_t b = want_accuracy ? cdiv(N, 4) : cdiv(N, 256);
+  const int64_t cap = want_accuracy ? kMaxGrid : 2048;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  *count = 3 * b;
+  return RGBX_OK;
+}
+
 extern "C" int rgbx_masked_nll_fwd_f32(const float* logp, int64_t ld, const int64_t* y, const uint8_t* mask,
-                                       int64_t N, int64_t C, double* stats, int want_accuracy,
-                                       rgbx_stream_t stream) {
+                                       int64_t N, int64_t C, double* stats, double* scratch,
+                                       int64_t scratch_doubles, int want_accuracy, rgbx_stream_t stream) {
   if (N < 0 || C <= 0 || !stats) return fail(RGBX_E_ARG, "masked_nll_fwd: bad argument");
   if (C >= INT32_MAX) return fail(RGBX_E_RANGE, "masked_nll_fwd: C exceeds int32");
   hipStream_t s = (hipStream_t)stream;
-  RGBX_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(double), s));
-  if (N == 0) return RGBX_OK;
-  if (!logp || !y || ld < C) return fail(RGBX_E_ARG, "masked_nll_fwd: null pointer or ld < C");
-  if (want_accuracy) {
-    int64_t b = cdiv(N, 4);
-    nll_acc_kernel<<<(int)(b < kMaxGrid ? b : kMaxGrid), 256, 0, s>>>(logp, ld, y, mask, N, (int)C, stats);
-  } else {
-    int64_t b = cdiv(N, 256);
-    nll_sum_kernel<<<(int)(b < 2048 ? b : 2048), 256, 0, s>>>(logp, ld, y, mask, N, (int)C, stats);
+  if (N == 0) {
+    RGBX_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(double), s));
+    return RGBX_OK;
   }
+  if (!logp || !y || ld < C) return fail(RGBX_E_ARG, "masked_nll_fwd: null pointer or ld < C");
+  int64_t need = 0;
+  if (int rc = rgbx_masked_nll_scratch_doubles(N, want_accuracy, &need)) return rc;
+  if (!scratch || scratch_doubles < need)
+    return fail(RGBX_E_WS, "masked_nll_fwd: scratch %lld < %lld doubles", (long long)scratch_doubles, (long long)need);
+  const int grid = (int)(need / 3);
+  if (want_accuracy)
+    nll_acc_kernel<<<grid, 256, 0, s>>>(logp, ld, y, mask, N, (int)C, scratch);
+  else
+    nll_sum_kernel<<<grid, 256, 0, s>>>(logp, ld, y, mask, N, (int)C, scratch);
   RGBX_CHECK_LAUNCH("masked_nll_fwd");
+  nll_finish_kernel<<<1, 256, 0, s>>>(scratch, grid, stats);
+  RGBX_CHECK_LAUNCH("nll_finish_kernel");
   return RGBX_OK;
 }
 

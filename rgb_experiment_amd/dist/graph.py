@@ -39,9 +39,7 @@ class HipAggregator:
 
     def gat(self, rect, x_ext, att_src, att_dst, n_tgt, H, C, slope):
         from .. import ops
-        a_src, a_dst = ops.gat_scores(x_ext, att_src, att_dst, H, C)
-        return ops.gat_aggregate(x_ext, a_src, a_dst[:n_tgt], rect, H, C, slope,
-                                 att_src=att_src if ops._scores_in_kernel(C) else None)
+        return ops._GATAttend.apply(x_ext, att_src, att_dst, rect, H, C, slope)
 
 
 class _RectGraph:

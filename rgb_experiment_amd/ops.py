@@ -238,30 +238,35 @@ class _GATAggregate(torch.autograd.Function):
         rows + records, produces g_hfeat, g_a_src and the per-edge score gradient ds; (3) g_a_dst is the
         width-H segment sum of ds over each target's in-edges (the SpMM kernel over the slot map)."""
         hfeat, a_src, a_dst, m, rden, out = ctx.saved_tensors
-        g, H, C, slope = ctx.graph, ctx.H, ctx.C, ctx.slope
-        gout = gout.contiguous()
-        N, n_src, dev = g.fwd.N, g.bwd.N, gout.device
-        lib = _lib.load()
-        nodeq = torch.empty((N, H, 4), dtype=torch.float32, device=dev)  # (a_dst, max, 1/sum, dsum) records
-        g_as = torch.empty((n_src, H), dtype=torch.float32, device=dev)
-        g_h = torch.empty_like(hfeat)
-        ph, ldh = _lib.mat(hfeat, "hfeat")
-        po, ldo = _lib.mat(out, "out")
-        pg, ldg = _lib.mat(gout, "gout")
-        pgh, ldgh = _lib.mat(g_h, "g_hfeat")
-        seg = gat_segment_csr(g)
-        ds = torch.empty((max(g.bwd.nnz, 1), H), dtype=torch.float32, device=dev)
-        with _Timed("gat_bwd_prep"):
-            _lib.check(
-                lib.rgbx_gat_bwd_prep_f32(_lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, pg, ldg,
-                                          _lib.ptr(nodeq), N, H, C, _lib.stream_ptr()), "rgbx_gat_bwd_prep_f32")
-        with _Timed("gat_bwd_src"):
-            _lib.check(
-                lib.rgbx_gat_bwd_src_f32(_lib.ptr(g.bwd.rowptr), _lib.ptr(g.bwd.col), ph, ldh, _lib.ptr(a_src),
-                                         _lib.ptr(nodeq), pg, ldg, pgh, ldgh, _lib.ptr(g_as), _lib.ptr(ds), n_src, H,
-                                         C, float(slope), _lib.stream_ptr()), "rgbx_gat_bwd_src_f32")
-        g_ad = spmm_raw(seg, None, None, ds, kind="gat_bwd_segsum")
+        g_h, g_as, g_ad = _gat_backward_core(ctx.graph, hfeat, a_src, a_dst, m, rden, out, gout.contiguous(), ctx.H,
+                                             ctx.C, ctx.slope)
         return g_h, g_as, g_ad, None, None, None, None, None
+
+
+def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope):
+    """(g_hfeat through the aggregation, g_a_src [n_src, H], g_a_dst [n_tgt, H])."""
+    N, n_src, dev = g.fwd.N, g.bwd.N, gout.device
+    lib = _lib.load()
+    nodeq = torch.empty((N, H, 4), dtype=torch.float32, device=dev)  # (a_dst, max, 1/sum, dsum) records
+    g_as = torch.empty((n_src, H), dtype=torch.float32, device=dev)
+    g_h = torch.empty_like(hfeat)
+    ph, ldh = _lib.mat(hfeat, "hfeat")
+    po, ldo = _lib.mat(out, "out")
+    pg, ldg = _lib.mat(gout, "gout")
+    pgh, ldgh = _lib.mat(g_h, "g_hfeat")
+    seg = gat_segment_csr(g)
+    ds = torch.empty((max(g.bwd.nnz, 1), H), dtype=torch.float32, device=dev)
+    with _Timed("gat_bwd_prep"):
+        _lib.check(
+            lib.rgbx_gat_bwd_prep_f32(_lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, pg, ldg,
+                                      _lib.ptr(nodeq), N, H, C, _lib.stream_ptr()), "rgbx_gat_bwd_prep_f32")
+    with _Timed("gat_bwd_src"):
+        _lib.check(
+            lib.rgbx_gat_bwd_src_f32(_lib.ptr(g.bwd.rowptr), _lib.ptr(g.bwd.col), ph, ldh, _lib.ptr(a_src),
+                                     _lib.ptr(nodeq), pg, ldg, pgh, ldgh, _lib.ptr(g_as), _lib.ptr(ds), n_src, H,
+                                     C, float(slope), _lib.stream_ptr()), "rgbx_gat_bwd_src_f32")
+    g_ad = spmm_raw(seg, None, None, ds, kind="gat_bwd_segsum")
+    return g_h, g_as, g_ad
 
 
 def gat_segment_csr(graph):
@@ -292,12 +297,71 @@ def gat_aggregate(hfeat, a_src, a_dst, graph, H, C, slope=0.2, att_src=None):
     return _GATAggregate.apply(hfeat, a_src, a_dst, graph, H, C, slope, att_src)
 
 
+class _GATAttend(torch.autograd.Function):
+    """One GATConv attention block as a single autograd node: scores (rgbx_gat_scores_f32) + fused
+    edge-softmax/aggregate forward; backward = prep + source pass + segment sum (as _GATAggregate) followed
+    by rgbx_gat_scores_bwd_f32, which folds the score gradients into g_hfeat in place and reduces the
+    attention-vector gradients without materialising [N, H, C] products."""
+
+    @staticmethod
+    def forward(ctx, hfeat, att_src, att_dst, graph, H, C, slope):
+        _lib.require_device(hfeat, att_src, att_dst)
+        hfeat = hfeat.contiguous()
+        att_s = att_src.detach().reshape(H, C).contiguous()
+        att_d = att_dst.detach().reshape(H, C).contiguous()
+        n_src, N, dev = hfeat.size(0), graph.fwd.N, hfeat.device
+        lib = _lib.load()
+        a_src = torch.empty((n_src, H), dtype=torch.float32, device=dev)
+        a_dst = torch.empty_like(a_src)
+        ph, ldh = _lib.mat(hfeat, "hfeat")
+        _lib.check(lib.rgbx_gat_scores_f32(ph, ldh, _lib.ptr(att_s), _lib.ptr(att_d), _lib.ptr(a_src), _lib.ptr(a_dst),
+                                           n_src, H, C, _lib.stream_ptr()), "rgbx_gat_scores_f32")
+        out = torch.empty((N, H * C), dtype=torch.float32, device=dev)
+        m = torch.empty((N, H), dtype=torch.float32, device=dev)
+        rden = torch.empty_like(m)
+        po, ldo = _lib.mat(out, "out")
+        att_k = att_s if _scores_in_kernel(C) else None
+        with _Timed("gat_fwd"):
+            _lib.check(
+                lib.rgbx_gat_aggregate_fwd_f32(_lib.ptr(graph.fwd.rowptr), _lib.ptr(graph.fwd.col), ph, ldh,
+                                               _lib.ptr(a_src), _lib.ptr(att_k), _lib.ptr(a_dst), po, ldo, _lib.ptr(m),
+                                               _lib.ptr(rden), N, H, C, float(slope), _lib.stream_ptr()),
+                "rgbx_gat_aggregate_fwd_f32")
+        ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out, att_s, att_d)
+        ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, slope
+        ctx.att_shapes = (att_src.shape, att_dst.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        hfeat, a_src, a_dst, m, rden, out, att_s, att_d = ctx.saved_tensors
+        H, C = ctx.H, ctx.C
+        g_h, g_as, g_ad = _gat_backward_core(ctx.graph, hfeat, a_src, a_dst, m, rden, out, gout.contiguous(), H, C,
+                                             ctx.slope)
+        lib = _lib.load()
+        n = hfeat.size(0)
+        n_scr = ctypes.c_int64(0)
+        _lib.check(lib.rgbx_gat_scores_bwd_scratch_floats(n, H, C, ctypes.byref(n_scr)),
+                   "rgbx_gat_scores_bwd_scratch_floats")
+        scratch = torch.empty(n_scr.value, dtype=torch.float32, device=hfeat.device)
+        g_att_s = torch.empty((H, C), dtype=torch.float32, device=hfeat.device)
+        g_att_d = torch.empty_like(g_att_s)
+        ph, ldh = _lib.mat(hfeat, "hfeat")
+        pgh, ldgh = _lib.mat(g_h, "g_hfeat")
+        with _Timed("gat_scores_bwd"):
+            _lib.check(
+                lib.rgbx_gat_scores_bwd_f32(ph, ldh, _lib.ptr(g_as), _lib.ptr(g_ad), g_ad.size(0), _lib.ptr(att_s),
+                                            _lib.ptr(att_d), pgh, ldgh, _lib.ptr(g_att_s), _lib.ptr(g_att_d),
+                                            _lib.ptr(scratch), n_scr.value, n, H, C, _lib.stream_ptr()),
+                "rgbx_gat_scores_bwd_f32")
+        return g_h, g_att_s.reshape(ctx.att_shapes[0]), g_att_d.reshape(ctx.att_shapes[1]), None, None, None, None
+
+
 def gat_attend(h, att_src, att_dst, graph, H, C, slope=0.2):
     """Scores + edge-softmax + aggregation of one GATConv; dispatches to the partitioned graph."""
     if _is_dist(graph):
         return graph.gat(h, att_src, att_dst, H, C, slope)
-    a_src, a_dst = gat_scores(h, att_src, att_dst, H, C)
-    return gat_aggregate(h, a_src, a_dst, graph, H, C, slope, att_src=att_src if _scores_in_kernel(C) else None)
+    return _GATAttend.apply(h, att_src, att_dst, graph, H, C, slope)
 
 
 def _scores_in_kernel(C):
@@ -391,12 +455,17 @@ def _nll_stats(logp, y, mask, want_acc):
     if mask is not None and mask.dtype not in (torch.bool, torch.uint8):
         raise RuntimeError(f"mask must be bool, got {mask.dtype}")
     pl, ld = _lib.mat(logp, "logp")
+    lib = _lib.load()
     stats = torch.empty(3, dtype=torch.float64, device=logp.device)
+    n_scr = ctypes.c_int64(0)
+    _lib.check(lib.rgbx_masked_nll_scratch_doubles(logp.size(0), int(want_acc), ctypes.byref(n_scr)),
+               "rgbx_masked_nll_scratch_doubles")
+    scratch = torch.empty(n_scr.value, dtype=torch.float64, device=logp.device)
     y = y.contiguous()
     mask = None if mask is None else mask.contiguous()
-    _lib.check(_lib.load().rgbx_masked_nll_fwd_f32(pl, ld, _lib.ptr(y), _lib.ptr(mask), logp.size(0), logp.size(1),
-                                                   _lib.ptr(stats), int(want_acc), _lib.stream_ptr()),
-               "rgbx_masked_nll_fwd_f32")
+    _lib.check(lib.rgbx_masked_nll_fwd_f32(pl, ld, _lib.ptr(y), _lib.ptr(mask), logp.size(0), logp.size(1),
+                                           _lib.ptr(stats), _lib.ptr(scratch), n_scr.value, int(want_acc),
+                                           _lib.stream_ptr()), "rgbx_masked_nll_fwd_f32")
     return stats, y, mask
 
 
