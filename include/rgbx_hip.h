@@ -20,6 +20,9 @@
  *   rgbx_gat_*            GATConv.forward/message + segment softmax (models/gat.py:28,30) [PyG].
  *   rgbx_gemm_tn_f32      dW = dY^T X of the nn.Linear / conv.lin layers under loss.backward()
  *                         (itexperiments.py:439; layers at models/gcn.py:18-21, appnp_stack.py:19-20).
+ *   rgbx_bn_* / rgbx_affine_cols_f32
+ *                         nn.BatchNorm1d over all N nodes between conv layers (models/gcn.py:23,28;
+ *                         graphsage.py:24,29; gat.py:23,29; appnp_stack.py:21,27), forward and backward.
  *   rgbx_masked_nll_*     nn.NLLLoss on out[mask] and the arg-max accuracy (itexperiments.py:400,
  *                         429,434,624-626,643).
  *   rgbx_gather_rows_f32 / rgbx_scatter_add_rows_f32
@@ -212,6 +215,32 @@ int rgbx_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N, size_t* bytes)
 int rgbx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                      int64_t K, int64_t M, int64_t N, float alpha, void* workspace,
                      size_t workspace_bytes, rgbx_stream_t stream);
+
+/* ---- BatchNorm1d over the node axis --------------------------------------------------------- */
+
+/* Doubles of scratch the two column-reduction entry points need. */
+int rgbx_bn_scratch_doubles(int64_t N, int64_t d, int64_t* count);
+
+/* sums[0,c] = sum_r x[r,c], sums[1,c] = sum_r x[r,c]^2 (fp64 accumulation; [2,d] doubles, device).
+ * The caller forms mean / biased variance (and, in a node-partitioned run, all-reduces `sums` first). */
+int rgbx_bn_stats_f32(const float* x, int64_t ldx, int64_t N, int64_t d, double* sums, double* scratch,
+                      int64_t scratch_doubles, rgbx_stream_t stream);
+
+/* y[r,c] = x[r,c] * scale[c] + shift[c] — BatchNorm's normalise+affine with
+ * scale = gamma * rstd, shift = beta - mean * scale (training or running statistics alike). */
+int rgbx_affine_cols_f32(const float* x, int64_t ldx, const float* scale, const float* shift, float* y,
+                         int64_t ldy, int64_t N, int64_t d, rgbx_stream_t stream);
+
+/* sums[0,c] = sum_r gy[r,c], sums[1,c] = sum_r gy[r,c] * xhat[r,c], xhat = (x - mean) * rstd. */
+int rgbx_bn_bwd_reduce_f32(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* mean,
+                           const float* rstd, int64_t N, int64_t d, double* sums, double* scratch,
+                           int64_t scratch_doubles, rgbx_stream_t stream);
+
+/* gx[r,c] = (gy[r,c] - ca[c] - xhat[r,c] * cb[c]) * ck[c]
+ * (ca = sum gy / n, cb = sum gy*xhat / n, ck = gamma * rstd). */
+int rgbx_bn_bwd_apply_f32(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* mean,
+                          const float* rstd, const float* ca, const float* cb, const float* ck, float* gx,
+                          int64_t ldgx, int64_t N, int64_t d, rgbx_stream_t stream);
 
 /* ---- loss / metrics on masked rows ---------------------------------------------------------- */
 

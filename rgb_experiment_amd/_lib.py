@@ -43,6 +43,11 @@ SIGNATURES = {
     "rgbx_gat_bwd_src_f32": [_P, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _F, _P],
     "rgbx_gemm_tn_workspace_bytes": [_I64, _I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
     "rgbx_gemm_tn_f32": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _F, _P, ctypes.c_size_t, _P],
+    "rgbx_bn_scratch_doubles": [_I64, _I64, ctypes.POINTER(ctypes.c_int64)],
+    "rgbx_bn_stats_f32": [_P, _I64, _I64, _I64, _P, _P, _I64, _P],
+    "rgbx_affine_cols_f32": [_P, _I64, _P, _P, _P, _I64, _I64, _I64, _P],
+    "rgbx_bn_bwd_reduce_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _P, _P, _I64, _P],
+    "rgbx_bn_bwd_apply_f32": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "rgbx_masked_nll_scratch_doubles": [_I64, _I, ctypes.POINTER(ctypes.c_int64)],
     "rgbx_masked_nll_fwd_f32": [_P, _I64, _P, _P, _I64, _I64, _P, _P, _I64, _I, _P],
     "rgbx_masked_nll_bwd_f32": [_P, _P, _I64, _I64, _P, _P, _I64, _P],

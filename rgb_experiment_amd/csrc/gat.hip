@@ -162,14 +162,26 @@ gat_scores_bwd_kernel(const float* __restrict__ hfeat, int64_t ldh, const float*
   }
 }
 
+// 32 consecutive columns per block; 8 lanes per column stride the per-block partial records, then the 8
+// sub-sums are added in lane order (fixed summation order).
 __global__ void __launch_bounds__(256)
 gat_scores_bwd_finish_kernel(const float* __restrict__ part, int n_blocks, int F, float* __restrict__ g_att_src,
                              float* __restrict__ g_att_dst) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < 2 * F; c += gridDim.x * blockDim.x) {
+  __shared__ float sh[8][32];
+  const int j = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + j;  // column of the [2, F] result
+  float s = 0.f;
+  if (c < 2 * F) {
     const int which = c / F, col = c % F;
-    float s = 0.f;
-    for (int b = 0; b < n_blocks; ++b) s += part[((int64_t)b * 2 + which) * F + col];
-    (which == 0 ? g_att_src : g_att_dst)[col] = s;
+    for (int b = q; b < n_blocks; b += 8) s += part[((int64_t)b * 2 + which) * F + col];
+  }
+  sh[q][j] = s;
+  __syncthreads();
+  if (q == 0 && c < 2 * F) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sh[k][j];
+    (c / F == 0 ? g_att_src : g_att_dst)[c % F] = t;
   }
 }
 
@@ -599,7 +611,7 @@ extern "C" int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const fl
   else RGBX_GAT_SB(1);
 #undef RGBX_GAT_SB
   RGBX_CHECK_LAUNCH("gat_scores_bwd_kernel");
-  gat_scores_bwd_finish_kernel<<<(int)cdiv(2 * F, 256), 256, 0, s>>>(scratch, grid, F, g_att_src, g_att_dst);
+  gat_scores_bwd_finish_kernel<<<(int)cdiv(2 * F, 32), 256, 0, s>>>(scratch, grid, F, g_att_src, g_att_dst);
   RGBX_CHECK_LAUNCH("gat_scores_bwd_finish_kernel");
   return RGBX_OK;
 }

@@ -396,5 +396,6 @@ def experiment(model_init_param: dict, *,
     if return_model:
         result["model"] = net
         result["history"] = hist
+        result["used_hip_graph"] = graphed is not None
         result["emb"] = final["emb"]
     return result

@@ -4,6 +4,8 @@ never uses it: models/gcn.py:15,25-31)."""
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..nn import BatchNorm1d
+
 
 def model_output(logits):
     """The reference's forward contract: {'out': log-probs, 'emb': logits} (models/gcn.py:31).
@@ -23,7 +25,7 @@ class ConvStack(nn.Module):
         self.num_layers = num_layers
         self.dropout_rate = dropout_rate
         self.convs = nn.ModuleList(make_conv(i, widths[i], widths[i + 1]) for i in range(num_layers))
-        self.bns = nn.ModuleList(nn.BatchNorm1d(bn_width) for _ in range(num_layers - 1))
+        self.bns = nn.ModuleList(BatchNorm1d(bn_width) for _ in range(num_layers - 1))
 
     def forward(self, x, edge_index):
         last = self.num_layers - 1

@@ -3,7 +3,7 @@ the propagation runs at width output_dim."""
 import torch.nn as nn
 
 from .. import ops
-from ..nn import APPNP
+from ..nn import APPNP, BatchNorm1d
 from ._stack import model_output
 
 
@@ -13,7 +13,7 @@ class APPNPStack(nn.Module):
         self.dropout_rate = dropout_rate
         self.lin1 = nn.Linear(input_dim, hidden_unit)
         self.lin2 = nn.Linear(hidden_unit, output_dim)
-        self.bn = nn.BatchNorm1d(hidden_unit)
+        self.bn = BatchNorm1d(hidden_unit)
         self.conv = APPNP(K, alpha)
 
     def forward(self, x, edge_index):

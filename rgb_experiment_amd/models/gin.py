@@ -3,13 +3,13 @@ train_eps=True), then lin1 -> ReLU -> dropout -> lin2."""
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..nn import GINConv
+from ..nn import BatchNorm1d, GINConv
 from ._stack import model_output
 
 
 def _block(fan_in, width):
     return nn.Sequential(nn.Linear(fan_in, width), nn.ReLU(), nn.Linear(width, width), nn.ReLU(),
-                         nn.BatchNorm1d(width))
+                         BatchNorm1d(width))
 
 
 class GIN(nn.Module):

@@ -3,6 +3,7 @@ The reference builds one more BatchNorm1d (over output_dim) than it applies (mlp
 so that state_dict keys match."""
 import torch.nn as nn
 
+from ..nn import BatchNorm1d
 from ._stack import model_output
 
 
@@ -13,8 +14,8 @@ class MLP(nn.Module):
         self.dropout_rate = dropout_rate
         widths = [input_dim] + [hidden_unit] * (num_layers - 1) + [output_dim]
         self.lins = nn.ModuleList(nn.Linear(widths[i], widths[i + 1]) for i in range(num_layers))
-        self.bns = nn.ModuleList([nn.BatchNorm1d(hidden_unit) for _ in range(num_layers - 1)] +
-                                 [nn.BatchNorm1d(output_dim)])
+        self.bns = nn.ModuleList([BatchNorm1d(hidden_unit) for _ in range(num_layers - 1)] +
+                                 [BatchNorm1d(output_dim)])
 
     def forward(self, x):
         for i in range(self.num_layers - 1):

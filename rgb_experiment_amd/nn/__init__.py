@@ -1,5 +1,6 @@
 from .conv import GCNConv, SAGEConv, MySAGEConv, GATConv, APPNP, SGConv, GINConv
+from .batchnorm import BatchNorm1d
 from .correct_and_smooth import CorrectAndSmooth, LabelPropagation
 
 __all__ = ["GCNConv", "SAGEConv", "MySAGEConv", "GATConv", "APPNP", "SGConv", "GINConv",
-           "CorrectAndSmooth", "LabelPropagation"]
+           "CorrectAndSmooth", "LabelPropagation", "BatchNorm1d"]

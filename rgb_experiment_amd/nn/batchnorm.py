@@ -1,0 +1,127 @@
+"""BatchNorm1d over the node axis on the HIP kernels (reference: nn.BatchNorm1d between conv layers,
+models/gcn.py:23,28; graphsage.py:24,29; gat.py:23,29; appnp_stack.py:21,27). Same parameters, buffers
+and state_dict keys as nn.BatchNorm1d. The column statistics are raw fp64 sums, which a node-partitioned
+run all-reduces before finishing (dist.DistBatchNorm1d overrides `_reduce`)."""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+def _scratch(n, d, device):
+    cnt = ctypes.c_int64(0)
+    _lib.check(_lib.load().rgbx_bn_scratch_doubles(n, d, ctypes.byref(cnt)), "rgbx_bn_scratch_doubles")
+    return torch.empty(cnt.value, dtype=torch.float64, device=device), cnt.value
+
+
+def column_sums(x):
+    """[2, d] float64: column sums of x and x^2."""
+    if not x.is_cuda:  # host tensors (MLP on the CPU, gloo tests): plain torch, still fp64 accumulation
+        xd = x.double()
+        return torch.stack([xd.sum(0), (xd * xd).sum(0)])
+    px, ldx = _lib.mat(x, "x")
+    n, d = x.shape
+    sums = torch.empty((2, d), dtype=torch.float64, device=x.device)
+    scratch, cnt = _scratch(n, d, x.device)
+    _lib.check(_lib.load().rgbx_bn_stats_f32(px, ldx, n, d, _lib.ptr(sums), _lib.ptr(scratch), cnt, _lib.stream_ptr()),
+               "rgbx_bn_stats_f32")
+    return sums
+
+
+def affine_cols(x, scale, shift):
+    if not x.is_cuda:
+        return x * scale + shift
+    px, ldx = _lib.mat(x, "x")
+    y = torch.empty((x.size(0), x.size(1)), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rgbx_affine_cols_f32(px, ldx, _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y), y.stride(0),
+                                                x.size(0), x.size(1), _lib.stream_ptr()), "rgbx_affine_cols_f32")
+    return y
+
+
+def bwd_sums(gy, x, mean, rstd):
+    """[2, d] float64: column sums of gy and gy * xhat."""
+    if not gy.is_cuda:
+        xhat = (x - mean) * rstd
+        return torch.stack([gy.double().sum(0), (gy * xhat).double().sum(0)])
+    pg, ldg = _lib.mat(gy, "gy")
+    px, ldx = _lib.mat(x, "x")
+    n, d = x.shape
+    sums = torch.empty((2, d), dtype=torch.float64, device=x.device)
+    scratch, cnt = _scratch(n, d, x.device)
+    _lib.check(_lib.load().rgbx_bn_bwd_reduce_f32(pg, ldg, px, ldx, _lib.ptr(mean), _lib.ptr(rstd), n, d, _lib.ptr(sums),
+                                                  _lib.ptr(scratch), cnt, _lib.stream_ptr()), "rgbx_bn_bwd_reduce_f32")
+    return sums
+
+
+def bwd_apply(gy, x, mean, rstd, ca, cb, ck):
+    if not gy.is_cuda:
+        return (gy - ca - (x - mean) * rstd * cb) * ck
+    pg, ldg = _lib.mat(gy, "gy")
+    px, ldx = _lib.mat(x, "x")
+    gx = torch.empty((x.size(0), x.size(1)), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rgbx_bn_bwd_apply_f32(pg, ldg, px, ldx, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(ca),
+                                                 _lib.ptr(cb), _lib.ptr(ck), _lib.ptr(gx), gx.stride(0), x.size(0),
+                                                 x.size(1), _lib.stream_ptr()), "rgbx_bn_bwd_apply_f32")
+    return gx
+
+
+class _BNTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, reduce, stats_out):
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        # the row count rides along as a device scalar made by a fill kernel (a host->device copy would break
+        # hipGraph capture)
+        count = torch.full((1,), float(x.size(0)), dtype=torch.float64, device=x.device)
+        packed = torch.cat([column_sums(x).reshape(-1), count])
+        packed = reduce(packed)  # identity on one GPU; all-reduce over the node partition otherwise
+        d = x.size(1)
+        n = packed[2 * d]
+        mean64 = packed[:d] / n
+        var64 = (packed[d:2 * d] / n - mean64 * mean64).clamp_(min=0.0)  # biased variance
+        mean, var = mean64.float(), var64.float()
+        rstd = torch.rsqrt(var + eps)
+        scale = weight * rstd
+        y = affine_cols(x, scale.contiguous(), (bias - mean * scale).contiguous())
+        stats_out.extend([mean, var, n])
+        ctx.save_for_backward(x, weight, mean, rstd, n)
+        ctx.reduce = reduce
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, mean, rstd, n = ctx.saved_tensors
+        gy = gy if gy.stride(-1) == 1 else gy.contiguous()
+        local = bwd_sums(gy, x, mean, rstd)            # [2, d]: sum gy, sum gy * xhat over the local rows
+        glob = ctx.reduce(local.reshape(-1).clone()).reshape(2, -1)
+        ca = (glob[0] / n).float().contiguous()
+        cb = (glob[1] / n).float().contiguous()
+        gx = bwd_apply(gy, x, mean, rstd, ca, cb, (weight * rstd).contiguous())
+        # parameter gradients are the LOCAL sums: a partitioned run all-reduces parameter gradients once
+        return gx, local[1].float(), local[0].float(), None, None, None
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    """Drop-in for nn.BatchNorm1d on [N, d] inputs (affine, running statistics)."""
+
+    def _reduce(self, packed):
+        return packed
+
+    def forward(self, x):
+        if x.dim() != 2 or not self.affine or not self.track_running_stats:
+            return super().forward(x)
+        if not self.training:
+            scale = self.weight * torch.rsqrt(self.running_var + self.eps)
+            return affine_cols(x if x.stride(-1) == 1 else x.contiguous(), scale.contiguous(),
+                               (self.bias - self.running_mean * scale).contiguous())
+        stats = []
+        y = _BNTrain.apply(x, self.weight, self.bias, self.eps, self._reduce, stats)
+        mean, var, n = stats
+        with torch.no_grad():
+            self.num_batches_tracked += 1
+            m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+            unbiased = var * (n / (n - 1).clamp(min=1)).float()
+            self.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            self.running_var.mul_(1 - m).add_(unbiased, alpha=m)
+        return y

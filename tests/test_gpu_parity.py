@@ -648,6 +648,7 @@ def test_hip_graph_epoch_equals_eager_loop(dev, name):
                            need_all_metrics=False)
         runs.append(res)
     a, b = runs
+    assert b["used_hip_graph"] and not a["used_hip_graph"]  # the capture really happened (no silent fallback)
     assert len(b["history"]["train_loss"]) == 8
     for key in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_acc"):
         assert np.allclose(a["history"][key], b["history"][key], rtol=0, atol=2e-6), key
@@ -679,6 +680,43 @@ def test_experiment_pta_and_sgc_run(dev):
                            model_name="MLP", learning_rate=0.01, epoch=15, need_to_reappear=True, print_print=False,
                            post_cs=True, cs_param=R.InitialParameters.default_cs_param)
     assert with_cs["ACC"] >= plain["ACC"] - 0.02  # homophilous graph: C&S does not hurt the MLP
+
+
+# ---- BatchNorm1d over the node axis ------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,d", [(2, 3), (1000, 7), (5000, 128), (3000, 300), (200003, 128), (700, 1100)])
+def test_batchnorm_matches_torch(dev, n, d):
+    from rgb_experiment_amd.nn import BatchNorm1d
+    gen = torch.Generator().manual_seed(n + d)
+    x = torch.randn(n, d, generator=gen) * 3 + 5  # mean >> 0: E[x^2] - mean^2 would cancel in fp32
+    go = torch.randn(n, d, generator=gen)
+    ref = torch.nn.BatchNorm1d(d)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 2.0)
+        ref.bias.uniform_(-1, 1)
+    mine = BatchNorm1d(d)
+    mine.load_state_dict(ref.state_dict())
+    mine.to(dev)
+    assert list(mine.state_dict()) == list(ref.state_dict())
+    for step in range(2):
+        xa = x.clone().requires_grad_(True)
+        xb = x.to(dev).requires_grad_(True)
+        ya, yb = ref(xa), mine(xb)
+        ya.backward(go)
+        yb.backward(go.to(dev))
+        assert (yb.detach().cpu() - ya.detach()).abs().max().item() < 2e-5
+        assert (xb.grad.cpu() - xa.grad).abs().max().item() < 2e-5 * max(1.0, xa.grad.abs().max().item())
+        for p, q in ((ref.weight, mine.weight), (ref.bias, mine.bias)):
+            assert (q.grad.cpu() - p.grad).abs().max().item() < 1e-4 * max(1.0, p.grad.abs().max().item())
+            p.grad = None
+            q.grad = None
+    assert torch.allclose(mine.running_mean.cpu(), ref.running_mean, atol=1e-5)
+    assert torch.allclose(mine.running_var.cpu(), ref.running_var, rtol=1e-5, atol=1e-6)
+    assert int(mine.num_batches_tracked) == 2
+    ref.eval(), mine.eval()
+    assert (mine(x.to(dev)).cpu() - ref(x)).abs().max().item() < 2e-5
+    wide = torch.randn(n, d + 5, generator=gen).to(dev)  # strided (non-contiguous rows) input
+    assert (mine(wide[:, 2:2 + d]).cpu() - ref(wide[:, 2:2 + d].cpu())).abs().max().item() < 2e-5
 
 
 # ---- halo pack / unpack -------------------------------------------------------------------------------
