@@ -267,6 +267,8 @@ def main():
                     help="gcn is the BASELINE.json headline; the others are its configs 3-5")
     ap.add_argument("--exchange", choices=["auto", "halo", "reshard"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--primary-only", action="store_true",
+                    help="skip the secondary legs (hipGraph replay, configs[1] block): clean rocprofv3 runs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -398,9 +400,9 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ei, x, N)
-    if world == 1:
+    if world == 1 and not args.primary_only:
         result["hip_graph_replay"] = time_graphed(step, args.steps, args.warmup)
-    if world == 1 and args.workload == "L" and args.model == "gcn":
+    if world == 1 and args.workload == "L" and args.model == "gcn" and not args.primary_only:
         del step, model
         from rgb_experiment_amd.graph import clear_cache
         clear_cache()
