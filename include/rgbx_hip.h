@@ -118,9 +118,10 @@ typedef struct rgbx_row_split {
   int32_t n_long;
   const int32_t* chunk_begin;    /* [n_chunks] */
   const int32_t* chunk_end;      /* [n_chunks] */
+  const int32_t* chunk_row;      /* [n_chunks] row id of every chunk (used by the GAT kernels) */
   const int32_t* long_row;       /* [n_long] row ids, ascending */
   const int32_t* long_chunk_ptr; /* [n_long + 1] */
-  float* partial;                /* [n_chunks, d] */
+  float* partial;                /* [n_chunks, d] fp32 scratch; GAT: [n_chunks, H*C + 2*H] */
 } rgbx_row_split_t;
 
 /* out[i,:] = a * rs[i] * sum_{p in row i} w[p] * x[col[p],:]  +  b * y[i,:]  +  bias[:]
@@ -167,11 +168,14 @@ int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const float* g_a_sr
  * Rows without edges produce 0 (m = 0, rden = 0).
  * Source scores: either `a_src` ([n_src, H], gathered per edge) or, when `att_src` ([H, C]) is not
  * NULL, recomputed inside the kernel from each gathered row as <hfeat[col[p],h,:], att_src[h,:]>
- * (saves one cache-line request per edge; `a_src` is then ignored and may be NULL). */
+ * (saves one cache-line request per edge; `a_src` is then ignored and may be NULL).
+ * `split` (optional): hub targets are cut into chunks whose online-softmax states are merged in chunk
+ * order; `split->partial` must hold n_chunks * (H*C + 2*H) floats. */
 int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                                int64_t ldh, const float* a_src, const float* att_src,
                                const float* a_dst, float* out, int64_t ldo, float* m, float* rden,
-                               int64_t N, int H, int C, float slope, rgbx_stream_t stream);
+                               int64_t N, int H, int C, float slope, const rgbx_row_split_t* split,
+                               rgbx_stream_t stream);
 
 /* Backward, target side (same CSR as forward). Per target i, head h:
  *   dsum[i,h]    = <gout[i,h,:], out[i,h,:]>
@@ -202,7 +206,7 @@ int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const float* rden,
 int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const float* hfeat,
                          int64_t ldh, const float* a_src, const float* nodeq, const float* gout,
                          int64_t ldg, float* g_hfeat, int64_t ldgh, float* g_a_src, float* ds, int64_t N,
-                         int H, int C, float slope, rgbx_stream_t stream);
+                         int H, int C, float slope, const rgbx_row_split_t* split, rgbx_stream_t stream);
 
 /* ---- dense weight gradient on the MFMA units ---------------------------------------------- */
 

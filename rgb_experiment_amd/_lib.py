@@ -20,7 +20,8 @@ _F = ctypes.c_float
 class RowSplit(ctypes.Structure):
     """rgbx_row_split_t"""
     _fields_ = [("threshold", ctypes.c_int32), ("n_chunks", ctypes.c_int32), ("n_long", ctypes.c_int32),
-                ("chunk_begin", ctypes.c_void_p), ("chunk_end", ctypes.c_void_p), ("long_row", ctypes.c_void_p),
+                ("chunk_begin", ctypes.c_void_p), ("chunk_end", ctypes.c_void_p), ("chunk_row", ctypes.c_void_p),
+                ("long_row", ctypes.c_void_p),
                 ("long_chunk_ptr", ctypes.c_void_p), ("partial", ctypes.c_void_p)]
 
 
@@ -36,11 +37,11 @@ SIGNATURES = {
     "rgbx_gat_scores_f32": [_P, _I64, _P, _P, _P, _P, _I64, _I, _I, _P],
     "rgbx_gat_scores_bwd_scratch_floats": [_I64, _I, _I, ctypes.POINTER(ctypes.c_int64)],
     "rgbx_gat_scores_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I, _I, _P],
-    "rgbx_gat_aggregate_fwd_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _I64, _P, _P, _I64, _I, _I, _F, _P],
+    "rgbx_gat_aggregate_fwd_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _I64, _P, _P, _I64, _I, _I, _F, _P, _P],
     "rgbx_gat_bwd_dst_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I,
                              _F, _P],
     "rgbx_gat_bwd_prep_f32": [_P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
-    "rgbx_gat_bwd_src_f32": [_P, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _F, _P],
+    "rgbx_gat_bwd_src_f32": [_P, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _F, _P, _P],
     "rgbx_gemm_tn_workspace_bytes": [_I64, _I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
     "rgbx_gemm_tn_f32": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _F, _P, ctypes.c_size_t, _P],
     "rgbx_bn_scratch_doubles": [_I64, _I64, ctypes.POINTER(ctypes.c_int64)],

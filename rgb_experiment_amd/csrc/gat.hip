@@ -24,6 +24,19 @@ struct GatLayout {
 constexpr float kNegBig = -1.0e30f;
 constexpr int U = 4;
 
+// Hub rows (rgbx_row_split_t): the row kernels skip rows longer than `threshold`; the same kernels,
+// instantiated with CHUNK = true, walk the chunks of those rows and store per-chunk partial states
+// (pacc [n_chunks, F], p0 / p1 [n_chunks, H]); a combine kernel merges them in chunk order.
+struct SplitDev {
+  int threshold;
+  const int* chunk_row;
+  const int* chunk_begin;
+  const int* chunk_end;
+  float* pacc;
+  float* p0;
+  float* p1;
+};
+
 template <int VEC>
 __device__ __forceinline__ float dot_vec(const float (&a)[VEC], const float (&b)[VEC]) {
   float s = 0.f;
@@ -186,14 +199,14 @@ gat_scores_bwd_finish_kernel(const float* __restrict__ part, int n_blocks, int F
 }
 
 // ------------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, bool CHUNK>
 __global__ void __launch_bounds__(256)
 gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
                const float* __restrict__ att_src, const float* __restrict__ a_dst, float* __restrict__ out,
                int64_t ldo,
                float* __restrict__ m_out, float* __restrict__ rden_out, int N, float slope,
-               const GatLayout L) {
+               const GatLayout L, const SplitDev sp) {
   const int lane = threadIdx.x & 63;
   const int NG = kWave / L.G;
   const int g = lane / L.G;
@@ -202,9 +215,19 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
   const int ch = (t % L.LPH) * VEC;
   const int wpb = blockDim.x >> 6;
 
-  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < N; row += gridDim.x * wpb) {
-    const int start = __builtin_amdgcn_readfirstlane(rowptr[row]);
-    const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+  const int F = L.H * L.C;
+  for (int item = blockIdx.x * wpb + (threadIdx.x >> 6); item < N; item += gridDim.x * wpb) {
+    int row, start, end;
+    if constexpr (CHUNK) {
+      row = __builtin_amdgcn_readfirstlane(sp.chunk_row[item]);
+      start = __builtin_amdgcn_readfirstlane(sp.chunk_begin[item]);
+      end = __builtin_amdgcn_readfirstlane(sp.chunk_end[item]);
+    } else {
+      row = item;
+      start = __builtin_amdgcn_readfirstlane(rowptr[row]);
+      end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+      if (sp.threshold > 0 && end - start > sp.threshold) continue;  // the chunk + combine kernels own it
+    }
     for (int hbase = 0; hbase < L.H; hbase += L.HPC) {
       const int head = hbase + hl;
       const bool active = hl < L.HPC && head < L.H && ch < L.C;
@@ -274,15 +297,72 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
         m = mn;
       }
       if (g == 0 && active) {
-        const float rd = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
-        float r[VEC];
+        if constexpr (CHUNK) {  // un-normalised online-softmax state of this chunk
+          store_vec<VEC>(sp.pacc + (int64_t)item * F + cofs, acc);
+          if (ch == 0) {
+            sp.p0[(int64_t)item * L.H + head] = m;
+            sp.p1[(int64_t)item * L.H + head] = l;
+          }
+        } else {
+          const float rd = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
+          float r[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) r[i] = acc[i] * rd;
-        store_vec<VEC>(out + (int64_t)row * ldo + cofs, r);
-        if (ch == 0) {
-          m_out[(int64_t)row * L.H + head] = l > 0.f ? m : 0.f;
-          rden_out[(int64_t)row * L.H + head] = rd;
+          for (int i = 0; i < VEC; ++i) r[i] = acc[i] * rd;
+          store_vec<VEC>(out + (int64_t)row * ldo + cofs, r);
+          if (ch == 0) {
+            m_out[(int64_t)row * L.H + head] = l > 0.f ? m : 0.f;
+            rden_out[(int64_t)row * L.H + head] = rd;
+          }
         }
+      }
+    }
+  }
+}
+
+// One wave per hub row: merge the chunk states in chunk order, normalise, store.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+gat_fwd_combine_kernel(int n_long, const int* __restrict__ long_row, const int* __restrict__ long_chunk_ptr,
+                       float* __restrict__ out, int64_t ldo, float* __restrict__ m_out,
+                       float* __restrict__ rden_out, const GatLayout L, const SplitDev sp) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane / L.G;
+  const int t = lane % L.G;
+  const int hl = t / L.LPH;
+  const int ch = (t % L.LPH) * VEC;
+  const int wpb = blockDim.x >> 6;
+  const int F = L.H * L.C;
+  for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < n_long; r += gridDim.x * wpb) {
+    const int row = long_row[r];
+    const int c0 = long_chunk_ptr[r], c1 = long_chunk_ptr[r + 1];
+    for (int hbase = 0; hbase < L.H; hbase += L.HPC) {
+      const int head = hbase + hl;
+      const bool active = g == 0 && hl < L.HPC && head < L.H && ch < L.C;
+      if (!active) continue;
+      const int cofs = head * L.C + ch;
+      float m = kNegBig, l = 0.f;
+      float acc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      for (int c = c0; c < c1; ++c) {
+        const float m2 = sp.p0[(int64_t)c * L.H + head];
+        const float l2 = sp.p1[(int64_t)c * L.H + head];
+        float a2[VEC];
+        load_vec<VEC>(a2, sp.pacc + (int64_t)c * F + cofs);
+        const float mn = fmaxf(m, m2);
+        const float s1 = expf(m - mn), s2 = expf(m2 - mn);
+        l = l * s1 + l2 * s2;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = acc[i] * s1 + a2[i] * s2;
+        m = mn;
+      }
+      const float rd = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] *= rd;
+      store_vec<VEC>(out + (int64_t)row * ldo + cofs, acc);
+      if (ch == 0) {
+        m_out[(int64_t)row * L.H + head] = l > 0.f ? m : 0.f;
+        rden_out[(int64_t)row * L.H + head] = rd;
       }
     }
   }
@@ -407,14 +487,14 @@ gat_bwd_prep_kernel(const float* __restrict__ a_dst, const float* __restrict__ m
 
 // ------------------------------------------------------------------------------------------
 // Backward, source side, over the transposed CSR: row = source j, col_t[p] = target i.
-template <int VEC>
+template <int VEC, bool CHUNK>
 __global__ void __launch_bounds__(256)
 gat_bwd_src_kernel(const int* __restrict__ rowptr_t, const int* __restrict__ col_t,
                    const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
                    const float4* __restrict__ nodeq, const float* __restrict__ gout, int64_t ldg,
                    float* __restrict__ g_hfeat,
                    int64_t ldgh, float* __restrict__ g_a_src, float* __restrict__ ds_out, int N, float slope,
-                   const GatLayout L) {
+                   const GatLayout L, const SplitDev sp) {
   const int lane = threadIdx.x & 63;
   const int NG = kWave / L.G;
   const int g = lane / L.G;
@@ -423,9 +503,19 @@ gat_bwd_src_kernel(const int* __restrict__ rowptr_t, const int* __restrict__ col
   const int ch = (t % L.LPH) * VEC;
   const int wpb = blockDim.x >> 6;
 
-  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < N; row += gridDim.x * wpb) {
-    const int start = __builtin_amdgcn_readfirstlane(rowptr_t[row]);
-    const int end = __builtin_amdgcn_readfirstlane(rowptr_t[row + 1]);
+  const int F = L.H * L.C;
+  for (int item = blockIdx.x * wpb + (threadIdx.x >> 6); item < N; item += gridDim.x * wpb) {
+    int row, start, end;
+    if constexpr (CHUNK) {
+      row = __builtin_amdgcn_readfirstlane(sp.chunk_row[item]);
+      start = __builtin_amdgcn_readfirstlane(sp.chunk_begin[item]);
+      end = __builtin_amdgcn_readfirstlane(sp.chunk_end[item]);
+    } else {
+      row = item;
+      start = __builtin_amdgcn_readfirstlane(rowptr_t[row]);
+      end = __builtin_amdgcn_readfirstlane(rowptr_t[row + 1]);
+      if (sp.threshold > 0 && end - start > sp.threshold) continue;
+    }
     for (int hbase = 0; hbase < L.H; hbase += L.HPC) {
       const int head = hbase + hl;
       const bool active = hl < L.HPC && head < L.H && ch < L.C;
@@ -486,14 +576,73 @@ gat_bwd_src_kernel(const int* __restrict__ rowptr_t, const int* __restrict__ col
         for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
       }
       if (g == 0 && active) {
-        store_vec<VEC>(g_hfeat + (int64_t)row * ldgh + cofs, acc);
-        if (ch == 0) g_a_src[(int64_t)row * L.H + head] = acc_as;
+        if constexpr (CHUNK) {
+          store_vec<VEC>(sp.pacc + (int64_t)item * F + cofs, acc);
+          if (ch == 0) sp.p0[(int64_t)item * L.H + head] = acc_as;
+        } else {
+          store_vec<VEC>(g_hfeat + (int64_t)row * ldgh + cofs, acc);
+          if (ch == 0) g_a_src[(int64_t)row * L.H + head] = acc_as;
+        }
       }
     }
   }
 }
 
+// One wave per hub source row: chunk sums added in chunk order.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+gat_bwd_src_combine_kernel(int n_long, const int* __restrict__ long_row, const int* __restrict__ long_chunk_ptr,
+                           float* __restrict__ g_hfeat, int64_t ldgh, float* __restrict__ g_a_src,
+                           const GatLayout L, const SplitDev sp) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane / L.G;
+  const int t = lane % L.G;
+  const int hl = t / L.LPH;
+  const int ch = (t % L.LPH) * VEC;
+  const int wpb = blockDim.x >> 6;
+  const int F = L.H * L.C;
+  for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < n_long; r += gridDim.x * wpb) {
+    const int row = long_row[r];
+    const int c0 = long_chunk_ptr[r], c1 = long_chunk_ptr[r + 1];
+    for (int hbase = 0; hbase < L.H; hbase += L.HPC) {
+      const int head = hbase + hl;
+      if (!(g == 0 && hl < L.HPC && head < L.H && ch < L.C)) continue;
+      const int cofs = head * L.C + ch;
+      float acc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      float as = 0.f;
+      for (int c = c0; c < c1; ++c) {
+        float a2[VEC];
+        load_vec<VEC>(a2, sp.pacc + (int64_t)c * F + cofs);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += a2[i];
+        as += sp.p0[(int64_t)c * L.H + head];
+      }
+      store_vec<VEC>(g_hfeat + (int64_t)row * ldgh + cofs, acc);
+      if (ch == 0) g_a_src[(int64_t)row * L.H + head] = as;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
+int split_view(const rgbx_row_split_t* split, int H, int C, SplitDev* sd, const char* name) {
+  *sd = SplitDev{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (!split || split->threshold <= 0 || split->n_chunks <= 0) return RGBX_OK;
+  if (split->n_long <= 0 || !split->chunk_row || !split->chunk_begin || !split->chunk_end || !split->long_row ||
+      !split->long_chunk_ptr || !split->partial)
+    return fail(RGBX_E_ARG, "%s: incomplete row-split plan", name);
+  const int64_t F = (int64_t)H * C;
+  sd->threshold = split->threshold;
+  sd->chunk_row = split->chunk_row;
+  sd->chunk_begin = split->chunk_begin;
+  sd->chunk_end = split->chunk_end;
+  sd->pacc = split->partial;                                   // [n_chunks, F]
+  sd->p0 = split->partial + (int64_t)split->n_chunks * F;      // [n_chunks, H]
+  sd->p1 = sd->p0 + (int64_t)split->n_chunks * H;              // [n_chunks, H]
+  return RGBX_OK;
+}
+
 int pow2ceil(int x) {
   int p = 1;
   while (p < x) p <<= 1;
@@ -619,19 +768,32 @@ extern "C" int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const fl
 extern "C" int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                                           int64_t ldh, const float* a_src, const float* att_src,
                                           const float* a_dst, float* out, int64_t ldo, float* m, float* rden,
-                                          int64_t N, int H, int C, float slope, rgbx_stream_t stream) {
+                                          int64_t N, int H, int C, float slope, const rgbx_row_split_t* split,
+                                          rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_fwd")) return rc;
   if (N == 0) return RGBX_OK;
   if (!rowptr || !col || !hfeat || (!a_src && !att_src) || !a_dst || !out || !m || !rden)
     return fail(RGBX_E_ARG, "gat_fwd: null pointer");
   if (ldh < (int64_t)H * C || ldo < (int64_t)H * C) return fail(RGBX_E_ARG, "gat_fwd: leading dimension < H*C");
-  const int vec = pick_vec(C, {hfeat, out, att_src}, {ldh, ldo});
+  SplitDev sd;
+  if (int rc = split_view(split, H, C, &sd, "gat_fwd")) return rc;
+  const int vec = pick_vec(C, {hfeat, out, att_src, sd.pacc}, {ldh, ldo});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_fwd")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int grid = gat_grid(N);
-#define RGBX_GAT_FWD(V) \
-  gat_fwd_kernel<V><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out, ldo, m, rden, (int)N, slope, L)
+#define RGBX_GAT_FWD(V)                                                                                         \
+  do {                                                                                                          \
+    gat_fwd_kernel<V, false><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out, ldo, m,  \
+                                                  rden, (int)N, slope, L, sd);                                  \
+    if (sd.threshold > 0) {                                                                                     \
+      gat_fwd_kernel<V, true><<<gat_grid(split->n_chunks), 256, 0, s>>>(                                        \
+          rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out, ldo, m, rden, split->n_chunks, slope, L, sd);    \
+      gat_fwd_combine_kernel<V><<<gat_grid(split->n_long), 256, 0, s>>>(split->n_long, split->long_row,         \
+                                                                      split->long_chunk_ptr, out, ldo, m, rden, \
+                                                                      L, sd);                                   \
+    }                                                                                                           \
+  } while (0)
   if (vec == 4) RGBX_GAT_FWD(4);
   else if (vec == 2) RGBX_GAT_FWD(2);
   else RGBX_GAT_FWD(1);
@@ -696,7 +858,8 @@ extern "C" int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const f
 extern "C" int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const float* hfeat,
                                     int64_t ldh, const float* a_src, const float* nodeq, const float* gout,
                                     int64_t ldg, float* g_hfeat, int64_t ldgh, float* g_a_src, float* ds,
-                                    int64_t N, int H, int C, float slope, rgbx_stream_t stream) {
+                                    int64_t N, int H, int C, float slope, const rgbx_row_split_t* split,
+                                    rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_bwd_src")) return rc;
   if (N == 0) return RGBX_OK;
   if (!rowptr_t || !col_t || !hfeat || !a_src || !nodeq || !gout || !g_hfeat || !g_a_src)
@@ -704,15 +867,26 @@ extern "C" int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_
   if (!aligned16(nodeq)) return fail(RGBX_E_ALIGN, "gat_bwd_src: nodeq must be 16-byte aligned");
   const int64_t F = (int64_t)H * C;
   if (ldh < F || ldg < F || ldgh < F) return fail(RGBX_E_ARG, "gat_bwd_src: leading dimension < H*C");
-  const int vec = pick_vec(C, {hfeat, gout, g_hfeat}, {ldh, ldg, ldgh});
+  SplitDev sd;
+  if (int rc = split_view(split, H, C, &sd, "gat_bwd_src")) return rc;
+  const int vec = pick_vec(C, {hfeat, gout, g_hfeat, sd.pacc}, {ldh, ldg, ldgh});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_bwd_src")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int grid = gat_grid(N);
-#define RGBX_GAT_BS(V)                                                                                \
-  gat_bwd_src_kernel<V><<<grid, 256, 0, s>>>(rowptr_t, col_t, hfeat, ldh, a_src,                          \
-                                             reinterpret_cast<const float4*>(nodeq), gout, ldg, g_hfeat, ldgh, \
-                                             g_a_src, ds, (int)N, slope, L)
+#define RGBX_GAT_BS(V)                                                                                          \
+  do {                                                                                                          \
+    gat_bwd_src_kernel<V, false><<<grid, 256, 0, s>>>(rowptr_t, col_t, hfeat, ldh, a_src,                       \
+                                                      reinterpret_cast<const float4*>(nodeq), gout, ldg,        \
+                                                      g_hfeat, ldgh, g_a_src, ds, (int)N, slope, L, sd);        \
+    if (sd.threshold > 0) {                                                                                     \
+      gat_bwd_src_kernel<V, true><<<gat_grid(split->n_chunks), 256, 0, s>>>(                                    \
+          rowptr_t, col_t, hfeat, ldh, a_src, reinterpret_cast<const float4*>(nodeq), gout, ldg, g_hfeat, ldgh, \
+          g_a_src, ds, split->n_chunks, slope, L, sd);                                                          \
+      gat_bwd_src_combine_kernel<V><<<gat_grid(split->n_long), 256, 0, s>>>(                                    \
+          split->n_long, split->long_row, split->long_chunk_ptr, g_hfeat, ldgh, g_a_src, L, sd);                \
+    }                                                                                                           \
+  } while (0)
   if (vec == 4) RGBX_GAT_BS(4);
   else if (vec == 2) RGBX_GAT_BS(2);
   else RGBX_GAT_BS(1);

@@ -44,8 +44,8 @@ class CSR:
         sp = self.split
         partial = torch.empty((sp["n_chunks"], d), dtype=torch.float32, device=device)
         st = _lib.RowSplit(sp["threshold"], sp["n_chunks"], sp["n_long"], sp["chunk_begin"].data_ptr(),
-                           sp["chunk_end"].data_ptr(), sp["long_row"].data_ptr(), sp["long_chunk_ptr"].data_ptr(),
-                           partial.data_ptr())
+                           sp["chunk_end"].data_ptr(), sp["chunk_row"].data_ptr(), sp["long_row"].data_ptr(),
+                           sp["long_chunk_ptr"].data_ptr(), partial.data_ptr())
         return st, partial
 
 
@@ -66,7 +66,8 @@ def make_row_split(rowptr, threshold=None):
     end = torch.minimum(begin + threshold, rowptr[long_row + 1].long()[owner])
     i32 = lambda t: t.to(torch.int32).contiguous()
     return {"threshold": int(threshold), "n_chunks": n_chunks, "n_long": int(long_row.numel()),
-            "chunk_begin": i32(begin), "chunk_end": i32(end), "long_row": i32(long_row), "long_chunk_ptr": i32(ptr)}
+            "chunk_begin": i32(begin), "chunk_end": i32(end), "chunk_row": i32(long_row[owner]),
+            "long_row": i32(long_row), "long_chunk_ptr": i32(ptr)}
 
 
 def build_csr(agg_row, other_row, N, loops_mode):

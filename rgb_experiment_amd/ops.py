@@ -220,12 +220,13 @@ class _GATAggregate(torch.autograd.Function):
         ph, ldh = _lib.mat(hfeat, "hfeat")
         po, ldo = _lib.mat(out, "out")
         csr = graph.fwd
+        split, _scratch = csr.split_arg(H * C + 2 * H, dev)
         with _Timed("gat_fwd"):
             _lib.check(
                 _lib.load().rgbx_gat_aggregate_fwd_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), ph, ldh,
                                                        _lib.ptr(a_src), _lib.ptr(att), _lib.ptr(a_dst), po, ldo,
-                                                       _lib.ptr(m),
-                                                       _lib.ptr(rden), N, H, C, float(slope),
+                                                       _lib.ptr(m), _lib.ptr(rden), N, H, C, float(slope),
+                                                       None if split is None else ctypes.byref(split),
                                                        _lib.stream_ptr()), "rgbx_gat_aggregate_fwd_f32")
         ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out)
         ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, slope
@@ -260,11 +261,13 @@ def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope):
         _lib.check(
             lib.rgbx_gat_bwd_prep_f32(_lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, pg, ldg,
                                       _lib.ptr(nodeq), N, H, C, _lib.stream_ptr()), "rgbx_gat_bwd_prep_f32")
+    split, _scratch = g.bwd.split_arg(H * C + 2 * H, dev)
     with _Timed("gat_bwd_src"):
         _lib.check(
             lib.rgbx_gat_bwd_src_f32(_lib.ptr(g.bwd.rowptr), _lib.ptr(g.bwd.col), ph, ldh, _lib.ptr(a_src),
                                      _lib.ptr(nodeq), pg, ldg, pgh, ldgh, _lib.ptr(g_as), _lib.ptr(ds), n_src, H,
-                                     C, float(slope), _lib.stream_ptr()), "rgbx_gat_bwd_src_f32")
+                                     C, float(slope), None if split is None else ctypes.byref(split),
+                                     _lib.stream_ptr()), "rgbx_gat_bwd_src_f32")
     g_ad = spmm_raw(seg, None, None, ds, kind="gat_bwd_segsum")
     return g_h, g_as, g_ad
 
@@ -321,11 +324,13 @@ class _GATAttend(torch.autograd.Function):
         rden = torch.empty_like(m)
         po, ldo = _lib.mat(out, "out")
         att_k = att_s if _scores_in_kernel(C) else None
+        split, _scratch = graph.fwd.split_arg(H * C + 2 * H, dev)
         with _Timed("gat_fwd"):
             _lib.check(
                 lib.rgbx_gat_aggregate_fwd_f32(_lib.ptr(graph.fwd.rowptr), _lib.ptr(graph.fwd.col), ph, ldh,
                                                _lib.ptr(a_src), _lib.ptr(att_k), _lib.ptr(a_dst), po, ldo, _lib.ptr(m),
-                                               _lib.ptr(rden), N, H, C, float(slope), _lib.stream_ptr()),
+                                               _lib.ptr(rden), N, H, C, float(slope),
+                                               None if split is None else ctypes.byref(split), _lib.stream_ptr()),
                 "rgbx_gat_aggregate_fwd_f32")
         ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out, att_s, att_d)
         ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, slope

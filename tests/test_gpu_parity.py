@@ -331,6 +331,50 @@ def test_gat_conv_forward_backward(dev, H, C):
             assert (p.grad.cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), name
 
 
+@pytest.mark.parametrize("H,C", [(4, 8), (1, 7), (8, 16)])
+def test_gat_hub_rows_are_split(dev, H, C, monkeypatch):
+    """Hub target (40k in-edges) and hub source (15k out-edges). Forward: the chunked online-softmax states
+    merge to the oracle's output (fp64-accumulating). Backward: the chunked path equals the unsplit path of
+    the same kernels (both fp32, identical LeakyReLU branch per edge — against an fp64 oracle a single edge
+    whose score sits at the kink flips its derivative and moves one row by O(0.1), which is not a defect).
+    Results are reproducible."""
+    from rgb_experiment_amd import graph as G
+    from rgb_experiment_amd.nn import GATConv
+    n, f = 50000, 12
+    gen = torch.Generator().manual_seed(H * 10 + C)
+    rnd = torch.randint(0, n, (2, 150000), generator=gen)
+    hub_in = torch.stack([torch.randint(0, n, (40000,), generator=gen), torch.full((40000,), 3)])
+    hub_out = torch.stack([torch.full((15000,), 11), torch.randint(0, n, (15000,), generator=gen)])
+    ei = torch.cat([rnd, hub_in, hub_out], dim=1)
+    x = torch.randn(n, f, generator=gen)
+    go = torch.randn(n, H * C, generator=gen)
+    torch.manual_seed(3)
+    conv = GATConv(f, C, H)
+    sd = {k: v.detach().clone().double() for k, v in conv.state_dict().items() if "lin_dst" not in k}
+    conv.to(dev)
+    ei_d = ei.to(dev)
+    runs = {}
+    for threshold in (1024, 10 ** 9):
+        monkeypatch.setattr(G, "LONG_ROW_SLOTS", threshold)
+        G.clear_cache()
+        conv.zero_grad()
+        xg = x.to(dev).requires_grad_(True)
+        og = conv(xg, ei_d)
+        g = G.get_graph(ei_d, n, 2)
+        assert (g.fwd.split is not None and g.bwd.split is not None) == (threshold == 1024)
+        og.backward(go.to(dev))
+        runs[threshold] = [og.detach(), xg.grad, conv.lin_src.weight.grad.clone(), conv.att_src.grad.clone(),
+                           conv.att_dst.grad.clone()]
+        if threshold == 1024:
+            with torch.no_grad():
+                assert torch.equal(conv(xg.detach(), ei_d), og.detach())  # reproducible
+    oc = O.gat_conv(x.double(), ei, sd["lin_src.weight"], sd["att_src"], sd["att_dst"], sd["bias"], H, True)
+    assert (runs[1024][0].cpu().double() - oc).abs().max().item() < TOL
+    for a, b in zip(runs[1024], runs[10 ** 9]):
+        assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
+    G.clear_cache()
+
+
 def test_gat_backward_two_implementations_agree(dev):
     """g_a_dst from the segment-sum path (ops) equals the direct target-side gather kernel
     rgbx_gat_bwd_dst_f32 (the first implementation, still exported)."""
@@ -353,7 +397,7 @@ def test_gat_backward_two_implementations_agree(dev):
     hd, asd, add = h.detach().contiguous(), a_s.detach().contiguous(), a_d.detach().contiguous()
     _lib.check(lib.rgbx_gat_aggregate_fwd_f32(g.fwd.rowptr.data_ptr(), g.fwd.col.data_ptr(), hd.data_ptr(), H * C,
                                               asd.data_ptr(), None, add.data_ptr(), out2.data_ptr(), H * C, m.data_ptr(),
-                                              rden.data_ptr(), n, H, C, 0.2, _lib.stream_ptr()), "fwd")
+                                              rden.data_ptr(), n, H, C, 0.2, None, _lib.stream_ptr()), "fwd")
     nodeq = torch.empty(n, H, 4, device=dev)
     ref = torch.empty(n, H, device=dev)
     _lib.check(lib.rgbx_gat_bwd_dst_f32(g.fwd.rowptr.data_ptr(), g.fwd.col.data_ptr(), hd.data_ptr(), H * C,

@@ -187,6 +187,7 @@ def test_row_split_plan_covers_long_rows_exactly():
     sp = make_row_split(rowptr, threshold=1024)
     assert sp["long_row"].tolist() == [2, 4, 6] and sp["n_long"] == 3
     assert sp["long_chunk_ptr"].tolist() == [0, 3, 5, 9] and sp["n_chunks"] == 9
+    assert sp["chunk_row"].tolist() == [2, 2, 2, 4, 4, 6, 6, 6, 6]
     for r, row in enumerate(sp["long_row"].tolist()):
         c0, c1 = sp["long_chunk_ptr"][r].item(), sp["long_chunk_ptr"][r + 1].item()
         b, e = sp["chunk_begin"][c0:c1].tolist(), sp["chunk_end"][c0:c1].tolist()
