@@ -14,6 +14,7 @@ succeeds, and then executes ONLY functions that never touch a placeholder:
   G4  utils.mask.get_whole_mask / get_classification_mask / get_random_mask
   G5  utils.subgraph.node_induced_subgraph
   G6  itexperiments.compare_pred_label (need_all_metrics=True)
+  G7  models.pta.PTA.forward / loss_function (train mode 0/1/2 at several epochs, eval mode)
 
 Outputs are inputs + expected outputs only (``*.npz``); no reference source text is stored.
 Usage:  python tests/golden/make_golden.py
@@ -164,6 +165,24 @@ def main():
     out["g6/pred"], out["g6/label"] = pred.numpy(), label.numpy()
     out["g6/metrics"] = np.asarray([res["ACC"], res["precision_score"], res["recall_score"], res["f1_macro"],
                                     res["f1_micro"]], dtype=np.float64)
+
+    # ---- G7 PTA forward + loss (pure torch; weights exported so the rebuild can load them) -------------
+    torch.manual_seed(77)
+    g = torch.Generator().manual_seed(78)
+    xin = torch.randn(30, 6, generator=g)
+    y_soft = torch.softmax(torch.randn(30, 4, generator=g), dim=-1)
+    for mode in (0, 1, 2):
+        model = pta.PTA(nfeat=6, nhid=5, nclass=4, dropout=0.0, epsilon=100, K=3, alpha=0.1, mode=mode)
+        for k, v in model.state_dict().items():
+            out[f"g7/mode{mode}/state/{k}"] = v.detach().numpy()
+        model.train()
+        y_hat = model(xin)
+        out[f"g7/mode{mode}/forward"] = y_hat.detach().numpy()
+        for epoch in (0, 7, 150):
+            out[f"g7/mode{mode}/train_loss/{epoch}"] = model.loss_function(y_hat, y_soft, epoch).detach().numpy()
+        model.eval()
+        out[f"g7/mode{mode}/eval_loss"] = model.loss_function(model(xin), y_soft).detach().numpy()
+    out["g7/x"], out["g7/y_soft"] = xin.numpy(), y_soft.numpy()
 
     path = os.path.join(OUT_DIR, "reference_pygfree.npz")
     np.savez_compressed(path, **{k.replace("/", "__"): v for k, v in out.items()})

@@ -193,3 +193,22 @@ def test_row_split_plan_covers_long_rows_exactly():
         b, e = sp["chunk_begin"][c0:c1].tolist(), sp["chunk_end"][c0:c1].tolist()
         assert b[0] == rowptr[row].item() and e[-1] == rowptr[row + 1].item()
         assert all(x == y for x, y in zip(e[:-1], b[1:])) and all(0 < y - x <= 1024 for x, y in zip(b, e))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_g7_pta_forward_and_loss(golden, mode):
+    """PTA.forward / loss_function (reference models/pta.py:41-77) reproduce the reference's outputs."""
+    from rgb_experiment_amd.models import PTA
+    model = PTA(nfeat=6, nhid=5, nclass=4, dropout=0.0, epsilon=100, K=3, alpha=0.1, mode=mode)
+    state = {k.split("state/")[1]: torch.from_numpy(v) for k, v in golden.items() if k.startswith(f"g7/mode{mode}/state/")}
+    model.load_state_dict(state)
+    x, y_soft = torch.from_numpy(golden["g7/x"]), torch.from_numpy(golden["g7/y_soft"])
+    model.train()
+    y_hat = model(x)
+    assert torch.allclose(y_hat, torch.from_numpy(golden[f"g7/mode{mode}/forward"]), atol=1e-6)
+    for epoch in (0, 7, 150):
+        want = float(golden[f"g7/mode{mode}/train_loss/{epoch}"])
+        assert abs(model.loss_function(y_hat, y_soft, epoch).item() - want) < 1e-6 * max(1.0, abs(want))
+    model.eval()
+    want = float(golden[f"g7/mode{mode}/eval_loss"])
+    assert abs(model.loss_function(model(x), y_soft).item() - want) < 1e-6 * max(1.0, abs(want))
