@@ -153,7 +153,7 @@ MODELS = {
 }
 AGG_KINDS = ("gcn_fwd", "gcn_bwd", "mean_fwd", "mean_bwd", "appnp_fwd", "appnp_bwd", "gat_fwd", "gat_bwd_prep",
              "gat_bwd_src", "gat_bwd_segsum", "dist_fwd_local", "dist_fwd_remote", "dist_bwd_local", "dist_bwd_remote",
-             "dist_fwd_colshard", "dist_bwd_colshard")
+             "dist_fwd_colshard", "dist_bwd_colshard", "dist_fwd_appnp_colshard", "dist_bwd_appnp_colshard")
 
 
 def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):

@@ -28,6 +28,11 @@ class HipAggregator:
         from .. import ops
         return ops.gather_rows(x, idx)
 
+    def appnp(self, handle, h, K, alpha, kind="dist_appnp_colshard"):
+        from .. import ops
+        csr, w = handle
+        return ops.appnp_raw(csr, w, h, K, alpha, kind=kind)
+
     def scatter_add(self, src, idx, dst):
         from .. import ops
         return ops.scatter_add_rows(src, idx, dst)
@@ -85,6 +90,21 @@ class _DistPropagate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         return ctx.dgraph._run(ctx.kind, "bwd", gy.contiguous()), None, None
+
+
+class _DistAPPNPColumns(torch.autograd.Function):
+    """APPNP under the reshard scheme: the recurrence z <- (1-alpha) A_hat z + alpha h acts on every column
+    independently, so ONE transpose to column shards, all K propagates on the whole graph at width d/P, and
+    ONE transpose back replace 2K all-to-alls. Backward: the same recurrence on the transposed graph."""
+
+    @staticmethod
+    def forward(ctx, h, dgraph, K, alpha):
+        ctx.dgraph, ctx.K, ctx.alpha = dgraph, K, alpha
+        return dgraph._appnp_columns("fwd", h.contiguous(), K, alpha)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ctx.dgraph._appnp_columns("bwd", gy.contiguous(), ctx.K, ctx.alpha), None, None, None
 
 
 class DistGraph:
@@ -159,18 +179,35 @@ class DistGraph:
             self._full[kind] = st
         return st
 
-    def _run_reshard(self, kind, direction, x):
-        P, n_loc, d = self.comm.world, self.n_local, x.size(1)
-        dc = d // P
-        # rows -> columns: peer q receives my rows restricted to its column slice
+    def _to_columns(self, x):
+        """[n_local, d] row shard -> [N, d/P] column shard (peer q receives my rows of its column slice)."""
+        P, n_loc, dc = self.comm.world, self.n_local, x.size(1) // self.comm.world
         send = x.view(n_loc, P, dc).permute(1, 0, 2).reshape(P * n_loc, dc)
         cols, work = self.comm.all_to_all_rows(send, [n_loc] * P, self.row_counts)
         work.wait()
-        y = self.backend.run(self._get_full(kind)[direction], cols, kind=f"dist_{direction}_colshard")
-        # columns -> rows
+        return cols
+
+    def _to_rows(self, y):
+        """[N, d/P] column shard -> [n_local, d] row shard."""
+        P, n_loc, dc = self.comm.world, self.n_local, y.size(1)
         back, work = self.comm.all_to_all_rows(y, self.row_counts, [n_loc] * P)
         work.wait()
-        return back.view(P, n_loc, dc).permute(1, 0, 2).reshape(n_loc, d)
+        return back.view(P, n_loc, dc).permute(1, 0, 2).reshape(n_loc, P * dc)
+
+    def _run_reshard(self, kind, direction, x):
+        y = self.backend.run(self._get_full(kind)[direction], self._to_columns(x), kind=f"dist_{direction}_colshard")
+        return self._to_rows(y)
+
+    def _appnp_columns(self, direction, h, K, alpha):
+        out = self.backend.appnp(self._get_full("gcn")[direction], self._to_columns(h), K, alpha,
+                                 kind=f"dist_{direction}_appnp_colshard")
+        return self._to_rows(out)
+
+    def appnp(self, h, K, alpha):
+        """K-step APPNP on the partitioned graph; `None` when the per-iteration path should be used."""
+        if self.comm.world > 1 and self.scheme(h.size(1)) == "reshard":
+            return _DistAPPNPColumns.apply(h, self, K, alpha)
+        return None
 
     # ---- choice --------------------------------------------------------------------------------
     def halo_rows(self):

@@ -163,8 +163,11 @@ class _APPNP(torch.autograd.Function):
 
 
 def appnp_propagate(h, graph, K, alpha):
-    if _is_dist(graph):  # one halo exchange per iteration; autograd chains the K distributed propagates
-        z = h
+    if _is_dist(graph):
+        out = graph.appnp(h, K, alpha)  # reshard scheme: all K steps inside one pair of transposes
+        if out is not None:
+            return out
+        z = h  # halo scheme: one exchange per iteration; autograd chains the K distributed propagates
         for _ in range(K):
             z = (1.0 - alpha) * graph.propagate(z, "gcn") + alpha * h
         return z

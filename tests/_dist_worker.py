@@ -31,6 +31,12 @@ class OracleAggregator:
     def scatter_add(self, src, idx, dst):
         return dst.index_add_(0, idx.long(), src)
 
+    def appnp(self, handle, h, K, alpha, kind=None):
+        z = h
+        for _ in range(K):
+            z = (1 - alpha) * self.run(handle, z) + alpha * h
+        return z
+
     def prepare_rect(self, agg, gather, n_tgt, n_src):
         return torch.stack([gather, agg]), n_tgt
 
@@ -87,6 +93,13 @@ def propagate_worker(rank, world, port, out_dir, exchange="halo"):
         out = dg.propagate(xl, kind)
         out.backward(go[lo:hi])
         res[f"{mode}_{kind}"] = (out.detach(), xl.grad)
+    # K-step APPNP through ops.appnp_propagate (reshard: one pair of transposes around all K steps)
+    from rgb_experiment_amd import ops
+    dg = DistGraph(ei, n, 1, Comm(), OracleAggregator(), exchange)
+    xl = x[lo:hi].clone().requires_grad_(True)
+    out = ops.appnp_propagate(xl, dg, 4, 0.15)
+    out.backward(go[lo:hi])
+    res["appnp"] = (out.detach(), xl.grad)
     torch.save(res, os.path.join(out_dir, f"prop_{rank}.pt"))
     dist.destroy_process_group()
 

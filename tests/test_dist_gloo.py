@@ -74,6 +74,11 @@ def test_distributed_propagate_matches_single_process(world, exchange, tmp_path)
         grad = torch.cat([p[f"{mode}_{kind}"][1] for p in parts])
         assert torch.allclose(out, want.detach(), atol=1e-5), (mode, kind)
         assert torch.allclose(grad, xr.grad, atol=1e-5), (mode, kind)
+    xr = x.clone().requires_grad_(True)
+    want = O.appnp(xr, ei, 4, 0.15)
+    want.backward(go)
+    assert torch.allclose(torch.cat([p["appnp"][0] for p in parts]), want.detach(), atol=1e-5)
+    assert torch.allclose(torch.cat([p["appnp"][1] for p in parts]), xr.grad, atol=1e-5)
 
 
 def _single_process_reference(model_name):
@@ -117,7 +122,7 @@ def _single_process_reference(model_name):
 @pytest.mark.parametrize("model_name,world,exchange", [("gcn", 2, "halo"), ("gcn", 3, "halo"), ("graphsage", 2, "halo"),
                                                         ("graphsage2", 2, "halo"), ("appnpstack", 2, "halo"),
                                                         ("gcn", 2, "reshard"), ("graphsage2", 2, "auto"), ("gat", 2, "halo"),
-                                                        ("gat", 3, "auto")])
+                                                        ("gat", 3, "auto"), ("appnpstack", 2, "reshard")])
 def test_dist_runner_training_matches_single_process(model_name, world, exchange, tmp_path):
     """Train-mode BatchNorm uses batch statistics in the oracle and reduced statistics in the runner, so
     train losses and trained WEIGHTS must agree; eval losses use running statistics, which the
