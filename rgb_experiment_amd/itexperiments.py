@@ -116,6 +116,21 @@ def _masks_usable(data):
     return False
 
 
+def _as_bool_mask(mask, n, device):
+    """The reference accepts masks as index lists, index tensors or boolean tensors (:193-209); the loop
+    works on boolean masks of length N."""
+    if isinstance(mask, Tensor) and mask.dtype == torch.bool and mask.numel() == n:
+        return mask.to(device)
+    idx = torch.as_tensor(mask, dtype=torch.long, device=device) if not isinstance(mask, Tensor) else mask.to(device)
+    if idx.dtype == torch.bool:  # shorter boolean mask: pad with False
+        out = torch.zeros(n, dtype=torch.bool, device=device)
+        out[:idx.numel()] = idx
+        return out
+    out = torch.zeros(n, dtype=torch.bool, device=device)
+    out[idx.long()] = True
+    return out
+
+
 def _make_masks(y, mode, ratio, num_train_per_class, num_val, num_test, seed):
     if mode == "ratio":
         return get_whole_mask(y, ratio, seed)
@@ -243,7 +258,9 @@ def experiment(model_init_param: dict, *,
     # ---- model (reference :315-391) ----------------------------------------------------------
     input_dim = data.num_node_features
     output_dim = int(data.y.max().item()) + 1
-    y, train_mask, val_mask, test_mask = data.y, data.train_mask, data.val_mask, data.test_mask
+    y = data.y
+    train_mask, val_mask, test_mask = (_as_bool_mask(m, data.num_nodes, device)
+                                       for m in (data.train_mask, data.val_mask, data.test_mask))
     is_pta = name == "pta"
     if is_pta:  # reference :351-374
         adj = normalized_adjacency(data.edge_index, data.num_nodes)

@@ -212,3 +212,16 @@ def test_g7_pta_forward_and_loss(golden, mode):
     model.eval()
     want = float(golden[f"g7/mode{mode}/eval_loss"])
     assert abs(model.loss_function(model(x), y_soft).item() - want) < 1e-6 * max(1.0, abs(want))
+
+
+def test_experiment_accepts_index_list_masks():
+    """Masks given as node-index lists (reference :193-209) are honoured (MLP: runs on the CPU)."""
+    d = _toy()
+    d.train_mask, d.val_mask, d.test_mask = list(range(0, 30)), list(range(30, 45)), list(range(45, 60))
+    res = R.experiment({"num_layers": 2, "hidden_unit": 8, "dropout_rate": 0.5}, specify_data=True, data=d,
+                       model_name="MLP", epoch=3, learning_rate=0.01, use_cpu=True, print_print=False)
+    assert 0.0 <= res["ACC"] <= 1.0
+    from rgb_experiment_amd.itexperiments import _as_bool_mask
+    m = _as_bool_mask([1, 3], 5, "cpu")
+    assert m.tolist() == [False, True, False, True, False]
+    assert _as_bool_mask(torch.tensor([True, False]), 4, "cpu").tolist() == [True, False, False, False]
