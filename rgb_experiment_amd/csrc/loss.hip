@@ -41,7 +41,26 @@ nll_sum_kernel(const float* __restrict__ logp, int64_t ld, const int64_t* __rest
   }
 }
 
-// One wave per selected row: additionally the number of rows whose first arg-max equals y_i
+// A wave takes 64 consecutive rows per step: mask and label are read coalesced (one lane per row), the
+// selected rows come out of a ballot, and the wave then sweeps them two at a time (both row loads issued
+// before either reduction), so no row waits on a dependent mask -> label -> row chain.
+__device__ __forceinline__ void row_argmax(const float* __restrict__ row, int C, int lane, float& best, int& arg) {
+  best = -INFINITY;
+  arg = INT32_MAX;
+  for (int c = lane; c < C; c += 64) {
+    const float v = row[c];
+    if (v > best) { best = v; arg = c; }
+  }
+}
+
+__device__ __forceinline__ void wave_argmax(float& best, int& arg) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int oa = __shfl_xor(arg, off);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 nll_acc_kernel(const float* __restrict__ logp, int64_t ld, const int64_t* __restrict__ y,
                const uint8_t* __restrict__ mask, int64_t N, int C, double* __restrict__ partials) {
@@ -49,26 +68,40 @@ nll_acc_kernel(const float* __restrict__ logp, int64_t ld, const int64_t* __rest
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   double loss = 0.0, cnt = 0.0, hit = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); i < N; i += (int64_t)gridDim.x * wpb) {
-    if (mask && !mask[i]) continue;  // wave-uniform
-    const int64_t t = y[i];
-    if (t < 0 || t >= C) continue;
-    const float* row = logp + i * ld;
-    float best = -INFINITY;
-    int arg = INT32_MAX;
-    for (int c = lane; c < C; c += 64) {
-      const float v = row[c];
-      if (v > best) { best = v; arg = c; }
+  for (int64_t base = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * 64; base < N;
+       base += (int64_t)gridDim.x * wpb * 64) {
+    const int64_t i = base + lane;
+    int t = -1;
+    if (i < N && (!mask || mask[i])) {
+      const int64_t ti = y[i];
+      if (ti >= 0 && ti < C) t = (int)ti;
     }
-    for (int off = 32; off > 0; off >>= 1) {
-      const float ob = __shfl_xor(best, off);
-      const int oa = __shfl_xor(arg, off);
-      if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
-    }
-    if (lane == 0) {
-      loss -= (double)row[t];
-      cnt += 1.0;
-      hit += arg == (int)t ? 1.0 : 0.0;
+    unsigned long long sel = __ballot(t >= 0);
+    while (sel) {
+      const int r0 = __builtin_ctzll(sel);
+      sel &= sel - 1;
+      const int r1 = sel ? __builtin_ctzll(sel) : -1;
+      if (r1 >= 0) sel &= sel - 1;
+      const float* row0 = logp + (base + r0) * ld;
+      const float* row1 = logp + (base + (r1 >= 0 ? r1 : r0)) * ld;
+      float b0, b1;
+      int a0, a1;
+      row_argmax(row0, C, lane, b0, a0);
+      row_argmax(row1, C, lane, b1, a1);
+      wave_argmax(b0, a0);
+      wave_argmax(b1, a1);
+      const int t0 = __shfl(t, r0);
+      const int t1 = __shfl(t, r1 >= 0 ? r1 : r0);
+      if (lane == 0) {
+        loss -= (double)row0[t0];
+        cnt += 1.0;
+        hit += a0 == t0 ? 1.0 : 0.0;
+        if (r1 >= 0) {
+          loss -= (double)row1[t1];
+          cnt += 1.0;
+          hit += a1 == t1 ? 1.0 : 0.0;
+        }
+      }
     }
   }
   loss = block_sum(loss, sh);
@@ -125,7 +158,7 @@ using namespace rgbx;
 
 extern "C" int rgbx_masked_nll_scratch_doubles(int64_t N, int want_accuracy, int64_t* count) {
   if (!count || N < 0) return fail(RGBX_E_ARG, "masked_nll_scratch_doubles: bad argument");
-  int64_t b = want_accuracy ? cdiv(N, 4) : cdiv(N, 256);
+  int64_t b = want_accuracy ? cdiv(N, 4 * 64) : cdiv(N, 256);
   const int64_t cap = want_accuracy ? kMaxGrid : 2048;
   if (b > cap) b = cap;
   if (b < 1) b = 1;
