@@ -45,6 +45,11 @@ class GCNConv(nn.Module):
 
     def forward(self, x, edge_index):
         graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
+        if self.training and not x.requires_grad and self.in_channels <= self.out_channels:
+            # Input layer in training: A_hat (x W^T) = (A_hat x) W^T. Aggregating first costs the same
+            # forward (in <= out) and makes dW = dy^T (A_hat x) a plain weight-gradient GEMM: no gradient
+            # has to travel back through A_hat^T, because x needs none (one transposed SpMM less per step).
+            return ops.linear(ops.propagate_gcn(x, graph), self.lin.weight, self.bias)
         return ops.propagate_gcn(ops.linear(x, self.lin.weight), graph, bias=self.bias)
 
 
