@@ -150,7 +150,7 @@ MODELS = {
     # gcn: 2 + 2 + 2 forward SpMMs and ONE transposed SpMM (layer 2); layer 1's weight gradient is taken
     # against A_hat x, so nothing flows back through A_hat^T there (nn/conv.py GCNConv)
     "gcn": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 7, 1, "gcn"),
-    "graphsage": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 8, 2, "mean"),
+    "graphsage": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 7, 2, "mean"),
     "graphsage2": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 7, 0, "mean"),
     "gat": (dict(num_layers=2, hidden_unit=16, heads=8, dropout_rate=0.5), 8, 2, "gat"),
     "appnpstack": (dict(hidden_unit=64, K=10, alpha=0.1, dropout_rate=0.5), 40, 1, "gcn"),

@@ -83,8 +83,14 @@ class MySAGEConv(nn.Module):
     def forward(self, x, edge_index):
         mode = LOOPS_REMOVE_ADD if self.add_self_loops else LOOPS_KEEP
         graph = get_graph(edge_index, x.size(0), mode)
+        x_r = ops.linear(x, self.lin_r.weight, self.lin_r.bias)
+        if self.training and not x.requires_grad and self.add_self_loops and self.in_channels <= self.out_channels:
+            # Input layer in training (see GCNConv.forward): with the self-loop every row's mean weights
+            # sum to 1, so mean_j(W x_j + b) = W mean_j(x_j) + b exactly; aggregating first removes the
+            # transposed SpMM from this layer's backward.
+            return ops.linear(ops.propagate_mean(x, graph), self.lin_l.weight, self.lin_l.bias) + x_r
         x_l = ops.linear(x, self.lin_l.weight, self.lin_l.bias)
-        return ops.propagate_mean(x_l, graph) + ops.linear(x, self.lin_r.weight, self.lin_r.bias)
+        return ops.propagate_mean(x_l, graph) + x_r
 
 
 class GATConv(nn.Module):
