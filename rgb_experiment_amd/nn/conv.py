@@ -45,6 +45,10 @@ class GCNConv(nn.Module):
 
     def forward(self, x, edge_index):
         graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
+        if ops.fused_linear_ok(graph, self.in_channels, self.out_channels):
+            # A_hat (x W^T) + b = (A_hat x) W^T + b in one kernel: the aggregate stays in LDS and the GEMM
+            # runs on the MFMA units underneath the gather (ops._PropagateLinear)
+            return ops.propagate_linear(x, graph, "gcn", self.lin.weight, self.bias)
         if self.training and not x.requires_grad and self.in_channels <= self.out_channels:
             # Input layer in training: A_hat (x W^T) = (A_hat x) W^T. Aggregating first costs the same
             # forward (in <= out) and makes dW = dy^T (A_hat x) a plain weight-gradient GEMM: no gradient
@@ -65,8 +69,11 @@ class SAGEConv(nn.Module):
 
     def forward(self, x, edge_index):
         graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
+        x_r = ops.linear(x, self.lin_r.weight)
+        if ops.fused_linear_ok(graph, self.in_channels, self.out_channels):
+            return ops.propagate_linear(x, graph, "mean", self.lin_l.weight, self.lin_l.bias) + x_r
         agg = ops.propagate_mean(x, graph)
-        return ops.linear(agg, self.lin_l.weight, self.lin_l.bias) + ops.linear(x, self.lin_r.weight)
+        return ops.linear(agg, self.lin_l.weight, self.lin_l.bias) + x_r
 
 
 class MySAGEConv(nn.Module):
@@ -84,6 +91,8 @@ class MySAGEConv(nn.Module):
         mode = LOOPS_REMOVE_ADD if self.add_self_loops else LOOPS_KEEP
         graph = get_graph(edge_index, x.size(0), mode)
         x_r = ops.linear(x, self.lin_r.weight, self.lin_r.bias)
+        if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels):
+            return ops.propagate_linear(x, graph, "mean", self.lin_l.weight, self.lin_l.bias) + x_r
         if self.training and not x.requires_grad and self.add_self_loops and self.in_channels <= self.out_channels:
             # Input layer in training (see GCNConv.forward): with the self-loop every row's mean weights
             # sum to 1, so mean_j(W x_j + b) = W mean_j(x_j) + b exactly; aggregating first removes the

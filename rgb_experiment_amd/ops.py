@@ -128,6 +128,68 @@ def propagate_sum(x, graph):
     return _PropagateSum.apply(x, graph)
 
 
+def fused_linear_ok(graph, in_channels, out_channels):
+    """The fused aggregate-then-transform kernel applies: single-GPU graph without hub rows, supported
+    widths, and aggregating at the input width is not the more expensive order."""
+    if _is_dist(graph) or in_channels > out_channels:
+        return False
+    if graph.fwd.split is not None:
+        return False
+    return bool(_lib.load().rgbx_spmm_linear_supported(in_channels, out_channels))
+
+
+class _PropagateLinear(torch.autograd.Function):
+    """y = (P x) W^T + b with P = A_hat ('gcn') or the mean operator ('mean'), in one launch
+    (rgbx_spmm_linear_f32). Backward: dW = dy^T (P x) on the split-K MFMA kernel (P x was stored by the
+    forward when a gradient is needed), db = column sums, and — only if x needs a gradient —
+    dx = P^T (dy W) as a GEMM followed by the transposed SpMM."""
+
+    @staticmethod
+    def forward(ctx, x, graph, kind, weight, bias, need_z=True):
+        _lib.require_device(x, weight, bias)
+        x = x.contiguous()
+        N, K = x.shape
+        n_out = weight.size(0)
+        wt = weight.detach().t().contiguous()
+        out = torch.empty((graph.fwd.N, n_out), dtype=torch.float32, device=x.device)
+        z = torch.empty((graph.fwd.N, K), dtype=torch.float32, device=x.device) if need_z else None
+        w, rs = (graph.w, None) if kind == "gcn" else (None, graph.inv_deg)
+        b = None if bias is None else bias.detach().contiguous()
+        csr = graph.fwd
+        with _Timed(f"{kind}_linear_fwd"):
+            _lib.check(
+                _lib.load().rgbx_spmm_linear_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
+                                                 _lib.ptr(x), x.stride(0), _lib.ptr(wt), _lib.ptr(b), _lib.ptr(out),
+                                                 out.stride(0), _lib.ptr(z), K, csr.N, K, n_out, _lib.stream_ptr()),
+                "rgbx_spmm_linear_f32")
+        ctx.save_for_backward(z, weight)
+        ctx.graph, ctx.kind, ctx.has_bias = graph, kind, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        z, weight = ctx.saved_tensors
+        g, kind = ctx.graph, ctx.kind
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[3]:
+            gw = gemm_tn(gy, z)
+        if ctx.has_bias and ctx.needs_input_grad[4]:
+            gb = gy.sum(0)
+        if ctx.needs_input_grad[0]:
+            gz = gy @ weight
+            wt = g.w_t if kind == "gcn" else g.w_mean_t
+            gx = spmm_raw(g.bwd, wt, None, gz, kind=f"{kind}_bwd")
+        return gx, None, None, gw, gb, None
+
+
+def propagate_linear(x, graph, kind, weight, bias=None):
+    # the aggregate is kept only when the weight gradient (dy^T (P x)) will be asked for; Function.forward
+    # cannot see the caller's grad mode, so the decision is taken here
+    need_z = torch.is_grad_enabled() and weight.requires_grad
+    return _PropagateLinear.apply(x, graph, kind, weight, bias, need_z)
+
+
 def appnp_raw(csr, w, h, K, alpha, kind="appnp"):
     _lib.require_device(h)
     h = h.contiguous()

@@ -199,6 +199,64 @@ def test_spmm_hub_rows_are_split_and_reproducible(dev, d):
     assert (ops.appnp_propagate(x.to(dev), g, 3, 0.1).cpu() - O.appnp(xd, ei, 3, 0.1)).abs().max().item() < TOL
 
 
+@pytest.mark.parametrize("K,n_out", [(128, 128), (64, 128), (32, 64), (96, 96), (256, 256), (20, 32), (4, 32)])
+@pytest.mark.parametrize("kind", ["gcn", "mean"])
+def test_fused_aggregate_transform(dev, K, n_out, kind):
+    """rgbx_spmm_linear_f32: (P x) W^T + b in one kernel, forward and every gradient, vs the oracle."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n = 1700  # not a multiple of the 32-row tile
+    mode = 1 if kind == "gcn" else 2
+    ei = rand_graph(n, 14000, K + n_out, loops=7, dups=9)
+    gen = torch.Generator().manual_seed(K * 7 + n_out)
+    x = torch.randn(n, K, generator=gen)
+    W = torch.randn(n_out, K, generator=gen) / K ** 0.5
+    b = torch.randn(n_out, generator=gen)
+    go = torch.randn(n, n_out, generator=gen)
+    g = Graph(ei.to(dev), n, mode)
+    assert ops.fused_linear_ok(g, K, n_out) == (K <= n_out)
+    rei, w = O.gcn_norm(ei, None, n) if kind == "gcn" else (O.rewrite_edges(ei, n, 2)[0], None)
+    xg, Wg, bg = (v.to(dev).requires_grad_(True) for v in (x.clone(), W.clone(), b.clone()))
+    xc, Wc, bc = (v.clone().requires_grad_(True) for v in (x, W, b))
+    out = ops.propagate_linear(xg, g, kind, Wg, bg)
+    ref = O.propagate(rei, xc, n, w, "add" if kind == "gcn" else "mean") @ Wc.t() + bc
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() < TOL
+    out.backward(go.to(dev))
+    ref.backward(go)
+    for a, r in ((xg, xc), (Wg, Wc), (bg, bc)):
+        assert (a.grad.cpu() - r.grad).abs().max().item() < 1e-4 * max(1.0, r.grad.abs().max().item())
+    with torch.no_grad():  # inference path: no aggregate is stored
+        again = ops.propagate_linear(x.to(dev), g, kind, W.to(dev), b.to(dev))
+    assert torch.equal(again, out.detach())
+
+
+def test_fused_path_inside_models(dev):
+    """GCN / GraphSAGE / GraphSAGE2 with in <= hidden (so the fused kernel is taken) still match the oracle."""
+    from rgb_experiment_amd import models as M
+    n, f, c = 3000, 64, 32
+    gen = torch.Generator().manual_seed(8)
+    ei = rand_graph(n, 20000, 9, loops=5, dups=5)
+    x = torch.randn(n, f, generator=gen)
+    y = torch.randint(0, c, (n,), generator=gen)
+    cases = [(M.GCN, lambda sd, tr: O.gcn_forward(sd, x, ei, 2, tr)),
+             (M.GraphSAGE, lambda sd, tr: O.graphsage_forward(sd, x, ei, 2, tr)),
+             (M.GraphSAGE2, lambda sd, tr: O.graphsage2_forward(sd, x, ei, 2, tr))]
+    for cls, oracle_fwd in cases:
+        torch.manual_seed(1)
+        model = cls(num_layers=2, hidden_unit=128, input_dim=f, output_dim=c, dropout_rate=0.5)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.to(dev).train()
+        out = model(x.to(dev), ei.to(dev))
+        torch.nn.functional.nll_loss(out["out"], y.to(dev)).backward()
+        ref_sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        ref = oracle_fwd(ref_sd, True)
+        torch.nn.functional.nll_loss(ref["out"], y).backward()
+        assert (out["emb"].detach().cpu() - ref["emb"].detach()).abs().max().item() < TOL, cls.__name__
+        for pname, p in model.named_parameters():
+            rg = ref_sd[pname].grad
+            assert (p.grad.cpu() - rg).abs().max().item() < 1e-4 * max(1.0, rg.abs().max().item()), (cls.__name__, pname)
+
+
 def test_spmm_epilogue_and_strides(dev):
     """a, b, y, row scale, and non-contiguous leading dimensions (column slices of wider matrices)."""
     from rgb_experiment_amd import ops
