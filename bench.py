@@ -156,7 +156,8 @@ MODELS = {
     "appnpstack": (dict(hidden_unit=64, K=10, alpha=0.1, dropout_rate=0.5), 40, 1, "gcn"),
 }
 AGG_KINDS = ("gcn_fwd", "gcn_bwd", "mean_fwd", "mean_bwd", "gcn_linear_fwd", "mean_linear_fwd", "appnp_fwd",
-             "appnp_bwd", "gat_fwd", "gat_bwd_prep", "gat_bwd_src", "gat_bwd_segsum", "dist_fwd_local", "dist_fwd_remote", "dist_bwd_local", "dist_bwd_remote",
+             "appnp_bwd", "gat_fwd", "gat_bwd_prep", "gat_bwd_src", "gat_bwd_segsum", "dist_fwd_local", "dist_fwd_remote",
+             "dist_bwd_local", "dist_bwd_remote", "dist_fwd_resident",
              "dist_fwd_colshard", "dist_bwd_colshard", "dist_fwd_appnp_colshard", "dist_bwd_appnp_colshard")
 
 
@@ -311,7 +312,7 @@ def main():
     wl_name = wl["name"].replace("GCN", {"gcn": "GCN", "graphsage": "GraphSAGE", "graphsage2": "GraphSAGE2",
                                          "gat": "GAT 8 heads", "appnpstack": "APPNP K=10"}[args.model])
 
-    comm_mb, scheme = 0.0, "single GPU"
+    comm_mb, scheme, alg_by_kind = 0.0, "single GPU", None
     if world > 1:
         from rgb_experiment_amd.dist import DistRunner
         runner = DistRunner(model, ei, x, y, (train_mask, val_mask, test_mask), rank, world, dev, lr=0.01,
@@ -328,16 +329,22 @@ def main():
             nnz_total = plan.nnz_total
             alg = gat_alg_bytes(n_loc, plan.nnz_local, d)
             comm_mb = plan.fwd.n_halo * d * 4 / 1e6
-        elif scheme == "reshard":  # whole graph at width d / P on every rank, two all-to-all transposes
-            nnz_total = dgraph._get_full(kind)["nnz"]
-            alg = spmm_alg_bytes(N, nnz_total, d // world)
-            comm_mb = 2 * n_loc * d * 4 * (world - 1) / world / 1e6
-        else:  # local-source SpMM + remote-source SpMM accumulating into the same rows
+        else:
+            # algorithmic bytes per launch of every aggregation kernel this rank runs (SURVEY 8d formula on the
+            # rows / edges / width that launch covers); the roofline line is total bytes / total kernel time
             plan = dgraph.plan(kind)
             nnz_total = plan.nnz_total
             nnz_loc, nnz_rem = int(plan.fwd.loc_agg.numel()), int(plan.fwd.rem_agg.numel())
-            alg = spmm_alg_bytes(n_loc, nnz_loc, d) + spmm_alg_bytes(n_loc, nnz_rem, d) + n_loc * 4 * d
-            comm_mb = plan.fwd.n_halo * d * 4 / 1e6
+            b_loc = spmm_alg_bytes(n_loc, nnz_loc, d)
+            b_rem = spmm_alg_bytes(n_loc, nnz_rem, d) + n_loc * 4 * d
+            b_col = spmm_alg_bytes(N, nnz_total, d // world)
+            alg_by_kind = {"dist_fwd_resident": spmm_alg_bytes(n_loc, nnz_loc + nnz_rem, d),
+                           "dist_fwd_local": b_loc, "dist_bwd_local": b_loc, "dist_fwd_remote": b_rem,
+                           "dist_bwd_remote": b_rem, "dist_fwd_colshard": b_col, "dist_bwd_colshard": b_col,
+                           "dist_fwd_appnp_colshard": 10 * (b_col + N * 4 * (d // world)),
+                           "dist_bwd_appnp_colshard": 10 * (b_col + N * 4 * (d // world))}
+            alg = b_col if scheme == "reshard" else b_loc + b_rem
+            comm_mb = (2 * n_loc * d * 4 * (world - 1) / world if scheme == "reshard" else plan.fwd.n_halo * d * 4) / 1e6
     else:
         step, nnz_total, alg = build_single_gpu(model, ei, x, y, (train_mask, val_mask, test_mask), dev, loops_mode,
                                                 kind, N, d)
@@ -366,6 +373,9 @@ def main():
     agg_total_ms = sum(s.elapsed_time(e) for k, s, e in events if k in AGG_KINDS)
     agg_avg_s = agg_total_ms * 1e-3 / (n_prop * args.steps)  # aggregation kernel time per propagate (this rank)
     achieved = alg / agg_avg_s / 1e9
+    if alg_by_kind:  # partitioned run: launches of different shapes, so sum bytes over the launches actually made
+        done = sum(alg_by_kind[k] for k, s, e in events if k in alg_by_kind)
+        achieved = done / (agg_total_ms * 1e-3) / 1e9
     by_kind = {}
     for k, s, e in events:
         by_kind.setdefault(k, []).append(s.elapsed_time(e))
@@ -391,7 +401,8 @@ def main():
         "config": {"workload": wl_name, "nodes": N, "edges_in": E, "edges_aggregated_per_propagate": nnz_total,
                    "width": d, "propagates_per_step": n_prop,
                    "parallelism": "single GPU" if world == 1 else
-                   f"1-D node partition x{world}, RCCL all-to-all ({scheme} exchange)"},
+                   f"1-D node partition x{world}, RCCL all-to-all ({scheme} exchange; boundary rows of the static "
+                   "input features resident in HBM)"},
         "epochs_per_s": args.steps / elapsed,
         "spmm_edges_per_s": nnz_total / agg_avg_s if world == 1 else None,
         "spmm_ms": agg_avg_s * 1e3,

@@ -128,6 +128,7 @@ class DistGraph:
         self.backend = backend or HipAggregator()
         self.exchange = exchange
         self._kinds, self._full, self._choice = {}, {}, {}
+        self._resident = None
         b = partition_bounds(self.N_global, self.comm.world)
         self.bounds = b
         self.n_local = b[self.comm.rank + 1] - b[self.comm.rank]
@@ -152,6 +153,45 @@ class DistGraph:
 
     def plan(self, kind):
         return self._get(kind)["plan"]
+
+    # ---- resident input features ---------------------------------------------------------------
+    # The first conv of every model aggregates the STATIC feature matrix. Its boundary rows never change, so
+    # they are fetched once and kept in HBM next to the local rows ([local; halo], at most N*d*4 B per rank:
+    # 1 GB on the 2M-node benchmark, of 288 GB); every later propagate of that tensor is one SpMM over the
+    # combined CSR with no exchange at all. Nothing computed is cached: the aggregation runs every time.
+    def pin_resident(self, x):
+        """Declare `x` (this rank's rows of the input features, never written again) resident."""
+        self._resident = {"ptr": x.data_ptr(), "shape": tuple(x.shape), "version": x._version, "ext": {}}
+
+    def is_resident(self, x):
+        r = self._resident
+        return (r is not None and x.data_ptr() == r["ptr"] and tuple(x.shape) == r["shape"]
+                and x._version == r["version"] and not x.requires_grad)
+
+    def _resident_ext(self, x, half, key):
+        """[x; halo rows of x] for the plan `half` belongs to, exchanged on first use (collective: every rank
+        reaches this with its own resident tensor at the same point of the model)."""
+        ext = self._resident["ext"].get(key)
+        if ext is None:
+            ext = x
+            if self.comm.world > 1:
+                send = self.backend.gather(x, half.send_idx) if half.n_send else x.new_empty((0, x.size(1)))
+                recv, work = self.comm.all_to_all_rows(send, half.send_counts, half.recv_counts)
+                work.wait()
+                if half.n_halo:
+                    ext = torch.cat([x, recv], dim=0)
+            self._resident["ext"][key] = ext
+        return ext
+
+    def _run_resident(self, kind, x):
+        st = self._get(kind)
+        half = st["fwd"]["half"]
+        if "ext_csr" not in st:
+            agg = torch.cat([half.loc_agg, half.rem_agg])
+            gather = torch.cat([half.loc_gather, half.n_local + half.rem_gather])
+            w = None if half.loc_w is None else torch.cat([half.loc_w, half.rem_w])
+            st["ext_csr"] = self.backend.prepare(agg, gather, half.n_local, w)
+        return self.backend.run(st["ext_csr"], self._resident_ext(x, half, kind), kind="dist_fwd_resident")
 
     def _run_halo(self, kind, direction, x):
         d = self._get(kind)[direction]
@@ -237,6 +277,8 @@ class DistGraph:
         return self._choice[key]
 
     def _run(self, kind, direction, x):
+        if direction == "fwd" and self.is_resident(x):
+            return self._run_resident(kind, x)
         if self.comm.world > 1 and self.scheme(x.size(1)) == "reshard":
             return self._run_reshard(kind, direction, x.contiguous())
         return self._run_halo(kind, direction, x)
@@ -247,7 +289,9 @@ class DistGraph:
     # ---- GAT: attention needs every in-edge of a target in one softmax, so the halo rows are appended to
     # the local rows and ONE rectangular CSR (local targets x [local; halo] sources) feeds the same fused
     # kernels as the single-GPU path. a_src of halo rows is recomputed locally from the received rows.
-    def gat(self, h, att_src, att_dst, H, C, slope):
+    def gat(self, h, att_src, att_dst, H, C, slope, weight=None):
+        """Attention aggregate of h = x W^T. With `weight` given, `h` is the resident input x itself and the
+        transform is applied here, to local and halo rows alike."""
         st = self._kinds.get("gat")
         if st is None:
             plan = PartitionPlan(self.edge_index, self.N_global, self.comm.world, self.comm.rank,
@@ -258,7 +302,13 @@ class DistGraph:
             st = {"plan": plan, "rect": self.backend.prepare_rect(agg, gather, f.n_local, f.n_local + f.n_halo)}
             self._kinds["gat"] = st
         half = st["plan"].fwd
-        x_ext = _HaloGather.apply(h, self, half) if self.comm.world > 1 else h
+        if weight is not None:
+            # resident input features: h of the halo rows is recomputed from the resident copies (a GEMM over
+            # n_local + n_halo rows) instead of being exchanged, forward and backward
+            from .. import ops
+            x_ext = ops.linear(self._resident_ext(h, half, "gat"), weight)
+        else:
+            x_ext = _HaloGather.apply(h, self, half) if self.comm.world > 1 else h
         return self.backend.gat(st["rect"], x_ext, att_src, att_dst, half.n_local, H, C, slope)
 
 

@@ -16,7 +16,7 @@ class DistRunner:
     rank keeps its node slice of x / y / masks and the whole edge list for index arithmetic."""
 
     def __init__(self, model, edge_index, x, y, masks, rank, world, device, lr=0.01, weight_decay=0.0,
-                 comm=None, backend=None, exchange="auto"):
+                 comm=None, backend=None, exchange="auto", resident_features=True):
         self.comm = comm or Comm()
         self.rank, self.world, self.device = rank, world, device
         N = x.size(0)
@@ -29,6 +29,9 @@ class DistRunner:
         # the conv layers see (x_local, token): the token's cache entries are the DistGraphs
         self.token = torch.zeros((2, 1), dtype=torch.int64, device=device)
         self.graphs = install(self.token, hi - lo, self.edge_index, N, self.comm, backend, exchange)
+        if resident_features:
+            for g in self.graphs.values():
+                g.pin_resident(self.x)  # boundary rows of the static features are fetched once and kept
         self.model = DistBatchNorm1d.convert(model.to(device), self.comm)
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
         cnt = torch.tensor([float(m.sum()) for m in self.masks], dtype=torch.float64, device=device)

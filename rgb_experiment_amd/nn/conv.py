@@ -49,10 +49,12 @@ class GCNConv(nn.Module):
             # A_hat (x W^T) + b = (A_hat x) W^T + b in one kernel: the aggregate stays in LDS and the GEMM
             # runs on the MFMA units underneath the gather (ops._PropagateLinear)
             return ops.propagate_linear(x, graph, "gcn", self.lin.weight, self.bias)
-        if self.training and not x.requires_grad and self.in_channels <= self.out_channels:
-            # Input layer in training: A_hat (x W^T) = (A_hat x) W^T. Aggregating first costs the same
-            # forward (in <= out) and makes dW = dy^T (A_hat x) a plain weight-gradient GEMM: no gradient
-            # has to travel back through A_hat^T, because x needs none (one transposed SpMM less per step).
+        if not x.requires_grad and self.in_channels <= self.out_channels:
+            # Input layer (and every layer under no_grad): A_hat (x W^T) = (A_hat x) W^T. Aggregating first
+            # costs the same forward (in <= out) and makes dW = dy^T (A_hat x) a plain weight-gradient GEMM: no
+            # gradient has to travel back through A_hat^T, because x needs none (one transposed SpMM less per
+            # step). On a partitioned graph the aggregated tensor is then the static feature matrix, whose
+            # boundary rows are resident (dist.DistGraph.pin_resident): no exchange either.
             return ops.linear(ops.propagate_gcn(x, graph), self.lin.weight, self.bias)
         return ops.propagate_gcn(ops.linear(x, self.lin.weight), graph, bias=self.bias)
 
@@ -93,8 +95,8 @@ class MySAGEConv(nn.Module):
         x_r = ops.linear(x, self.lin_r.weight, self.lin_r.bias)
         if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels):
             return ops.propagate_linear(x, graph, "mean", self.lin_l.weight, self.lin_l.bias) + x_r
-        if self.training and not x.requires_grad and self.add_self_loops and self.in_channels <= self.out_channels:
-            # Input layer in training (see GCNConv.forward): with the self-loop every row's mean weights
+        if not x.requires_grad and self.add_self_loops and self.in_channels <= self.out_channels:
+            # Input layer (see GCNConv.forward): with the self-loop every row's mean weights
             # sum to 1, so mean_j(W x_j + b) = W mean_j(x_j) + b exactly; aggregating first removes the
             # transposed SpMM from this layer's backward.
             return ops.linear(ops.propagate_mean(x, graph), self.lin_l.weight, self.lin_l.bias) + x_r
@@ -128,8 +130,11 @@ class GATConv(nn.Module):
     def forward(self, x, edge_index):
         H, C = self.heads, self.out_channels
         graph = get_graph(edge_index, x.size(0), LOOPS_REMOVE_ADD)
-        h = ops.linear(x, self.lin_src.weight)
-        out = ops.gat_attend(h, self.att_src, self.att_dst, graph, H, C, self.negative_slope)
+        if getattr(graph, "is_distributed", False) and graph.is_resident(x):
+            out = graph.gat(x, self.att_src, self.att_dst, H, C, self.negative_slope, weight=self.lin_src.weight)
+        else:
+            h = ops.linear(x, self.lin_src.weight)
+            out = ops.gat_attend(h, self.att_src, self.att_dst, graph, H, C, self.negative_slope)
         if not self.concat:
             out = out.view(-1, H, C).mean(dim=1)
         return out + self.bias

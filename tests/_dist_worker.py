@@ -121,6 +121,32 @@ def runner_worker(rank, world, port, out_dir, model_name, exchange="halo"):
     dist.destroy_process_group()
 
 
+def exchange_count_worker(rank, world, port, out_dir, model_name, resident):
+    """Counts the row exchanges of one steady-state epoch, with and without resident input features."""
+    _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import Comm, DistRunner
+
+    class CountingComm(Comm):
+        calls = 0
+
+        def all_to_all_rows(self, send, send_counts, recv_counts):
+            CountingComm.calls += 1
+            return super().all_to_all_rows(send, send_counts, recv_counts)
+
+    ei, x, y, masks = make_problem()
+    torch.manual_seed(14530529)
+    model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
+    r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=CountingComm(),
+                   backend=OracleAggregator(), exchange="halo", resident_features=resident)
+    hist = [r.epoch()]
+    CountingComm.calls = 0
+    hist.append(r.epoch())
+    torch.save({"hist": hist, "exchanges": CountingComm.calls},
+               os.path.join(out_dir, f"cnt_{model_name}_{int(resident)}_{rank}.pt"))
+    dist.destroy_process_group()
+
+
 def build_model(M, name, f, c):
     if name == "gcn":
         return M.GCN(num_layers=3, hidden_unit=16, input_dim=f, output_dim=c, dropout_rate=0.5)

@@ -149,6 +149,28 @@ def test_dist_runner_training_matches_single_process(model_name, world, exchange
     assert parts[0]["lo"] == 0 and parts[-1]["hi"] == 97
 
 
+@pytest.mark.parametrize("model_name,with_resident,without", [("gcn", 8, 11), ("graphsage2", 4, 7), ("gat", 4, 8)])
+def test_resident_input_features_remove_the_first_layer_exchange(model_name, with_resident, without, tmp_path):
+    """The boundary rows of the static feature matrix are fetched once (DistGraph.pin_resident): a steady-state
+    epoch (1 train forward + backward, 2 eval forwards) then exchanges only for the layers whose input is an
+    activation, and the numbers do not move. gcn (3 layers): 3x3 forward + 2 backward exchanges -> 3x2 + 2;
+    graphsage2 (2 layers): 3x2 + 1 -> 3x1 + 1; gat (2 layers): 3x2 + 2 -> 3x1 + 1 (the halo rows of h = xW
+    are recomputed from the resident x, so layer 1 needs no reverse exchange either)."""
+    res = {}
+    for resident in (True, False):
+        mp.spawn(W.exchange_count_worker, args=(2, _free_port(), str(tmp_path), model_name, resident), nprocs=2,
+                 join=True)
+        res[resident] = [torch.load(os.path.join(tmp_path, f"cnt_{model_name}_{int(resident)}_{r}.pt"))
+                         for r in range(2)]
+    assert res[True][0]["exchanges"] == res[True][1]["exchanges"] == with_resident
+    assert res[False][0]["exchanges"] == res[False][1]["exchanges"] == without
+    for a, b in zip(res[True][0]["hist"], res[False][0]["hist"]):
+        assert abs(a[0] - b[0]) < 1e-5, (a, b)  # train loss
+        # eval losses see the pre-BatchNorm biases, whose zero true gradient Adam turns into +-lr noise that
+        # depends on the summation order (see test_dist_runner_training_matches_single_process)
+        assert abs(a[1] - b[1]) < 5e-3 and abs(a[3] - b[3]) < 5e-3, (a, b)
+
+
 def test_dist_batchnorm_matches_full_batch_bn():
     """world = 1 (no process group): DistBatchNorm1d == nn.BatchNorm1d incl. running stats and grads."""
     from rgb_experiment_amd.dist import Comm, DistBatchNorm1d
