@@ -183,13 +183,15 @@ int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const float* g_a_sr
  * Source scores: either `a_src` ([n_src, H], gathered per edge) or, when `att_src` ([H, C]) is not
  * NULL, recomputed inside the kernel from each gathered row as <hfeat[col[p],h,:], att_src[h,:]>
  * (saves one cache-line request per edge; `a_src` is then ignored and may be NULL).
+ * `bias` ([H*C], optional): added to every stored row (GATConv's `out + bias` with concat=True, or heads=1);
+ * pass the same pointer to rgbx_gat_bwd_prep_f32, which needs the bare aggregate.
  * `split` (optional): hub targets are cut into chunks whose online-softmax states are merged in chunk
  * order; `split->partial` must hold n_chunks * (H*C + 2*H) floats. */
 int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                                int64_t ldh, const float* a_src, const float* att_src,
-                               const float* a_dst, float* out, int64_t ldo, float* m, float* rden,
-                               int64_t N, int H, int C, float slope, const rgbx_row_split_t* split,
-                               rgbx_stream_t stream);
+                               const float* a_dst, const float* bias, float* out, int64_t ldo, float* m,
+                               float* rden, int64_t N, int H, int C, float slope,
+                               const rgbx_row_split_t* split, rgbx_stream_t stream);
 
 /* Backward, target side (same CSR as forward). Per target i, head h:
  *   dsum[i,h]    = <gout[i,h,:], out[i,h,:]>
@@ -204,10 +206,11 @@ int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, const float*
                          float slope, rgbx_stream_t stream);
 
 /* The per-target record alone (no neighbour loop, one streaming pass over out / gout):
- *   nodeq[i,h] = (a_dst[i,h], m[i,h], rden[i,h], <gout[i,h,:], out[i,h,:]>). */
+ *   nodeq[i,h] = (a_dst[i,h], m[i,h], rden[i,h], <gout[i,h,:], out[i,h,:] - bias[h,:]>)
+ * (`bias` = the pointer given to the forward, or NULL). */
 int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const float* rden, const float* out,
-                          int64_t ldo, const float* gout, int64_t ldg, float* nodeq, int64_t N, int H,
-                          int C, rgbx_stream_t stream);
+                          int64_t ldo, const float* bias, const float* gout, int64_t ldg, float* nodeq,
+                          int64_t N, int H, int C, rgbx_stream_t stream);
 
 /* Backward, source side, over the TRANSPOSED CSR (rows = sources j, col = targets i):
  *   g_hfeat[j,h,:] = sum_{p: j->i} alpha_p * gout[i,h,:]

@@ -203,8 +203,8 @@ template <int VEC, bool CHUNK>
 __global__ void __launch_bounds__(256)
 gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
-               const float* __restrict__ att_src, const float* __restrict__ a_dst, float* __restrict__ out,
-               int64_t ldo,
+               const float* __restrict__ att_src, const float* __restrict__ a_dst,
+               const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
                float* __restrict__ m_out, float* __restrict__ rden_out, int N, float slope,
                const GatLayout L, const SplitDev sp) {
   const int lane = threadIdx.x & 63;
@@ -305,9 +305,12 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
           }
         } else {
           const float rd = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
-          float r[VEC];
+          float r[VEC], bv[VEC];
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) r[i] = acc[i] * rd;
+          for (int i = 0; i < VEC; ++i) bv[i] = 0.f;
+          if (bias) load_vec<VEC>(bv, bias + cofs);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) r[i] = acc[i] * rd + bv[i];
           store_vec<VEC>(out + (int64_t)row * ldo + cofs, r);
           if (ch == 0) {
             m_out[(int64_t)row * L.H + head] = l > 0.f ? m : 0.f;
@@ -323,7 +326,7 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
 template <int VEC>
 __global__ void __launch_bounds__(256)
 gat_fwd_combine_kernel(int n_long, const int* __restrict__ long_row, const int* __restrict__ long_chunk_ptr,
-                       float* __restrict__ out, int64_t ldo, float* __restrict__ m_out,
+                       const float* __restrict__ bias, float* __restrict__ out, int64_t ldo, float* __restrict__ m_out,
                        float* __restrict__ rden_out, const GatLayout L, const SplitDev sp) {
   const int lane = threadIdx.x & 63;
   const int g = lane / L.G;
@@ -357,8 +360,12 @@ gat_fwd_combine_kernel(int n_long, const int* __restrict__ long_row, const int* 
         m = mn;
       }
       const float rd = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
+      float bv[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] *= rd;
+      for (int i = 0; i < VEC; ++i) bv[i] = 0.f;
+      if (bias) load_vec<VEC>(bv, bias + cofs);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = acc[i] * rd + bv[i];
       store_vec<VEC>(out + (int64_t)row * ldo + cofs, acc);
       if (ch == 0) {
         m_out[(int64_t)row * L.H + head] = l > 0.f ? m : 0.f;
@@ -453,8 +460,8 @@ template <int VEC>
 __global__ void __launch_bounds__(256)
 gat_bwd_prep_kernel(const float* __restrict__ a_dst, const float* __restrict__ m_in,
                     const float* __restrict__ rden_in, const float* __restrict__ out, int64_t ldo,
-                    const float* __restrict__ gout, int64_t ldg, float4* __restrict__ nodeq_out, int N,
-                    const GatLayout L) {
+                    const float* __restrict__ bias, const float* __restrict__ gout, int64_t ldg,
+                    float4* __restrict__ nodeq_out, int N, const GatLayout L) {
   const int lane = threadIdx.x & 63;
   const int t = lane % L.G;
   const int g = lane / L.G;
@@ -475,6 +482,12 @@ gat_bwd_prep_kernel(const float* __restrict__ a_dst, const float* __restrict__ m
       if (active) {
         load_vec<VEC>(go, gout + (int64_t)row * ldg + cofs);
         load_vec<VEC>(o, out + (int64_t)row * ldo + cofs);
+        if (bias) {  // `out` was stored with the bias added: the softmax Jacobian needs the bare aggregate
+          float bv[VEC];
+          load_vec<VEC>(bv, bias + cofs);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] -= bv[i];
+        }
       }
       const float dsum = head_sum(dot_vec<VEC>(go, o), L.LPH);
       if (active && ch == 0) {
@@ -766,9 +779,9 @@ extern "C" int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const fl
 
 extern "C" int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                                           int64_t ldh, const float* a_src, const float* att_src,
-                                          const float* a_dst, float* out, int64_t ldo, float* m, float* rden,
-                                          int64_t N, int H, int C, float slope, const rgbx_row_split_t* split,
-                                          rgbx_stream_t stream) {
+                                          const float* a_dst, const float* bias, float* out, int64_t ldo,
+                                          float* m, float* rden, int64_t N, int H, int C, float slope,
+                                          const rgbx_row_split_t* split, rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_fwd")) return rc;
   if (N == 0) return RGBX_OK;
   if (!rowptr || !col || !hfeat || (!a_src && !att_src) || !a_dst || !out || !m || !rden)
@@ -776,21 +789,21 @@ extern "C" int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* 
   if (ldh < (int64_t)H * C || ldo < (int64_t)H * C) return fail(RGBX_E_ARG, "gat_fwd: leading dimension < H*C");
   SplitDev sd;
   if (int rc = split_view(split, H, C, &sd, "gat_fwd")) return rc;
-  const int vec = pick_vec(C, {hfeat, out, att_src, sd.pacc}, {ldh, ldo});
+  const int vec = pick_vec(C, {hfeat, out, att_src, bias, sd.pacc}, {ldh, ldo});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_fwd")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int grid = gat_grid(N);
 #define RGBX_GAT_FWD(V)                                                                                         \
   do {                                                                                                          \
-    gat_fwd_kernel<V, false><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out, ldo, m,  \
-                                                  rden, (int)N, slope, L, sd);                                  \
+    gat_fwd_kernel<V, false><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, att_src, a_dst, bias, out,    \
+                                                  ldo, m, rden, (int)N, slope, L, sd);                          \
     if (sd.threshold > 0) {                                                                                     \
       gat_fwd_kernel<V, true><<<gat_grid(split->n_chunks), 256, 0, s>>>(                                        \
-          rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out, ldo, m, rden, split->n_chunks, slope, L, sd);    \
-      gat_fwd_combine_kernel<V><<<gat_grid(split->n_long), 256, 0, s>>>(split->n_long, split->long_row,         \
-                                                                      split->long_chunk_ptr, out, ldo, m, rden, \
-                                                                      L, sd);                                   \
+          rowptr, col, hfeat, ldh, a_src, att_src, a_dst, bias, out, ldo, m, rden, split->n_chunks, slope, L,   \
+          sd);                                                                                                  \
+      gat_fwd_combine_kernel<V><<<gat_grid(split->n_long), 256, 0, s>>>(                                        \
+          split->n_long, split->long_row, split->long_chunk_ptr, bias, out, ldo, m, rden, L, sd);               \
     }                                                                                                           \
   } while (0)
   if (vec == 4) RGBX_GAT_FWD(4);
@@ -830,22 +843,22 @@ extern "C" int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, c
 }
 
 extern "C" int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const float* rden, const float* out,
-                                     int64_t ldo, const float* gout, int64_t ldg, float* nodeq, int64_t N, int H,
-                                     int C, rgbx_stream_t stream) {
+                                     int64_t ldo, const float* bias, const float* gout, int64_t ldg, float* nodeq,
+                                     int64_t N, int H, int C, rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_bwd_prep")) return rc;
   if (N == 0) return RGBX_OK;
   if (!a_dst || !m || !rden || !out || !gout || !nodeq) return fail(RGBX_E_ARG, "gat_bwd_prep: null pointer");
   const int64_t F = (int64_t)H * C;
   if (ldo < F || ldg < F) return fail(RGBX_E_ARG, "gat_bwd_prep: leading dimension < H*C");
   if (!aligned16(nodeq)) return fail(RGBX_E_ALIGN, "gat_bwd_prep: nodeq must be 16-byte aligned");
-  const int vec = pick_vec(C, {out, gout}, {ldo, ldg});
+  const int vec = pick_vec(C, {out, gout, bias}, {ldo, ldg});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_bwd_prep")) return rc;
   hipStream_t s = (hipStream_t)stream;
   int64_t b = cdiv(N, 4 * (kWave / L.G));
   const int grid = (int)(b < kMaxGrid ? b : kMaxGrid);
 #define RGBX_GAT_BP(V) \
-  gat_bwd_prep_kernel<V><<<grid, 256, 0, s>>>(a_dst, m, rden, out, ldo, gout, ldg, reinterpret_cast<float4*>(nodeq), (int)N, L)
+  gat_bwd_prep_kernel<V><<<grid, 256, 0, s>>>(a_dst, m, rden, out, ldo, bias, gout, ldg, reinterpret_cast<float4*>(nodeq), (int)N, L)
   if (vec == 4) RGBX_GAT_BP(4);
   else if (vec == 2) RGBX_GAT_BP(2);
   else RGBX_GAT_BP(1);

@@ -130,14 +130,20 @@ class GATConv(nn.Module):
     def forward(self, x, edge_index):
         H, C = self.heads, self.out_channels
         graph = get_graph(edge_index, x.size(0), LOOPS_REMOVE_ADD)
+        # the bias rides in the aggregation kernel's store when it applies to the stored row as is
+        # (concatenated heads, or a single head, whose "mean over heads" is the identity)
+        in_kernel = self.concat or H == 1
         if getattr(graph, "is_distributed", False) and graph.is_resident(x):
             out = graph.gat(x, self.att_src, self.att_dst, H, C, self.negative_slope, weight=self.lin_src.weight)
+            if in_kernel:
+                return out + self.bias
         else:
             h = ops.linear(x, self.lin_src.weight)
-            out = ops.gat_attend(h, self.att_src, self.att_dst, graph, H, C, self.negative_slope)
-        if not self.concat:
-            out = out.view(-1, H, C).mean(dim=1)
-        return out + self.bias
+            out = ops.gat_attend(h, self.att_src, self.att_dst, graph, H, C, self.negative_slope,
+                                 bias=self.bias if in_kernel else None)
+            if in_kernel:
+                return out
+        return out.view(-1, H, C).mean(dim=1) + self.bias
 
 
 class APPNP(nn.Module):

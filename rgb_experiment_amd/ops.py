@@ -289,8 +289,8 @@ class _GATAggregate(torch.autograd.Function):
         with _Timed("gat_fwd"):
             _lib.check(
                 _lib.load().rgbx_gat_aggregate_fwd_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), ph, ldh,
-                                                       _lib.ptr(a_src), _lib.ptr(att), _lib.ptr(a_dst), po, ldo,
-                                                       _lib.ptr(m), _lib.ptr(rden), N, H, C, float(slope),
+                                                       _lib.ptr(a_src), _lib.ptr(att), _lib.ptr(a_dst), None, po,
+                                                       ldo, _lib.ptr(m), _lib.ptr(rden), N, H, C, float(slope),
                                                        None if split is None else ctypes.byref(split),
                                                        _lib.stream_ptr()), "rgbx_gat_aggregate_fwd_f32")
         ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out)
@@ -309,8 +309,9 @@ class _GATAggregate(torch.autograd.Function):
         return g_h, g_as, g_ad, None, None, None, None, None
 
 
-def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope):
-    """(g_hfeat through the aggregation, g_a_src [n_src, H], g_a_dst [n_tgt, H])."""
+def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope, bias=None):
+    """(g_hfeat through the aggregation, g_a_src [n_src, H], g_a_dst [n_tgt, H]). `bias`: the vector the
+    forward added to `out` in its store, if any."""
     N, n_src, dev = g.fwd.N, g.bwd.N, gout.device
     lib = _lib.load()
     nodeq = torch.empty((N, H, 4), dtype=torch.float32, device=dev)  # (a_dst, max, 1/sum, dsum) records
@@ -324,7 +325,7 @@ def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope):
     ds = torch.empty((max(g.bwd.nnz, 1), H), dtype=torch.float32, device=dev)
     with _Timed("gat_bwd_prep"):
         _lib.check(
-            lib.rgbx_gat_bwd_prep_f32(_lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, pg, ldg,
+            lib.rgbx_gat_bwd_prep_f32(_lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, _lib.ptr(bias), pg, ldg,
                                       _lib.ptr(nodeq), N, H, C, _lib.stream_ptr()), "rgbx_gat_bwd_prep_f32")
     split, _scratch = g.bwd.split_arg(H * C + 2 * H, dev)
     with _Timed("gat_bwd_src"):
@@ -369,12 +370,14 @@ class _GATAttend(torch.autograd.Function):
     """One GATConv attention block as a single autograd node: scores (rgbx_gat_scores_f32) + fused
     edge-softmax/aggregate forward; backward = prep + source pass + segment sum (as _GATAggregate) followed
     by rgbx_gat_scores_bwd_f32, which folds the score gradients into g_hfeat in place and reduces the
-    attention-vector gradients without materialising [N, H, C] products."""
+    attention-vector gradients without materialising [N, H, C] products. `bias` ([H*C], optional) is added
+    in the aggregation kernel's store (GATConv's `+ bias` for concatenated heads)."""
 
     @staticmethod
-    def forward(ctx, hfeat, att_src, att_dst, graph, H, C, slope):
-        _lib.require_device(hfeat, att_src, att_dst)
+    def forward(ctx, hfeat, att_src, att_dst, graph, H, C, slope, bias=None):
+        _lib.require_device(hfeat, att_src, att_dst, bias)
         hfeat = hfeat.contiguous()
+        b = None if bias is None else bias.detach().reshape(H * C).contiguous()
         att_s = att_src.detach().reshape(H, C).contiguous()
         att_d = att_dst.detach().reshape(H, C).contiguous()
         n_src, N, dev = hfeat.size(0), graph.fwd.N, hfeat.device
@@ -393,21 +396,23 @@ class _GATAttend(torch.autograd.Function):
         with _Timed("gat_fwd"):
             _lib.check(
                 lib.rgbx_gat_aggregate_fwd_f32(_lib.ptr(graph.fwd.rowptr), _lib.ptr(graph.fwd.col), ph, ldh,
-                                               _lib.ptr(a_src), _lib.ptr(att_k), _lib.ptr(a_dst), po, ldo, _lib.ptr(m),
-                                               _lib.ptr(rden), N, H, C, float(slope),
+                                               _lib.ptr(a_src), _lib.ptr(att_k), _lib.ptr(a_dst), _lib.ptr(b), po, ldo,
+                                               _lib.ptr(m), _lib.ptr(rden), N, H, C, float(slope),
                                                None if split is None else ctypes.byref(split), _lib.stream_ptr()),
                 "rgbx_gat_aggregate_fwd_f32")
-        ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out, att_s, att_d)
+        ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out, att_s, att_d, b)
         ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, slope
         ctx.att_shapes = (att_src.shape, att_dst.shape)
+        ctx.bias_shape = None if bias is None else bias.shape
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        hfeat, a_src, a_dst, m, rden, out, att_s, att_d = ctx.saved_tensors
+        hfeat, a_src, a_dst, m, rden, out, att_s, att_d, b = ctx.saved_tensors
         H, C = ctx.H, ctx.C
-        g_h, g_as, g_ad = _gat_backward_core(ctx.graph, hfeat, a_src, a_dst, m, rden, out, gout.contiguous(), H, C,
-                                             ctx.slope)
+        gout = gout.contiguous()
+        g_h, g_as, g_ad = _gat_backward_core(ctx.graph, hfeat, a_src, a_dst, m, rden, out, gout, H, C, ctx.slope, b)
+        g_b = gout.sum(0).reshape(ctx.bias_shape) if b is not None and ctx.needs_input_grad[7] else None
         lib = _lib.load()
         n = hfeat.size(0)
         n_scr = ctypes.c_int64(0)
@@ -424,14 +429,15 @@ class _GATAttend(torch.autograd.Function):
                                             _lib.ptr(att_d), pgh, ldgh, _lib.ptr(g_att_s), _lib.ptr(g_att_d),
                                             _lib.ptr(scratch), n_scr.value, n, H, C, _lib.stream_ptr()),
                 "rgbx_gat_scores_bwd_f32")
-        return g_h, g_att_s.reshape(ctx.att_shapes[0]), g_att_d.reshape(ctx.att_shapes[1]), None, None, None, None
+        return g_h, g_att_s.reshape(ctx.att_shapes[0]), g_att_d.reshape(ctx.att_shapes[1]), None, None, None, None, g_b
 
 
-def gat_attend(h, att_src, att_dst, graph, H, C, slope=0.2):
-    """Scores + edge-softmax + aggregation of one GATConv; dispatches to the partitioned graph."""
+def gat_attend(h, att_src, att_dst, graph, H, C, slope=0.2, bias=None):
+    """Scores + edge-softmax + aggregation (+ bias) of one GATConv; dispatches to the partitioned graph."""
     if _is_dist(graph):
-        return graph.gat(h, att_src, att_dst, H, C, slope)
-    return _GATAttend.apply(h, att_src, att_dst, graph, H, C, slope)
+        out = graph.gat(h, att_src, att_dst, H, C, slope)
+        return out if bias is None else out + bias
+    return _GATAttend.apply(h, att_src, att_dst, graph, H, C, slope, bias)
 
 
 def _scores_in_kernel(C):

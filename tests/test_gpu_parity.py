@@ -408,6 +408,8 @@ def test_gat_hub_rows_are_split(dev, H, C, monkeypatch):
     go = torch.randn(n, H * C, generator=gen)
     torch.manual_seed(3)
     conv = GATConv(f, C, H)
+    with torch.no_grad():
+        conv.bias.uniform_(-1, 1)  # added in the store of the row kernel AND of the hub-row combine kernel
     sd = {k: v.detach().clone().double() for k, v in conv.state_dict().items() if "lin_dst" not in k}
     conv.to(dev)
     ei_d = ei.to(dev)
@@ -454,8 +456,8 @@ def test_gat_backward_two_implementations_agree(dev):
     lib = _lib.load()
     hd, asd, add = h.detach().contiguous(), a_s.detach().contiguous(), a_d.detach().contiguous()
     _lib.check(lib.rgbx_gat_aggregate_fwd_f32(g.fwd.rowptr.data_ptr(), g.fwd.col.data_ptr(), hd.data_ptr(), H * C,
-                                              asd.data_ptr(), None, add.data_ptr(), out2.data_ptr(), H * C, m.data_ptr(),
-                                              rden.data_ptr(), n, H, C, 0.2, None, _lib.stream_ptr()), "fwd")
+                                              asd.data_ptr(), None, add.data_ptr(), None, out2.data_ptr(), H * C,
+                                              m.data_ptr(), rden.data_ptr(), n, H, C, 0.2, None, _lib.stream_ptr()), "fwd")
     nodeq = torch.empty(n, H, 4, device=dev)
     ref = torch.empty(n, H, device=dev)
     _lib.check(lib.rgbx_gat_bwd_dst_f32(g.fwd.rowptr.data_ptr(), g.fwd.col.data_ptr(), hd.data_ptr(), H * C,
