@@ -1,6 +1,7 @@
 """Shared skeleton of the reference's conv-stack models: (conv -> BatchNorm1d) x (L-1), conv,
 log_softmax. No activation and no dropout are applied (the reference stores ``dropout_rate`` but
 never uses it: models/gcn.py:15,25-31)."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -30,5 +31,10 @@ class ConvStack(nn.Module):
     def forward(self, x, edge_index):
         last = self.num_layers - 1
         for conv, bn in zip(self.convs[:last], self.bns):
-            x = bn(conv(x, edge_index))
+            fold = getattr(bn, "eval_affine", None) if getattr(conv, "folds_post_affine", False) else None
+            affine = fold() if fold is not None and not torch.is_grad_enabled() else None
+            if affine is not None:  # eval forward: BatchNorm's affine map folded into the conv's weights
+                x = conv(x, edge_index, post_affine=affine)
+            else:
+                x = bn(conv(x, edge_index))
         return model_output(self.convs[last](x, edge_index))

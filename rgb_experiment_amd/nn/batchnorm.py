@@ -108,13 +108,19 @@ class BatchNorm1d(nn.BatchNorm1d):
     def _reduce(self, packed):
         return packed
 
+    def eval_affine(self):
+        """(scale, shift) with eval-mode BN(x) = x * scale + shift, or None when that form does not apply."""
+        if self.training or not self.affine or not self.track_running_stats:
+            return None
+        scale = self.weight * torch.rsqrt(self.running_var + self.eps)
+        return scale, self.bias - self.running_mean * scale
+
     def forward(self, x):
         if x.dim() != 2 or not self.affine or not self.track_running_stats:
             return super().forward(x)
         if not self.training:
-            scale = self.weight * torch.rsqrt(self.running_var + self.eps)
-            return affine_cols(x if x.stride(-1) == 1 else x.contiguous(), scale.contiguous(),
-                               (self.bias - self.running_mean * scale).contiguous())
+            scale, shift = self.eval_affine()
+            return affine_cols(x if x.stride(-1) == 1 else x.contiguous(), scale.contiguous(), shift.contiguous())
         stats = []
         y = _BNTrain.apply(x, self.weight, self.bias, self.eps, self._reduce, stats)
         mean, var, n = stats

@@ -32,6 +32,8 @@ class GCNConv(nn.Module):
     (gcn_norm restated at reference models/dagnn.py:12-31; message norm*x_j at dagnn.py:57-59).
     Parameters: ``lin.weight`` [out, in] (glorot, no bias), ``bias`` [out] (zeros)."""
 
+    folds_post_affine = True  # forward(..., post_affine=(scale, shift)): see models/_stack.py
+
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
@@ -43,25 +45,37 @@ class GCNConv(nn.Module):
         glorot_(self.lin.weight)
         nn.init.zeros_(self.bias)
 
-    def forward(self, x, edge_index):
+    def forward(self, x, edge_index, post_affine=None):
+        """`post_affine` = (scale, shift) of an eval-mode BatchNorm that follows this layer (no_grad only): a
+        per-column affine map of a linear layer's output is the same layer with rows of W and b rescaled, so the
+        normalisation costs two [out]-sized vector ops instead of a pass over [N, out]."""
+        weight, bias = self.lin.weight, self.bias
+        if post_affine is not None:
+            scale, shift = post_affine
+            weight, bias = weight * scale[:, None], bias * scale + shift
+        return self._conv(x, edge_index, weight, bias)
+
+    def _conv(self, x, edge_index, weight, bias):
         graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
         if ops.fused_linear_ok(graph, self.in_channels, self.out_channels):
             # A_hat (x W^T) + b = (A_hat x) W^T + b in one kernel: the aggregate stays in LDS and the GEMM
             # runs on the MFMA units underneath the gather (ops._PropagateLinear)
-            return ops.propagate_linear(x, graph, "gcn", self.lin.weight, self.bias)
+            return ops.propagate_linear(x, graph, "gcn", weight, bias)
         if not x.requires_grad and self.in_channels <= self.out_channels:
             # Input layer (and every layer under no_grad): A_hat (x W^T) = (A_hat x) W^T. Aggregating first
             # costs the same forward (in <= out) and makes dW = dy^T (A_hat x) a plain weight-gradient GEMM: no
             # gradient has to travel back through A_hat^T, because x needs none (one transposed SpMM less per
             # step). On a partitioned graph the aggregated tensor is then the static feature matrix, whose
             # boundary rows are resident (dist.DistGraph.pin_resident): no exchange either.
-            return ops.linear(ops.propagate_gcn(x, graph), self.lin.weight, self.bias)
-        return ops.propagate_gcn(ops.linear(x, self.lin.weight), graph, bias=self.bias)
+            return ops.linear(ops.propagate_gcn(x, graph), weight, bias)
+        return ops.propagate_gcn(ops.linear(x, weight), graph, bias=bias)
 
 
 class SAGEConv(nn.Module):
     """out = lin_l(mean_{j in N(i)} x_j) + lin_r(x_i); no self-loops; nodes without in-edges
     aggregate 0 [PyG SAGEConv defaults: aggr='mean', root_weight=True, lin_l bias, lin_r no bias]."""
+
+    folds_post_affine = True  # forward(..., post_affine=(scale, shift)): see models/_stack.py
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
@@ -69,18 +83,24 @@ class SAGEConv(nn.Module):
         self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
         self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
 
-    def forward(self, x, edge_index):
+    def forward(self, x, edge_index, post_affine=None):
+        w_l, b_l, w_r = self.lin_l.weight, self.lin_l.bias, self.lin_r.weight
+        if post_affine is not None:  # see GCNConv.forward
+            scale, shift = post_affine
+            w_l, b_l, w_r = w_l * scale[:, None], b_l * scale + shift, w_r * scale[:, None]
         graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
-        x_r = ops.linear(x, self.lin_r.weight)
+        x_r = ops.linear(x, w_r)
         if ops.fused_linear_ok(graph, self.in_channels, self.out_channels):
-            return ops.propagate_linear(x, graph, "mean", self.lin_l.weight, self.lin_l.bias) + x_r
+            return ops.propagate_linear(x, graph, "mean", w_l, b_l) + x_r
         agg = ops.propagate_mean(x, graph)
-        return ops.linear(agg, self.lin_l.weight, self.lin_l.bias) + x_r
+        return ops.linear(agg, w_l, b_l) + x_r
 
 
 class MySAGEConv(nn.Module):
     """reference models/graphsage.py:36-62: x_l = lin_l(x), x_r = lin_r(x) (both with bias),
     remove_self_loops + add_self_loops, mean over N(i) ∪ {i} of x_l, then += x_r."""
+
+    folds_post_affine = True  # forward(..., post_affine=(scale, shift)): see models/_stack.py
 
     def __init__(self, in_channels, out_channels, add_self_loops=True):
         super().__init__()
@@ -89,18 +109,29 @@ class MySAGEConv(nn.Module):
         self.lin_l = nn.Linear(in_channels, out_channels)
         self.lin_r = nn.Linear(in_channels, out_channels)
 
-    def forward(self, x, edge_index):
+    def forward(self, x, edge_index, post_affine=None):
+        w_l, b_l, w_r, b_r = self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, self.lin_r.bias
+        if post_affine is not None and self.add_self_loops:  # see GCNConv.forward; the mean weights sum to 1
+            scale, shift = post_affine
+            w_l, b_l = w_l * scale[:, None], b_l * scale
+            w_r, b_r = w_r * scale[:, None], b_r * scale + shift
+        out = self._conv(x, edge_index, w_l, b_l, w_r, b_r)
+        if post_affine is not None and not self.add_self_loops:
+            out = out * post_affine[0] + post_affine[1]
+        return out
+
+    def _conv(self, x, edge_index, w_l, b_l, w_r, b_r):
         mode = LOOPS_REMOVE_ADD if self.add_self_loops else LOOPS_KEEP
         graph = get_graph(edge_index, x.size(0), mode)
-        x_r = ops.linear(x, self.lin_r.weight, self.lin_r.bias)
+        x_r = ops.linear(x, w_r, b_r)
         if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels):
-            return ops.propagate_linear(x, graph, "mean", self.lin_l.weight, self.lin_l.bias) + x_r
+            return ops.propagate_linear(x, graph, "mean", w_l, b_l) + x_r
         if not x.requires_grad and self.add_self_loops and self.in_channels <= self.out_channels:
             # Input layer (see GCNConv.forward): with the self-loop every row's mean weights
             # sum to 1, so mean_j(W x_j + b) = W mean_j(x_j) + b exactly; aggregating first removes the
             # transposed SpMM from this layer's backward.
-            return ops.linear(ops.propagate_mean(x, graph), self.lin_l.weight, self.lin_l.bias) + x_r
-        x_l = ops.linear(x, self.lin_l.weight, self.lin_l.bias)
+            return ops.linear(ops.propagate_mean(x, graph), w_l, b_l) + x_r
+        x_l = ops.linear(x, w_l, b_l)
         return ops.propagate_mean(x_l, graph) + x_r
 
 

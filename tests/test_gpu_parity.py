@@ -257,6 +257,36 @@ def test_fused_path_inside_models(dev):
             assert (p.grad.cpu() - rg).abs().max().item() < 1e-4 * max(1.0, rg.abs().max().item()), (cls.__name__, pname)
 
 
+@pytest.mark.parametrize("name,f,hid", [("GCN", 64, 128), ("GCN", 40, 24), ("GraphSAGE", 64, 64), ("GraphSAGE2", 32, 96)])
+def test_eval_batchnorm_folded_into_conv_weights(dev, name, f, hid):
+    """Under no_grad the stack folds the eval-mode BatchNorm that follows a conv into that conv's weights
+    (models/_stack.py): same logits as conv -> BatchNorm run separately (the enable_grad route), and as the oracle."""
+    from rgb_experiment_amd import models as M
+    n, c = 2500, 16
+    gen = torch.Generator().manual_seed(21)
+    ei = rand_graph(n, 18000, 4, loops=5, dups=5)
+    x = torch.randn(n, f, generator=gen)
+    y = torch.randint(0, c, (n,), generator=gen)
+    torch.manual_seed(2)
+    model = getattr(M, name)(num_layers=3, hidden_unit=hid, input_dim=f, output_dim=c, dropout_rate=0.5).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    xd, eid = x.to(dev), ei.to(dev)
+    model.train()
+    for _ in range(3):  # move the running statistics and the affine parameters off their initial values
+        opt.zero_grad()
+        torch.nn.functional.nll_loss(model(xd, eid)["out"], y.to(dev)).backward()
+        opt.step()
+    model.eval()
+    with torch.no_grad():
+        folded = model(xd, eid)["emb"]
+    separate = model(xd, eid)["emb"].detach()
+    assert (folded - separate).abs().max().item() < 2e-5 * max(1.0, separate.abs().max().item())
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    fwd = {"GCN": O.gcn_forward, "GraphSAGE": O.graphsage_forward, "GraphSAGE2": O.graphsage2_forward}[name]
+    ref = fwd(sd, x, ei, 3, False)["emb"]
+    assert (folded.cpu() - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item())
+
+
 def test_spmm_epilogue_and_strides(dev):
     """a, b, y, row scale, and non-contiguous leading dimensions (column slices of wider matrices)."""
     from rgb_experiment_amd import ops
