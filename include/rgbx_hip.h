@@ -227,14 +227,16 @@ int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const fl
 
 /* ---- dense weight gradient on the MFMA units ---------------------------------------------- */
 
-/* Scratch bytes for rgbx_gemm_tn_f32 (split-K partial tiles). */
+/* Scratch bytes for rgbx_gemm_tn_f32 (split-K partial tiles + partial column sums). */
 int rgbx_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N, size_t* bytes);
 
 /* C[M,N] = alpha * A^T B, A [K,M] (lda), B [K,N] (ldb), fp32 row-major, K = node count (huge),
  * M,N = feature widths. Split-K over the whole chip on v_mfma_f32_32x32x2_f32 (exact fp32), partials
- * reduced in slab order (bitwise reproducible). This is dW = dY^T X of every Linear on the path. */
+ * reduced in slab order (bitwise reproducible). This is dW = dY^T X of every Linear on the path.
+ * `a_colsum` ([M], optional): also receives the column sums of A (unscaled) — the bias gradient
+ * db = sum_rows dY, taken from the A tiles the kernel stages anyway. */
 int rgbx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
-                     int64_t K, int64_t M, int64_t N, float alpha, void* workspace,
+                     float* a_colsum, int64_t K, int64_t M, int64_t N, float alpha, void* workspace,
                      size_t workspace_bytes, rgbx_stream_t stream);
 
 /* ---- BatchNorm1d over the node axis --------------------------------------------------------- */

@@ -45,7 +45,7 @@ SIGNATURES = {
     "rgbx_gat_bwd_prep_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _P, _I64, _I, _I, _P],
     "rgbx_gat_bwd_src_f32": [_P, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _F, _P, _P],
     "rgbx_gemm_tn_workspace_bytes": [_I64, _I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
-    "rgbx_gemm_tn_f32": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _F, _P, ctypes.c_size_t, _P],
+    "rgbx_gemm_tn_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _F, _P, ctypes.c_size_t, _P],
     "rgbx_bn_scratch_doubles": [_I64, _I64, ctypes.POINTER(ctypes.c_int64)],
     "rgbx_bn_stats_f32": [_P, _I64, _I64, _I64, _P, _P, _I64, _P],
     "rgbx_affine_cols_f32": [_P, _I64, _P, _P, _P, _I64, _I64, _I64, _P],

@@ -11,6 +11,8 @@
 // read along their contiguous dimension: lane l of a fragment holds row k0 + (l >> 5), column
 // c0 + (l & 31) — no transposes anywhere. Partial tiles go to a workspace with plain stores.
 // Kernel 2: sums the S partials in slab order (bitwise reproducible, no float atomics).
+// Optionally the column sums of A (= the bias gradient when A = dY) are taken from the staged A tiles by the
+// workgroups of the first N-tile and reduced the same way: dY is then read once for dW and db together.
 #include "rgbx_common.h"
 
 namespace rgbx {
@@ -50,7 +52,8 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ lds, const float*
 template <bool VEC4>
 __global__ void __launch_bounds__(256)
 gemm_tn_partial_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
-                       float* __restrict__ part, int64_t K, int M, int N, int64_t slab) {
+                       float* __restrict__ part, float* __restrict__ colpart, int64_t K, int M, int N,
+                       int64_t slab) {
   __shared__ float lds[2 * KT * 128];
   float* la = lds;
   float* lb = lds + KT * 128;
@@ -70,11 +73,17 @@ gemm_tn_partial_kernel(const float* __restrict__ A, int64_t lda, const float* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const bool sums = colpart != nullptr && blockIdx.z == 0 && threadIdx.x < BM;
+  float csum = 0.f;
   for (int64_t k0 = k_begin; k0 < k_end; k0 += KT) {
     __syncthreads();
     stage_tile<VEC4>(la, A, lda, k0, k_end, m0, M);
     stage_tile<VEC4>(lb, B, ldb, k0, k_end, n0, N);
     __syncthreads();
+    if (sums) {  // thread t owns column m0 + t of A (rows past k_end were zero-filled)
+#pragma unroll 8
+      for (int r = 0; r < KT; ++r) csum += la[r * 128 + threadIdx.x];
+    }
 #pragma unroll 4
     for (int kk = 0; kk < KT; kk += 2) {
       const float a0 = la[(kk + kr) * 128 + wm + cc];
@@ -88,6 +97,7 @@ gemm_tn_partial_kernel(const float* __restrict__ A, int64_t lda, const float* __
     }
   }
 
+  if (sums && m0 + (int)threadIdx.x < M) colpart[(int64_t)split * M + m0 + threadIdx.x] = csum;
   // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   float* out = part + (int64_t)split * M * N;
 #pragma unroll
@@ -143,13 +153,14 @@ using namespace rgbx;
 extern "C" int rgbx_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N, size_t* bytes) {
   if (!bytes || K < 0 || M < 0 || N < 0) return fail(RGBX_E_ARG, "gemm_tn_workspace_bytes: bad argument");
   if (M >= INT32_MAX || N >= INT32_MAX) return fail(RGBX_E_RANGE, "gemm_tn: M or N exceeds int32");
-  *bytes = (size_t)choose_splits(K, (int)M, (int)N) * (size_t)M * (size_t)N * sizeof(float);
+  // S partial tiles of C, then S partial column-sum vectors of A
+  *bytes = (size_t)choose_splits(K, (int)M, (int)N) * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
   return RGBX_OK;
 }
 
 extern "C" int rgbx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
-                                int64_t ldc, int64_t K, int64_t M, int64_t N, float alpha, void* workspace,
-                                size_t workspace_bytes, rgbx_stream_t stream) {
+                                int64_t ldc, float* a_colsum, int64_t K, int64_t M, int64_t N, float alpha,
+                                void* workspace, size_t workspace_bytes, rgbx_stream_t stream) {
   if (K < 0 || M < 0 || N < 0) return fail(RGBX_E_ARG, "gemm_tn: negative size");
   if (M == 0 || N == 0) return RGBX_OK;
   if (!C || (K > 0 && (!A || !B))) return fail(RGBX_E_ARG, "gemm_tn: null pointer");
@@ -163,17 +174,22 @@ extern "C" int rgbx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int
   const int S = choose_splits(K, (int)M, (int)N);
   const int64_t slab = cdiv(cdiv(K > 0 ? K : 1, S), KT) * KT;
   float* part = static_cast<float*>(workspace);
+  float* colpart = a_colsum ? part + (size_t)S * M * N : nullptr;
   dim3 grid(S, (unsigned)cdiv(M, BM), (unsigned)cdiv(N, BN));
   const bool v4 = aligned16(A) && aligned16(B) && lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0;
   if (v4)
-    gemm_tn_partial_kernel<true><<<grid, 256, 0, s>>>(A, lda, B, ldb, part, K, (int)M, (int)N, slab);
+    gemm_tn_partial_kernel<true><<<grid, 256, 0, s>>>(A, lda, B, ldb, part, colpart, K, (int)M, (int)N, slab);
   else
-    gemm_tn_partial_kernel<false><<<grid, 256, 0, s>>>(A, lda, B, ldb, part, K, (int)M, (int)N, slab);
+    gemm_tn_partial_kernel<false><<<grid, 256, 0, s>>>(A, lda, B, ldb, part, colpart, K, (int)M, (int)N, slab);
   RGBX_CHECK_LAUNCH("gemm_tn_partial_kernel");
   const int64_t MN = M * N;
   int64_t rb = cdiv(MN, 32);
   if (rb > kMaxGrid) rb = kMaxGrid;
   gemm_tn_reduce_kernel<<<(int)rb, 256, 0, s>>>(part, S, MN, C, (int)N, ldc, alpha);
   RGBX_CHECK_LAUNCH("gemm_tn_reduce_kernel");
+  if (a_colsum) {  // the same slab-ordered reduction over the [S, M] column-sum partials (unscaled)
+    gemm_tn_reduce_kernel<<<(int)cdiv(M, 32), 256, 0, s>>>(colpart, S, M, a_colsum, (int)M, M, 1.0f);
+    RGBX_CHECK_LAUNCH("gemm_tn_reduce_kernel");
+  }
   return RGBX_OK;
 }

@@ -172,9 +172,13 @@ class _PropagateLinear(torch.autograd.Function):
         g, kind = ctx.graph, ctx.kind
         gy = gy.contiguous()
         gx = gw = gb = None
+        want_b = ctx.has_bias and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[3]:
-            gw = gemm_tn(gy, z)
-        if ctx.has_bias and ctx.needs_input_grad[4]:
+            if want_b:
+                gw, gb = gemm_tn(gy, z, colsum=True)  # dy is read once for dW and db
+            else:
+                gw = gemm_tn(gy, z)
+        elif want_b:
             gb = gy.sum(0)
         if ctx.needs_input_grad[0]:
             gz = gy @ weight
@@ -477,8 +481,9 @@ def scatter_add_rows(src, idx, dst):
 
 # ---- dense layers: forward through hipBLASLt, weight gradient through the split-K MFMA kernel --------
 
-def gemm_tn(a, b, alpha=1.0):
-    """a^T b for a [K,M], b [K,N] (fp32, device): rgbx_gemm_tn_f32."""
+def gemm_tn(a, b, alpha=1.0, colsum=False):
+    """a^T b for a [K,M], b [K,N] (fp32, device): rgbx_gemm_tn_f32. With `colsum` also the column sums of `a`
+    ([M], from the same pass): returns (a^T b, a.sum(0))."""
     _lib.require_device(a, b)
     a = a if a.stride(-1) == 1 else a.contiguous()
     b = b if b.stride(-1) == 1 else b.contiguous()
@@ -491,10 +496,11 @@ def gemm_tn(a, b, alpha=1.0):
     _lib.check(lib.rgbx_gemm_tn_workspace_bytes(K, M, N, ctypes.byref(nbytes)), "rgbx_gemm_tn_workspace_bytes")
     ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=a.device)
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    sums = torch.empty(M, dtype=torch.float32, device=a.device) if colsum else None
     with _Timed("gemm_tn"):
-        _lib.check(lib.rgbx_gemm_tn_f32(pa, lda, pb, ldb, _lib.ptr(out), N, K, M, N, float(alpha), _lib.ptr(ws),
-                                        ws.numel(), _lib.stream_ptr()), "rgbx_gemm_tn_f32")
-    return out
+        _lib.check(lib.rgbx_gemm_tn_f32(pa, lda, pb, ldb, _lib.ptr(out), N, _lib.ptr(sums), K, M, N, float(alpha),
+                                        _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "rgbx_gemm_tn_f32")
+    return (out, sums) if colsum else out
 
 
 class _Linear(torch.autograd.Function):
@@ -511,10 +517,14 @@ class _Linear(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gy @ weight if ctx.needs_input_grad[0] else None
-        gw = None
-        if ctx.needs_input_grad[1]:
-            gw = gemm_tn(gy, x) if gy.is_cuda else gy.t() @ x
-        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        gw = gb = None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and gy.is_cuda and want_b:
+            gw, gb = gemm_tn(gy, x, colsum=True)  # dy is read once for dW and db
+        else:
+            if ctx.needs_input_grad[1]:
+                gw = gemm_tn(gy, x) if gy.is_cuda else gy.t() @ x
+            gb = gy.sum(0) if want_b else None
         return gx, gw, gb
 
 

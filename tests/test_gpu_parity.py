@@ -617,8 +617,11 @@ def test_gemm_tn(dev, K, M, N):
     tol = 1e-5 + 2e-6 * K ** 0.5 * 4
     assert got.shape == (M, N)
     assert (got.double() - want).abs().max().item() < tol
-    again = ops.gemm_tn(a.to(dev), b.to(dev)).cpu()
-    assert torch.equal(got, again)  # fixed-order split-K reduction: bitwise reproducible
+    again, sums = ops.gemm_tn(a.to(dev), b.to(dev), colsum=True)
+    assert torch.equal(got, again.cpu())  # fixed-order split-K reduction: bitwise reproducible
+    want_sums = a.double().sum(0)  # column sums of A from the same pass (= the bias gradient when A = dY)
+    assert sums.shape == (M,)
+    assert (sums.cpu().double() - want_sums).abs().max().item() < 1e-5 + 2e-6 * K ** 0.5 * 4
 
 
 def test_gemm_tn_strided_inputs(dev):
