@@ -137,16 +137,20 @@ int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w,
 /* Fused aggregate-then-transform for layers whose propagate commutes with their Linear
  * (GCNConv, the mean branch of SAGEConv / my_SAGEConv):
  *   z[i,:]   = rs[i] * sum_{p in row i} w[p] * x[col[p],:]          (w, rs optional as above)
- *   out[i,:] = z[i,:] * wt + bias,   wt = W^T as a [K, Nout] row-major matrix
+ *   out[i,:] = z[i,:] * wt + x_root[i,:] * wt_root + bias,   wt = W^T as a [K, Nout] row-major matrix
  * The [32 x K] tile of z lives in LDS and is multiplied on v_mfma_f32_32x32x2_f32 (exact fp32). If z_out is
  * not NULL the aggregate is also stored (ldz), for the weight gradient dy^T z of a training pass.
- * Supported shapes: K % 4 == 0, K <= 256, Nout % 32 == 0 (rgbx_spmm_linear_supported); otherwise
- * RGBX_E_SHAPE and the caller runs rgbx_spmm_csr_f32 + a GEMM. Hub rows are not split here. */
-int rgbx_spmm_linear_supported(int64_t K, int64_t Nout);
+ * Root term (optional; x_root and wt_root both NULL or both set): SAGEConv's lin_r(x_i)
+ * (models/graphsage.py:50,60; graphsage2.py:29 [PyG]) — x_root [N, K] (ldr) are the targets' own rows
+ * (usually x itself), wt_root = Wr^T [K, Nout].
+ * Supported shapes: K % 4 == 0, K <= 256, Nout % 32 == 0, and Nout <= 256 with a root term
+ * (rgbx_spmm_linear_supported); otherwise RGBX_E_SHAPE and the caller runs rgbx_spmm_csr_f32 + GEMMs.
+ * Hub rows are not split here. */
+int rgbx_spmm_linear_supported(int64_t K, int64_t Nout, int has_root);
 int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
-                         const float* x, int64_t ldx, const float* wt, const float* bias, float* out,
-                         int64_t ldo, float* z_out, int64_t ldz, int64_t N, int64_t K, int64_t Nout,
-                         rgbx_stream_t stream);
+                         const float* x, int64_t ldx, const float* wt, const float* x_root, int64_t ldr,
+                         const float* wt_root, const float* bias, float* out, int64_t ldo, float* z_out,
+                         int64_t ldz, int64_t N, int64_t K, int64_t Nout, rgbx_stream_t stream);
 
 /* z_0 = h;  z_{k+1} = (1-alpha) * A_hat z_k + alpha * h, k = 0..K-1; result in `out`.
  * `tmp` is an [N, d] scratch (ld = ldo); h, out, tmp must not alias. K >= 0. */

@@ -11,6 +11,10 @@
 // output tiles going round the waves; B fragments come straight from wt = Wᵀ [K, Nout] (L2-resident, two
 // contiguous 128-byte segments per wave-instruction). Optionally the aggregate is also written out
 // (z_out) because the weight gradient of the training pass is dyᵀ (Âx).
+// Root term (SAGEConv / my_SAGEConv: lin_l(mean_j x_j) + lin_r(x_i)): after the first product the workgroup
+// reloads the SAME LDS tile with its 32 nodes' own rows (coalesced 16-byte loads) and accumulates
+// x_root · Wrᵀ into the same MFMA accumulators — a second tile would halve the workgroups per CU, which costs
+// the gather 5 % (measured), two more barriers cost nothing measurable.
 #include "rgbx_common.h"
 
 namespace rgbx {
@@ -25,18 +29,98 @@ struct FusedArgs {
   const float* rs;
   const float* x;
   const float* wt;
+  const float* xr;   // root rows [N, K] (ldr) or NULL
+  const float* wtr;  // Wr^T [K, Nout]
   const float* bias;
   float* out;
   float* z_out;
-  int64_t ldx, ldo, ldz;
+  int64_t ldx, ldo, ldz, ldr;
   int N, K, Nout;
 };
 
-constexpr int TM = 32;
+#ifndef RGBX_FUSED_RT
+#define RGBX_FUSED_RT 1
+#endif
+constexpr int RT = RGBX_FUSED_RT;  // 32-row tiles per workgroup: one B fragment load feeds RT MFMAs
+constexpr int TM = 32 * RT;        // destination rows per workgroup; 4 * RT waves aggregate 8 rows each
+constexpr int NT_ROOT = 2;  // 32-column output tiles a wave may own when a root term is present (Nout <= 256)
+// Registers: the row-per-wave gather needs ~47 VGPRs and is bound by how many waves keep loads in flight, so this
+// kernel must not fall below the plain SpMM's 8 waves per SIMD: VGPRs + AGPRs <= 64 (`__launch_bounds__(.., 8)`);
+// the first build (84 registers, 5 waves per SIMD) lost 8 % to occupancy alone.
+
+// acc[rt] += zt[rt*32 .. rt*32+31, K] * wt[K, n0 : n0 + 32] for the RT row tiles of the workgroup: one B fragment
+// (from L2) feeds RT MFMAs. Lane l holds A[row l&31][k + (l>>5)] and B[k + (l>>5)][col l&31].
+constexpr int KB = 16;  // MFMA steps (2 k each) whose B values are fetched as one batch of independent loads
+
+// B values of steps [s0, s0 + KB) of the column tile n0: b[i] = wt[2 (s0 + i) + kr][n0 + cc]
+__device__ __forceinline__ void load_b_batch(float (&b)[KB], const float* __restrict__ wt, int Nout, int n0,
+                                             int s0, int kr, int cc) {
+#pragma unroll
+  for (int i = 0; i < KB; ++i) b[i] = wt[(int64_t)(2 * (s0 + i) + kr) * Nout + n0 + cc];
+}
+
+template <int RT>
+__device__ __forceinline__ void mfma_batch(f32x16 (&acc)[RT], const float (&b)[KB], const float* __restrict__ zt,
+                                           int ldz, int s0, int kr, int cc) {
+#pragma unroll
+  for (int i = 0; i < KB; ++i) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float a = zt[(rt * 32 + cc) * ldz + 2 * (s0 + i) + kr];
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[i], acc[rt], 0, 0, 0);
+    }
+  }
+}
+
+// KC > 0 (K % 64 == 0): the B values come in batches of KB independent loads, so the L2 latency is paid once per
+// batch instead of once per MFMA (the compiler's own schedule waited on almost every load); `first` may hold
+// batch 0, fetched before the barrier that guards zt.
+template <int KC, int RT>
+__device__ __forceinline__ void tile_times_wt(f32x16 (&acc)[RT], const float* __restrict__ zt, int ldz,
+                                              const float* __restrict__ wt, int K, int Nout, int n0, int kr,
+                                              int cc, const float (*first)[KB] = nullptr) {
+  if constexpr (KC > 0) {
+    static_assert(KC % (2 * KB) == 0, "KC must be a multiple of 2 * KB");
+    int s0 = 0;
+    if (first) {
+      mfma_batch<RT>(acc, *first, zt, ldz, 0, kr, cc);
+      s0 = KB;
+    }
+#pragma unroll 1
+    for (; s0 < KC / 2; s0 += KB) {  // one batch in registers at a time (unrolled, the scheduler hoists them all)
+      float b[KB];
+      load_b_batch(b, wt, Nout, n0, s0, kr, cc);
+      mfma_batch<RT>(acc, b, zt, ldz, s0, kr, cc);
+    }
+  } else {
+    for (int ks = 0; ks < K; ks += 4) {  // K % 4 == 0: two MFMA steps per trip
+      const float b0 = wt[(int64_t)(ks + kr) * Nout + n0 + cc];
+      const float b1 = wt[(int64_t)(ks + 2 + kr) * Nout + n0 + cc];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const float a0 = zt[(rt * 32 + cc) * ldz + ks + kr], a1 = zt[(rt * 32 + cc) * ldz + ks + 2 + kr];
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[rt], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// C/D layout of the 32x32 MFMA: column l&31, row (r&3) + 8*(r>>2) + 4*(l>>5)
+__device__ __forceinline__ void store_tile(const f32x16& acc, const float* __restrict__ bias,
+                                           float* __restrict__ out, int64_t ldo, int row_base, int N, int n0,
+                                           int kr, int cc) {
+  const float bb = bias ? bias[n0 + cc] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * kr;
+    if (row < N) out[(int64_t)row * ldo + n0 + cc] = acc[r] + bb;
+  }
+}
 
 // KC = K when it is one of the common widths (the MFMA loop then unrolls fully), 0 = any supported K.
-template <int G, bool HAS_W, int KC>
-__global__ void __launch_bounds__(256) spmm_linear_kernel(const FusedArgs A) {
+template <int G, bool HAS_W, int KC, int NT>
+__global__ void __launch_bounds__(256 * RT, NT == 2 ? 6 : 8) spmm_linear_kernel(const FusedArgs A) {
   constexpr int NG = kWave / G;
   constexpr int U = 4;
   extern __shared__ float zt[];  // [TM][K + 4]
@@ -49,8 +133,8 @@ __global__ void __launch_bounds__(256) spmm_linear_kernel(const FusedArgs A) {
   const int row_base = blockIdx.x * TM;
 
   // ---- phase 1: 8 rows per wave into the LDS tile
-  for (int rr = 0; rr < TM / 4; ++rr) {
-    const int lr = wave * (TM / 4) + rr;
+  for (int rr = 0; rr < 8; ++rr) {
+    const int lr = wave * 8 + rr;
     const int row = row_base + lr;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (row < A.N) {
@@ -105,36 +189,103 @@ __global__ void __launch_bounds__(256) spmm_linear_kernel(const FusedArgs A) {
       if (A.z_out && row < A.N) store_vec<4>(A.z_out + (int64_t)row * A.ldz + c, acc);
     }
   }
-  __syncthreads();
-
-  // ---- phase 2: out[32, Nout] = zt[32, K] * wt[K, Nout] + bias; lane l holds A[row l&31][k + (l>>5)] and
-  // B[k + (l>>5)][col l&31]; C/D: column l&31, row (r&3) + 8*(r>>2) + 4*(l>>5)
+  // the first batch of W^T values of this wave's first column tile does not depend on the tile: fetch it now, so its
+  // L2 latency passes while the workgroup's slower waves finish their rows
   const int kr = lane >> 5, cc = lane & 31;
-  for (int n0 = wave * 32; n0 < A.Nout; n0 += 4 * 32) {
-    f32x16 acc;
+  float bpre[KB];
+  const bool pre = KC > 0 && NT > 0 && wave < 4 && wave * 32 < A.Nout;
+  if constexpr (KC > 0) {
+    if (pre) load_b_batch(bpre, A.wt, A.Nout, wave * 32, 0, kr, cc);
+  }
+  // likewise the workgroup's own rows for the root term (K <= 128: at most 4 float4 per thread): their HBM latency
+  // passes under the barrier and the first product instead of between two barriers
+  constexpr bool kRootRegs = KC > 0 && KC <= 128 && NT > 0;
+  constexpr int kRootVecs = kRootRegs ? (TM * (KC / 4)) / (256 * RT) : 1;
+  float rootv[kRootVecs][4];
+  if constexpr (kRootRegs) {
+    if (A.xr) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if constexpr (KC > 0) {
-#pragma unroll 16
-      for (int ks = 0; ks < KC; ks += 2) {
-        const float a = zt[cc * ldz + ks + kr];
-        const float b = A.wt[(int64_t)(ks + kr) * A.Nout + n0 + cc];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-      }
-    } else {
-      for (int ks = 0; ks < K; ks += 4) {  // K % 4 == 0: two MFMA steps per trip
-        const float a0 = zt[cc * ldz + ks + kr], a1 = zt[cc * ldz + ks + 2 + kr];
-        const float b0 = A.wt[(int64_t)(ks + kr) * A.Nout + n0 + cc];
-        const float b1 = A.wt[(int64_t)(ks + 2 + kr) * A.Nout + n0 + cc];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+      for (int j = 0; j < kRootVecs; ++j) {
+        const int idx = threadIdx.x + j * 256 * RT;
+        const int r = idx / (KC / 4), c4 = (idx - r * (KC / 4)) * 4;
+        const int row = row_base + r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rootv[j][i] = 0.f;
+        if (row < A.N) load_vec<4>(rootv[j], A.xr + (int64_t)row * A.ldr + c4);
       }
     }
-    const float bb = A.bias ? A.bias[n0 + cc] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- phase 2: out[TM, Nout] = zt[TM, K] * wt[K, Nout] (+ xroot[TM, K] * wtr[K, Nout]) + bias. Waves 0..3
+  // own the 32-column tiles (all RT row tiles of each: the MFMA time is small, the L2 traffic for W is what costs)
+  if (NT == 0) {  // Nout > 256 (no root term): column tiles one after the other
+    if (wave >= 4) return;
+    for (int n0 = wave * 32; n0 < A.Nout; n0 += 4 * 32) {
+      f32x16 acc[RT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * kr;
-      if (row < A.N) A.out[(int64_t)row * A.ldo + n0 + cc] = acc[r] + bb;
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+      tile_times_wt<KC, RT>(acc, zt, ldz, A.wt, K, A.Nout, n0, kr, cc);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) store_tile(acc[rt], A.bias, A.out, A.ldo, row_base + rt * 32, A.N, n0, kr, cc);
+    }
+    return;
+  }
+  constexpr int NTT = NT > 0 ? NT : 1;
+  f32x16 acc[NTT][RT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tt][rt][r] = 0.f;
+    const int n0 = wave * 32 + tt * 128;
+    if (wave < 4 && n0 < A.Nout)
+      tile_times_wt<KC, RT>(acc[tt], zt, ldz, A.wt, K, A.Nout, n0, kr, cc, pre && tt == 0 ? &bpre : nullptr);
+  }
+  if (!A.xr) {  // no root term (uniform): store and leave
+    if (wave >= 4) return;
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      const int n0 = wave * 32 + tt * 128;
+      if (n0 < A.Nout) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          store_tile(acc[tt][rt], A.bias, A.out, A.ldo, row_base + rt * 32, A.N, n0, kr, cc);
+      }
+    }
+    return;
+  }
+  __syncthreads();  // every wave is done reading the aggregate tile
+  if constexpr (kRootRegs) {
+#pragma unroll
+    for (int j = 0; j < kRootVecs; ++j) {
+      const int idx = threadIdx.x + j * 256 * RT;
+      const int r = idx / (KC / 4), c4 = (idx - r * (KC / 4)) * 4;
+      store_vec<4>(&zt[r * ldz + c4], rootv[j]);
+    }
+  } else {
+    const int k4 = K >> 2;
+    for (int idx = threadIdx.x; idx < TM * k4; idx += 256 * RT) {
+      const int r = idx / k4, c4 = (idx - r * k4) * 4;
+      const int row = row_base + r;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (row < A.N) load_vec<4>(v, A.xr + (int64_t)row * A.ldr + c4);
+      store_vec<4>(&zt[r * ldz + c4], v);
+    }
+  }
+  __syncthreads();
+  if (wave >= 4) return;
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    const int n0 = wave * 32 + tt * 128;
+    if (n0 < A.Nout) {
+      tile_times_wt<KC, RT>(acc[tt], zt, ldz, A.wtr, K, A.Nout, n0, kr, cc);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        store_tile(acc[tt][rt], A.bias, A.out, A.ldo, row_base + rt * 32, A.N, n0, kr, cc);
     }
   }
 }
@@ -143,10 +294,19 @@ template <int G, int KC>
 int launch(const FusedArgs& A, hipStream_t s) {
   const int64_t blocks = cdiv(A.N, TM);
   const size_t lds = (size_t)TM * (A.K + 4) * sizeof(float);
-  if (A.w)
-    spmm_linear_kernel<G, true, KC><<<(int)blocks, 256, lds, s>>>(A);
-  else
-    spmm_linear_kernel<G, false, KC><<<(int)blocks, 256, lds, s>>>(A);
+  // NT = 32-column tiles a wave keeps accumulators for (Nout <= 128: 1, <= 256: 2); 0 = any Nout, tile by tile
+  const int nt = A.Nout <= 128 ? 1 : (A.Nout <= 128 * NT_ROOT ? NT_ROOT : 0);
+#define RGBX_FUSED(HW, NTV) spmm_linear_kernel<G, HW, KC, NTV><<<(int)blocks, 256 * RT, lds, s>>>(A)
+  if (A.w) {
+    if (nt == 0) RGBX_FUSED(true, 0);
+    else if (nt == 1) RGBX_FUSED(true, 1);
+    else RGBX_FUSED(true, 2);
+  } else {
+    if (nt == 0) RGBX_FUSED(false, 0);
+    else if (nt == 1) RGBX_FUSED(false, 1);
+    else RGBX_FUSED(false, 2);
+  }
+#undef RGBX_FUSED
   RGBX_CHECK_LAUNCH("spmm_linear_kernel");
   return RGBX_OK;
 }
@@ -156,25 +316,29 @@ int launch(const FusedArgs& A, hipStream_t s) {
 
 using namespace rgbx;
 
-extern "C" int rgbx_spmm_linear_supported(int64_t K, int64_t Nout) {
-  return K >= 4 && K % 4 == 0 && K <= 256 && Nout >= 32 && Nout % 32 == 0;
+extern "C" int rgbx_spmm_linear_supported(int64_t K, int64_t Nout, int has_root) {
+  return K >= 4 && K % 4 == 0 && K <= 256 && Nout >= 32 && Nout % 32 == 0 && (!has_root || Nout <= 128 * NT_ROOT);
 }
 
 extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
-                                    const float* x, int64_t ldx, const float* wt, const float* bias, float* out,
-                                    int64_t ldo, float* z_out, int64_t ldz, int64_t N, int64_t K, int64_t Nout,
-                                    rgbx_stream_t stream) {
+                                    const float* x, int64_t ldx, const float* wt, const float* x_root, int64_t ldr,
+                                    const float* wt_root, const float* bias, float* out, int64_t ldo, float* z_out,
+                                    int64_t ldz, int64_t N, int64_t K, int64_t Nout, rgbx_stream_t stream) {
   if (N < 0 || K <= 0 || Nout <= 0) return fail(RGBX_E_ARG, "spmm_linear: bad size");
   if (N == 0) return RGBX_OK;
   if (!rowptr || !col || !x || !wt || !out) return fail(RGBX_E_ARG, "spmm_linear: null pointer");
   if (N >= INT32_MAX) return fail(RGBX_E_RANGE, "spmm_linear: N exceeds int32");
-  if (!rgbx_spmm_linear_supported(K, Nout))
-    return fail(RGBX_E_SHAPE, "spmm_linear: needs K %% 4 == 0, K <= 256, Nout %% 32 == 0 (got K=%lld, Nout=%lld)",
-                (long long)K, (long long)Nout);
-  if (ldx < K || ldo < Nout || (z_out && ldz < K)) return fail(RGBX_E_ARG, "spmm_linear: leading dimension too small");
-  if (!aligned16(x) || ldx % 4 || (z_out && (!aligned16(z_out) || ldz % 4)))
-    return fail(RGBX_E_ALIGN, "spmm_linear: x / z_out must be 16-byte aligned with ld %% 4 == 0");
-  FusedArgs A{rowptr, col, w, rs, x, wt, bias, out, z_out, ldx, ldo, ldz, (int)N, (int)K, (int)Nout};
+  if ((x_root != nullptr) != (wt_root != nullptr))
+    return fail(RGBX_E_ARG, "spmm_linear: x_root and wt_root go together");
+  if (!rgbx_spmm_linear_supported(K, Nout, x_root != nullptr))
+    return fail(RGBX_E_SHAPE,
+                "spmm_linear: needs K %% 4 == 0, K <= 256, Nout %% 32 == 0, Nout <= 256 with a root term (got K=%lld, "
+                "Nout=%lld)", (long long)K, (long long)Nout);
+  if (ldx < K || ldo < Nout || (z_out && ldz < K) || (x_root && ldr < K))
+    return fail(RGBX_E_ARG, "spmm_linear: leading dimension too small");
+  if (!aligned16(x) || ldx % 4 || (z_out && (!aligned16(z_out) || ldz % 4)) || (x_root && (!aligned16(x_root) || ldr % 4)))
+    return fail(RGBX_E_ALIGN, "spmm_linear: x / x_root / z_out must be 16-byte aligned with ld %% 4 == 0");
+  FusedArgs A{rowptr, col, w, rs, x, wt, x_root, wt_root, bias, out, z_out, ldx, ldo, ldz, ldr, (int)N, (int)K, (int)Nout};
   hipStream_t s = (hipStream_t)stream;
   if (K == 128) return launch<32, 128>(A, s);
   if (K == 64) return launch<16, 64>(A, s);

@@ -128,29 +128,32 @@ def propagate_sum(x, graph):
     return _PropagateSum.apply(x, graph)
 
 
-def fused_linear_ok(graph, in_channels, out_channels):
+def fused_linear_ok(graph, in_channels, out_channels, root=False):
     """The fused aggregate-then-transform kernel applies: single-GPU graph without hub rows, supported
-    widths, and aggregating at the input width is not the more expensive order."""
+    widths, and aggregating at the input width is not the more expensive order. `root`: with the
+    SAGE-style root term x_i Wr^T accumulated in the same kernel."""
     if _is_dist(graph) or in_channels > out_channels:
         return False
     if graph.fwd.split is not None:
         return False
-    return bool(_lib.load().rgbx_spmm_linear_supported(in_channels, out_channels))
+    return bool(_lib.load().rgbx_spmm_linear_supported(in_channels, out_channels, int(root)))
 
 
 class _PropagateLinear(torch.autograd.Function):
-    """y = (P x) W^T + b with P = A_hat ('gcn') or the mean operator ('mean'), in one launch
+    """y = (P x) W^T + b (+ x Wr^T) with P = A_hat ('gcn') or the mean operator ('mean'), in one launch
     (rgbx_spmm_linear_f32). Backward: dW = dy^T (P x) on the split-K MFMA kernel (P x was stored by the
-    forward when a gradient is needed), db = column sums, and — only if x needs a gradient —
-    dx = P^T (dy W) as a GEMM followed by the transposed SpMM."""
+    forward when a gradient is needed), db = column sums from the same pass, dWr = dy^T x, and — only if x
+    needs a gradient — dx = P^T (dy W) + dy Wr: GEMMs, then the transposed SpMM with the root part as its
+    additive term."""
 
     @staticmethod
-    def forward(ctx, x, graph, kind, weight, bias, need_z=True):
-        _lib.require_device(x, weight, bias)
+    def forward(ctx, x, graph, kind, weight, bias, need_z=True, root_weight=None):
+        _lib.require_device(x, weight, bias, root_weight)
         x = x.contiguous()
         N, K = x.shape
         n_out = weight.size(0)
         wt = weight.detach().t().contiguous()
+        wtr = None if root_weight is None else root_weight.detach().t().contiguous()
         out = torch.empty((graph.fwd.N, n_out), dtype=torch.float32, device=x.device)
         z = torch.empty((graph.fwd.N, K), dtype=torch.float32, device=x.device) if need_z else None
         w, rs = (graph.w, None) if kind == "gcn" else (None, graph.inv_deg)
@@ -159,19 +162,21 @@ class _PropagateLinear(torch.autograd.Function):
         with _Timed(f"{kind}_linear_fwd"):
             _lib.check(
                 _lib.load().rgbx_spmm_linear_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
-                                                 _lib.ptr(x), x.stride(0), _lib.ptr(wt), _lib.ptr(b), _lib.ptr(out),
-                                                 out.stride(0), _lib.ptr(z), K, csr.N, K, n_out, _lib.stream_ptr()),
+                                                 _lib.ptr(x), x.stride(0), _lib.ptr(wt),
+                                                 _lib.ptr(x) if wtr is not None else None, x.stride(0), _lib.ptr(wtr),
+                                                 _lib.ptr(b), _lib.ptr(out), out.stride(0), _lib.ptr(z), K, csr.N, K,
+                                                 n_out, _lib.stream_ptr()),
                 "rgbx_spmm_linear_f32")
-        ctx.save_for_backward(z, weight)
+        ctx.save_for_backward(z, weight, root_weight, x if root_weight is not None else None)
         ctx.graph, ctx.kind, ctx.has_bias = graph, kind, bias is not None
         return out
 
     @staticmethod
     def backward(ctx, gy):
-        z, weight = ctx.saved_tensors
+        z, weight, root_weight, x = ctx.saved_tensors
         g, kind = ctx.graph, ctx.kind
         gy = gy.contiguous()
-        gx = gw = gb = None
+        gx = gw = gb = gwr = None
         want_b = ctx.has_bias and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[3]:
             if want_b:
@@ -180,18 +185,24 @@ class _PropagateLinear(torch.autograd.Function):
                 gw = gemm_tn(gy, z)
         elif want_b:
             gb = gy.sum(0)
+        if root_weight is not None and ctx.needs_input_grad[6]:
+            gwr = gemm_tn(gy, x)
         if ctx.needs_input_grad[0]:
             gz = gy @ weight
+            gr = gy @ root_weight if root_weight is not None else None
             wt = g.w_t if kind == "gcn" else g.w_mean_t
-            gx = spmm_raw(g.bwd, wt, None, gz, kind=f"{kind}_bwd")
-        return gx, None, None, gw, gb, None
+            if gr is None:
+                gx = spmm_raw(g.bwd, wt, None, gz, kind=f"{kind}_bwd")
+            else:
+                gx = spmm_raw(g.bwd, wt, None, gz, y=gr, a=1.0, b=1.0, out=gr, kind=f"{kind}_bwd")
+        return gx, None, None, gw, gb, None, gwr
 
 
-def propagate_linear(x, graph, kind, weight, bias=None):
+def propagate_linear(x, graph, kind, weight, bias=None, root_weight=None):
     # the aggregate is kept only when the weight gradient (dy^T (P x)) will be asked for; Function.forward
     # cannot see the caller's grad mode, so the decision is taken here
     need_z = torch.is_grad_enabled() and weight.requires_grad
-    return _PropagateLinear.apply(x, graph, kind, weight, bias, need_z)
+    return _PropagateLinear.apply(x, graph, kind, weight, bias, need_z, root_weight)
 
 
 def appnp_raw(csr, w, h, K, alpha, kind="appnp"):

@@ -230,6 +230,39 @@ def test_fused_aggregate_transform(dev, K, n_out, kind):
     assert torch.equal(again, out.detach())
 
 
+@pytest.mark.parametrize("K,n_out", [(128, 128), (64, 256), (32, 160), (96, 96), (8, 32), (256, 256)])
+@pytest.mark.parametrize("loops_mode", [0, 2])
+def test_fused_aggregate_transform_with_root_term(dev, K, n_out, loops_mode):
+    """SAGE form: (mean_j x_j) Wl^T + b + x_i Wr^T in one kernel (second product through the same LDS tile),
+    forward and all four gradients, vs the oracle."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n = 1234
+    ei = rand_graph(n, 9000, K + n_out + loops_mode, loops=7, dups=9)
+    gen = torch.Generator().manual_seed(K * 3 + n_out)
+    x = torch.randn(n, K, generator=gen)
+    Wl = torch.randn(n_out, K, generator=gen) / K ** 0.5
+    Wr = torch.randn(n_out, K, generator=gen) / K ** 0.5
+    b = torch.randn(n_out, generator=gen)
+    go = torch.randn(n, n_out, generator=gen)
+    g = Graph(ei.to(dev), n, loops_mode)
+    assert ops.fused_linear_ok(g, K, n_out, root=True)
+    assert not ops.fused_linear_ok(g, 64, 512, root=True) and ops.fused_linear_ok(g, 64, 512)
+    rei = O.rewrite_edges(ei, n, loops_mode)[0]
+    dv = [v.to(dev).requires_grad_(True) for v in (x.clone(), Wl.clone(), b.clone(), Wr.clone())]
+    cv = [v.clone().requires_grad_(True) for v in (x, Wl, b, Wr)]
+    out = ops.propagate_linear(dv[0], g, "mean", dv[1], dv[2], root_weight=dv[3])
+    ref = O.propagate(rei, cv[0], n, None, "mean") @ cv[1].t() + cv[2] + cv[0] @ cv[3].t()
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() < TOL
+    out.backward(go.to(dev))
+    ref.backward(go)
+    for a, r in zip(dv, cv):
+        assert (a.grad.cpu() - r.grad).abs().max().item() < 1e-4 * max(1.0, r.grad.abs().max().item())
+    with torch.no_grad():
+        again = ops.propagate_linear(x.to(dev), g, "mean", Wl.to(dev), b.to(dev), root_weight=Wr.to(dev))
+    assert torch.equal(again, out.detach())
+
+
 def test_fused_path_inside_models(dev):
     """GCN / GraphSAGE / GraphSAGE2 with in <= hidden (so the fused kernel is taken) still match the oracle."""
     from rgb_experiment_amd import models as M
