@@ -22,8 +22,9 @@ class GraphedEpoch:
     """capture(): build the graph; run(): replay it and return
     (train_loss, train_acc, val_loss, val_acc, test_loss, test_acc)."""
 
-    def __init__(self, net, optimizer, fwd, y, masks):
+    def __init__(self, net, optimizer, fwd, y, masks, share_eval_forward=False):
         self.net, self.opt, self.fwd, self.y = net, optimizer, fwd, y
+        self.share_eval_forward = share_eval_forward
         self.train_mask, self.val_mask, self.test_mask = masks
         self.graph = None
         self.stats = None       # [3, 3] float64: rows train / val / test, columns (nll sum, count, correct)
@@ -41,8 +42,10 @@ class GraphedEpoch:
         self.opt.step()
         net.eval()
         with torch.no_grad():
-            val_stats = ops.masked_nll_accuracy(net(**self.fwd)["out"], y, self.val_mask)
-            test_res = net(**self.fwd)
+            val_res = net(**self.fwd)
+            val_stats = ops.masked_nll_accuracy(val_res["out"], y, self.val_mask)
+            # the reference runs a second, identical eval forward for the test mask (itexperiments.py:470)
+            test_res = val_res if self.share_eval_forward else net(**self.fwd)
             test_stats = ops.masked_nll_accuracy(test_res["out"], y, self.test_mask)
         return out, test_res, torch.stack([train_stats, val_stats, test_stats])
 

@@ -202,12 +202,16 @@ def experiment(model_init_param: dict, *,
                specify_model: bool = True, model: nn.Module = None,
                begin_early_stopping: int = 20,
                return_model: bool = False,
-               use_hip_graph: bool = True):
+               use_hip_graph: bool = True,
+               share_eval_forward: bool = False):
     """Train + evaluate one model on one graph; returns {'ACC', 'precision_score', 'recall_score',
     'f1_macro', 'f1_micro'} (reference :603-605). ``return_model=True`` (an addition) also returns
     the trained module and the per-epoch curves under 'model' / 'history'. ``use_hip_graph=True`` (an
     addition) captures one epoch of the loop into a hipGraph and replays it (epoch_graph.py); the
-    arithmetic is unchanged, only launch latency and host round-trips go away."""
+    arithmetic is unchanged, only launch latency and host round-trips go away. ``share_eval_forward=True``
+    (an addition, off by default) takes the per-epoch test metrics from the val pass's eval-mode outputs
+    instead of running the reference's second, identical eval forward (itexperiments.py:464-473): same
+    numbers, two forwards per epoch instead of three."""
     say = print if print_print else (lambda *a, **k: None)
     say(f"running node classification: {'custom' if specify_data else dataset_name} data, model {model_name}")
 
@@ -281,7 +285,8 @@ def experiment(model_init_param: dict, *,
     if use_hip_graph and device.type == "cuda" and not is_pta:
         from .epoch_graph import GraphedEpoch
         try:
-            graphed = GraphedEpoch(net, optimizer, fwd, y, (train_mask, val_mask, test_mask)).capture()
+            graphed = GraphedEpoch(net, optimizer, fwd, y, (train_mask, val_mask, test_mask),
+                                   share_eval_forward).capture()
         except Exception as exc:  # stay on the (GPU) eager loop; never a CPU path
             say(f"hipGraph capture failed ({exc!r}); running the eager loop")
             torch.cuda.synchronize()
@@ -323,7 +328,12 @@ def experiment(model_init_param: dict, *,
         optimizer.step()
         val = test(net, fwd, y, val_mask, loop_metrics)
         val_loss = criterion(val["test_op"][val_mask], y[val_mask]).item()
-        tst = test(net, fwd, y, test_mask, loop_metrics)
+        if share_eval_forward:  # same eval-mode outputs, second mask (opt-in: the reference forwards twice)
+            tst = {"test_op": val["test_op"],
+                   "ACC": compare_pred_label(val["test_op"][test_mask].max(dim=1)[1], y[test_mask],
+                                             loop_metrics)["ACC"]}
+        else:
+            tst = test(net, fwd, y, test_mask, loop_metrics)
         hist["test_acc"].append(tst["ACC"])
         hist["test_loss"].append(criterion(tst["test_op"][test_mask], y[test_mask]).item())
         return val["ACC"], val_loss, None

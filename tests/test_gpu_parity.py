@@ -827,6 +827,27 @@ def test_hip_graph_epoch_equals_eager_loop(dev, name):
     assert abs(a["ACC"] - b["ACC"]) < 1e-9
 
 
+@pytest.mark.parametrize("graphed", [False, True])
+def test_shared_eval_forward_changes_nothing_but_the_forward_count(dev, graphed):
+    """share_eval_forward=True: per-epoch test metrics from the val pass's outputs (the reference forwards a second
+    time with identical results): identical curves, weights and final metrics."""
+    import rgb_experiment_amd as R
+    n, f, c = 1500, 40, 5
+    gen = torch.Generator().manual_seed(12)
+    ei = rand_graph(n, 9000, 14, loops=4, dups=4)
+    data = R.Data(x=torch.randn(n, f, generator=gen), y=torch.randint(0, c, (n,), generator=gen), edge_index=ei)
+    params = R.InitialParameters.defaults_for("gcn")
+    runs = [R.experiment(params, specify_data=True, data=data, model_name="gcn", learning_rate=0.01, epoch=6,
+                         need_to_reappear=True, print_print=False, return_model=True, use_hip_graph=graphed,
+                         need_all_metrics=False, share_eval_forward=share) for share in (False, True)]
+    a, b = runs
+    for key in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_acc"):
+        assert a["history"][key] == b["history"][key], key
+    for (ka, va), (kb, vb) in zip(a["model"].state_dict().items(), b["model"].state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    assert a["ACC"] == b["ACC"]
+
+
 def test_experiment_pta_and_sgc_run(dev):
     import rgb_experiment_amd as R
     n, f, c = 800, 16, 4
