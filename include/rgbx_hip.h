@@ -229,7 +229,7 @@ int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const fl
                          int64_t ldg, float* g_hfeat, int64_t ldgh, float* g_a_src, float* ds, int64_t N,
                          int H, int C, float slope, const rgbx_row_split_t* split, rgbx_stream_t stream);
 
-/* ---- dense weight gradient on the MFMA units ---------------------------------------------- */
+/* ---- dense layers on the MFMA units -------------------------------------------------------- */
 
 /* Scratch bytes for rgbx_gemm_tn_f32 (split-K partial tiles + partial column sums). */
 int rgbx_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N, size_t* bytes);
