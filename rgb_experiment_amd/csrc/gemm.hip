@@ -49,6 +49,32 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ lds, const float*
   }
 }
 
+// Register-staged variant of stage_tile (16-byte path): fetch_tile issues the global loads of one [KT x 128] tile
+// into registers, put_tile writes them to LDS. Splitting the two lets the loads of tile i+1 fly while the MFMAs
+// of tile i run (the plain loop waits for HBM once per 32 rows of K with nothing else to do).
+constexpr int kTileVecs = KT * 32 / 256;  // float4 per thread and tile
+
+__device__ __forceinline__ void fetch_tile(float4 (&regs)[kTileVecs], const float* __restrict__ src, int64_t ld,
+                                           int64_t k0, int64_t k_end, int c0, int ncols) {
+#pragma unroll
+  for (int p = 0; p < kTileVecs; ++p) {
+    const int idx = p * 256 + threadIdx.x;
+    const int r = idx >> 5, c = (idx & 31) * 4;
+    const int64_t k = k0 + r;
+    regs[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < k_end && c0 + c < ncols) regs[p] = *reinterpret_cast<const float4*>(src + k * ld + c0 + c);
+  }
+}
+
+__device__ __forceinline__ void put_tile(float* __restrict__ lds, const float4 (&regs)[kTileVecs]) {
+#pragma unroll
+  for (int p = 0; p < kTileVecs; ++p) {
+    const int idx = p * 256 + threadIdx.x;
+    const int r = idx >> 5, c = (idx & 31) * 4;
+    *reinterpret_cast<float4*>(lds + r * 128 + c) = regs[p];
+  }
+}
+
 template <bool VEC4>
 __global__ void __launch_bounds__(256)
 gemm_tn_partial_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
@@ -75,11 +101,7 @@ gemm_tn_partial_kernel(const float* __restrict__ A, int64_t lda, const float* __
 
   const bool sums = colpart != nullptr && blockIdx.z == 0 && threadIdx.x < BM;
   float csum = 0.f;
-  for (int64_t k0 = k_begin; k0 < k_end; k0 += KT) {
-    __syncthreads();
-    stage_tile<VEC4>(la, A, lda, k0, k_end, m0, M);
-    stage_tile<VEC4>(lb, B, ldb, k0, k_end, n0, N);
-    __syncthreads();
+  auto consume = [&]() {  // one staged [KT x 128] pair of tiles: column sums of A (optional) + 16 MFMA steps
     if (sums) {  // thread t owns column m0 + t of A (rows past k_end were zero-filled)
 #pragma unroll 8
       for (int r = 0; r < KT; ++r) csum += la[r * 128 + threadIdx.x];
@@ -94,6 +116,30 @@ gemm_tn_partial_kernel(const float* __restrict__ A, int64_t lda, const float* __
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  };
+  if constexpr (VEC4) {
+    float4 ra[kTileVecs], rb[kTileVecs];
+    fetch_tile(ra, A, lda, k_begin, k_end, m0, M);
+    fetch_tile(rb, B, ldb, k_begin, k_end, n0, N);
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += KT) {
+      __syncthreads();  // the previous tile pair is fully consumed
+      put_tile(la, ra);
+      put_tile(lb, rb);
+      __syncthreads();
+      if (k0 + KT < k_end) {  // next pair in flight while this one is multiplied
+        fetch_tile(ra, A, lda, k0 + KT, k_end, m0, M);
+        fetch_tile(rb, B, ldb, k0 + KT, k_end, n0, N);
+      }
+      consume();
+    }
+  } else {
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += KT) {
+      __syncthreads();
+      stage_tile<false>(la, A, lda, k0, k_end, m0, M);
+      stage_tile<false>(lb, B, ldb, k0, k_end, n0, N);
+      __syncthreads();
+      consume();
     }
   }
 
