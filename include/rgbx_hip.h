@@ -145,12 +145,15 @@ int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w,
  * (usually x itself), wt_root = Wr^T [K, Nout].
  * Supported shapes: K % 4 == 0, K <= 256, Nout % 32 == 0, and Nout <= 256 with a root term
  * (rgbx_spmm_linear_supported); otherwise RGBX_E_SHAPE and the caller runs rgbx_spmm_csr_f32 + GEMMs.
- * Hub rows are not split here. */
+ * `split` (optional): hub rows are aggregated first by the split-row kernels (chunk sums added in chunk order)
+ * and the fused kernel copies their finished aggregates; `split->partial` must then hold
+ * (n_chunks + n_long) * K floats. */
 int rgbx_spmm_linear_supported(int64_t K, int64_t Nout, int has_root);
 int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
                          const float* x, int64_t ldx, const float* wt, const float* x_root, int64_t ldr,
                          const float* wt_root, const float* bias, float* out, int64_t ldo, float* z_out,
-                         int64_t ldz, int64_t N, int64_t K, int64_t Nout, rgbx_stream_t stream);
+                         int64_t ldz, int64_t N, int64_t K, int64_t Nout, const rgbx_row_split_t* split,
+                         rgbx_stream_t stream);
 
 /* z_0 = h;  z_{k+1} = (1-alpha) * A_hat z_k + alpha * h, k = 0..K-1; result in `out`.
  * `tmp` is an [N, d] scratch (ld = ldo); h, out, tmp must not alias. K >= 0. */

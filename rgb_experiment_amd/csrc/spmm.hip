@@ -17,6 +17,7 @@
 // into fixed chunks summed by separate waves into a partial buffer, and a last pass adds each
 // row's partials in chunk order (bitwise reproducible) and applies the epilogue.
 #include "rgbx_common.h"
+#include "spmm_internal.h"
 
 namespace rgbx {
 namespace {
@@ -179,6 +180,51 @@ spmm_combine_kernel(const SpmmArgs A, int n_long, const int* __restrict__ long_r
   }
 }
 
+// One wave per long row, compact output: zlong[r, :] = rs[row] * (partials added in chunk order).
+template <int VEC>
+__global__ void __launch_bounds__(256)
+spmm_combine_compact_kernel(const float* __restrict__ rs, int d, int n_long, const int* __restrict__ long_row,
+                            const int* __restrict__ long_chunk_ptr, const float* __restrict__ partial,
+                            float* __restrict__ zlong) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < n_long; r += gridDim.x * wpb) {
+    const float scale = rs ? rs[long_row[r]] : 1.0f;
+    const int c0 = long_chunk_ptr[r], c1 = long_chunk_ptr[r + 1];
+    for (int c = lane * VEC; c < d; c += kWave * VEC) {
+      float acc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      for (int ch = c0; ch < c1; ++ch) {
+        float p[VEC];
+        load_vec<VEC>(p, partial + (int64_t)ch * d + c);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += p[i];
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] *= scale;
+      store_vec<VEC>(zlong + (int64_t)r * d + c, acc);
+    }
+  }
+}
+
+template <int G>
+int launch_long_compact(const SpmmArgs& A, const rgbx_row_split_t* sp, float* zlong, hipStream_t s) {
+  int64_t cb = cdiv(sp->n_chunks, 4);
+  if (cb > kMaxGrid) cb = kMaxGrid;
+  if (A.w)
+    spmm_chunk_kernel<G, 4, true><<<(int)cb, 256, 0, s>>>(A, sp->n_chunks, sp->chunk_begin, sp->chunk_end, sp->partial);
+  else
+    spmm_chunk_kernel<G, 4, false><<<(int)cb, 256, 0, s>>>(A, sp->n_chunks, sp->chunk_begin, sp->chunk_end, sp->partial);
+  RGBX_CHECK_LAUNCH("spmm_chunk_kernel");
+  int64_t lb = cdiv(sp->n_long, 4);
+  if (lb > kMaxGrid) lb = kMaxGrid;
+  spmm_combine_compact_kernel<4><<<(int)lb, 256, 0, s>>>(A.rs, A.d, sp->n_long, sp->long_row, sp->long_chunk_ptr,
+                                                         sp->partial, zlong);
+  RGBX_CHECK_LAUNCH("spmm_combine_compact_kernel");
+  return RGBX_OK;
+}
+
 template <int G, int VEC>
 int launch(const SpmmArgs& A, const rgbx_row_split_t* sp, hipStream_t s) {
   constexpr int kWavesPerBlock = 4;
@@ -244,6 +290,25 @@ int spmm_dispatch(SpmmArgs A, const rgbx_row_split_t* split, hipStream_t s) {
 }
 
 }  // namespace
+
+int spmm_long_rows_compact(const int* rowptr, const int* col, const float* w, const float* rs, const float* x,
+                           int64_t ldx, int d, const rgbx_row_split_t* split, float* zlong, hipStream_t s) {
+  if (!split || split->n_long <= 0 || split->n_chunks <= 0 || !split->chunk_begin || !split->chunk_end ||
+      !split->long_row || !split->long_chunk_ptr || !split->partial || !zlong)
+    return fail(RGBX_E_ARG, "spmm_long_rows: incomplete row-split plan");
+  if (d % 4 || !aligned16(x) || ldx % 4 || !aligned16(split->partial) || !aligned16(zlong))
+    return fail(RGBX_E_ALIGN, "spmm_long_rows: needs d %% 4 == 0 and 16-byte aligned x / partial / zlong");
+  SpmmArgs A{rowptr, col, w, rs, x, nullptr, nullptr, zlong, ldx, 0, d, 0, d, 1.0f, 0.0f, 0};
+  const int lanes = d / 4;
+  if (lanes <= 1) return launch_long_compact<1>(A, split, zlong, s);
+  if (lanes <= 2) return launch_long_compact<2>(A, split, zlong, s);
+  if (lanes <= 4) return launch_long_compact<4>(A, split, zlong, s);
+  if (lanes <= 8) return launch_long_compact<8>(A, split, zlong, s);
+  if (lanes <= 16) return launch_long_compact<16>(A, split, zlong, s);
+  if (lanes <= 32) return launch_long_compact<32>(A, split, zlong, s);
+  return launch_long_compact<64>(A, split, zlong, s);
+}
+
 }  // namespace rgbx
 
 using namespace rgbx;

@@ -16,6 +16,7 @@
 // x_root · Wrᵀ into the same MFMA accumulators — a second tile would halve the workgroups per CU, which costs
 // the gather 5 % (measured), two more barriers cost nothing measurable.
 #include "rgbx_common.h"
+#include "spmm_internal.h"
 
 namespace rgbx {
 namespace {
@@ -35,6 +36,10 @@ struct FusedArgs {
   float* out;
   float* z_out;
   int64_t ldx, ldo, ldz, ldr;
+  // hub rows (more than `threshold` slots): aggregates precomputed by the split-row kernels, compact in hub order
+  const int* long_row;
+  const float* zlong;
+  int threshold, n_long;
   int N, K, Nout;
 };
 
@@ -140,48 +145,60 @@ __global__ void __launch_bounds__(256 * RT, NT == 2 ? 6 : 8) spmm_linear_kernel(
     if (row < A.N) {
       const int start = __builtin_amdgcn_readfirstlane(A.rowptr[row]);
       const int end = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
-      const float* xc = A.x + c;
-      for (int base = start; base < end; base += kWave) {
-        const int n = min(kWave, end - base);
-        int mycol = 0;
-        float myw = 0.f;
-        if (lane < n) {
-          mycol = A.col[base + lane];
-          if constexpr (HAS_W) myw = A.w[base + lane];
+      if (A.threshold > 0 && end - start > A.threshold) {
+        // hub row (wave-uniform branch): its aggregate was finished by the split-row kernels; find the row in
+        // the sorted hub list and copy
+        int lo = 0, hi = A.n_long - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (A.long_row[mid] < row) lo = mid + 1;
+          else hi = mid;
         }
-        for (int k = 0; k < n; k += NG * U) {
-          float v[U][4];
-          float ww[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int idx = k + u * NG + g;
-            const int src = __shfl(mycol, idx & 63);
-            if constexpr (HAS_W) ww[u] = __shfl(myw, idx & 63);
-            const bool ok = active && idx < n;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[u][i] = 0.f;
-            if (ok) load_vec<4>(v[u], xc + (int64_t)src * A.ldx);
-            if constexpr (HAS_W) { if (!ok) ww[u] = 0.f; }
+        if (g == 0 && active) load_vec<4>(acc, A.zlong + (int64_t)lo * K + c);
+      } else {
+        const float* xc = A.x + c;
+        for (int base = start; base < end; base += kWave) {
+          const int n = min(kWave, end - base);
+          int mycol = 0;
+          float myw = 0.f;
+          if (lane < n) {
+            mycol = A.col[base + lane];
+            if constexpr (HAS_W) myw = A.w[base + lane];
           }
+          for (int k = 0; k < n; k += NG * U) {
+            float v[U][4];
+            float ww[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < U; ++u) {
+              const int idx = k + u * NG + g;
+              const int src = __shfl(mycol, idx & 63);
+              if constexpr (HAS_W) ww[u] = __shfl(myw, idx & 63);
+              const bool ok = active && idx < n;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              if constexpr (HAS_W) acc[i] = fmaf(ww[u], v[u][i], acc[i]);
-              else acc[i] += v[u][i];
+              for (int i = 0; i < 4; ++i) v[u][i] = 0.f;
+              if (ok) load_vec<4>(v[u], xc + (int64_t)src * A.ldx);
+              if constexpr (HAS_W) { if (!ok) ww[u] = 0.f; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if constexpr (HAS_W) acc[i] = fmaf(ww[u], v[u][i], acc[i]);
+                else acc[i] += v[u][i];
+              }
             }
           }
         }
-      }
 #pragma unroll
-      for (int off = 32; off >= G; off >>= 1) {
+        for (int off = 32; off >= G; off >>= 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], off);
-      }
-      if (A.rs) {
-        const float s = A.rs[row];
+          for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], off);
+        }
+        if (A.rs) {
+          const float s = A.rs[row];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] *= s;
+          for (int i = 0; i < 4; ++i) acc[i] *= s;
+        }
       }
     }
     if (g == 0 && active) {
@@ -323,7 +340,8 @@ extern "C" int rgbx_spmm_linear_supported(int64_t K, int64_t Nout, int has_root)
 extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
                                     const float* x, int64_t ldx, const float* wt, const float* x_root, int64_t ldr,
                                     const float* wt_root, const float* bias, float* out, int64_t ldo, float* z_out,
-                                    int64_t ldz, int64_t N, int64_t K, int64_t Nout, rgbx_stream_t stream) {
+                                    int64_t ldz, int64_t N, int64_t K, int64_t Nout,
+                                    const rgbx_row_split_t* split, rgbx_stream_t stream) {
   if (N < 0 || K <= 0 || Nout <= 0) return fail(RGBX_E_ARG, "spmm_linear: bad size");
   if (N == 0) return RGBX_OK;
   if (!rowptr || !col || !x || !wt || !out) return fail(RGBX_E_ARG, "spmm_linear: null pointer");
@@ -338,8 +356,22 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
     return fail(RGBX_E_ARG, "spmm_linear: leading dimension too small");
   if (!aligned16(x) || ldx % 4 || (z_out && (!aligned16(z_out) || ldz % 4)) || (x_root && (!aligned16(x_root) || ldr % 4)))
     return fail(RGBX_E_ALIGN, "spmm_linear: x / x_root / z_out must be 16-byte aligned with ld %% 4 == 0");
-  FusedArgs A{rowptr, col, w, rs, x, wt, x_root, wt_root, bias, out, z_out, ldx, ldo, ldz, ldr, (int)N, (int)K, (int)Nout};
   hipStream_t s = (hipStream_t)stream;
+  const int* long_row = nullptr;
+  const float* zlong = nullptr;
+  int threshold = 0, n_long = 0;
+  if (split && split->threshold > 0 && split->n_chunks > 0) {
+    // hub rows first: chunk sums + ordered combine into the tail of the caller's scratch, [n_long, K] after the
+    // [n_chunks, K] partials
+    float* zl = split->partial ? split->partial + (size_t)split->n_chunks * K : nullptr;
+    if (int rc = spmm_long_rows_compact(rowptr, col, w, rs, x, ldx, (int)K, split, zl, s)) return rc;
+    long_row = split->long_row;
+    zlong = zl;
+    threshold = split->threshold;
+    n_long = split->n_long;
+  }
+  FusedArgs A{rowptr, col, w,  rs,  x,   wt,  x_root,   wt_root, bias,      out,    z_out,
+              ldx,    ldo, ldz, ldr, long_row, zlong, threshold, n_long,    (int)N, (int)K, (int)Nout};
   if (K == 128) return launch<32, 128>(A, s);
   if (K == 64) return launch<16, 64>(A, s);
   if (K == 256) return launch<64, 256>(A, s);

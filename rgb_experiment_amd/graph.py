@@ -37,12 +37,15 @@ class CSR:
     def __init__(self, rowptr, col, perm, N, nnz, split=None):
         self.rowptr, self.col, self.perm, self.N, self.nnz, self.split = rowptr, col, perm, N, nnz, split
 
-    def split_arg(self, d, device):
-        """ctypes rgbx_row_split_t for one launch at width d (allocates the partial scratch), or None."""
+    def split_arg(self, d, device, hub_rows=False):
+        """ctypes rgbx_row_split_t for one launch at width d (allocates the partial scratch), or None.
+        `hub_rows`: room for the n_long finished hub-row aggregates after the chunk partials
+        (rgbx_spmm_linear_f32)."""
         if self.split is None:
             return None, None
         sp = self.split
-        partial = torch.empty((sp["n_chunks"], d), dtype=torch.float32, device=device)
+        partial = torch.empty((sp["n_chunks"] + (sp["n_long"] if hub_rows else 0), d), dtype=torch.float32,
+                              device=device)
         st = _lib.RowSplit(sp["threshold"], sp["n_chunks"], sp["n_long"], sp["chunk_begin"].data_ptr(),
                            sp["chunk_end"].data_ptr(), sp["chunk_row"].data_ptr(), sp["long_row"].data_ptr(),
                            sp["long_chunk_ptr"].data_ptr(), partial.data_ptr())

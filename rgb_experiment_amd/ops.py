@@ -129,12 +129,10 @@ def propagate_sum(x, graph):
 
 
 def fused_linear_ok(graph, in_channels, out_channels, root=False):
-    """The fused aggregate-then-transform kernel applies: single-GPU graph without hub rows, supported
-    widths, and aggregating at the input width is not the more expensive order. `root`: with the
-    SAGE-style root term x_i Wr^T accumulated in the same kernel."""
+    """The fused aggregate-then-transform kernel applies: single-GPU graph, supported widths, and aggregating
+    at the input width is not the more expensive order. `root`: with the SAGE-style root term x_i Wr^T
+    accumulated in the same kernel."""
     if _is_dist(graph) or in_channels > out_channels:
-        return False
-    if graph.fwd.split is not None:
         return False
     return bool(_lib.load().rgbx_spmm_linear_supported(in_channels, out_channels, int(root)))
 
@@ -159,13 +157,15 @@ class _PropagateLinear(torch.autograd.Function):
         w, rs = (graph.w, None) if kind == "gcn" else (None, graph.inv_deg)
         b = None if bias is None else bias.detach().contiguous()
         csr = graph.fwd
+        split, _scratch = csr.split_arg(K, x.device, hub_rows=True)
         with _Timed(f"{kind}_linear_fwd"):
             _lib.check(
                 _lib.load().rgbx_spmm_linear_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
                                                  _lib.ptr(x), x.stride(0), _lib.ptr(wt),
                                                  _lib.ptr(x) if wtr is not None else None, x.stride(0), _lib.ptr(wtr),
                                                  _lib.ptr(b), _lib.ptr(out), out.stride(0), _lib.ptr(z), K, csr.N, K,
-                                                 n_out, _lib.stream_ptr()),
+                                                 n_out, None if split is None else ctypes.byref(split),
+                                                 _lib.stream_ptr()),
                 "rgbx_spmm_linear_f32")
         ctx.save_for_backward(z, weight, root_weight, x if root_weight is not None else None)
         ctx.graph, ctx.kind, ctx.has_bias = graph, kind, bias is not None

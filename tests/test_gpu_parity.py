@@ -452,6 +452,51 @@ def test_gat_conv_forward_backward(dev, H, C):
             assert (p.grad.cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), name
 
 
+@pytest.mark.parametrize("K,n_out,kind", [(128, 128, "gcn"), (32, 64, "mean"), (64, 160, "gcn")])
+def test_fused_kernel_takes_hub_rows_from_the_split_row_kernels(dev, K, n_out, kind):
+    """Graph with hub targets (60k and 3k in-edges): rgbx_spmm_linear_f32 with a row-split plan = the chunked
+    aggregate of the hub rows + the fused kernel for the rest; equal to SpMM-then-GEMM on the same device and to the
+    fp64-accumulating oracle; root-term variant and gradients included; reproducible."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n = 70000
+    gen = torch.Generator().manual_seed(K + n_out)
+    rnd = torch.randint(0, n, (2, 200000), generator=gen)
+    hub_in = torch.stack([torch.randint(0, n, (60000,), generator=gen), torch.full((60000,), 5)])
+    hub_in2 = torch.stack([torch.randint(0, n, (3000,), generator=gen), torch.full((3000,), 77)])
+    hub_out = torch.stack([torch.full((20000,), 9), torch.randint(0, n, (20000,), generator=gen)])
+    ei = torch.cat([rnd, hub_in, hub_in2, hub_out], dim=1)
+    mode = 1 if kind == "gcn" else 2
+    g = Graph(ei.to(dev), n, mode)
+    assert g.fwd.split is not None and g.fwd.split["n_long"] == 2
+    assert ops.fused_linear_ok(g, K, n_out) and ops.fused_linear_ok(g, K, n_out, root=True)
+    x = torch.randn(n, K, generator=gen)
+    W = torch.randn(n_out, K, generator=gen) / K ** 0.5
+    Wr = torch.randn(n_out, K, generator=gen) / K ** 0.5
+    b = torch.randn(n_out, generator=gen)
+    xd, Wd, Wrd, bd = (v.to(dev) for v in (x, W, Wr, b))
+    with torch.no_grad():
+        fused = ops.propagate_linear(xd, g, kind, Wd, bd)
+        agg = ops.propagate_gcn(xd, g) if kind == "gcn" else ops.propagate_mean(xd, g)
+        assert (fused - (agg @ Wd.t() + bd)).abs().max().item() < 1e-4
+        assert torch.equal(fused, ops.propagate_linear(xd, g, kind, Wd, bd))
+        fused_r = ops.propagate_linear(xd, g, kind, Wd, bd, root_weight=Wrd)
+        assert (fused_r - (agg @ Wd.t() + bd + xd @ Wrd.t())).abs().max().item() < 1e-4
+    rei, w = O.gcn_norm(ei, None, n) if kind == "gcn" else (O.rewrite_edges(ei, n, 2)[0], None)
+    want = O.propagate(rei, x.double(), n, None if w is None else w.double(), "add" if kind == "gcn" else "mean") \
+        @ W.double().t() + b.double()
+    assert (fused.cpu().double() - want).abs().max().item() < TOL
+    # gradients through the fused op (dW needs the stored aggregate, hub rows included)
+    xg, Wg = xd.clone().requires_grad_(True), Wd.clone().requires_grad_(True)
+    go = torch.randn(n, n_out, generator=gen).to(dev)
+    ops.propagate_linear(xg, g, kind, Wg, bd).backward(go)
+    xr, Wr2 = xd.clone().requires_grad_(True), Wd.clone().requires_grad_(True)
+    aggr = ops.propagate_gcn(xr, g) if kind == "gcn" else ops.propagate_mean(xr, g)
+    (aggr @ Wr2.t() + bd).backward(go)
+    assert (Wg.grad - Wr2.grad).abs().max().item() < 1e-4 * max(1.0, Wr2.grad.abs().max().item())
+    assert (xg.grad - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("H,C", [(4, 8), (1, 7), (8, 16)])
 def test_gat_hub_rows_are_split(dev, H, C, monkeypatch):
     """Hub target (40k in-edges) and hub source (15k out-edges). Forward: the chunked online-softmax states
