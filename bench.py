@@ -338,7 +338,8 @@ def main():
             b_loc = spmm_alg_bytes(n_loc, nnz_loc, d)
             b_rem = spmm_alg_bytes(n_loc, nnz_rem, d) + n_loc * 4 * d
             b_col = spmm_alg_bytes(N, nnz_total, d // world)
-            alg_by_kind = {"dist_fwd_resident": spmm_alg_bytes(n_loc, nnz_loc + nnz_rem, d),
+            b_res = spmm_alg_bytes(n_loc, nnz_loc + nnz_rem, d)  # first conv: resident [local; halo] features
+            alg_by_kind = {"dist_fwd_resident": b_res, "gcn_linear_fwd": b_res, "mean_linear_fwd": b_res,
                            "dist_fwd_local": b_loc, "dist_bwd_local": b_loc, "dist_fwd_remote": b_rem,
                            "dist_bwd_remote": b_rem, "dist_fwd_colshard": b_col, "dist_bwd_colshard": b_col,
                            "dist_fwd_appnp_colshard": 10 * (b_col + N * 4 * (d // world)),

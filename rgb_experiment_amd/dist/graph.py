@@ -47,6 +47,13 @@ class HipAggregator:
         return ops._GATAttend.apply(x_ext, att_src, att_dst, rect, H, C, slope)
 
 
+class _ExtGraph:
+    """What ops._PropagateLinear reads of a graph, for a rectangular [targets x (local; halo)] CSR."""
+
+    def __init__(self, fwd, w):
+        self.fwd, self.w, self.inv_deg = fwd, w, None
+
+
 class _RectGraph:
     def __init__(self, fwd, bwd):
         self.fwd, self.bwd = fwd, bwd
@@ -183,7 +190,8 @@ class DistGraph:
             self._resident["ext"][key] = ext
         return ext
 
-    def _run_resident(self, kind, x):
+    def _ext_csr(self, kind):
+        """CSR of this rank's targets over [local; halo] sources (+ per-edge weights in its slot order)."""
         st = self._get(kind)
         half = st["fwd"]["half"]
         if "ext_csr" not in st:
@@ -191,7 +199,27 @@ class DistGraph:
             gather = torch.cat([half.loc_gather, half.n_local + half.rem_gather])
             w = None if half.loc_w is None else torch.cat([half.loc_w, half.rem_w])
             st["ext_csr"] = self.backend.prepare(agg, gather, half.n_local, w)
-        return self.backend.run(st["ext_csr"], self._resident_ext(x, half, kind), kind="dist_fwd_resident")
+        return st["ext_csr"], half
+
+    def _run_resident(self, kind, x):
+        handle, half = self._ext_csr(kind)
+        return self.backend.run(handle, self._resident_ext(x, half, kind), kind="dist_fwd_resident")
+
+    def fused_resident_ok(self, x, in_channels, out_channels, root):
+        """The fused aggregate+transform kernel can serve this propagate: resident input features on the GPU
+        through the HIP backend, supported widths."""
+        from .. import _lib
+        return (x.is_cuda and isinstance(self.backend, HipAggregator) and self.is_resident(x)
+                and bool(_lib.load().rgbx_spmm_linear_supported(in_channels, out_channels, int(root))))
+
+    def propagate_linear(self, x, kind, weight, bias, root_weight):
+        """(P x) W^T + b (+ x Wr^T) for the resident input features: rgbx_spmm_linear_f32 over the [local; halo]
+        CSR, no exchange; every weighting kind arrives as per-edge weights (plan.edge_weights)."""
+        from .. import ops
+        (csr, ws), half = self._ext_csr(kind)
+        x_ext = self._resident_ext(x, half, kind)
+        need_z = torch.is_grad_enabled() and weight.requires_grad
+        return ops._PropagateLinear.apply(x_ext, _ExtGraph(csr, ws), "gcn", weight, bias, need_z, root_weight, x)
 
     def _run_halo(self, kind, direction, x):
         d = self._get(kind)[direction]

@@ -57,7 +57,7 @@ class GCNConv(nn.Module):
 
     def _conv(self, x, edge_index, weight, bias):
         graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
-        if ops.fused_linear_ok(graph, self.in_channels, self.out_channels):
+        if ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x):
             # A_hat (x W^T) + b = (A_hat x) W^T + b in one kernel: the aggregate stays in LDS and the GEMM
             # runs on the MFMA units underneath the gather (ops._PropagateLinear)
             return ops.propagate_linear(x, graph, "gcn", weight, bias)
@@ -89,11 +89,11 @@ class SAGEConv(nn.Module):
             scale, shift = post_affine
             w_l, b_l, w_r = w_l * scale[:, None], b_l * scale + shift, w_r * scale[:, None]
         graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
-        if ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True):
+        if ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x):
             # lin_l(mean_j x_j) + lin_r(x_i) in one kernel: both products accumulate in the same MFMA tile
             return ops.propagate_linear(x, graph, "mean", w_l, b_l, root_weight=w_r)
         x_r = ops.linear(x, w_r)
-        if ops.fused_linear_ok(graph, self.in_channels, self.out_channels):
+        if ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x):
             return ops.propagate_linear(x, graph, "mean", w_l, b_l) + x_r
         agg = ops.propagate_mean(x, graph)
         return ops.linear(agg, w_l, b_l) + x_r
@@ -126,11 +126,11 @@ class MySAGEConv(nn.Module):
     def _conv(self, x, edge_index, w_l, b_l, w_r, b_r):
         mode = LOOPS_REMOVE_ADD if self.add_self_loops else LOOPS_KEEP
         graph = get_graph(edge_index, x.size(0), mode)
-        if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True):
+        if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x):
             # mean_j(lin_l(x_j)) + lin_r(x_i) = (mean_j x_j) Wl^T + x_i Wr^T + (b_l + b_r), one kernel
             return ops.propagate_linear(x, graph, "mean", w_l, b_l + b_r, root_weight=w_r)
         x_r = ops.linear(x, w_r, b_r)
-        if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels):
+        if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x):
             return ops.propagate_linear(x, graph, "mean", w_l, b_l) + x_r
         if not x.requires_grad and self.add_self_loops and self.in_channels <= self.out_channels:
             # Input layer (see GCNConv.forward): with the self-loop every row's mean weights

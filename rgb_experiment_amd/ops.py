@@ -128,12 +128,15 @@ def propagate_sum(x, graph):
     return _PropagateSum.apply(x, graph)
 
 
-def fused_linear_ok(graph, in_channels, out_channels, root=False):
-    """The fused aggregate-then-transform kernel applies: single-GPU graph, supported widths, and aggregating
-    at the input width is not the more expensive order. `root`: with the SAGE-style root term x_i Wr^T
-    accumulated in the same kernel."""
-    if _is_dist(graph) or in_channels > out_channels:
+def fused_linear_ok(graph, in_channels, out_channels, root=False, x=None):
+    """The fused aggregate-then-transform kernel applies: supported widths, aggregating at the input width is
+    not the more expensive order, and the graph is a single-GPU one — or a partitioned one asked to propagate its
+    resident input features `x` (dist.DistGraph.pin_resident), which needs no exchange. `root`: with the
+    SAGE-style root term x_i Wr^T accumulated in the same kernel."""
+    if in_channels > out_channels:
         return False
+    if _is_dist(graph):
+        return x is not None and graph.fused_resident_ok(x, in_channels, out_channels, root)
     return bool(_lib.load().rgbx_spmm_linear_supported(in_channels, out_channels, int(root)))
 
 
@@ -145,9 +148,12 @@ class _PropagateLinear(torch.autograd.Function):
     additive term."""
 
     @staticmethod
-    def forward(ctx, x, graph, kind, weight, bias, need_z=True, root_weight=None):
-        _lib.require_device(x, weight, bias, root_weight)
+    def forward(ctx, x, graph, kind, weight, bias, need_z=True, root_weight=None, x_root=None):
+        """`x_root`: the targets' own rows when they are not simply the first rows of `x` viewed as a separate
+        tensor (partitioned graph: x = [local; halo], x_root = local)."""
+        _lib.require_device(x, weight, bias, root_weight, x_root)
         x = x.contiguous()
+        xr = x if x_root is None else x_root.contiguous()
         N, K = x.shape
         n_out = weight.size(0)
         wt = weight.detach().t().contiguous()
@@ -162,12 +168,12 @@ class _PropagateLinear(torch.autograd.Function):
             _lib.check(
                 _lib.load().rgbx_spmm_linear_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
                                                  _lib.ptr(x), x.stride(0), _lib.ptr(wt),
-                                                 _lib.ptr(x) if wtr is not None else None, x.stride(0), _lib.ptr(wtr),
+                                                 _lib.ptr(xr) if wtr is not None else None, xr.stride(0), _lib.ptr(wtr),
                                                  _lib.ptr(b), _lib.ptr(out), out.stride(0), _lib.ptr(z), K, csr.N, K,
                                                  n_out, None if split is None else ctypes.byref(split),
                                                  _lib.stream_ptr()),
                 "rgbx_spmm_linear_f32")
-        ctx.save_for_backward(z, weight, root_weight, x if root_weight is not None else None)
+        ctx.save_for_backward(z, weight, root_weight, xr if root_weight is not None else None)
         ctx.graph, ctx.kind, ctx.has_bias = graph, kind, bias is not None
         return out
 
@@ -195,10 +201,12 @@ class _PropagateLinear(torch.autograd.Function):
                 gx = spmm_raw(g.bwd, wt, None, gz, kind=f"{kind}_bwd")
             else:
                 gx = spmm_raw(g.bwd, wt, None, gz, y=gr, a=1.0, b=1.0, out=gr, kind=f"{kind}_bwd")
-        return gx, None, None, gw, gb, None, gwr
+        return gx, None, None, gw, gb, None, gwr, None
 
 
 def propagate_linear(x, graph, kind, weight, bias=None, root_weight=None):
+    if _is_dist(graph):  # resident input features of a partitioned graph (fused_linear_ok checked it)
+        return graph.propagate_linear(x, kind, weight, bias, root_weight)
     # the aggregate is kept only when the weight gradient (dy^T (P x)) will be asked for; Function.forward
     # cannot see the caller's grad mode, so the decision is taken here
     need_z = torch.is_grad_enabled() and weight.requires_grad

@@ -148,6 +148,9 @@ def exchange_count_worker(rank, world, port, out_dir, model_name, resident):
 
 
 def build_model(M, name, f, c):
+    if name.endswith("_wide"):  # in <= hidden, hidden % 32 == 0: the first conv takes the fused / resident route
+        cls = {"gcn_wide": M.GCN, "graphsage_wide": M.GraphSAGE, "graphsage2_wide": M.GraphSAGE2}[name]
+        return cls(num_layers=2, hidden_unit=64, input_dim=f, output_dim=c, dropout_rate=0.5)
     if name == "gcn":
         return M.GCN(num_layers=3, hidden_unit=16, input_dim=f, output_dim=c, dropout_rate=0.5)
     if name == "graphsage":
