@@ -681,6 +681,49 @@ def test_experiment_cora_shaped_gcn(dev):
     assert (emb - O.gcn_forward(sd, xn, ei, 2, False)["emb"]).abs().max().item() < TOL
 
 
+def test_index_arithmetic_beyond_2_31_elements(dev):
+    """|V| = 17M, |E| = 300M, d = 128: N*d and E'*d exceed 2^31, so any 32-bit element offset in a kernel would
+    wrap. Oracle-free properties: SpMM of ones = in-degree exactly; A_hat row sums; fused kernel = SpMM + GEMM; GAT of
+    constant features returns them. (~50 GB of HBM, a few seconds.)"""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph, clear_cache
+    if torch.cuda.get_device_properties(0).total_memory < 120e9:
+        pytest.skip("needs a 100+ GB device")
+    N, E, d = 17_000_000, 300_000_000, 128
+    assert N * d > 2 ** 31
+    gen = torch.Generator(device=dev).manual_seed(1)
+    ei = torch.randint(0, N, (2, E), generator=gen, device=dev, dtype=torch.int64)
+    g = Graph(ei, N, 1)
+    counts = (g.fwd.rowptr[1:] - g.fwd.rowptr[:-1])
+    assert int(g.fwd.rowptr[-1]) == g.fwd.nnz and g.fwd.nnz > E
+    ones = torch.ones(N, d, device=dev)
+    y = ops.spmm_raw(g.fwd, None, None, ones)
+    assert torch.equal(y[:, 0], counts.float()) and torch.equal(y[:, d - 1], counts.float())
+    yw = ops.spmm_raw(g.fwd, g.w, None, ones)
+    owner = torch.repeat_interleave(torch.arange(N, device=dev), counts.long())
+    wsum = torch.zeros(N, dtype=torch.float64, device=dev).index_add_(0, owner, g.w.double())
+    del owner, ones, y
+    assert (yw[:, 77].double() - wsum).abs().max().item() < 1e-4
+    del yw, wsum
+    x = torch.randn(N, d, generator=gen, device=dev)
+    W = torch.randn(d, d, generator=gen, device=dev) / d ** 0.5
+    b = torch.randn(d, generator=gen, device=dev)
+    with torch.no_grad():
+        fused = ops.propagate_linear(x, g, "gcn", W, b)
+        ref = torch.addmm(b, ops.spmm_raw(g.fwd, g.w, None, x), W.t())
+        assert (fused - ref).abs().max().item() < 1e-4
+        assert fused[-1].abs().sum().item() > 0  # the last row (largest offsets) was written
+        del fused, ref, x
+        g2 = Graph(ei, N, 2)
+        h = torch.full((N, d), 0.5, device=dev)
+        out = ops.gat_aggregate(h, torch.randn(N, 8, generator=gen, device=dev),
+                                torch.randn(N, 8, generator=gen, device=dev), g2, 8, 16, 0.2)
+        assert (out - 0.5).abs().max().item() < 1e-5
+    del g, g2, ei, h, out
+    clear_cache()
+    torch.cuda.empty_cache()
+
+
 # ---- dense weight gradient (split-K MFMA) and masked NLL ----------------------------------------------
 
 @pytest.mark.parametrize("K,M,N", [(1, 1, 1), (7, 3, 5), (33, 128, 128), (2708, 64, 1433), (2708, 7, 64),
