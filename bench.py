@@ -99,12 +99,14 @@ def host_cores():
     return n
 
 
-def cpu_baseline(ei, x, N, budget_s=20.0):
+def cpu_baseline(ei, x, N, budget_s=20.0, hip_propagate=None):
     """The oracle timed on the host cores, one GCN propagate at d = 128 (rank 0, N = 1 only).
     Primary: the C/OpenMP restatement (oracle/propagate_ref.c, per-target CSR sums over all host threads)
     on the WHOLE rewritten edge list — the strongest plain CPU form of the same arithmetic.
     Also reported: the PyG-style dataflow of the Python oracle (index_select -> multiply -> index_add_,
-    which materialises [E, d]) on a bounded 8 M-edge sample, which is what the reference's CPU path does."""
+    which materialises [E, d]) on a bounded 8 M-edge sample, which is what the reference's CPU path does.
+    `hip_propagate` (the HIP kernel's result of the same propagate, on the host) is checked against the C result:
+    the full-size parity of this very run rides along on the line."""
     from oracle import ref_cpu as O
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -127,7 +129,12 @@ def cpu_baseline(ei, x, N, budget_s=20.0):
         rowptr, col, perm = O.csr_from_edges(rei[1], rei[0], torch.arange(rei.size(1)), N)
         ws = w[perm.long()].contiguous()
         threads = min(O.c_threads(), cores)
-        O.propagate_c_csr(rowptr, col, ws, x, "add", threads)  # warm-up (page faults, thread pool)
+        cpu_out = O.propagate_c_csr(rowptr, col, ws, x, "add", threads)  # warm-up (page faults, thread pool)
+        parity = None
+        if hip_propagate is not None:
+            parity = {"max_abs_diff_hip_vs_cpu": (hip_propagate - cpu_out).abs().max().item(),
+                      "max_abs_value": cpu_out.abs().max().item(), "rows": N, "width": x.size(1)}
+        del cpu_out
         t2 = []
         t_end = time.perf_counter() + budget_s / 2
         while len(t2) < 3 or (time.perf_counter() < t_end and len(t2) < 20):
@@ -139,7 +146,7 @@ def cpu_baseline(ei, x, N, budget_s=20.0):
         return {"value": rei.size(1) / m2, "unit": "edges/s", "cores": threads, "kind": "port",
                 "sample": f"oracle/propagate_ref.c oracle_propagate_csr_f32 (C + OpenMP, {threads} threads) over all "
                           f"{rei.size(1)} rewritten edges of one GCN propagate, d=128, median of {len(t2)} runs",
-                "seconds_per_run": m2, "pyg_dataflow_variant": dataflow}
+                "seconds_per_run": m2, "pyg_dataflow_variant": dataflow, "parity_at_full_size": parity}
     except Exception as exc:  # C restatement not built: fall back to the Python oracle's number
         dataflow.update({"kind": "port", "sample": dataflow.pop("what"), "c_restatement_error": repr(exc)})
         return dataflow
@@ -417,7 +424,11 @@ def main():
                      "note": "rank 0's share of one propagate" if world > 1 else "whole graph, one propagate"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(ei, x, N)
+        from rgb_experiment_amd.graph import get_graph
+        with torch.no_grad():  # one GCN propagate of the whole workload by the HIP kernel, for the parity field
+            hip_out = ops.propagate_gcn(x.to(dev), get_graph(ei.to(dev), N, 1)).cpu()
+        result["cpu_baseline"] = cpu_baseline(ei, x, N, hip_propagate=hip_out)
+        del hip_out
     if world == 1 and not args.primary_only:
         result["hip_graph_replay"] = time_graphed(step, args.steps, args.warmup)
     if world == 1 and args.workload == "L" and args.model == "gcn" and not args.primary_only:
