@@ -43,18 +43,14 @@ struct FusedArgs {
   int N, K, Nout;
 };
 
-#ifndef RGBX_FUSED_RT
-#define RGBX_FUSED_RT 1
-#endif
-constexpr int RT = RGBX_FUSED_RT;  // 32-row tiles per workgroup: one B fragment load feeds RT MFMAs
-constexpr int TM = 32 * RT;        // destination rows per workgroup; 4 * RT waves aggregate 8 rows each
+constexpr int TM = 32;       // destination rows per workgroup = one MFMA row tile; 4 waves aggregate 8 rows each
+                            // (64- and 128-row tiles, one B fragment feeding 2-4 MFMAs, measured slower: DESIGN 3.2a)
 constexpr int NT_ROOT = 2;  // 32-column output tiles a wave may own when a root term is present (Nout <= 256)
 // Registers: the row-per-wave gather needs ~47 VGPRs and is bound by how many waves keep loads in flight, so this
 // kernel must not fall below the plain SpMM's 8 waves per SIMD: VGPRs + AGPRs <= 64 (`__launch_bounds__(.., 8)`);
 // the first build (84 registers, 5 waves per SIMD) lost 8 % to occupancy alone.
 
-// acc[rt] += zt[rt*32 .. rt*32+31, K] * wt[K, n0 : n0 + 32] for the RT row tiles of the workgroup: one B fragment
-// (from L2) feeds RT MFMAs. Lane l holds A[row l&31][k + (l>>5)] and B[k + (l>>5)][col l&31].
+// acc += zt[32, K] * wt[K, n0 : n0 + 32]. Lane l holds A[row l&31][k + (l>>5)] and B[k + (l>>5)][col l&31].
 constexpr int KB = 16;  // MFMA steps (2 k each) whose B values are fetched as one batch of independent loads
 
 // B values of steps [s0, s0 + KB) of the column tile n0: b[i] = wt[2 (s0 + i) + kr][n0 + cc]
@@ -64,49 +60,42 @@ __device__ __forceinline__ void load_b_batch(float (&b)[KB], const float* __rest
   for (int i = 0; i < KB; ++i) b[i] = wt[(int64_t)(2 * (s0 + i) + kr) * Nout + n0 + cc];
 }
 
-template <int RT>
-__device__ __forceinline__ void mfma_batch(f32x16 (&acc)[RT], const float (&b)[KB], const float* __restrict__ zt,
-                                           int ldz, int s0, int kr, int cc) {
+__device__ __forceinline__ void mfma_batch(f32x16& acc, const float (&b)[KB], const float* __restrict__ zt, int ldz,
+                                           int s0, int kr, int cc) {
 #pragma unroll
   for (int i = 0; i < KB; ++i) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const float a = zt[(rt * 32 + cc) * ldz + 2 * (s0 + i) + kr];
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[i], acc[rt], 0, 0, 0);
-    }
+    const float a = zt[cc * ldz + 2 * (s0 + i) + kr];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[i], acc, 0, 0, 0);
   }
 }
 
 // KC > 0 (K % 64 == 0): the B values come in batches of KB independent loads, so the L2 latency is paid once per
 // batch instead of once per MFMA (the compiler's own schedule waited on almost every load); `first` may hold
 // batch 0, fetched before the barrier that guards zt.
-template <int KC, int RT>
-__device__ __forceinline__ void tile_times_wt(f32x16 (&acc)[RT], const float* __restrict__ zt, int ldz,
+template <int KC>
+__device__ __forceinline__ void tile_times_wt(f32x16& acc, const float* __restrict__ zt, int ldz,
                                               const float* __restrict__ wt, int K, int Nout, int n0, int kr,
                                               int cc, const float (*first)[KB] = nullptr) {
   if constexpr (KC > 0) {
     static_assert(KC % (2 * KB) == 0, "KC must be a multiple of 2 * KB");
     int s0 = 0;
     if (first) {
-      mfma_batch<RT>(acc, *first, zt, ldz, 0, kr, cc);
+      mfma_batch(acc, *first, zt, ldz, 0, kr, cc);
       s0 = KB;
     }
 #pragma unroll 1
     for (; s0 < KC / 2; s0 += KB) {  // one batch in registers at a time (unrolled, the scheduler hoists them all)
       float b[KB];
       load_b_batch(b, wt, Nout, n0, s0, kr, cc);
-      mfma_batch<RT>(acc, b, zt, ldz, s0, kr, cc);
+      mfma_batch(acc, b, zt, ldz, s0, kr, cc);
     }
   } else {
     for (int ks = 0; ks < K; ks += 4) {  // K % 4 == 0: two MFMA steps per trip
       const float b0 = wt[(int64_t)(ks + kr) * Nout + n0 + cc];
       const float b1 = wt[(int64_t)(ks + 2 + kr) * Nout + n0 + cc];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const float a0 = zt[(rt * 32 + cc) * ldz + ks + kr], a1 = zt[(rt * 32 + cc) * ldz + ks + 2 + kr];
-        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[rt], 0, 0, 0);
-        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[rt], 0, 0, 0);
-      }
+      const float a0 = zt[cc * ldz + ks + kr], a1 = zt[cc * ldz + ks + 2 + kr];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
     }
   }
 }
@@ -125,7 +114,7 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __res
 
 // KC = K when it is one of the common widths (the MFMA loop then unrolls fully), 0 = any supported K.
 template <int G, bool HAS_W, int KC, int NT>
-__global__ void __launch_bounds__(256 * RT, NT == 2 ? 6 : 8) spmm_linear_kernel(const FusedArgs A) {
+__global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const FusedArgs A) {
   constexpr int NG = kWave / G;
   constexpr int U = 4;
   extern __shared__ float zt[];  // [TM][K + 4]
@@ -217,13 +206,13 @@ __global__ void __launch_bounds__(256 * RT, NT == 2 ? 6 : 8) spmm_linear_kernel(
   // likewise the workgroup's own rows for the root term (K <= 128: at most 4 float4 per thread): their HBM latency
   // passes under the barrier and the first product instead of between two barriers
   constexpr bool kRootRegs = KC > 0 && KC <= 128 && NT > 0;
-  constexpr int kRootVecs = kRootRegs ? (TM * (KC / 4)) / (256 * RT) : 1;
+  constexpr int kRootVecs = kRootRegs ? (TM * (KC / 4)) / 256 : 1;
   float rootv[kRootVecs][4];
   if constexpr (kRootRegs) {
     if (A.xr) {
 #pragma unroll
       for (int j = 0; j < kRootVecs; ++j) {
-        const int idx = threadIdx.x + j * 256 * RT;
+        const int idx = threadIdx.x + j * 256;
         const int r = idx / (KC / 4), c4 = (idx - r * (KC / 4)) * 4;
         const int row = row_base + r;
 #pragma unroll
@@ -235,43 +224,34 @@ __global__ void __launch_bounds__(256 * RT, NT == 2 ? 6 : 8) spmm_linear_kernel(
   __syncthreads();
 
   // ---- phase 2: out[TM, Nout] = zt[TM, K] * wt[K, Nout] (+ xroot[TM, K] * wtr[K, Nout]) + bias. Waves 0..3
-  // own the 32-column tiles (all RT row tiles of each: the MFMA time is small, the L2 traffic for W is what costs)
+  // own the 32-column tiles
   if (NT == 0) {  // Nout > 256 (no root term): column tiles one after the other
     if (wave >= 4) return;
     for (int n0 = wave * 32; n0 < A.Nout; n0 += 4 * 32) {
-      f32x16 acc[RT];
+      f32x16 acc;
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
-      tile_times_wt<KC, RT>(acc, zt, ldz, A.wt, K, A.Nout, n0, kr, cc);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) store_tile(acc[rt], A.bias, A.out, A.ldo, row_base + rt * 32, A.N, n0, kr, cc);
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      tile_times_wt<KC>(acc, zt, ldz, A.wt, K, A.Nout, n0, kr, cc);
+      store_tile(acc, A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc);
     }
     return;
   }
   constexpr int NTT = NT > 0 ? NT : 1;
-  f32x16 acc[NTT][RT];
+  f32x16 acc[NTT];
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tt][rt][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
     const int n0 = wave * 32 + tt * 128;
     if (wave < 4 && n0 < A.Nout)
-      tile_times_wt<KC, RT>(acc[tt], zt, ldz, A.wt, K, A.Nout, n0, kr, cc, pre && tt == 0 ? &bpre : nullptr);
+      tile_times_wt<KC>(acc[tt], zt, ldz, A.wt, K, A.Nout, n0, kr, cc, pre && tt == 0 ? &bpre : nullptr);
   }
   if (!A.xr) {  // no root term (uniform): store and leave
     if (wave >= 4) return;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       const int n0 = wave * 32 + tt * 128;
-      if (n0 < A.Nout) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          store_tile(acc[tt][rt], A.bias, A.out, A.ldo, row_base + rt * 32, A.N, n0, kr, cc);
-      }
+      if (n0 < A.Nout) store_tile(acc[tt], A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc);
     }
     return;
   }
@@ -279,13 +259,13 @@ __global__ void __launch_bounds__(256 * RT, NT == 2 ? 6 : 8) spmm_linear_kernel(
   if constexpr (kRootRegs) {
 #pragma unroll
     for (int j = 0; j < kRootVecs; ++j) {
-      const int idx = threadIdx.x + j * 256 * RT;
+      const int idx = threadIdx.x + j * 256;
       const int r = idx / (KC / 4), c4 = (idx - r * (KC / 4)) * 4;
       store_vec<4>(&zt[r * ldz + c4], rootv[j]);
     }
   } else {
     const int k4 = K >> 2;
-    for (int idx = threadIdx.x; idx < TM * k4; idx += 256 * RT) {
+    for (int idx = threadIdx.x; idx < TM * k4; idx += 256) {
       const int r = idx / k4, c4 = (idx - r * k4) * 4;
       const int row = row_base + r;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -299,10 +279,8 @@ __global__ void __launch_bounds__(256 * RT, NT == 2 ? 6 : 8) spmm_linear_kernel(
   for (int tt = 0; tt < NTT; ++tt) {
     const int n0 = wave * 32 + tt * 128;
     if (n0 < A.Nout) {
-      tile_times_wt<KC, RT>(acc[tt], zt, ldz, A.wtr, K, A.Nout, n0, kr, cc);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        store_tile(acc[tt][rt], A.bias, A.out, A.ldo, row_base + rt * 32, A.N, n0, kr, cc);
+      tile_times_wt<KC>(acc[tt], zt, ldz, A.wtr, K, A.Nout, n0, kr, cc);
+      store_tile(acc[tt], A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc);
     }
   }
 }
@@ -313,7 +291,7 @@ int launch(const FusedArgs& A, hipStream_t s) {
   const size_t lds = (size_t)TM * (A.K + 4) * sizeof(float);
   // NT = 32-column tiles a wave keeps accumulators for (Nout <= 128: 1, <= 256: 2); 0 = any Nout, tile by tile
   const int nt = A.Nout <= 128 ? 1 : (A.Nout <= 128 * NT_ROOT ? NT_ROOT : 0);
-#define RGBX_FUSED(HW, NTV) spmm_linear_kernel<G, HW, KC, NTV><<<(int)blocks, 256 * RT, lds, s>>>(A)
+#define RGBX_FUSED(HW, NTV) spmm_linear_kernel<G, HW, KC, NTV><<<(int)blocks, 256, lds, s>>>(A)
   if (A.w) {
     if (nt == 0) RGBX_FUSED(true, 0);
     else if (nt == 1) RGBX_FUSED(true, 1);
