@@ -97,23 +97,24 @@ col_reduce_kernel(const float* __restrict__ a, int64_t lda, const float* __restr
   }
 }
 
-// sums[k, c] = sum over blocks of part[b, k, c] in block order; 32 columns per block, 8 lanes per column.
+// sums[k, c] = sum over blocks of part[b, k, c]; 8 columns per block, 32 split lanes per column (lane q adds
+// partials q, q + 32, ...; the 32 sub-sums are then added in lane order: a fixed order, reproducible).
 __global__ void __launch_bounds__(256)
 col_finish_kernel(const double* __restrict__ part, int n_blocks, int d, double* __restrict__ sums) {
-  __shared__ double sh[8][32];
-  const int j = threadIdx.x & 31, q = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + j;
+  __shared__ double sh[32][8];
+  const int j = threadIdx.x & 7, q = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + j;
   double s = 0.0;
   if (c < 2 * d) {
     const int which = c / d, col = c % d;
-    for (int b = q; b < n_blocks; b += 8) s += part[((int64_t)b * 2 + which) * d + col];
+    for (int b = q; b < n_blocks; b += 32) s += part[((int64_t)b * 2 + which) * d + col];
   }
   sh[q][j] = s;
   __syncthreads();
   if (q == 0 && c < 2 * d) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += sh[k][j];
+    for (int k = 0; k < 32; ++k) t += sh[k][j];
     sums[c] = t;
   }
 }
@@ -205,7 +206,7 @@ int run_reduce(const float* a, int64_t lda, const float* b, int64_t ldb, const f
   else
     col_reduce_kernel<1, BWD><<<grid, 256, lds, s>>>(a, lda, b, ldb, mean, rstd, N, (int)d, scratch);
   RGBX_CHECK_LAUNCH(name);
-  col_finish_kernel<<<(int)cdiv(2 * d, 32), 256, 0, s>>>(scratch, grid, (int)d, sums);
+  col_finish_kernel<<<(int)cdiv(2 * d, 8), 256, 0, s>>>(scratch, grid, (int)d, sums);
   RGBX_CHECK_LAUNCH("col_finish_kernel");
   return RGBX_OK;
 }

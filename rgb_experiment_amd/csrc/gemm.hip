@@ -185,7 +185,8 @@ gemm_tn_reduce_kernel(const float* __restrict__ part, int S, int64_t MN, float* 
 int choose_splits(int64_t K, int M, int N) {
   const int64_t tiles = cdiv(M, BM) * cdiv(N, BN);
   int64_t s = cdiv(1024, tiles);            // ~4 workgroups per CU over the whole grid
-  const int64_t max_s = cdiv(K, 4 * KT);    // keep at least 4 staged tiles per slab
+  const int64_t max_s = cdiv(K, 16 * KT);   // at least 16 staged tiles per slab: fewer, longer slabs for small K
+                                            // (K = 200 k: 391 partial tiles to reduce instead of 1024)
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   return (int)s;
