@@ -27,6 +27,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# dmabuf IPC for RCCL between the ranks of one node: must be in the environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 import torch.distributed as dist
@@ -294,7 +296,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RGBX_DIST_BACKEND=gloo rehearses the N>1 code path with several ranks on ONE GPU (host-staged
         # collectives); the real runs use RCCL ("nccl").
         backend = os.environ.get("RGBX_DIST_BACKEND", "nccl")
