@@ -256,6 +256,21 @@ int rgbx_bn_scratch_doubles(int64_t N, int64_t d, int64_t* count);
 int rgbx_bn_stats_f32(const float* x, int64_t ldx, int64_t N, int64_t d, double* sums, double* scratch,
                       int64_t scratch_doubles, rgbx_stream_t stream);
 
+/* Between the raw sums and the apply pass, one launch. `packed` = [sum x (d), sum x^2 (d), row count (1)] in fp64,
+ * after any cross-rank reduction. Produces mean, rstd = 1/sqrt(biased var + eps), the training forward's affine map
+ * scale = weight * rstd, shift = bias - mean * scale, and (running_* not NULL) the nn.BatchNorm1d update
+ * running = (1 - momentum) * running + momentum * (mean | unbiased var). */
+int rgbx_bn_finalize_f32(const double* packed, const float* weight, const float* bias, float eps, float momentum,
+                         float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
+                         float* shift, int64_t d, rgbx_stream_t stream);
+
+/* Backward counterpart: ca = glob[0]/n, cb = glob[1]/n, ck = weight * rstd for rgbx_bn_bwd_apply_f32 (`glob` = the
+ * [2, d] sums of rgbx_bn_bwd_reduce_f32 after any cross-rank reduction, `count` = device pointer to n), and the
+ * parameter gradients of this rank, g_bias = local[0], g_weight = local[1]. */
+int rgbx_bn_bwd_finalize_f32(const double* glob, const double* local, const double* count, const float* weight,
+                             const float* rstd, float* ca, float* cb, float* ck, float* g_weight, float* g_bias,
+                             int64_t d, rgbx_stream_t stream);
+
 /* y[r,c] = x[r,c] * scale[c] + shift[c] — BatchNorm's normalise+affine with
  * scale = gamma * rstd, shift = beta - mean * scale (training or running statistics alike). */
 int rgbx_affine_cols_f32(const float* x, int64_t ldx, const float* scale, const float* shift, float* y,

@@ -211,6 +211,52 @@ int run_reduce(const float* a, int64_t lda, const float* b, int64_t ldb, const f
   return RGBX_OK;
 }
 
+// Everything between the (possibly all-reduced) raw sums and the apply pass, one thread per column:
+// packed = [sum x (d), sum x^2 (d), row count (1)] in fp64 -> mean, biased variance, rstd, the affine map of the
+// training forward, and the running-statistics update (unbiased variance, momentum) of nn.BatchNorm1d.
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(const double* __restrict__ packed, const float* __restrict__ weight,
+                   const float* __restrict__ bias, float eps, float momentum, float* __restrict__ running_mean,
+                   float* __restrict__ running_var, float* __restrict__ mean, float* __restrict__ rstd,
+                   float* __restrict__ scale, float* __restrict__ shift, int d) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  const double n = packed[2 * d];
+  const double m64 = packed[c] / n;
+  double v64 = packed[d + c] / n - m64 * m64;  // biased variance; fp64, so the difference does not cancel
+  v64 = v64 > 0.0 ? v64 : 0.0;
+  const float m = (float)m64, var = (float)v64;
+  const float r = 1.0f / sqrtf(var + eps);
+  const float sc = weight[c] * r;
+  mean[c] = m;
+  rstd[c] = r;
+  scale[c] = sc;
+  shift[c] = bias[c] - m * sc;
+  if (running_mean) {
+    const double nm1 = n > 1.0 ? n - 1.0 : 1.0;
+    const float unbiased = var * (float)(n / nm1);
+    running_mean[c] = running_mean[c] * (1.0f - momentum) + momentum * m;
+    running_var[c] = running_var[c] * (1.0f - momentum) + momentum * unbiased;
+  }
+}
+
+// Backward: the per-column coefficients of the apply pass from the (all-reduced) sums, and the parameter
+// gradients from this rank's own sums.
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(const double* __restrict__ glob, const double* __restrict__ local,
+                       const double* __restrict__ count, const float* __restrict__ weight,
+                       const float* __restrict__ rstd, float* __restrict__ ca, float* __restrict__ cb,
+                       float* __restrict__ ck, float* __restrict__ g_weight, float* __restrict__ g_bias, int d) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  const double n = *count;
+  ca[c] = (float)(glob[c] / n);
+  cb[c] = (float)(glob[d + c] / n);
+  ck[c] = weight[c] * rstd[c];
+  g_bias[c] = (float)local[c];
+  g_weight[c] = (float)local[d + c];
+}
+
 int elt_grid(int64_t total) {
   int64_t b = cdiv(total, 256);
   return (int)(b < kMaxGrid ? (b < 1 ? 1 : b) : kMaxGrid);
@@ -238,6 +284,30 @@ extern "C" int rgbx_bn_bwd_reduce_f32(const float* gy, int64_t ldg, const float*
                                       int64_t scratch_doubles, rgbx_stream_t stream) {
   return run_reduce<true>(gy, ldg, x, ldx, mean, rstd, N, d, sums, scratch, scratch_doubles, (hipStream_t)stream,
                           "bn_bwd_reduce");
+}
+
+extern "C" int rgbx_bn_finalize_f32(const double* packed, const float* weight, const float* bias, float eps,
+                                    float momentum, float* running_mean, float* running_var, float* mean,
+                                    float* rstd, float* scale, float* shift, int64_t d, rgbx_stream_t stream) {
+  if (d <= 0 || d >= INT32_MAX) return fail(RGBX_E_ARG, "bn_finalize: bad width");
+  if (!packed || !weight || !bias || !mean || !rstd || !scale || !shift || (running_mean != nullptr) != (running_var != nullptr))
+    return fail(RGBX_E_ARG, "bn_finalize: null pointer");
+  bn_finalize_kernel<<<(int)cdiv(d, 256), 256, 0, (hipStream_t)stream>>>(packed, weight, bias, eps, momentum, running_mean,
+                                                                    running_var, mean, rstd, scale, shift, (int)d);
+  RGBX_CHECK_LAUNCH("bn_finalize_kernel");
+  return RGBX_OK;
+}
+
+extern "C" int rgbx_bn_bwd_finalize_f32(const double* glob, const double* local, const double* count,
+                                        const float* weight, const float* rstd, float* ca, float* cb, float* ck,
+                                        float* g_weight, float* g_bias, int64_t d, rgbx_stream_t stream) {
+  if (d <= 0 || d >= INT32_MAX) return fail(RGBX_E_ARG, "bn_bwd_finalize: bad width");
+  if (!glob || !local || !count || !weight || !rstd || !ca || !cb || !ck || !g_weight || !g_bias)
+    return fail(RGBX_E_ARG, "bn_bwd_finalize: null pointer");
+  bn_bwd_finalize_kernel<<<(int)cdiv(d, 256), 256, 0, (hipStream_t)stream>>>(glob, local, count, weight, rstd, ca, cb, ck,
+                                                                        g_weight, g_bias, (int)d);
+  RGBX_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  return RGBX_OK;
 }
 
 extern "C" int rgbx_affine_cols_f32(const float* x, int64_t ldx, const float* scale, const float* shift, float* y,

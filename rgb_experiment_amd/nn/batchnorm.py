@@ -68,23 +68,41 @@ def bwd_apply(gy, x, mean, rstd, ca, cb, ck):
 
 
 class _BNTrain(torch.autograd.Function):
+    """Training-mode BatchNorm over the node axis. On the GPU: column sums (2 launches) -> [reduce over ranks] ->
+    rgbx_bn_finalize_f32 (mean, rstd, affine map, running statistics: 1 launch) -> affine apply; backward: column
+    sums -> [reduce] -> rgbx_bn_bwd_finalize_f32 -> apply. `running` = (running_mean, running_var, momentum) or
+    None; on host tensors (MLP on the CPU, gloo tests) the same arithmetic in plain torch."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, reduce, stats_out):
+    def forward(ctx, x, weight, bias, eps, reduce, running):
         x = x if x.stride(-1) == 1 else x.contiguous()
+        d = x.size(1)
         # the row count rides along as a device scalar made by a fill kernel (a host->device copy would break
         # hipGraph capture)
         count = torch.full((1,), float(x.size(0)), dtype=torch.float64, device=x.device)
         packed = torch.cat([column_sums(x).reshape(-1), count])
         packed = reduce(packed)  # identity on one GPU; all-reduce over the node partition otherwise
-        d = x.size(1)
-        n = packed[2 * d]
-        mean64 = packed[:d] / n
-        var64 = (packed[d:2 * d] / n - mean64 * mean64).clamp_(min=0.0)  # biased variance
-        mean, var = mean64.float(), var64.float()
-        rstd = torch.rsqrt(var + eps)
-        scale = weight * rstd
-        y = affine_cols(x, scale.contiguous(), (bias - mean * scale).contiguous())
-        stats_out.extend([mean, var, n])
+        n = packed[2 * d:2 * d + 1]
+        if x.is_cuda:
+            mean, rstd, scale, shift = (torch.empty(d, dtype=torch.float32, device=x.device) for _ in range(4))
+            rm, rv, mom = running if running is not None else (None, None, 0.0)
+            _lib.check(_lib.load().rgbx_bn_finalize_f32(
+                _lib.ptr(packed), _lib.ptr(weight.detach().contiguous()), _lib.ptr(bias.detach().contiguous()),
+                float(eps), float(mom), _lib.ptr(rm), _lib.ptr(rv), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(scale),
+                _lib.ptr(shift), d, _lib.stream_ptr()), "rgbx_bn_finalize_f32")
+        else:
+            mean64 = packed[:d] / n
+            var64 = (packed[d:2 * d] / n - mean64 * mean64).clamp_(min=0.0)  # biased variance
+            mean, var = mean64.float(), var64.float()
+            rstd = torch.rsqrt(var + eps)
+            scale = weight.detach() * rstd
+            shift = bias.detach() - mean * scale
+            if running is not None:
+                rm, rv, mom = running
+                unbiased = var * (n / (n - 1).clamp(min=1)).float()
+                rm.mul_(1 - mom).add_(mean, alpha=mom)
+                rv.mul_(1 - mom).add_(unbiased, alpha=mom)
+        y = affine_cols(x, scale.contiguous(), shift.contiguous())
         ctx.save_for_backward(x, weight, mean, rstd, n)
         ctx.reduce = reduce
         return y
@@ -93,13 +111,24 @@ class _BNTrain(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight, mean, rstd, n = ctx.saved_tensors
         gy = gy if gy.stride(-1) == 1 else gy.contiguous()
+        d = x.size(1)
         local = bwd_sums(gy, x, mean, rstd)            # [2, d]: sum gy, sum gy * xhat over the local rows
-        glob = ctx.reduce(local.reshape(-1).clone()).reshape(2, -1)
-        ca = (glob[0] / n).float().contiguous()
-        cb = (glob[1] / n).float().contiguous()
-        gx = bwd_apply(gy, x, mean, rstd, ca, cb, (weight * rstd).contiguous())
+        glob = ctx.reduce(local.reshape(-1).clone())
         # parameter gradients are the LOCAL sums: a partitioned run all-reduces parameter gradients once
-        return gx, local[1].float(), local[0].float(), None, None, None
+        if gy.is_cuda:
+            ca, cb, ck, gw, gb = (torch.empty(d, dtype=torch.float32, device=gy.device) for _ in range(5))
+            _lib.check(_lib.load().rgbx_bn_bwd_finalize_f32(
+                _lib.ptr(glob), _lib.ptr(local), _lib.ptr(n), _lib.ptr(weight.detach().contiguous()), _lib.ptr(rstd),
+                _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(ck), _lib.ptr(gw), _lib.ptr(gb), d, _lib.stream_ptr()),
+                "rgbx_bn_bwd_finalize_f32")
+        else:
+            glob = glob.reshape(2, -1)
+            ca = (glob[0] / n).float().contiguous()
+            cb = (glob[1] / n).float().contiguous()
+            ck = (weight * rstd).contiguous()
+            gw, gb = local[1].float(), local[0].float()
+        gx = bwd_apply(gy, x, mean, rstd, ca, cb, ck)
+        return gx, gw, gb, None, None, None
 
 
 class BatchNorm1d(nn.BatchNorm1d):
@@ -121,13 +150,11 @@ class BatchNorm1d(nn.BatchNorm1d):
         if not self.training:
             scale, shift = self.eval_affine()
             return affine_cols(x if x.stride(-1) == 1 else x.contiguous(), scale.contiguous(), shift.contiguous())
-        stats = []
-        y = _BNTrain.apply(x, self.weight, self.bias, self.eps, self._reduce, stats)
-        mean, var, n = stats
         with torch.no_grad():
             self.num_batches_tracked += 1
-            m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
-            unbiased = var * (n / (n - 1).clamp(min=1)).float()
-            self.running_mean.mul_(1 - m).add_(mean, alpha=m)
-            self.running_var.mul_(1 - m).add_(unbiased, alpha=m)
-        return y
+        if self.momentum is None:  # cumulative moving average: the factor depends on a device counter
+            m = 1.0 / float(self.num_batches_tracked)
+        else:
+            m = self.momentum
+        return _BNTrain.apply(x, self.weight, self.bias, self.eps, self._reduce,
+                              (self.running_mean, self.running_var, m))
