@@ -164,7 +164,8 @@ MODELS = {
     "gat": (dict(num_layers=2, hidden_unit=16, heads=8, dropout_rate=0.5), 8, 2, "gat"),
     "appnpstack": (dict(hidden_unit=64, K=10, alpha=0.1, dropout_rate=0.5), 40, 1, "gcn"),
 }
-AGG_KINDS = ("gcn_fwd", "gcn_bwd", "mean_fwd", "mean_bwd", "gcn_linear_fwd", "mean_linear_fwd", "appnp_fwd",
+AGG_KINDS = ("gcn_fwd", "gcn_bwd", "mean_fwd", "mean_bwd", "gcn_linear_fwd", "mean_linear_fwd", "gcn_linear_bwd",
+             "mean_linear_bwd", "appnp_fwd",
              "appnp_bwd", "gat_fwd", "gat_bwd_prep", "gat_bwd_src", "gat_bwd_segsum", "dist_fwd_local", "dist_fwd_remote",
              "dist_bwd_local", "dist_bwd_remote", "dist_fwd_resident",
              "dist_fwd_colshard", "dist_bwd_colshard", "dist_fwd_appnp_colshard", "dist_bwd_appnp_colshard")
@@ -262,7 +263,8 @@ def secondary_config(dev, steps, warmup):
     elapsed = time.perf_counter() - t0
     ops.set_event_sink(None)
     n_prop = MODELS["gcn"][1]
-    spmm_s = sum(s.elapsed_time(e) for k, s, e in events if k in ("gcn_fwd", "gcn_bwd", "gcn_linear_fwd")) * 1e-3 / (n_prop * steps)
+    kinds = ("gcn_fwd", "gcn_bwd", "gcn_linear_fwd", "gcn_linear_bwd")
+    spmm_s = sum(s.elapsed_time(e) for k, s, e in events if k in kinds) * 1e-3 / (n_prop * steps)
     replay = time_graphed(step, steps, warmup)
     clear_cache()
     return {"workload": wl["name"], "value": n_prop * nnz * steps / elapsed, "unit": "edges/s",
@@ -390,7 +392,7 @@ def main():
         by_kind.setdefault(k, []).append(s.elapsed_time(e))
     by_kind = {k: {"n": len(v), "avg_ms": sum(v) / len(v)} for k, v in sorted(by_kind.items())}
     kernel = {"gat": "gat_fwd_kernel<4> / gat_bwd_src_kernel<4> (+ prep, segment sum)"}.get(
-        args.model, "spmm_linear_kernel<32,*,128> (aggregate + MFMA transform, forward) / spmm_csr_kernel<32,4,*> (backward)"
+        args.model, "spmm_linear_kernel<32,*,128,1> (aggregate + fp32 MFMA transform; forward, and backward on the transposed CSR)"
         if scheme != "reshard" else f"spmm_csr_kernel at width {d // world}")
 
     result = {

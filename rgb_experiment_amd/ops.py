@@ -140,39 +140,50 @@ def fused_linear_ok(graph, in_channels, out_channels, root=False, x=None):
     return bool(_lib.load().rgbx_spmm_linear_supported(in_channels, out_channels, int(root)))
 
 
+def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_root=None, kind="linear"):
+    """out = (rs * sum_p w_p x[col_p]) wt + bias (+ x_root wt_root) on rgbx_spmm_linear_f32; `wt` / `wt_root` are
+    [K, Nout] row-major. Returns (out, z) with z the stored aggregate [N, K] if `want_z`."""
+    _lib.require_device(x, wt, bias, x_root, wt_root)
+    x = x if x.stride(-1) == 1 else x.contiguous()
+    K, n_out = x.size(1), wt.size(1)
+    wt = wt.contiguous()
+    out = torch.empty((csr.N, n_out), dtype=torch.float32, device=x.device)
+    z = torch.empty((csr.N, K), dtype=torch.float32, device=x.device) if want_z else None
+    xr = ldr = wtr = None
+    if wt_root is not None:
+        xr = x_root if x_root.stride(-1) == 1 else x_root.contiguous()
+        ldr, wtr = xr.stride(0), wt_root.contiguous()
+    b = None if bias is None else bias.contiguous()
+    split, _scratch = csr.split_arg(K, x.device, hub_rows=True)
+    with _Timed(kind):
+        _lib.check(
+            _lib.load().rgbx_spmm_linear_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
+                                             _lib.ptr(x), x.stride(0), _lib.ptr(wt), _lib.ptr(xr), ldr or K,
+                                             _lib.ptr(wtr), _lib.ptr(b), _lib.ptr(out), out.stride(0), _lib.ptr(z), K,
+                                             csr.N, K, n_out, None if split is None else ctypes.byref(split),
+                                             _lib.stream_ptr()),
+            "rgbx_spmm_linear_f32")
+    return out, z
+
+
 class _PropagateLinear(torch.autograd.Function):
     """y = (P x) W^T + b (+ x Wr^T) with P = A_hat ('gcn') or the mean operator ('mean'), in one launch
     (rgbx_spmm_linear_f32). Backward: dW = dy^T (P x) on the split-K MFMA kernel (P x was stored by the
     forward when a gradient is needed), db = column sums from the same pass, dWr = dy^T x, and — only if x
-    needs a gradient — dx = P^T (dy W) + dy Wr: GEMMs, then the transposed SpMM with the root part as its
-    additive term."""
+    needs a gradient — dx = P^T (dy W) + dy Wr = (P^T dy) W + dy Wr: the SAME fused kernel on the transposed CSR
+    (W as stored is already the [K, Nout] operand) when in == out, else GEMMs and the transposed SpMM with the
+    root part as its additive term."""
 
     @staticmethod
     def forward(ctx, x, graph, kind, weight, bias, need_z=True, root_weight=None, x_root=None):
         """`x_root`: the targets' own rows when they are not simply the first rows of `x` viewed as a separate
         tensor (partitioned graph: x = [local; halo], x_root = local)."""
-        _lib.require_device(x, weight, bias, root_weight, x_root)
         x = x.contiguous()
         xr = x if x_root is None else x_root.contiguous()
-        N, K = x.shape
-        n_out = weight.size(0)
-        wt = weight.detach().t().contiguous()
-        wtr = None if root_weight is None else root_weight.detach().t().contiguous()
-        out = torch.empty((graph.fwd.N, n_out), dtype=torch.float32, device=x.device)
-        z = torch.empty((graph.fwd.N, K), dtype=torch.float32, device=x.device) if need_z else None
         w, rs = (graph.w, None) if kind == "gcn" else (None, graph.inv_deg)
-        b = None if bias is None else bias.detach().contiguous()
-        csr = graph.fwd
-        split, _scratch = csr.split_arg(K, x.device, hub_rows=True)
-        with _Timed(f"{kind}_linear_fwd"):
-            _lib.check(
-                _lib.load().rgbx_spmm_linear_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
-                                                 _lib.ptr(x), x.stride(0), _lib.ptr(wt),
-                                                 _lib.ptr(xr) if wtr is not None else None, xr.stride(0), _lib.ptr(wtr),
-                                                 _lib.ptr(b), _lib.ptr(out), out.stride(0), _lib.ptr(z), K, csr.N, K,
-                                                 n_out, None if split is None else ctypes.byref(split),
-                                                 _lib.stream_ptr()),
-                "rgbx_spmm_linear_f32")
+        out, z = spmm_linear_raw(graph.fwd, w, rs, x, weight.detach().t(), None if bias is None else bias.detach(),
+                                 need_z, xr if root_weight is not None else None,
+                                 None if root_weight is None else root_weight.detach().t(), kind=f"{kind}_linear_fwd")
         ctx.save_for_backward(z, weight, root_weight, xr if root_weight is not None else None)
         ctx.graph, ctx.kind, ctx.has_bias = graph, kind, bias is not None
         return out
@@ -194,13 +205,20 @@ class _PropagateLinear(torch.autograd.Function):
         if root_weight is not None and ctx.needs_input_grad[6]:
             gwr = gemm_tn(gy, x)
         if ctx.needs_input_grad[0]:
-            gz = gy @ weight
-            gr = gy @ root_weight if root_weight is not None else None
             wt = g.w_t if kind == "gcn" else g.w_mean_t
-            if gr is None:
-                gx = spmm_raw(g.bwd, wt, None, gz, kind=f"{kind}_bwd")
+            n_out, n_in = weight.shape
+            if n_out <= n_in and _lib.load().rgbx_spmm_linear_supported(n_out, n_in, int(root_weight is not None)):
+                gx, _ = spmm_linear_raw(g.bwd, wt, None, gy, weight.detach(), None, False,
+                                        gy if root_weight is not None else None,
+                                        None if root_weight is None else root_weight.detach(),
+                                        kind=f"{kind}_linear_bwd")
             else:
-                gx = spmm_raw(g.bwd, wt, None, gz, y=gr, a=1.0, b=1.0, out=gr, kind=f"{kind}_bwd")
+                gz = gy @ weight
+                gr = gy @ root_weight if root_weight is not None else None
+                if gr is None:
+                    gx = spmm_raw(g.bwd, wt, None, gz, kind=f"{kind}_bwd")
+                else:
+                    gx = spmm_raw(g.bwd, wt, None, gz, y=gr, a=1.0, b=1.0, out=gr, kind=f"{kind}_bwd")
         return gx, None, None, gw, gb, None, gwr, None
 
 
