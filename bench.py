@@ -195,18 +195,21 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
         model.eval()
         with torch.no_grad():
             out = model(x_d, ei_d)["out"]
-        s = ops.masked_nll_accuracy(out, y_d, mask).tolist()  # NLLLoss on out[mask] + arg-max accuracy
-        return s[0] / s[1], s[2] / s[1]
+        return ops.masked_nll_accuracy(out, y_d, mask)  # device [nll sum, count, correct]: NLLLoss on out[mask] + accuracy
 
     def step():
+        """The numbers the reference reads with .item() at three points of the loop body (itexperiments.py:437,
+        467, 472) are only used after the epoch (early stopping, curves): they stay on the device and come back in
+        ONE copy at the end, so the GPU queue does not drain three times per epoch."""
         model.train()
         opt.zero_grad()
         out = model(x_d, ei_d)["out"]
         loss = ops.masked_nll_loss(out, y_d, tm)
-        train_loss = loss.item()
         loss.backward()
         opt.step()
-        return (train_loss,) + evaluate(vm) + evaluate(sm)
+        val, tst = evaluate(vm), evaluate(sm)
+        s = torch.cat([loss.detach().double().reshape(1), val, tst]).tolist()  # the one host sync of the epoch
+        return s[0], s[1] / s[2], s[3] / s[2], s[4] / s[5], s[6] / s[5]
 
     def graphed():
         """The same epoch captured once as a hipGraph and replayed (rgb_experiment_amd.epoch_graph): needs a

@@ -56,7 +56,9 @@ class DistRunner:
             return ops.masked_nll_loss(out, self.y, m, reduction="sum")
         return F.nll_loss(out[m], self.y[m], reduction="sum")
 
-    def train_step(self):
+    def train_step(self, sync=True):
+        """One training step. `sync=False`: returns this rank's share of the loss as a device tensor [1]
+        (float64) instead of the all-reduced Python float — epoch() reduces everything once."""
         self.model.train()
         self.opt.zero_grad()
         out = self.model(self.x, self.token)["out"]
@@ -65,9 +67,14 @@ class DistRunner:
         loss.backward()
         self._sync_grads()
         self.opt.step()
-        return self.comm.all_reduce_sum_(loss.detach().clone()).item()
+        part = loss.detach().double().reshape(1)
+        if not sync:
+            return part
+        return self.comm.all_reduce_sum_(part.clone()).item()
 
-    def evaluate(self, which):
+    def evaluate(self, which, sync=True):
+        """Eval forward + (masked NLL sum, correct count) of this rank's rows. `sync=True`: all-reduced and
+        normalised Python floats (loss, accuracy, outputs); `sync=False`: the raw device tensor [2] and outputs."""
         self.model.eval()
         with torch.no_grad():
             res = self.model(self.x, self.token)
@@ -78,15 +85,22 @@ class DistRunner:
         else:  # gloo/CPU tests
             stats = torch.stack([F.nll_loss(out[m], self.y[m], reduction="sum"),
                                  (out[m].max(dim=1)[1] == self.y[m]).sum().float()]).double()
+        if not sync:
+            return stats, res
         stats = (self.comm.all_reduce_sum_(stats) / self.mask_counts[which]).tolist()
         return stats[0], stats[1], res
 
     def epoch(self):
-        """1 train forward+backward+Adam, then val and test forwards, as the reference loop body."""
-        tl = self.train_step()
-        vl, va, _ = self.evaluate(1)
-        sl, sa, _ = self.evaluate(2)
-        return tl, vl, va, sl, sa
+        """1 train forward+backward+Adam, then val and test forwards, as the reference loop body. The five
+        numbers the reference reads with .item() along the way are only used after the epoch: they are reduced
+        over the ranks in ONE all-reduce and read back in ONE copy, so the queues drain once per epoch, not three
+        times."""
+        tl = self.train_step(sync=False)
+        v, _ = self.evaluate(1, sync=False)
+        s, _ = self.evaluate(2, sync=False)
+        p = self.comm.all_reduce_sum_(torch.cat([tl, v, s])).tolist()
+        cv, cs = self.mask_counts[1], self.mask_counts[2]
+        return p[0], p[1] / cv, p[2] / cv, p[3] / cs, p[4] / cs
 
     def logits(self, training=False):
         self.model.train(training)
