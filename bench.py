@@ -194,8 +194,9 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
     def evaluate(mask):
         model.eval()
         with torch.no_grad():
-            out = model(x_d, ei_d)["out"]
-        return ops.masked_nll_accuracy(out, y_d, mask)  # device [nll sum, count, correct]: NLLLoss on out[mask] + accuracy
+            logits = model(x_d, ei_d)["emb"]
+        # device [nll sum, count, correct] = NLLLoss on log_softmax(logits)[mask] + arg-max accuracy, from the logits
+        return ops.masked_ce_accuracy(logits, y_d, mask)
 
     def step():
         """The numbers the reference reads with .item() at three points of the loop body (itexperiments.py:437,
@@ -203,8 +204,7 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
         ONE copy at the end, so the GPU queue does not drain three times per epoch."""
         model.train()
         opt.zero_grad()
-        out = model(x_d, ei_d)["out"]
-        loss = ops.masked_nll_loss(out, y_d, tm)
+        loss = ops.masked_ce_loss(model(x_d, ei_d)["emb"], y_d, tm)  # = NLLLoss(log_softmax(.)[mask], y[mask])
         loss.backward()
         opt.step()
         val, tst = evaluate(vm), evaluate(sm)

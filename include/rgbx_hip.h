@@ -306,6 +306,19 @@ int rgbx_masked_nll_fwd_f32(const float* logp, int64_t ld, const int64_t* y, con
 int rgbx_masked_nll_bwd_f32(const int64_t* y, const uint8_t* mask, int64_t N, int64_t C,
                             const float* scale, float* grad, int64_t ldg, rgbx_stream_t stream);
 
+/* The same loss taken from the LOGITS (cross-entropy = NLLLoss(log_softmax(z)), models/gcn.py:31 +
+ * itexperiments.py:400,429): stats as rgbx_masked_nll_fwd_f32 with -logp[i, y_i] = logsumexp(z_i) - z[i, y_i]
+ * and the arg-max taken on z (same as on log_softmax(z)); log-softmax is never written out.
+ * Scratch: rgbx_masked_nll_scratch_doubles(N, 1). */
+int rgbx_masked_ce_fwd_f32(const float* logits, int64_t ld, const int64_t* y, const uint8_t* mask, int64_t N,
+                           int64_t C, double* stats, double* scratch, int64_t scratch_doubles,
+                           rgbx_stream_t stream);
+
+/* grad[i,c] = scale[0] * (softmax(z_i)[c] - [c == y[i]]) for selected rows, 0 otherwise: the gradient of
+ * scale * stats[0] w.r.t. the logits, one pass. `scale` is a device scalar. */
+int rgbx_masked_ce_bwd_f32(const float* logits, int64_t ld, const int64_t* y, const uint8_t* mask, int64_t N,
+                           int64_t C, const float* scale, float* grad, int64_t ldg, rgbx_stream_t stream);
+
 /* ---- halo pack / unpack (multi-GPU node partition) ----------------------------------------- */
 
 /* dst[r,:] = src[idx[r],:] for r in [0,n) — pack boundary rows into a send buffer. */

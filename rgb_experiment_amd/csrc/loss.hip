@@ -1,3 +1,9 @@
+// Also the same loss taken straight from the logits (cross-entropy = NLL of log_softmax): the model's forward
+// ends in F.log_softmax (models/gcn.py:31) and the loop applies NLLLoss to it; when the loop only wants the loss
+// value, its gradient and the accuracy, log-softmax never has to be written out: rgbx_masked_ce_fwd_f32 reads the
+// selected rows once (logsumexp, label logit, arg-max), rgbx_masked_ce_bwd_f32 writes
+// scale * (softmax - onehot) in one pass.
+//
 // Masked NLL over log-probabilities + accuracy, forward and backward: the reference's
 // `criterion(out[mask], y[mask])` with nn.NLLLoss() and `out[mask].max(dim=1)[1].eq(y[mask])`
 // (itexperiments.py:400,429,434,467,472,624-626,643) without materialising out[mask]: one pass over
@@ -114,6 +120,86 @@ nll_acc_kernel(const float* __restrict__ logp, int64_t ld, const int64_t* __rest
   }
 }
 
+// logsumexp of one row by a wave (lane-strided), plus the arg-max (lowest index on ties); every lane gets both
+__device__ __forceinline__ void row_lse_argmax(const float* __restrict__ row, int C, int lane, float& lse, int& arg) {
+  float best;
+  row_argmax(row, C, lane, best, arg);
+  wave_argmax(best, arg);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += expf(row[c] - best);
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  lse = best + logf(s);
+}
+
+// Cross-entropy from logits over the selected rows: loss = sum(lse_i - z[i, y_i]), count, arg-max hits.
+__global__ void __launch_bounds__(256)
+ce_fwd_kernel(const float* __restrict__ z, int64_t ld, const int64_t* __restrict__ y,
+              const uint8_t* __restrict__ mask, int64_t N, int C, double* __restrict__ partials) {
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  double loss = 0.0, cnt = 0.0, hit = 0.0;
+  for (int64_t base = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * 64; base < N;
+       base += (int64_t)gridDim.x * wpb * 64) {
+    const int64_t i = base + lane;
+    int t = -1;
+    if (i < N && (!mask || mask[i])) {
+      const int64_t ti = y[i];
+      if (ti >= 0 && ti < C) t = (int)ti;
+    }
+    unsigned long long sel = __ballot(t >= 0);
+    while (sel) {
+      const int r0 = __builtin_ctzll(sel);
+      sel &= sel - 1;
+      const float* row = z + (base + r0) * ld;
+      float lse;
+      int arg;
+      row_lse_argmax(row, C, lane, lse, arg);
+      const int t0 = __shfl(t, r0);
+      if (lane == 0) {
+        loss += (double)(lse - row[t0]);
+        cnt += 1.0;
+        hit += arg == t0 ? 1.0 : 0.0;
+      }
+    }
+  }
+  loss = block_sum(loss, sh);
+  cnt = block_sum(cnt, sh);
+  hit = block_sum(hit, sh);
+  if (threadIdx.x == 0) {
+    partials[3 * blockIdx.x + 0] = loss;
+    partials[3 * blockIdx.x + 1] = cnt;
+    partials[3 * blockIdx.x + 2] = hit;
+  }
+}
+
+// grad[i, c] = scale * (softmax(z_i)[c] - [c == y_i]) for selected rows, 0 for the others; one wave per row.
+__global__ void __launch_bounds__(256)
+ce_bwd_kernel(const float* __restrict__ z, int64_t ld, const int64_t* __restrict__ y,
+              const uint8_t* __restrict__ mask, int64_t N, int C, const float* __restrict__ scale,
+              float* __restrict__ grad, int64_t ldg) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const float s = scale[0];
+  for (int64_t i = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); i < N; i += (int64_t)gridDim.x * wpb) {
+    int t = -1;
+    if (!mask || mask[i]) {
+      const int64_t ti = y[i];
+      if (ti >= 0 && ti < C) t = (int)ti;
+    }
+    float* g = grad + i * ldg;
+    if (t < 0) {
+      for (int c = lane; c < C; c += 64) g[c] = 0.f;
+      continue;
+    }
+    const float* row = z + i * ld;
+    float lse;
+    int arg;
+    row_lse_argmax(row, C, lane, lse, arg);
+    for (int c = lane; c < C; c += 64) g[c] = s * (expf(row[c] - lse) - (c == t ? 1.f : 0.f));
+  }
+}
+
 // stats[k] = sum over blocks of partials[b, k], in block order (one block; reproducible, no atomics)
 __global__ void __launch_bounds__(256)
 nll_finish_kernel(const double* __restrict__ partials, int n_blocks, double* __restrict__ stats) {
@@ -189,6 +275,44 @@ extern "C" int rgbx_masked_nll_fwd_f32(const float* logp, int64_t ld, const int6
   RGBX_CHECK_LAUNCH("masked_nll_fwd");
   nll_finish_kernel<<<1, 256, 0, s>>>(scratch, grid, stats);
   RGBX_CHECK_LAUNCH("nll_finish_kernel");
+  return RGBX_OK;
+}
+
+extern "C" int rgbx_masked_ce_fwd_f32(const float* logits, int64_t ld, const int64_t* y, const uint8_t* mask,
+                                      int64_t N, int64_t C, double* stats, double* scratch, int64_t scratch_doubles,
+                                      rgbx_stream_t stream) {
+  if (N < 0 || C <= 0 || !stats) return fail(RGBX_E_ARG, "masked_ce_fwd: bad argument");
+  if (C >= INT32_MAX) return fail(RGBX_E_RANGE, "masked_ce_fwd: C exceeds int32");
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0) {
+    RGBX_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(double), s));
+    return RGBX_OK;
+  }
+  if (!logits || !y || ld < C) return fail(RGBX_E_ARG, "masked_ce_fwd: null pointer or ld < C");
+  int64_t need = 0;
+  if (int rc = rgbx_masked_nll_scratch_doubles(N, 1, &need)) return rc;
+  if (!scratch || scratch_doubles < need)
+    return fail(RGBX_E_WS, "masked_ce_fwd: scratch %lld < %lld doubles", (long long)scratch_doubles, (long long)need);
+  const int grid = (int)(need / 3);
+  ce_fwd_kernel<<<grid, 256, 0, s>>>(logits, ld, y, mask, N, (int)C, scratch);
+  RGBX_CHECK_LAUNCH("ce_fwd_kernel");
+  nll_finish_kernel<<<1, 256, 0, s>>>(scratch, grid, stats);
+  RGBX_CHECK_LAUNCH("nll_finish_kernel");
+  return RGBX_OK;
+}
+
+extern "C" int rgbx_masked_ce_bwd_f32(const float* logits, int64_t ld, const int64_t* y, const uint8_t* mask,
+                                      int64_t N, int64_t C, const float* scale, float* grad, int64_t ldg,
+                                      rgbx_stream_t stream) {
+  if (N < 0 || C <= 0) return fail(RGBX_E_ARG, "masked_ce_bwd: bad size");
+  if (N == 0) return RGBX_OK;
+  if (!logits || !y || !scale || !grad || ld < C || ldg < C)
+    return fail(RGBX_E_ARG, "masked_ce_bwd: null pointer or ld < C");
+  if (C >= INT32_MAX) return fail(RGBX_E_RANGE, "masked_ce_bwd: C exceeds int32");
+  int64_t b = cdiv(N, 4);
+  const int grid = (int)(b < 4 * kMaxGrid ? b : 4 * kMaxGrid);
+  ce_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits, ld, y, mask, N, (int)C, scale, grad, ldg);
+  RGBX_CHECK_LAUNCH("ce_bwd_kernel");
   return RGBX_OK;
 }
 

@@ -50,20 +50,21 @@ class DistRunner:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
 
-    def _nll_sum(self, out, m):
-        if out.is_cuda:
+    def _nll_sum(self, res, m):
+        """Sum over this rank's masked rows of NLLLoss(log_softmax(emb)): from the logits on the GPU."""
+        if res["emb"].is_cuda:
             from .. import ops
-            return ops.masked_nll_loss(out, self.y, m, reduction="sum")
-        return F.nll_loss(out[m], self.y[m], reduction="sum")
+            return ops.masked_ce_loss(res["emb"], self.y, m, reduction="sum")
+        return F.nll_loss(res["out"][m], self.y[m], reduction="sum")
 
     def train_step(self, sync=True):
         """One training step. `sync=False`: returns this rank's share of the loss as a device tensor [1]
         (float64) instead of the all-reduced Python float — epoch() reduces everything once."""
         self.model.train()
         self.opt.zero_grad()
-        out = self.model(self.x, self.token)["out"]
+        res = self.model(self.x, self.token)
         m = self.masks[0]
-        loss = self._nll_sum(out, m) / self.mask_counts[0]
+        loss = self._nll_sum(res, m) / self.mask_counts[0]
         loss.backward()
         self._sync_grads()
         self.opt.step()
@@ -78,11 +79,12 @@ class DistRunner:
         self.model.eval()
         with torch.no_grad():
             res = self.model(self.x, self.token)
-        out, m = res["out"], self.masks[which]
-        if out.is_cuda:
+        m = self.masks[which]
+        if res["emb"].is_cuda:
             from .. import ops
-            stats = ops.masked_nll_accuracy(out, self.y, m)[[0, 2]]
+            stats = ops.masked_ce_accuracy(res["emb"], self.y, m)[[0, 2]]
         else:  # gloo/CPU tests
+            out = res["out"]
             stats = torch.stack([F.nll_loss(out[m], self.y[m], reduction="sum"),
                                  (out[m].max(dim=1)[1] == self.y[m]).sum().float()]).double()
         if not sync:

@@ -35,18 +35,19 @@ class GraphedEpoch:
         net, y = self.net, self.y
         net.train()
         self.opt.zero_grad(set_to_none=True)
-        out = net(**self.fwd)["out"]
-        loss = ops.masked_nll_loss(out, y, self.train_mask)
-        train_stats = ops.masked_nll_accuracy(out, y, self.train_mask)
+        out = net(**self.fwd)
+        # NLLLoss(log_softmax(emb)[mask], y[mask]) (reference :429) and the train accuracy (:434) in one pass
+        # over the logits; log-softmax itself is never written (models/_stack.ModelOutput)
+        loss, train_stats = ops.masked_ce_loss(out["emb"], y, self.train_mask, with_stats=True)
         loss.backward()
         self.opt.step()
         net.eval()
         with torch.no_grad():
             val_res = net(**self.fwd)
-            val_stats = ops.masked_nll_accuracy(val_res["out"], y, self.val_mask)
+            val_stats = ops.masked_ce_accuracy(val_res["emb"], y, self.val_mask)
             # the reference runs a second, identical eval forward for the test mask (itexperiments.py:470)
             test_res = val_res if self.share_eval_forward else net(**self.fwd)
-            test_stats = ops.masked_nll_accuracy(test_res["out"], y, self.test_mask)
+            test_stats = ops.masked_ce_accuracy(test_res["emb"], y, self.test_mask)
         return out, test_res, torch.stack([train_stats, val_stats, test_stats])
 
     def capture(self, warmup=3):

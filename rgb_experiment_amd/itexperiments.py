@@ -316,13 +316,17 @@ def experiment(model_init_param: dict, *,
             return va, vl, None
         net.train()
         optimizer.zero_grad()
-        out = net(**fwd)["out"]
-        if out.is_cuda:  # NLLLoss on out[train_mask] (reference :429) in one masked pass
-            loss = ops.masked_nll_loss(out, y, train_mask)
+        res = net(**fwd)
+        if res["emb"].is_cuda:
+            # NLLLoss on out[train_mask] (reference :429) and the train accuracy (:434) in one masked pass over
+            # the logits — the same kernels as the captured epoch, so both loops train bit-identically
+            loss, stats = ops.masked_ce_loss(res["emb"], y, train_mask, with_stats=True)
+            hist["train_acc"].append((stats[2] / stats[1]).item())
         else:
+            out = res["out"]
             loss = criterion(out[train_mask], y[train_mask])
-        hist["train_acc"].append(compare_pred_label(out[train_mask].max(dim=1)[1], y[train_mask],
-                                                    loop_metrics)["ACC"])
+            hist["train_acc"].append(compare_pred_label(out[train_mask].max(dim=1)[1], y[train_mask],
+                                                        loop_metrics)["ACC"])
         hist["train_loss"].append(loss.item())
         loss.backward()
         optimizer.step()

@@ -619,6 +619,69 @@ def masked_nll_loss(logp, y, mask=None, reduction="mean"):
     return _MaskedNLL.apply(logp, y, mask, reduction)
 
 
+def _ce_stats(logits, y, mask):
+    _lib.require_device(logits, y, mask)
+    if y.dtype != torch.int64:
+        raise RuntimeError(f"labels must be int64, got {y.dtype}")
+    if mask is not None and mask.dtype not in (torch.bool, torch.uint8):
+        raise RuntimeError(f"mask must be bool, got {mask.dtype}")
+    pz, ld = _lib.mat(logits, "logits")
+    lib = _lib.load()
+    stats = torch.empty(3, dtype=torch.float64, device=logits.device)
+    n_scr = ctypes.c_int64(0)
+    _lib.check(lib.rgbx_masked_nll_scratch_doubles(logits.size(0), 1, ctypes.byref(n_scr)),
+               "rgbx_masked_nll_scratch_doubles")
+    scratch = torch.empty(n_scr.value, dtype=torch.float64, device=logits.device)
+    y = y.contiguous()
+    mask = None if mask is None else mask.contiguous()
+    _lib.check(lib.rgbx_masked_ce_fwd_f32(pz, ld, _lib.ptr(y), _lib.ptr(mask), logits.size(0), logits.size(1),
+                                          _lib.ptr(stats), _lib.ptr(scratch), n_scr.value, _lib.stream_ptr()),
+               "rgbx_masked_ce_fwd_f32")
+    return stats, y, mask
+
+
+class _MaskedCE(torch.autograd.Function):
+    """NLLLoss(log_softmax(z)[mask], y[mask]) taken from the logits z: the loss, its gradient
+    scale * (softmax - onehot) and (stats[2]) the arg-max hits, without writing log-softmax or a one-hot
+    gradient. Returns (loss, stats [3] float64: nll sum, selected rows, correct)."""
+
+    @staticmethod
+    def forward(ctx, logits, y, mask, reduction):
+        logits = logits if logits.stride(-1) == 1 else logits.contiguous()
+        stats, y, mask = _ce_stats(logits, y, mask)
+        ctx.save_for_backward(logits)
+        ctx.y, ctx.mask, ctx.reduction = y, mask, reduction
+        ctx.count = stats[1]
+        ctx.mark_non_differentiable(stats)
+        return (stats[0] / stats[1] if reduction == "mean" else stats[0]).float(), stats
+
+    @staticmethod
+    def backward(ctx, g, _g_stats):
+        (logits,) = ctx.saved_tensors
+        scale = (g.double() / ctx.count if ctx.reduction == "mean" else g.double()).float().reshape(1).contiguous()
+        N, C = logits.shape
+        grad = torch.empty((N, C), dtype=torch.float32, device=g.device)
+        pz, ld = _lib.mat(logits, "logits")
+        _lib.check(_lib.load().rgbx_masked_ce_bwd_f32(pz, ld, _lib.ptr(ctx.y), _lib.ptr(ctx.mask), N, C,
+                                                      _lib.ptr(scale), _lib.ptr(grad), C, _lib.stream_ptr()),
+                   "rgbx_masked_ce_bwd_f32")
+        return grad, None, None, None
+
+
+def masked_ce_loss(logits, y, mask=None, reduction="mean", with_stats=False):
+    """Cross-entropy of the raw logits on the masked rows = masked_nll_loss(log_softmax(logits), ...), in one
+    pass each way. `with_stats`: also the [nll sum, count, correct] tensor of the same pass."""
+    loss, stats = _MaskedCE.apply(logits, y, mask, reduction)
+    return (loss, stats) if with_stats else loss
+
+
+def masked_ce_accuracy(logits, y, mask=None):
+    """masked_nll_accuracy(log_softmax(logits), ...) from the logits: float64 device tensor [3]."""
+    logits = logits.detach()
+    logits = logits if logits.stride(-1) == 1 else logits.contiguous()
+    return _ce_stats(logits, y, mask)[0]
+
+
 def masked_nll_accuracy(logp, y, mask=None):
     """(sum of -logp[i,y_i], selected-row count, correct arg-max count) as a float64 device tensor [3]."""
     logp = logp.detach()

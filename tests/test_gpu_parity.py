@@ -756,6 +756,40 @@ def test_gemm_tn_strided_inputs(dev):
         assert (got - want).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("C", [7, 128, 300])
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+def test_masked_cross_entropy_from_logits(dev, C, reduction):
+    """ops.masked_ce_loss / masked_ce_accuracy = NLLLoss(log_softmax(z)[mask], y[mask]) + arg-max accuracy taken from
+    the logits in one pass each way (log-softmax never written): value, statistics, gradient; labels outside
+    [0, C) are skipped like masked-out rows."""
+    from rgb_experiment_amd import ops
+    n = 5000
+    gen = torch.Generator().manual_seed(C)
+    z = torch.randn(n, C, generator=gen) * 3
+    y = torch.randint(0, C, (n,), generator=gen)
+    mask = torch.rand(n, generator=gen) < 0.6
+    y[torch.randint(0, n, (25,), generator=gen)] = -1
+    sel = mask & (y >= 0)
+    zc = z.clone().requires_grad_(True)
+    ref = torch.nn.functional.nll_loss(torch.log_softmax(zc, dim=1)[sel], y[sel], reduction=reduction)
+    zg = z.to(dev).requires_grad_(True)
+    loss, stats = ops.masked_ce_loss(zg, y.to(dev), mask.to(dev), reduction=reduction, with_stats=True)
+    assert abs(loss.item() - ref.item()) < 1e-4 * max(1.0, abs(ref.item()))
+    s = stats.tolist()
+    assert s[1] == int(sel.sum())
+    assert s[2] == int((z[sel].argmax(dim=1) == y[sel]).sum())
+    assert abs(s[0] - torch.nn.functional.nll_loss(torch.log_softmax(z.double(), 1)[sel], y[sel], reduction="sum").item()) < 1e-2
+    (loss * 1.7).backward()
+    (ref * 1.7).backward()
+    assert (zg.grad.cpu() - zc.grad).abs().max().item() < 1e-6 * max(1.0, zc.grad.abs().max().item() * 10)
+    assert torch.equal(zg.grad[~sel.to(dev)], torch.zeros_like(zg.grad[~sel.to(dev)]))
+    # same numbers as the two-step route through log-probabilities
+    logp = torch.log_softmax(z, dim=1).to(dev)
+    two = ops.masked_nll_accuracy(logp, y.to(dev), mask.to(dev)).tolist()
+    one = ops.masked_ce_accuracy(z.to(dev), y.to(dev), mask.to(dev)).tolist()
+    assert one[1:] == two[1:] and abs(one[0] - two[0]) < 1e-2
+
+
 def test_linear_autograd_uses_mfma_wgrad(dev):
     from rgb_experiment_amd import ops
     gen = torch.Generator().manual_seed(1)

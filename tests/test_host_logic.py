@@ -225,3 +225,28 @@ def test_experiment_accepts_index_list_masks():
     m = _as_bool_mask([1, 3], 5, "cpu")
     assert m.tolist() == [False, True, False, True, False]
     assert _as_bool_mask(torch.tensor([True, False]), 4, "cpu").tolist() == [True, False, False, False]
+
+
+def test_model_output_is_the_reference_dict_with_lazy_log_probs():
+    """models/_stack.ModelOutput: {'out', 'emb', 'x'} as the reference's forward returns (models/gcn.py:31), with
+    'out' / 'x' = log_softmax(emb) produced on first access."""
+    import torch
+    from rgb_experiment_amd.models._stack import model_output
+    z = torch.randn(6, 4)
+    res = model_output(z)
+    assert isinstance(res, dict) and res["emb"] is z
+    assert "out" in res and "x" in res and "emb" in res and "nope" not in res
+    assert list(res.keys()) == ["out", "emb", "x"] and len(res) == 3
+    assert not dict.__contains__(res, "out")          # nothing computed yet
+    want = torch.log_softmax(z, dim=1)
+    assert torch.equal(res["out"], want) and res["x"] is res["out"]
+    assert dict.__contains__(res, "out")              # cached
+    assert torch.equal(model_output(z).get("x"), want) and model_output(z).get("nope", 5) == 5
+    assert {k: v.shape for k, v in model_output(z).items()} == {k: z.shape for k in ("out", "emb", "x")}
+    assert torch.equal(dict(model_output(z))["out"], want)
+    try:
+        res["nope"]
+    except KeyError:
+        pass
+    else:
+        raise AssertionError("missing key must raise KeyError")
