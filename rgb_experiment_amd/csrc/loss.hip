@@ -200,6 +200,110 @@ ce_bwd_kernel(const float* __restrict__ z, int64_t ld, const int64_t* __restrict
   }
 }
 
+// ---- C % 4 == 0, C <= 256: a row is ONE float4 per lane of a group of LPR = pow2ceil(C / 4) lanes, so a wave holds
+// 64 / LPR rows in registers at once: one global read per row, group-wide shuffles for max / sum / arg-max.
+__device__ __forceinline__ void group_lse_argmax(const float (&v)[4], int c, int C, int lpr, float& lse, int& arg) {
+  float best = -INFINITY;
+  arg = INT32_MAX;
+  if (c < C) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (v[k] > best) { best = v[k]; arg = c + k; }
+  }
+  for (int off = lpr >> 1; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int oa = __shfl_xor(arg, off);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+  }
+  float s = 0.f;
+  if (c < C) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += expf(v[k] - best);
+  }
+  for (int off = lpr >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  lse = best + logf(s);
+}
+
+__global__ void __launch_bounds__(256)
+ce_fwd_vec_kernel(const float* __restrict__ z, int64_t ld, const int64_t* __restrict__ y,
+                  const uint8_t* __restrict__ mask, int64_t N, int C, int lpr, double* __restrict__ partials) {
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int nr = 64 / lpr;               // rows in flight per wave
+  const int grp = lane / lpr, c = (lane % lpr) * 4;
+  double loss = 0.0, cnt = 0.0, hit = 0.0;
+  for (int64_t base = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * 64; base < N;
+       base += (int64_t)gridDim.x * wpb * 64) {
+    const int64_t i = base + lane;
+    int t = -1;
+    if (i < N && (!mask || mask[i])) {
+      const int64_t ti = y[i];
+      if (ti >= 0 && ti < C) t = (int)ti;
+    }
+    unsigned long long sel = __ballot(t >= 0);
+    while (sel) {
+      // the next `nr` selected rows of this 64-row window, one per lane group
+      int myrow = -1;
+      for (int k = 0; k < nr && sel; ++k) {
+        const int r = __builtin_ctzll(sel);
+        sel &= sel - 1;
+        if (k == grp) myrow = r;
+      }
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* row = z + (base + (myrow >= 0 ? myrow : 0)) * ld;
+      if (myrow >= 0 && c < C) load_vec<4>(v, row + c);
+      float lse;
+      int arg;
+      group_lse_argmax(v, c, C, lpr, lse, arg);
+      const int tr = __shfl(t, myrow >= 0 ? myrow : 0);
+      if (myrow >= 0 && c == 0) {
+        loss += (double)(lse - row[tr]);
+        cnt += 1.0;
+        hit += arg == tr ? 1.0 : 0.0;
+      }
+    }
+  }
+  loss = block_sum(loss, sh);
+  cnt = block_sum(cnt, sh);
+  hit = block_sum(hit, sh);
+  if (threadIdx.x == 0) {
+    partials[3 * blockIdx.x + 0] = loss;
+    partials[3 * blockIdx.x + 1] = cnt;
+    partials[3 * blockIdx.x + 2] = hit;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+ce_bwd_vec_kernel(const float* __restrict__ z, int64_t ld, const int64_t* __restrict__ y,
+                  const uint8_t* __restrict__ mask, int64_t N, int C, int lpr, const float* __restrict__ scale,
+                  float* __restrict__ grad, int64_t ldg) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int nr = 64 / lpr;
+  const int grp = lane / lpr, c = (lane % lpr) * 4;
+  const float s = scale[0];
+  for (int64_t i0 = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * nr; i0 < N; i0 += (int64_t)gridDim.x * wpb * nr) {
+    const int64_t i = i0 + grp;
+    int t = -1;
+    if (i < N && (!mask || mask[i])) {
+      const int64_t ti = y[i];
+      if (ti >= 0 && ti < C) t = (int)ti;
+    }
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t >= 0 && c < C) load_vec<4>(v, z + i * ld + c);
+    float lse;
+    int arg;
+    group_lse_argmax(v, c, C, lpr, lse, arg);  // every lane takes part in the shuffles
+    if (i < N && c < C) {
+      float g[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = t >= 0 ? s * (expf(v[k] - lse) - (c + k == t ? 1.f : 0.f)) : 0.f;
+      store_vec<4>(grad + i * ldg + c, g);
+    }
+  }
+}
+
 // stats[k] = sum over blocks of partials[b, k], in block order (one block; reproducible, no atomics)
 __global__ void __launch_bounds__(256)
 nll_finish_kernel(const double* __restrict__ partials, int n_blocks, double* __restrict__ stats) {
@@ -294,7 +398,13 @@ extern "C" int rgbx_masked_ce_fwd_f32(const float* logits, int64_t ld, const int
   if (!scratch || scratch_doubles < need)
     return fail(RGBX_E_WS, "masked_ce_fwd: scratch %lld < %lld doubles", (long long)scratch_doubles, (long long)need);
   const int grid = (int)(need / 3);
-  ce_fwd_kernel<<<grid, 256, 0, s>>>(logits, ld, y, mask, N, (int)C, scratch);
+  if (C % 4 == 0 && C <= 256 && ld % 4 == 0 && aligned16(logits)) {
+    int lpr = 1;
+    while (lpr * 4 < C) lpr *= 2;
+    ce_fwd_vec_kernel<<<grid, 256, 0, s>>>(logits, ld, y, mask, N, (int)C, lpr, scratch);
+  } else {
+    ce_fwd_kernel<<<grid, 256, 0, s>>>(logits, ld, y, mask, N, (int)C, scratch);
+  }
   RGBX_CHECK_LAUNCH("ce_fwd_kernel");
   nll_finish_kernel<<<1, 256, 0, s>>>(scratch, grid, stats);
   RGBX_CHECK_LAUNCH("nll_finish_kernel");
@@ -309,9 +419,17 @@ extern "C" int rgbx_masked_ce_bwd_f32(const float* logits, int64_t ld, const int
   if (!logits || !y || !scale || !grad || ld < C || ldg < C)
     return fail(RGBX_E_ARG, "masked_ce_bwd: null pointer or ld < C");
   if (C >= INT32_MAX) return fail(RGBX_E_RANGE, "masked_ce_bwd: C exceeds int32");
-  int64_t b = cdiv(N, 4);
-  const int grid = (int)(b < 4 * kMaxGrid ? b : 4 * kMaxGrid);
-  ce_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits, ld, y, mask, N, (int)C, scale, grad, ldg);
+  if (C % 4 == 0 && C <= 256 && ld % 4 == 0 && ldg % 4 == 0 && aligned16(logits) && aligned16(grad)) {
+    int lpr = 1;
+    while (lpr * 4 < C) lpr *= 2;
+    int64_t b = cdiv(N, 4 * (64 / lpr));
+    const int grid = (int)(b < 4 * kMaxGrid ? b : 4 * kMaxGrid);
+    ce_bwd_vec_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits, ld, y, mask, N, (int)C, lpr, scale, grad, ldg);
+  } else {
+    int64_t b = cdiv(N, 4);
+    const int grid = (int)(b < 4 * kMaxGrid ? b : 4 * kMaxGrid);
+    ce_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits, ld, y, mask, N, (int)C, scale, grad, ldg);
+  }
   RGBX_CHECK_LAUNCH("ce_bwd_kernel");
   return RGBX_OK;
 }

@@ -756,7 +756,7 @@ def test_gemm_tn_strided_inputs(dev):
         assert (got - want).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("C", [7, 128, 300])
+@pytest.mark.parametrize("C", [4, 7, 12, 40, 128, 256, 300])
 @pytest.mark.parametrize("reduction", ["mean", "sum"])
 def test_masked_cross_entropy_from_logits(dev, C, reduction):
     """ops.masked_ce_loss / masked_ce_accuracy = NLLLoss(log_softmax(z)[mask], y[mask]) + arg-max accuracy taken from
