@@ -528,7 +528,6 @@ def gemm_tn(a, b, alpha=1.0, colsum=False):
     pb, ldb = _lib.mat(b, "b")
     K, M, N = a.size(0), a.size(1), b.size(1)
     lib = _lib.load()
-    import ctypes
     nbytes = ctypes.c_size_t(0)
     _lib.check(lib.rgbx_gemm_tn_workspace_bytes(K, M, N, ctypes.byref(nbytes)), "rgbx_gemm_tn_workspace_bytes")
     ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=a.device)
