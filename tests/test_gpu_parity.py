@@ -263,6 +263,29 @@ def test_fused_aggregate_transform_with_root_term(dev, K, n_out, loops_mode):
     assert torch.equal(again, out.detach())
 
 
+@pytest.mark.parametrize("n,e", [(1, 0), (2, 1), (31, 40), (33, 0), (65, 500)])
+def test_fused_kernel_tiny_and_edgeless_graphs(dev, n, e):
+    """Tiles with fewer than 32 rows, rows without in-edges (GraphSAGE2: no self-loops -> zero aggregate), one node."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    gen = torch.Generator().manual_seed(n * 7 + e)
+    ei = torch.randint(0, n, (2, e), generator=gen) if e else torch.zeros((2, 0), dtype=torch.int64)
+    x = torch.randn(n, 32, generator=gen)
+    W = torch.randn(64, 32, generator=gen) / 6
+    Wr = torch.randn(64, 32, generator=gen) / 6
+    b = torch.randn(64, generator=gen)
+    for mode, kind in ((1, "gcn"), (0, "mean"), (2, "mean")):
+        g = Graph(ei.to(dev), n, mode)
+        rei = O.rewrite_edges(ei, n, mode)[0]
+        w = O.gcn_norm(ei, None, n)[1] if kind == "gcn" else None
+        agg = O.propagate(rei, x, n, w, "add" if kind == "gcn" else "mean")
+        with torch.no_grad():
+            got = ops.propagate_linear(x.to(dev), g, kind, W.to(dev), b.to(dev)).cpu()
+            got_r = ops.propagate_linear(x.to(dev), g, kind, W.to(dev), b.to(dev), root_weight=Wr.to(dev)).cpu()
+        assert (got - (agg @ W.t() + b)).abs().max().item() < TOL, (mode, kind)
+        assert (got_r - (agg @ W.t() + b + x @ Wr.t())).abs().max().item() < TOL, (mode, kind)
+
+
 def test_fused_path_inside_models(dev):
     """GCN / GraphSAGE / GraphSAGE2 with in <= hidden (so the fused kernel is taken) still match the oracle."""
     from rgb_experiment_amd import models as M
