@@ -204,8 +204,8 @@ int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const 
  *   dsum[i,h]    = <gout[i,h,:], out[i,h,:]>
  *   g_a_dst[i,h] = sum_p alpha_p * (<gout[i,h,:], hfeat[col[p],h,:]> - dsum[i,h]) * lrelu'(s_p)
  * `nodeq` ([N,H,4] floats, 16-byte aligned) is an output consumed by the source-side pass: the record
- * (a_dst, m, rden, dsum) of every (target, head), so that pass needs one 16-byte gather per edge and
- * head instead of four 4-byte ones. */
+ * (a_dst, m - log(rden), dsum, 0) of every (target, head) — alpha = exp(e - m) * rden = exp(e - (m - log rden)) —
+ * so that pass needs one 16-byte gather per edge and head instead of four 4-byte ones. */
 int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                          int64_t ldh, const float* a_src, const float* a_dst, const float* m,
                          const float* rden, const float* out, int64_t ldo, const float* gout,
@@ -213,7 +213,7 @@ int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, const float*
                          float slope, rgbx_stream_t stream);
 
 /* The per-target record alone (no neighbour loop, one streaming pass over out / gout):
- *   nodeq[i,h] = (a_dst[i,h], m[i,h], rden[i,h], <gout[i,h,:], out[i,h,:] - bias[h,:]>)
+ *   nodeq[i,h] = (a_dst[i,h], m[i,h] - log(rden[i,h]), <gout[i,h,:], out[i,h,:] - bias[h,:]>, 0)
  * (`bias` = the pointer given to the forward, or NULL). */
 int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const float* rden, const float* out,
                           int64_t ldo, const float* bias, const float* gout, int64_t ldg, float* nodeq,
