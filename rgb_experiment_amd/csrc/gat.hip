@@ -510,15 +510,17 @@ gat_bwd_prep_kernel(const float* __restrict__ a_dst, const float* __restrict__ m
 // Backward, source side, over the transposed CSR: row = source j, col_t[p] = target i.
 // IDX = uint32_t when every element offset into gout / nodeq fits 32 bits (two VGPRs per load in flight instead of
 // four): with the combined softmax constant that brings the kernel from 78 to 69 registers = 7 waves per SIMD
-// instead of 6 (9.98 -> 9.58 ms for the whole backward at L).
+// instead of 6 (9.98 -> 9.58 ms for the whole backward at L); with 3 instead of 4 neighbour rows in flight per lane
+// group and the SGPR cap it fits 59 VGPRs / 78 SGPRs = 8 waves (9.28 -> 9.17 ms; H=1, C=128: 8.59 -> 8.26 ms).
 template <int VEC, bool CHUNK, typename IDX>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80)))
 gat_bwd_src_kernel(const int* __restrict__ rowptr_t, const int* __restrict__ col_t,
                    const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
                    const float4* __restrict__ nodeq, const float* __restrict__ gout, int64_t ldg,
                    float* __restrict__ g_hfeat,
                    int64_t ldgh, float* __restrict__ g_a_src, float* __restrict__ ds_out, int N, float slope,
                    const GatLayout L, const SplitDev sp) {
+  constexpr int U = 3;  // neighbour rows in flight per lane group: 3 x 8 waves per SIMD beat 4 x 7 (registers)
   const int lane = threadIdx.x & 63;
   const int NG = kWave / L.G;
   const int g = lane / L.G;
