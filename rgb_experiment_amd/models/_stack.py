@@ -54,6 +54,22 @@ class ModelOutput(dict):
     def items(self):
         return [(k, self[k]) for k in self.keys()]
 
+    def copy(self):
+        return dict(self.items())
+
+    def pop(self, key, *default):
+        if key in self._LAZY and not dict.__contains__(self, key):
+            self._log_probs()
+        return dict.pop(self, key, *default)
+
+    def __eq__(self, other):
+        return dict(self.items()) == other
+
+    __hash__ = None
+
+    def __repr__(self):
+        return repr(dict(self.items()))
+
 
 def model_output(logits):
     return ModelOutput(logits)

@@ -250,3 +250,6 @@ def test_model_output_is_the_reference_dict_with_lazy_log_probs():
         pass
     else:
         raise AssertionError("missing key must raise KeyError")
+    fresh = model_output(z)
+    assert "'out'" in repr(fresh) and set(fresh.copy()) == {"out", "emb", "x"}
+    assert torch.equal(model_output(z).pop("out"), want)
