@@ -350,14 +350,18 @@ def main():
             nnz_loc, nnz_rem = int(plan.fwd.loc_agg.numel()), int(plan.fwd.rem_agg.numel())
             b_loc = spmm_alg_bytes(n_loc, nnz_loc, d)
             b_rem = spmm_alg_bytes(n_loc, nnz_rem, d) + n_loc * 4 * d
-            b_col = spmm_alg_bytes(N, nnz_total, d // world)
+            b_col_full = spmm_alg_bytes(N, nnz_total, d // world)  # whole graph on this rank's d / P columns
+            # the column-shard SpMM runs as reshard_chunks * P launches (one per piece of every peer's row block,
+            # so that the transpose back overlaps it): bytes per launch accordingly
+            pieces = max(int(dgraph._chunks()), 1)
+            b_col = b_col_full / (pieces * world if pieces > 1 else 1)
             b_res = spmm_alg_bytes(n_loc, nnz_loc + nnz_rem, d)  # first conv: resident [local; halo] features
             alg_by_kind = {"dist_fwd_resident": b_res, "gcn_linear_fwd": b_res, "mean_linear_fwd": b_res,
                            "dist_fwd_local": b_loc, "dist_bwd_local": b_loc, "dist_fwd_remote": b_rem,
                            "dist_bwd_remote": b_rem, "dist_fwd_colshard": b_col, "dist_bwd_colshard": b_col,
-                           "dist_fwd_appnp_colshard": 10 * (b_col + N * 4 * (d // world)),
-                           "dist_bwd_appnp_colshard": 10 * (b_col + N * 4 * (d // world))}
-            alg = b_col if scheme == "reshard" else b_loc + b_rem
+                           "dist_fwd_appnp_colshard": 10 * (b_col_full + N * 4 * (d // world)),
+                           "dist_bwd_appnp_colshard": 10 * (b_col_full + N * 4 * (d // world))}
+            alg = b_col_full if scheme == "reshard" else b_loc + b_rem
             comm_mb = (2 * n_loc * d * 4 * (world - 1) / world if scheme == "reshard" else plan.fwd.n_halo * d * 4) / 1e6
     else:
         step, nnz_total, alg = build_single_gpu(model, ei, x, y, (train_mask, val_mask, test_mask), dev, loops_mode,

@@ -24,6 +24,18 @@ class HipAggregator:
             return ops.spmm_raw(csr, w, None, x, kind=kind)
         return ops.spmm_raw(csr, w, None, x, y=y, a=1.0, b=1.0, out=y, kind=kind)
 
+    def run_rows(self, handle, x, lo, hi, out, kind="dist_spmm"):
+        """Rows [lo, hi) of the same product, written into `out` ([hi - lo, d]); False when the CSR carries a
+        hub-row plan (row ids in the plan are absolute: the caller then takes the unchunked route)."""
+        from .. import ops
+        csr, w = handle
+        if csr.split is not None:
+            return False
+        if hi > lo:
+            view = _graph.CSR(csr.rowptr[lo:hi + 1], csr.col, csr.perm, hi - lo, csr.nnz, None)
+            ops.spmm_raw(view, w, None, x, out=out, kind=kind)
+        return True
+
     def gather(self, x, idx):
         from .. import ops
         return ops.gather_rows(x, idx)
@@ -262,9 +274,56 @@ class DistGraph:
         work.wait()
         return back.view(P, n_loc, dc).permute(1, 0, 2).reshape(n_loc, P * dc)
 
+    # pieces the outgoing transpose is cut into (1 = one all-to-all after the whole SpMM); every piece costs one SpMM
+    # launch per peer, so fewer pieces at larger world sizes keep the host ahead of the GPU
+    reshard_chunks = None
+
+    def _chunks(self):
+        if self.reshard_chunks is not None:
+            return int(self.reshard_chunks)
+        return 4 if self.comm.world <= 4 else 2
+
     def _run_reshard(self, kind, direction, x):
-        y = self.backend.run(self._get_full(kind)[direction], self._to_columns(x), kind=f"dist_{direction}_colshard")
-        return self._to_rows(y)
+        handle = self._get_full(kind)[direction]
+        cols = self._to_columns(x)
+        tag = f"dist_{direction}_colshard"
+        out = self._reshard_pipelined(handle, cols, tag)
+        if out is not None:
+            return out
+        return self._to_rows(self.backend.run(handle, cols, kind=tag))
+
+    def _reshard_pipelined(self, handle, cols, tag):
+        """SpMM and the transpose back to row shards, overlapped: every peer's block of destination rows is cut
+        into `reshard_chunks` pieces; piece c of ALL peers is aggregated (one launch per peer block, straight into
+        the send buffer) and handed to an asynchronous all-to-all, which runs on RCCL's stream while piece c + 1
+        is being aggregated. Only the last piece's exchange is exposed. Returns None when the backend cannot
+        aggregate row ranges (hub-row plan, test doubles without run_rows)."""
+        C = self._chunks()
+        run_rows = getattr(self.backend, "run_rows", None)
+        if C <= 1 or run_rows is None:
+            return None
+        P, n_loc, dc, b = self.comm.world, self.n_local, cols.size(1), self.bounds
+        cut = lambda n, c: (n * c) // C  # piece c of a block of n rows = rows [cut(n, c), cut(n, c + 1))
+        pending = []
+        for c in range(C):
+            counts = [cut(b[q + 1] - b[q], c + 1) - cut(b[q + 1] - b[q], c) for q in range(P)]
+            send = cols.new_empty((sum(counts), dc))
+            off = 0
+            for q in range(P):
+                lo = b[q] + cut(b[q + 1] - b[q], c)
+                if run_rows(handle, cols, lo, lo + counts[q], send[off:off + counts[q]], kind=tag) is False:
+                    if pending:
+                        raise RuntimeError("reshard: backend refused a row range after accepting one")
+                    return None
+                off += counts[q]
+            m = cut(n_loc, c + 1) - cut(n_loc, c)
+            recv, work = self.comm.all_to_all_rows(send, counts, [m] * P)
+            pending.append((recv, work, m, send))  # `send` stays referenced until its exchange has been waited on
+        parts = []
+        for recv, work, m, _send in pending:
+            work.wait()
+            parts.append(recv.view(P, m, dc).permute(1, 0, 2).reshape(m, P * dc))
+        return torch.cat(parts, dim=0)
 
     def _appnp_columns(self, direction, h, K, alpha):
         out = self.backend.appnp(self._get_full("gcn")[direction], self._to_columns(h), K, alpha,

@@ -25,6 +25,10 @@ class OracleAggregator:
         out = O.propagate(ei, x, n_rows, w, "add")
         return out if y is None else y.add_(out)
 
+    def run_rows(self, handle, x, lo, hi, out, kind=None):
+        out.copy_(self.run(handle, x)[lo:hi])
+        return True
+
     def gather(self, x, idx):
         return x[idx.long()]
 
@@ -101,6 +105,26 @@ def propagate_worker(rank, world, port, out_dir, exchange="halo"):
     out.backward(go[lo:hi])
     res["appnp"] = (out.detach(), xl.grad)
     torch.save(res, os.path.join(out_dir, f"prop_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def reshard_chunk_worker(rank, world, port, out_dir):
+    """The column-shard propagate with the outgoing transpose in 1, 3 (ragged) and 4 pieces: identical rows."""
+    _init(rank, world, port)
+    from rgb_experiment_amd.dist import Comm, DistGraph, partition_bounds
+    ei, x, _, _ = make_problem(n=103, e=1200, f=12)
+    n = x.size(0)
+    lo, hi = partition_bounds(n, world)[rank:rank + 2]
+    outs = {}
+    for chunks in (1, 3, 4):
+        dg = DistGraph(ei, n, 1, Comm(), OracleAggregator(), "reshard")
+        dg.reshard_chunks = chunks
+        assert dg.scheme(x.size(1)) == "reshard"
+        xl = x[lo:hi].clone().requires_grad_(True)
+        out = dg.propagate(xl, "gcn")
+        out.sum().backward()
+        outs[chunks] = (out.detach(), xl.grad)
+    torch.save(outs, os.path.join(out_dir, f"chunks_{rank}.pt"))
     dist.destroy_process_group()
 
 

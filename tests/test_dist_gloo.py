@@ -171,6 +171,18 @@ def test_resident_input_features_remove_the_first_layer_exchange(model_name, wit
         assert abs(a[1] - b[1]) < 5e-3 and abs(a[3] - b[3]) < 5e-3, (a, b)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_reshard_equals_the_single_exchange(world, tmp_path):
+    """DistGraph._reshard_pipelined (SpMM by pieces of every peer's row block, each piece's all-to-all in flight
+    while the next is aggregated) returns exactly the rows of the one-shot transpose, forward and backward, also
+    with ragged pieces (103 nodes, 3 pieces, 3 ranks; f = 12 columns, 4 per rank)."""
+    mp.spawn(W.reshard_chunk_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        outs = torch.load(os.path.join(tmp_path, f"chunks_{r}.pt"))
+        for chunks in (3, 4):
+            assert torch.equal(outs[chunks][0], outs[1][0]) and torch.equal(outs[chunks][1], outs[1][1]), (r, chunks)
+
+
 def test_dist_batchnorm_matches_full_batch_bn():
     """world = 1 (no process group): DistBatchNorm1d == nn.BatchNorm1d incl. running stats and grads."""
     from rgb_experiment_amd.dist import Comm, DistBatchNorm1d
