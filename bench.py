@@ -2,11 +2,16 @@
 """bench.py — the reference's hot loop (itexperiments.py:417-473) on synthetic graphs, MI355X.
 
 One STEP = one epoch of the reference loop body for a 2-layer GCN at d = 128: 1 train forward +
-backward + Adam step, then 2 eval forwards (val, test) = 7 CSR SpMM launches (6 forward, 1
-transposed: the input layer aggregates first in training, so its weight gradient needs no pass
-through A_hat^T) + 8 dense GEMMs + BatchNorm / log-softmax passes. `value` counts the edges actually
-aggregated (7 * E' per step), not the 8 propagates of the transform-first formulation. Inputs are resident in HBM before the
-timed region.
+backward + Adam step, then 2 eval forwards (val, test) = 7 aggregations over all E' edges (6 forward, 1
+transposed: the input layer aggregates first, so its weight gradient needs no pass through A_hat^T), each
+fused with its layer's dense transform (fp32 MFMA) where the shapes allow, + the weight-gradient GEMMs,
+BatchNorm and the loss. `value` counts the edges actually aggregated (7 * E' per step), not the 8 propagates
+of the transform-first formulation. Nothing of the epoch is skipped or cached across steps; two things are
+computed in a different FORM than the reference writes them, with the same values: the eval-mode BatchNorm is
+folded into the preceding layer's weights, and loss / accuracy / loss gradient are taken from the logits
+(cross-entropy = NLLLoss o log_softmax) so the log-probabilities are never written out.
+The five numbers the reference reads with .item() inside the loop body are read once, at the end of the step.
+Inputs are resident in HBM before the timed region.
 
 Metric (BASELINE.json): "aggregated edges/sec + training epochs/sec, full-graph GCN d=128".
   value            = edges aggregated per second over the WHOLE step = 7 * E' * steps / wall time
