@@ -278,28 +278,45 @@ __global__ void __launch_bounds__(256)
 ce_bwd_vec_kernel(const float* __restrict__ z, int64_t ld, const int64_t* __restrict__ y,
                   const uint8_t* __restrict__ mask, int64_t N, int C, int lpr, const float* __restrict__ scale,
                   float* __restrict__ grad, int64_t ldg) {
+  constexpr int R = 4;  // rows per lane group and iteration: all R row loads are issued before the first reduction
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int nr = 64 / lpr;
   const int grp = lane / lpr, c = (lane % lpr) * 4;
   const float s = scale[0];
-  for (int64_t i0 = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * nr; i0 < N; i0 += (int64_t)gridDim.x * wpb * nr) {
-    const int64_t i = i0 + grp;
-    int t = -1;
-    if (i < N && (!mask || mask[i])) {
-      const int64_t ti = y[i];
-      if (ti >= 0 && ti < C) t = (int)ti;
-    }
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (t >= 0 && c < C) load_vec<4>(v, z + i * ld + c);
-    float lse;
-    int arg;
-    group_lse_argmax(v, c, C, lpr, lse, arg);  // every lane takes part in the shuffles
-    if (i < N && c < C) {
-      float g[4];
+  for (int64_t i0 = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * nr * R; i0 < N;
+       i0 += (int64_t)gridDim.x * wpb * nr * R) {
+    int t[R];
+    float v[R][4];
+    // mask and label of all R rows first (independent loads), then the R row loads: no mask -> label -> row chain
+    uint8_t mk[R];
+    int64_t lab[R];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) g[k] = t >= 0 ? s * (expf(v[k] - lse) - (c + k == t ? 1.f : 0.f)) : 0.f;
-      store_vec<4>(grad + i * ldg + c, g);
+    for (int r = 0; r < R; ++r) {
+      const int64_t i = i0 + r * nr + grp;
+      mk[r] = (i < N) ? (mask ? mask[i] : (uint8_t)1) : (uint8_t)0;
+      lab[r] = (i < N) ? y[i] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t i = i0 + r * nr + grp;
+      t[r] = (mk[r] && lab[r] >= 0 && lab[r] < C) ? (int)lab[r] : -1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[r][k] = 0.f;
+      if (t[r] >= 0 && c < C) load_vec<4>(v[r], z + i * ld + c);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t i = i0 + r * nr + grp;
+      float lse;
+      int arg;
+      group_lse_argmax(v[r], c, C, lpr, lse, arg);  // every lane takes part in the shuffles
+      if (i < N && c < C) {
+        float g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = t[r] >= 0 ? s * (expf(v[r][k] - lse) - (c + k == t[r] ? 1.f : 0.f)) : 0.f;
+        store_vec<4>(grad + i * ldg + c, g);
+      }
     }
   }
 }
@@ -422,7 +439,7 @@ extern "C" int rgbx_masked_ce_bwd_f32(const float* logits, int64_t ld, const int
   if (C % 4 == 0 && C <= 256 && ld % 4 == 0 && ldg % 4 == 0 && aligned16(logits) && aligned16(grad)) {
     int lpr = 1;
     while (lpr * 4 < C) lpr *= 2;
-    int64_t b = cdiv(N, 4 * (64 / lpr));
+    int64_t b = cdiv(N, 4 * (64 / lpr) * 4);  // 4 waves x (64 / lpr) lane groups x R = 4 rows per iteration
     const int grid = (int)(b < 4 * kMaxGrid ? b : 4 * kMaxGrid);
     ce_bwd_vec_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits, ld, y, mask, N, (int)C, lpr, scale, grad, ldg);
   } else {
