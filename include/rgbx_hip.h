@@ -192,12 +192,14 @@ int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const float* g_a_sr
  * (saves one cache-line request per edge; `a_src` is then ignored and may be NULL).
  * `bias` ([H*C], optional): added to every stored row (GATConv's `out + bias` with concat=True, or heads=1);
  * pass the same pointer to rgbx_gat_bwd_prep_f32, which needs the bare aggregate.
+ * `out_scale` ([H*C], optional, inference only): stored row = aggregate * out_scale + bias — an eval-mode
+ * BatchNorm after the layer (models/gat.py:29) folded into the store (bias then = bias * scale + shift).
  * `split` (optional): hub targets are cut into chunks whose online-softmax states are merged in chunk
  * order; `split->partial` must hold n_chunks * (H*C + 2*H) floats. */
 int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                                int64_t ldh, const float* a_src, const float* att_src,
-                               const float* a_dst, const float* bias, float* out, int64_t ldo, float* m,
-                               float* rden, int64_t N, int H, int C, float slope,
+                               const float* a_dst, const float* out_scale, const float* bias, float* out,
+                               int64_t ldo, float* m, float* rden, int64_t N, int H, int C, float slope,
                                const rgbx_row_split_t* split, rgbx_stream_t stream);
 
 /* Backward, target side (same CSR as forward). Per target i, head h:

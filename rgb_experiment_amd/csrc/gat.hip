@@ -207,7 +207,8 @@ __global__ void __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80)))
 gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
                const float* __restrict__ att_src, const float* __restrict__ a_dst,
-               const float* __restrict__ bias, float* __restrict__ out, int64_t ldo,
+               const float* __restrict__ oscale, const float* __restrict__ bias, float* __restrict__ out,
+               int64_t ldo,
                float* __restrict__ m_out, float* __restrict__ rden_out, int N, float slope,
                const GatLayout L, const SplitDev sp) {
   const int lane = threadIdx.x & 63;
@@ -308,12 +309,13 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
           }
         } else {
           const float rd = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
-          float r[VEC], bv[VEC];
+          float r[VEC], bv[VEC], sv[VEC];
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) bv[i] = 0.f;
+          for (int i = 0; i < VEC; ++i) { bv[i] = 0.f; sv[i] = 1.f; }
           if (bias) load_vec<VEC>(bv, bias + cofs);
+          if (oscale) load_vec<VEC>(sv, oscale + cofs);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) r[i] = acc[i] * rd + bv[i];
+          for (int i = 0; i < VEC; ++i) r[i] = acc[i] * rd * sv[i] + bv[i];
           store_vec<VEC>(out + (int64_t)row * ldo + cofs, r);
           if (ch == 0) {
             m_out[(int64_t)row * L.H + head] = l > 0.f ? m : 0.f;
@@ -329,7 +331,7 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
 template <int VEC>
 __global__ void __launch_bounds__(256)
 gat_fwd_combine_kernel(int n_long, const int* __restrict__ long_row, const int* __restrict__ long_chunk_ptr,
-                       const float* __restrict__ bias, float* __restrict__ out, int64_t ldo, float* __restrict__ m_out,
+                       const float* __restrict__ oscale, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo, float* __restrict__ m_out,
                        float* __restrict__ rden_out, const GatLayout L, const SplitDev sp) {
   const int lane = threadIdx.x & 63;
   const int g = lane / L.G;
@@ -363,12 +365,13 @@ gat_fwd_combine_kernel(int n_long, const int* __restrict__ long_row, const int* 
         m = mn;
       }
       const float rd = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
-      float bv[VEC];
+      float bv[VEC], sv[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) bv[i] = 0.f;
+      for (int i = 0; i < VEC; ++i) { bv[i] = 0.f; sv[i] = 1.f; }
       if (bias) load_vec<VEC>(bv, bias + cofs);
+      if (oscale) load_vec<VEC>(sv, oscale + cofs);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = acc[i] * rd + bv[i];
+      for (int i = 0; i < VEC; ++i) acc[i] = acc[i] * rd * sv[i] + bv[i];
       store_vec<VEC>(out + (int64_t)row * ldo + cofs, acc);
       if (ch == 0) {
         m_out[(int64_t)row * L.H + head] = l > 0.f ? m : 0.f;
@@ -791,9 +794,9 @@ extern "C" int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const fl
 
 extern "C" int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                                           int64_t ldh, const float* a_src, const float* att_src,
-                                          const float* a_dst, const float* bias, float* out, int64_t ldo,
-                                          float* m, float* rden, int64_t N, int H, int C, float slope,
-                                          const rgbx_row_split_t* split, rgbx_stream_t stream) {
+                                          const float* a_dst, const float* out_scale, const float* bias,
+                                          float* out, int64_t ldo, float* m, float* rden, int64_t N, int H, int C,
+                                          float slope, const rgbx_row_split_t* split, rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_fwd")) return rc;
   if (N == 0) return RGBX_OK;
   if (!rowptr || !col || !hfeat || (!a_src && !att_src) || !a_dst || !out || !m || !rden)
@@ -801,21 +804,21 @@ extern "C" int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* 
   if (ldh < (int64_t)H * C || ldo < (int64_t)H * C) return fail(RGBX_E_ARG, "gat_fwd: leading dimension < H*C");
   SplitDev sd;
   if (int rc = split_view(split, H, C, &sd, "gat_fwd")) return rc;
-  const int vec = pick_vec(C, {hfeat, out, att_src, bias, sd.pacc}, {ldh, ldo});
+  const int vec = pick_vec(C, {hfeat, out, att_src, bias, out_scale, sd.pacc}, {ldh, ldo});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_fwd")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int grid = gat_grid(N);
 #define RGBX_GAT_FWD(V)                                                                                         \
   do {                                                                                                          \
-    gat_fwd_kernel<V, false><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, att_src, a_dst, bias, out,    \
-                                                  ldo, m, rden, (int)N, slope, L, sd);                          \
+    gat_fwd_kernel<V, false><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out_scale,    \
+                                                  bias, out, ldo, m, rden, (int)N, slope, L, sd);               \
     if (sd.threshold > 0) {                                                                                     \
       gat_fwd_kernel<V, true><<<gat_grid(split->n_chunks), 256, 0, s>>>(                                        \
-          rowptr, col, hfeat, ldh, a_src, att_src, a_dst, bias, out, ldo, m, rden, split->n_chunks, slope, L,   \
-          sd);                                                                                                  \
+          rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out_scale, bias, out, ldo, m, rden, split->n_chunks,  \
+          slope, L, sd);                                                                                        \
       gat_fwd_combine_kernel<V><<<gat_grid(split->n_long), 256, 0, s>>>(                                        \
-          split->n_long, split->long_row, split->long_chunk_ptr, bias, out, ldo, m, rden, L, sd);               \
+          split->n_long, split->long_row, split->long_chunk_ptr, out_scale, bias, out, ldo, m, rden, L, sd);    \
     }                                                                                                           \
   } while (0)
   if (vec == 4) RGBX_GAT_FWD(4);

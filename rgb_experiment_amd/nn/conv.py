@@ -164,23 +164,34 @@ class GATConv(nn.Module):
         glorot_(self.att_dst)
         nn.init.zeros_(self.bias)
 
-    def forward(self, x, edge_index):
+    folds_post_affine = True  # forward(..., post_affine=(scale, shift)): see models/_stack.py
+
+    def forward(self, x, edge_index, post_affine=None):
+        """`post_affine` = (scale, shift) of an eval-mode BatchNorm that follows this layer (no_grad only): applied in
+        the aggregation kernel's store, out = aggregate * scale + (bias * scale + shift), when the bias rides there
+        too; otherwise after the layer."""
         H, C = self.heads, self.out_channels
         graph = get_graph(edge_index, x.size(0), LOOPS_REMOVE_ADD)
         # the bias rides in the aggregation kernel's store when it applies to the stored row as is
         # (concatenated heads, or a single head, whose "mean over heads" is the identity)
         in_kernel = self.concat or H == 1
-        if getattr(graph, "is_distributed", False) and graph.is_resident(x):
+        dist_resident = getattr(graph, "is_distributed", False) and graph.is_resident(x)
+        if dist_resident:
             out = graph.gat(x, self.att_src, self.att_dst, H, C, self.negative_slope, weight=self.lin_src.weight)
-            if in_kernel:
-                return out + self.bias
+            out = out + self.bias if in_kernel else out.view(-1, H, C).mean(dim=1) + self.bias
         else:
             h = ops.linear(x, self.lin_src.weight)
+            if in_kernel and post_affine is not None and not getattr(graph, "is_distributed", False):
+                scale, shift = post_affine
+                return ops.gat_attend(h, self.att_src, self.att_dst, graph, H, C, self.negative_slope,
+                                      bias=self.bias * scale + shift, out_scale=scale)
             out = ops.gat_attend(h, self.att_src, self.att_dst, graph, H, C, self.negative_slope,
                                  bias=self.bias if in_kernel else None)
-            if in_kernel:
-                return out
-        return out.view(-1, H, C).mean(dim=1) + self.bias
+            if not in_kernel:
+                out = out.view(-1, H, C).mean(dim=1) + self.bias
+        if post_affine is not None:
+            out = out * post_affine[0] + post_affine[1]
+        return out
 
 
 class APPNP(nn.Module):

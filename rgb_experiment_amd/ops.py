@@ -330,8 +330,8 @@ class _GATAggregate(torch.autograd.Function):
         with _Timed("gat_fwd"):
             _lib.check(
                 _lib.load().rgbx_gat_aggregate_fwd_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), ph, ldh,
-                                                       _lib.ptr(a_src), _lib.ptr(att), _lib.ptr(a_dst), None, po,
-                                                       ldo, _lib.ptr(m), _lib.ptr(rden), N, H, C, float(slope),
+                                                       _lib.ptr(a_src), _lib.ptr(att), _lib.ptr(a_dst), None, None,
+                                                       po, ldo, _lib.ptr(m), _lib.ptr(rden), N, H, C, float(slope),
                                                        None if split is None else ctypes.byref(split),
                                                        _lib.stream_ptr()), "rgbx_gat_aggregate_fwd_f32")
         ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out)
@@ -412,13 +412,17 @@ class _GATAttend(torch.autograd.Function):
     edge-softmax/aggregate forward; backward = prep + source pass + segment sum (as _GATAggregate) followed
     by rgbx_gat_scores_bwd_f32, which folds the score gradients into g_hfeat in place and reduces the
     attention-vector gradients without materialising [N, H, C] products. `bias` ([H*C], optional) is added
-    in the aggregation kernel's store (GATConv's `+ bias` for concatenated heads)."""
+    in the aggregation kernel's store (GATConv's `+ bias` for concatenated heads). `out_scale` ([H*C], inference
+    only — the stored rows are then not the aggregate the backward needs): stored row = aggregate * out_scale + bias,
+    an eval-mode BatchNorm after the layer folded into the store."""
 
     @staticmethod
-    def forward(ctx, hfeat, att_src, att_dst, graph, H, C, slope, bias=None):
-        _lib.require_device(hfeat, att_src, att_dst, bias)
+    def forward(ctx, hfeat, att_src, att_dst, graph, H, C, slope, bias=None, out_scale=None):
+        _lib.require_device(hfeat, att_src, att_dst, bias, out_scale)
         hfeat = hfeat.contiguous()
         b = None if bias is None else bias.detach().reshape(H * C).contiguous()
+        sc = None if out_scale is None else out_scale.detach().reshape(H * C).contiguous()
+        ctx.inference_only = sc is not None
         att_s = att_src.detach().reshape(H, C).contiguous()
         att_d = att_dst.detach().reshape(H, C).contiguous()
         n_src, N, dev = hfeat.size(0), graph.fwd.N, hfeat.device
@@ -437,8 +441,8 @@ class _GATAttend(torch.autograd.Function):
         with _Timed("gat_fwd"):
             _lib.check(
                 lib.rgbx_gat_aggregate_fwd_f32(_lib.ptr(graph.fwd.rowptr), _lib.ptr(graph.fwd.col), ph, ldh,
-                                               _lib.ptr(a_src), _lib.ptr(att_k), _lib.ptr(a_dst), _lib.ptr(b), po, ldo,
-                                               _lib.ptr(m), _lib.ptr(rden), N, H, C, float(slope),
+                                               _lib.ptr(a_src), _lib.ptr(att_k), _lib.ptr(a_dst), _lib.ptr(sc),
+                                               _lib.ptr(b), po, ldo, _lib.ptr(m), _lib.ptr(rden), N, H, C, float(slope),
                                                None if split is None else ctypes.byref(split), _lib.stream_ptr()),
                 "rgbx_gat_aggregate_fwd_f32")
         ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out, att_s, att_d, b)
@@ -449,6 +453,8 @@ class _GATAttend(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        if ctx.inference_only:
+            raise RuntimeError("gat_attend(out_scale=...) is an inference-only form (eval-mode BatchNorm fold)")
         hfeat, a_src, a_dst, m, rden, out, att_s, att_d, b = ctx.saved_tensors
         H, C = ctx.H, ctx.C
         gout = gout.contiguous()
@@ -470,15 +476,21 @@ class _GATAttend(torch.autograd.Function):
                                             _lib.ptr(att_d), pgh, ldgh, _lib.ptr(g_att_s), _lib.ptr(g_att_d),
                                             _lib.ptr(scratch), n_scr.value, n, H, C, _lib.stream_ptr()),
                 "rgbx_gat_scores_bwd_f32")
-        return g_h, g_att_s.reshape(ctx.att_shapes[0]), g_att_d.reshape(ctx.att_shapes[1]), None, None, None, None, g_b
+        return (g_h, g_att_s.reshape(ctx.att_shapes[0]), g_att_d.reshape(ctx.att_shapes[1]), None, None, None, None, g_b,
+                None)
 
 
-def gat_attend(h, att_src, att_dst, graph, H, C, slope=0.2, bias=None):
-    """Scores + edge-softmax + aggregation (+ bias) of one GATConv; dispatches to the partitioned graph."""
+def gat_attend(h, att_src, att_dst, graph, H, C, slope=0.2, bias=None, out_scale=None):
+    """Scores + edge-softmax + aggregation (* out_scale + bias) of one GATConv; dispatches to the partitioned
+    graph. `out_scale` is for inference (no_grad) only."""
     if _is_dist(graph):
         out = graph.gat(h, att_src, att_dst, H, C, slope)
+        if out_scale is not None:
+            out = out * out_scale
         return out if bias is None else out + bias
-    return _GATAttend.apply(h, att_src, att_dst, graph, H, C, slope, bias)
+    if out_scale is not None and torch.is_grad_enabled():
+        raise RuntimeError("gat_attend(out_scale=...) is an inference-only form")
+    return _GATAttend.apply(h, att_src, att_dst, graph, H, C, slope, bias, out_scale)
 
 
 def _scores_in_kernel(C):

@@ -313,7 +313,8 @@ def test_fused_path_inside_models(dev):
             assert (p.grad.cpu() - rg).abs().max().item() < 1e-4 * max(1.0, rg.abs().max().item()), (cls.__name__, pname)
 
 
-@pytest.mark.parametrize("name,f,hid", [("GCN", 64, 128), ("GCN", 40, 24), ("GraphSAGE", 64, 64), ("GraphSAGE2", 32, 96)])
+@pytest.mark.parametrize("name,f,hid", [("GCN", 64, 128), ("GCN", 40, 24), ("GraphSAGE", 64, 64), ("GraphSAGE2", 32, 96),
+                                        ("GAT", 32, 8)])
 def test_eval_batchnorm_folded_into_conv_weights(dev, name, f, hid):
     """Under no_grad the stack folds the eval-mode BatchNorm that follows a conv into that conv's weights
     (models/_stack.py): same logits as conv -> BatchNorm run separately (the enable_grad route), and as the oracle."""
@@ -324,7 +325,8 @@ def test_eval_batchnorm_folded_into_conv_weights(dev, name, f, hid):
     x = torch.randn(n, f, generator=gen)
     y = torch.randint(0, c, (n,), generator=gen)
     torch.manual_seed(2)
-    model = getattr(M, name)(num_layers=3, hidden_unit=hid, input_dim=f, output_dim=c, dropout_rate=0.5).to(dev)
+    extra = {"heads": 4} if name == "GAT" else {}
+    model = getattr(M, name)(num_layers=3, hidden_unit=hid, input_dim=f, output_dim=c, dropout_rate=0.5, **extra).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=0.01)
     xd, eid = x.to(dev), ei.to(dev)
     model.train()
@@ -338,8 +340,11 @@ def test_eval_batchnorm_folded_into_conv_weights(dev, name, f, hid):
     separate = model(xd, eid)["emb"].detach()
     assert (folded - separate).abs().max().item() < 2e-5 * max(1.0, separate.abs().max().item())
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    fwd = {"GCN": O.gcn_forward, "GraphSAGE": O.graphsage_forward, "GraphSAGE2": O.graphsage2_forward}[name]
-    ref = fwd(sd, x, ei, 3, False)["emb"]
+    if name == "GAT":
+        ref = O.gat_forward(sd, x, ei, 3, 4, False)["emb"]
+    else:
+        fwd = {"GCN": O.gcn_forward, "GraphSAGE": O.graphsage_forward, "GraphSAGE2": O.graphsage2_forward}[name]
+        ref = fwd(sd, x, ei, 3, False)["emb"]
     assert (folded.cpu() - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item())
 
 
@@ -587,7 +592,7 @@ def test_gat_backward_two_implementations_agree(dev):
     lib = _lib.load()
     hd, asd, add = h.detach().contiguous(), a_s.detach().contiguous(), a_d.detach().contiguous()
     _lib.check(lib.rgbx_gat_aggregate_fwd_f32(g.fwd.rowptr.data_ptr(), g.fwd.col.data_ptr(), hd.data_ptr(), H * C,
-                                              asd.data_ptr(), None, add.data_ptr(), None, out2.data_ptr(), H * C,
+                                              asd.data_ptr(), None, add.data_ptr(), None, None, out2.data_ptr(), H * C,
                                               m.data_ptr(), rden.data_ptr(), n, H, C, 0.2, None, _lib.stream_ptr()), "fwd")
     nodeq = torch.empty(n, H, 4, device=dev)
     ref = torch.empty(n, H, device=dev)
