@@ -282,6 +282,22 @@ def secondary_config(dev, steps, warmup):
             "note": "X fits the Infinity Cache at this size: the fraction is cache-served, not HBM"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` as typed: start N ranks (one per GPU) with torch.distributed.run as CHILD
+    processes and return their exit status. Rank 0 of the children prints the JSON line on the inherited stdout.
+    Called before anything in this process has touched the GPU; this process never execs."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -299,16 +315,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        sys.exit("bench.py: --gpus N > 1 must be launched with `python -m torch.distributed.run "
-                 "--nproc-per-node N ...` (one rank per GPU)")
-    local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed as `python bench.py --gpus N`: this process has made no GPU call yet; it only starts the N ranks
+        # as children (one per GPU) and leaves with their status — it never replaces itself
+        sys.exit(launch_ranks(args.gpus))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    backend = os.environ.get("RGBX_DIST_BACKEND", "nccl")
+    test_backend = None
+    if backend == "gloo" and not torch.cuda.is_available():
+        # CPU rehearsal of the N > 1 host logic (tests/test_bench_cli.py): gloo collectives and an aggregator the TEST
+        # injects; the product has no CPU aggregation path of its own, so without one this is an error
+        spec = os.environ.get("RGBX_TEST_AGGREGATOR")
+        if world == 1 or not spec:
+            sys.exit("bench.py: no MI355X visible; the only CPU mode is the gloo rehearsal of --gpus N > 1 with "
+                     "RGBX_TEST_AGGREGATOR=module:Class set by a test")
+        mod, cls_name = spec.split(":")
+        test_backend = getattr(__import__(mod, fromlist=[cls_name]), cls_name)()
+        dev = torch.device("cpu")
+    else:
+        local_rank %= max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         # RGBX_DIST_BACKEND=gloo rehearses the N>1 code path with several ranks on ONE GPU (host-staged
-        # collectives); the real runs use RCCL ("nccl").
-        backend = os.environ.get("RGBX_DIST_BACKEND", "nccl")
+        # collectives) or on the CPU (above); the real runs use RCCL ("nccl").
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:

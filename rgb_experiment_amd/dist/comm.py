@@ -2,6 +2,8 @@
 tensors, the all-to-all runs asynchronously on RCCL's stream so the local-edge SpMM overlaps it.
 Rehearsal/tests: backend 'gloo'; device tensors are staged through host memory (gloo has no device
 all-to-all), CPU tensors go straight through."""
+import threading
+
 import torch
 import torch.distributed as dist
 
@@ -11,29 +13,94 @@ class _Done:
         return True
 
 
+class TakeTurns:
+    """Two (or more) host threads issue work for ONE communicator in a fixed, rank-independent order: a thread
+    runs until it is about to WAIT for an exchange it has issued, then hands the turn to the next thread that is
+    still running. With one eval forward per thread (DistRunner.epoch) the second forward's kernels and exchanges
+    are enqueued while the first one's exchange is in flight, so the collectives of both forwards interleave on
+    RCCL's one stream in the same order on every rank (the hand-over points depend only on the model and the
+    scheme, which all ranks share) and each forward's exchange overlaps the other's aggregation."""
+
+    def __init__(self, n):
+        self.cv = threading.Condition()
+        self.turn = 0
+        self.alive = [True] * n
+        self.local = threading.local()
+
+    def enter(self, me):
+        self.local.me = me
+        with self.cv:
+            self.cv.wait_for(lambda: self.turn == me)
+
+    def _pass_on(self, me):
+        n = len(self.alive)
+        for step in range(1, n + 1):
+            cand = (me + step) % n
+            if self.alive[cand]:
+                self.turn = cand
+                break
+        self.cv.notify_all()
+
+    def hand_over(self):
+        me = getattr(self.local, "me", None)
+        if me is None:
+            return
+        with self.cv:
+            self._pass_on(me)
+            self.cv.wait_for(lambda: self.turn == me)
+
+    def leave(self):
+        me = self.local.me
+        with self.cv:
+            self.alive[me] = False
+            self._pass_on(me)
+        self.local.me = None
+
+
+class _TurnWork:
+    """`work.wait()` that first lets the other forward issue its share (TakeTurns)."""
+
+    def __init__(self, work, turns):
+        self.work, self.turns = work, turns
+
+    def wait(self):
+        self.turns.hand_over()
+        return self.work.wait()
+
+
 class Comm:
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.turns = None  # a TakeTurns while two forwards are being interleaved
+        self.bytes_sent = 0  # payload this rank handed to all-to-alls (rows * width * 4), for the bench line
+        self.exchanges = 0
 
-    def all_to_all_rows(self, send, send_counts, recv_counts):
+    def _account(self, send, send_counts):
+        own = send_counts[self.rank] if self.rank < len(send_counts) else 0
+        self.bytes_sent += (int(sum(send_counts)) - int(own)) * send.size(1) * send.element_size()
+        self.exchanges += 1
+
+    def all_to_all_rows(self, send, send_counts, recv_counts, tag=None):
         """Row-wise all-to-all: rank q receives send[offs[q]:offs[q+1]] of every peer, concatenated in
-        rank order. Returns (recv, work); call work.wait() before reading recv."""
+        rank order. Returns (recv, work); call work.wait() before reading recv. `tag` names the exchange's role
+        ("in", "out k/n", "halo", "resident", ...) for the emulated run's link table."""
         n_recv = int(sum(recv_counts))
         recv = torch.empty((n_recv, send.size(1)), dtype=send.dtype, device=send.device)
         if self.world == 1:
             return recv, _Done()
+        self._account(send, send_counts)
         if self.backend == "nccl" or not send.is_cuda:
             work = dist.all_to_all_single(recv, send.contiguous(), list(recv_counts), list(send_counts),
                                           group=self.group, async_op=True)
-            return recv, work
+            return recv, (work if self.turns is None else _TurnWork(work, self.turns))
         host_recv = torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_to_all_single(host_recv, send.cpu().contiguous(), list(recv_counts), list(send_counts),
                                group=self.group)
         recv.copy_(host_recv)
-        return recv, _Done()
+        return recv, (_Done() if self.turns is None else _TurnWork(_Done(), self.turns))
 
     def all_reduce_sum_(self, t):
         if self.world == 1:
@@ -49,3 +116,40 @@ class Comm:
     def barrier(self):
         if self.world > 1:
             dist.barrier(group=self.group)
+
+
+class EmulatedComm(Comm):
+    """ONE process standing in for rank `rank` of a `world`-rank job (bench.py --emulate-rank): every structure
+    and every kernel launch is exactly that rank's; an exchange delivers stand-in rows (copies of the rows being
+    sent — the values are meaningless, the shapes and the memory traffic of the kernels that consume them are not)
+    and records the bytes every link would carry. Timing such a run gives the rank's COMPUTE per epoch; the
+    exchange time is then link arithmetic on `link_bytes`."""
+
+    def __init__(self, world, rank=0):
+        self.group = None
+        self.world, self.rank, self.backend = int(world), int(rank), "emulated"
+        self.turns = None
+        self.bytes_sent = 0
+        self.exchanges = 0
+        self.log = []  # (tag, max bytes sent to one peer, max bytes received from one peer) per exchange
+
+    def all_to_all_rows(self, send, send_counts, recv_counts, tag=None):
+        n_recv = int(sum(recv_counts))
+        width = send.size(1)
+        self._account(send, send_counts)
+        peers_out = [c for q, c in enumerate(send_counts) if q != self.rank]
+        peers_in = [c for q, c in enumerate(recv_counts) if q != self.rank]
+        self.log.append((tag, max(peers_out, default=0) * width * 4, max(peers_in, default=0) * width * 4))
+        if send.size(0) == 0 or n_recv == 0:
+            return send.new_zeros((n_recv, width)), _Done()
+        reps = -(-n_recv // send.size(0))
+        recv = (send if reps == 1 else send.repeat(reps, 1))[:n_recv].contiguous()
+        if recv.data_ptr() == send.data_ptr():
+            recv = recv.clone()
+        return recv, (_Done() if self.turns is None else _TurnWork(_Done(), self.turns))
+
+    def all_reduce_sum_(self, t):
+        return t.mul_(self.world)  # as if every rank had contributed this rank's share
+
+    def barrier(self):
+        pass

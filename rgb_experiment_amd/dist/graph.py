@@ -4,7 +4,7 @@ import torch
 
 from .. import graph as _graph
 from .comm import Comm
-from .plan import PartitionPlan, edge_weights, partition_bounds, rewrite_global
+from .plan import GridPlan, PartitionPlan, partition_bounds, rewrite_global
 
 
 class HipAggregator:
@@ -81,7 +81,7 @@ class _HaloGather(torch.autograd.Function):
         ctx.dgraph, ctx.half = dgraph, half
         x = x.contiguous()
         send = dgraph.backend.gather(x, half.send_idx) if half.n_send else x.new_empty((0, x.size(1)))
-        recv, work = dgraph.comm.all_to_all_rows(send, half.send_counts, half.recv_counts)
+        recv, work = dgraph.comm.all_to_all_rows(send, half.send_counts, half.recv_counts, tag="halo")
         work.wait()
         return torch.cat([x, recv], dim=0)
 
@@ -90,7 +90,8 @@ class _HaloGather(torch.autograd.Function):
         dgraph, half = ctx.dgraph, ctx.half
         n = half.n_local
         g_loc = g_ext[:n].clone()
-        back, work = dgraph.comm.all_to_all_rows(g_ext[n:].contiguous(), half.recv_counts, half.send_counts)
+        back, work = dgraph.comm.all_to_all_rows(g_ext[n:].contiguous(), half.recv_counts, half.send_counts,
+                                                 tag="halo")
         work.wait()
         off = 0
         for cnt in half.send_counts:
@@ -128,47 +129,71 @@ class _DistAPPNPColumns(torch.autograd.Function):
 
 class DistGraph:
     """What `get_graph` returns on a rank of a partitioned run. `edge_index` is the GLOBAL int64 edge
-    list (every rank holds it at set-up; only index arithmetic touches it), `num_nodes` the global N.
+    list, needed only while the per-rank structures are being built (index arithmetic); `release_edges()` drops
+    it afterwards, so what stays resident is this rank's share. `num_nodes` is the global N.
 
-    Two exchange schemes, chosen per (kind, width) by the bytes a rank must receive per propagate:
-      * "halo"    — ship the boundary rows a rank's edges gather from (n_halo * d * 4 B), overlap with
-                    the local-edge SpMM. Wins when the partition has a small boundary.
-      * "reshard" — all-to-all transpose the row-sharded [n_local, d] activations into column shards
-                    [N, d/P], run the WHOLE graph's SpMM on d/P columns with no halo, transpose back
-                    (2 * n_local * d * 4 * (P-1)/P B). Wins on expander-like graphs (the benchmark's
-                    uniform random graph: every remote row is a boundary row).
+    Exchange schemes, chosen per feature width by a cost model (`scheme`):
+      * "halo"     - ship the boundary rows a rank's edges gather from (n_halo * d * 4 B), overlapped with
+                     the local-edge SpMM. Wins when the partition has a small boundary.
+      * "reshard"  - all-to-all transpose the row-sharded [n_local, d] activations into column shards
+                     [N, d/P], aggregate the WHOLE graph on d/P columns, transpose back
+                     (2 * n_local * d * 4 * (P-1)/P B). Least bytes on expander-like graphs (the benchmark's
+                     uniform random graph: every remote row is a boundary row).
+      * "gridRxC"  - R row groups x C column slices (plan.GridHalf; reshard is R = 1): the rank aggregates the
+                     rows of its row group at width d/C. At P = 8, d = 128 the 2 x 4 grid keeps d/C = 32 floats
+                     = one full 128-byte line per gathered row (a 16-float row costs the same line), i.e. half the
+                     line requests of the plain transpose, for twice its inbound bytes.
     """
 
     is_distributed = True
 
-    def __init__(self, edge_index, num_nodes, loops_mode, comm=None, backend=None, exchange="auto"):
+    def __init__(self, edge_index, num_nodes, loops_mode, comm=None, backend=None, exchange="auto", pieces=None):
         self.edge_index, self.N_global, self.loops_mode = edge_index, int(num_nodes), loops_mode
         self.comm = comm or Comm()
         self.backend = backend or HipAggregator()
         self.exchange = exchange
-        self._kinds, self._full, self._choice = {}, {}, {}
+        self._kinds, self._grid, self._choice = {}, {}, {}
         self._resident = None
         b = partition_bounds(self.N_global, self.comm.world)
         self.bounds = b
         self.n_local = b[self.comm.rank + 1] - b[self.comm.rank]
         self.row_counts = [b[q + 1] - b[q] for q in range(self.comm.world)]
+        # pieces the outgoing exchange of the grid schemes is cut into: piece k's all-to-all is in flight while
+        # piece k + 1 is aggregated (one SpMM launch per piece), so 1/pieces of it is exposed
+        self.pieces = int(pieces) if pieces else 4
+
+    def _edges(self):
+        if self.edge_index is None:
+            raise RuntimeError("DistGraph: the global edge list was released (release_edges()); a structure that "
+                               "was not built before the release is being asked for")
+        return self.edge_index
+
+    def release_edges(self):
+        """Drop the global edge list: from here on only the structures already built (this rank's CSRs, send /
+        receive lists, resident boundary rows) stay in HBM."""
+        self.edge_index = None
 
     # ---- halo scheme ---------------------------------------------------------------------------
     def _get(self, kind):
         st = self._kinds.get(kind)
         if st is None:
-            plan = PartitionPlan(self.edge_index, self.N_global, self.comm.world, self.comm.rank,
+            plan = PartitionPlan(self._edges(), self.N_global, self.comm.world, self.comm.rank,
                                  self.loops_mode, kind)
             st = {"plan": plan}
-            for name, half in (("fwd", plan.fwd), ("bwd", plan.bwd)):
-                st[name] = {
-                    "half": half,
-                    "loc": self.backend.prepare(half.loc_agg, half.loc_gather, half.n_local, half.loc_w),
-                    "rem": self.backend.prepare(half.rem_agg, half.rem_gather, half.n_local, half.rem_w)
-                    if half.n_halo else None,
-                }
             self._kinds[kind] = st
         return st
+
+    def _halo_csrs(self, kind, direction):
+        st = self._get(kind)
+        if direction not in st:
+            half = getattr(st["plan"], direction)
+            st[direction] = {
+                "half": half,
+                "loc": self.backend.prepare(half.loc_agg, half.loc_gather, half.n_local, half.loc_w),
+                "rem": self.backend.prepare(half.rem_agg, half.rem_gather, half.n_local, half.rem_w)
+                if half.n_halo else None,
+            }
+        return st[direction]
 
     def plan(self, kind):
         return self._get(kind)["plan"]
@@ -195,7 +220,7 @@ class DistGraph:
             ext = x
             if self.comm.world > 1:
                 send = self.backend.gather(x, half.send_idx) if half.n_send else x.new_empty((0, x.size(1)))
-                recv, work = self.comm.all_to_all_rows(send, half.send_counts, half.recv_counts)
+                recv, work = self.comm.all_to_all_rows(send, half.send_counts, half.recv_counts, tag="resident")
                 work.wait()
                 if half.n_halo:
                     ext = torch.cat([x, recv], dim=0)
@@ -205,7 +230,7 @@ class DistGraph:
     def _ext_csr(self, kind):
         """CSR of this rank's targets over [local; halo] sources (+ per-edge weights in its slot order)."""
         st = self._get(kind)
-        half = st["fwd"]["half"]
+        half = st["plan"].fwd
         if "ext_csr" not in st:
             agg = torch.cat([half.loc_agg, half.rem_agg])
             gather = torch.cat([half.loc_gather, half.n_local + half.rem_gather])
@@ -234,12 +259,12 @@ class DistGraph:
         return ops._PropagateLinear.apply(x_ext, _ExtGraph(csr, ws), "gcn", weight, bias, need_z, root_weight, x)
 
     def _run_halo(self, kind, direction, x):
-        d = self._get(kind)[direction]
+        d = self._halo_csrs(kind, direction)
         half = d["half"]
         work = recv = None
         if self.comm.world > 1:
             send = self.backend.gather(x, half.send_idx) if half.n_send else x.new_empty((0, x.size(1)))
-            recv, work = self.comm.all_to_all_rows(send, half.send_counts, half.recv_counts)
+            recv, work = self.comm.all_to_all_rows(send, half.send_counts, half.recv_counts, tag="halo")
         out = self.backend.run(d["loc"], x, kind=f"dist_{direction}_local")  # overlaps the exchange
         if work is not None:
             work.wait()
@@ -247,127 +272,189 @@ class DistGraph:
                 out = self.backend.run(d["rem"], recv, y=out, kind=f"dist_{direction}_remote")
         return out
 
-    # ---- reshard scheme ------------------------------------------------------------------------
-    def _get_full(self, kind):
-        st = self._full.get(kind)
+    # ---- grid schemes (reshard = 1 x P) ----------------------------------------------------------
+    def _get_grid(self, kind, C, pieces):
+        key = (kind, C, pieces)
+        st = self._grid.get(key)
         if st is None:
-            src, dst = rewrite_global(self.edge_index, self.N_global, self.loops_mode)
-            w = edge_weights(src, dst, self.N_global, kind)
-            st = {"nnz": int(src.numel()),
-                  "fwd": self.backend.prepare(dst, src, self.N_global, w),
-                  "bwd": self.backend.prepare(src, dst, self.N_global, w)}
-            self._full[kind] = st
+            plan = GridPlan(self._edges(), self.N_global, self.comm.world, self.comm.rank, self.loops_mode, kind,
+                            C, pieces)
+            st = {"plan": plan}
+            self._grid[key] = st
         return st
 
-    def _to_columns(self, x):
-        """[n_local, d] row shard -> [N, d/P] column shard (peer q receives my rows of its column slice)."""
-        P, n_loc, dc = self.comm.world, self.n_local, x.size(1) // self.comm.world
-        send = x.view(n_loc, P, dc).permute(1, 0, 2).reshape(P * n_loc, dc)
-        cols, work = self.comm.all_to_all_rows(send, [n_loc] * P, self.row_counts)
+    def _grid_half(self, kind, C, pieces, direction):
+        st = self._get_grid(kind, C, pieces)
+        if direction not in st:
+            half = getattr(st["plan"], direction)
+            st[direction] = (half, self.backend.prepare(half.agg, half.gather, half.n_group, half.w))
+            half.agg = half.gather = half.w = None  # the CSR holds them now
+        return st[direction]
+
+    def grid_plan(self, kind, d):
+        """(GridPlan, R, C) the propagate of width d runs under, or None under the halo scheme."""
+        shape = self.shape(d)
+        if shape is None:
+            return None
+        return self._get_grid(kind, shape[1], self.pieces)["plan"], shape[0], shape[1]
+
+    def _to_column_slice(self, x, R, C):
+        """[n_local, d] row shard -> [N, d/C]: column slice c of EVERY node's row, c = this rank's slice. Every
+        peer (r', c') is sent slice c' of my rows, so a slice travels to the R ranks that share it."""
+        P, n_loc, dc = self.comm.world, self.n_local, x.size(1) // C
+        send = x.view(n_loc, 1, C, dc).expand(n_loc, R, C, dc).permute(1, 2, 0, 3).reshape(P * n_loc, dc)
+        cols, work = self.comm.all_to_all_rows(send, [n_loc] * P, self.row_counts, tag="in")
         work.wait()
         return cols
 
-    def _to_rows(self, y):
-        """[N, d/P] column shard -> [n_local, d] row shard."""
-        P, n_loc, dc = self.comm.world, self.n_local, y.size(1)
-        back, work = self.comm.all_to_all_rows(y, self.row_counts, [n_loc] * P)
+    def _aggregate_and_return(self, half, handle, cols, tag):
+        """The row group's aggregate at this rank's column slice, returned to the owners of the rows, overlapped:
+        piece k of every member's block is ONE contiguous row range of the piece-major CSR, aggregated by one launch
+        straight into a send buffer and handed to an asynchronous all-to-all, which runs on RCCL's stream while piece
+        k + 1 is aggregated. Only the last piece's exchange is exposed."""
+        P, C, dc = self.comm.world, half.C, cols.size(1)
+        run_rows = getattr(self.backend, "run_rows", None)
+        out = cols.new_empty((half.n_local, C * dc))
+        full = None
+        pending = []
+        for k in range(half.pieces):
+            lo, hi = half.piece_ptr[k], half.piece_ptr[k + 1]
+            send = None
+            if full is None and run_rows is not None:
+                send = cols.new_empty((hi - lo, dc))
+                if run_rows(handle, cols, lo, hi, send, kind=tag) is False:
+                    if pending:
+                        raise RuntimeError("grid exchange: backend refused a row range after accepting one")
+                    send = None
+            if send is None:  # hub-row plan (row ids in it are absolute) or a backend without row ranges
+                if full is None:
+                    full = self.backend.run(handle, cols, kind=tag)
+                send = full[lo:hi]
+            a, b = half.my_piece[k]
+            recv_counts = [b - a if q in half.members else 0 for q in range(P)]
+            recv, work = self.comm.all_to_all_rows(send, half.piece_counts[k], recv_counts,
+                                                   tag=f"out {k + 1}/{half.pieces}")
+            pending.append((recv, work, a, b - a, send))  # `send` stays referenced until its exchange was waited on
+        for recv, work, a, m, _send in pending:
+            work.wait()
+            if m:
+                out[a:a + m].view(m, C, dc).copy_(recv.view(C, m, dc).permute(1, 0, 2))
+        return out
+
+    def _run_grid(self, kind, direction, x, shape):
+        R, C = shape
+        half, handle = self._grid_half(kind, C, self.pieces, direction)
+        cols = self._to_column_slice(x, R, C)
+        return self._aggregate_and_return(half, handle, cols, f"dist_{direction}_colshard")
+
+    def _appnp_columns(self, direction, h, K, alpha):
+        """All K steps on the whole graph at width d/P between ONE pair of transposes (R = 1, one piece: the rows
+        stay in node order, which the recurrence needs)."""
+        P = self.comm.world
+        half, handle = self._grid_half("gcn", P, 1, direction)
+        cols = self._to_column_slice(h, 1, P)
+        out = self.backend.appnp(handle, cols, K, alpha, kind=f"dist_{direction}_appnp_colshard")
+        n_loc, dc = self.n_local, out.size(1)
+        back, work = self.comm.all_to_all_rows(out, self.row_counts, [n_loc] * P, tag="out 1/1")
         work.wait()
         return back.view(P, n_loc, dc).permute(1, 0, 2).reshape(n_loc, P * dc)
 
-    # pieces the outgoing transpose is cut into (1 = one all-to-all after the whole SpMM); every piece costs one SpMM
-    # launch per peer, so fewer pieces at larger world sizes keep the host ahead of the GPU
-    reshard_chunks = None
-
-    def _chunks(self):
-        if self.reshard_chunks is not None:
-            return int(self.reshard_chunks)
-        return 4 if self.comm.world <= 4 else 2
-
-    def _run_reshard(self, kind, direction, x):
-        handle = self._get_full(kind)[direction]
-        cols = self._to_columns(x)
-        tag = f"dist_{direction}_colshard"
-        out = self._reshard_pipelined(handle, cols, tag)
-        if out is not None:
-            return out
-        return self._to_rows(self.backend.run(handle, cols, kind=tag))
-
-    def _reshard_pipelined(self, handle, cols, tag):
-        """SpMM and the transpose back to row shards, overlapped: every peer's block of destination rows is cut
-        into `reshard_chunks` pieces; piece c of ALL peers is aggregated (one launch per peer block, straight into
-        the send buffer) and handed to an asynchronous all-to-all, which runs on RCCL's stream while piece c + 1
-        is being aggregated. Only the last piece's exchange is exposed. Returns None when the backend cannot
-        aggregate row ranges (hub-row plan, test doubles without run_rows)."""
-        C = self._chunks()
-        run_rows = getattr(self.backend, "run_rows", None)
-        if C <= 1 or run_rows is None:
-            return None
-        P, n_loc, dc, b = self.comm.world, self.n_local, cols.size(1), self.bounds
-        cut = lambda n, c: (n * c) // C  # piece c of a block of n rows = rows [cut(n, c), cut(n, c + 1))
-        pending = []
-        for c in range(C):
-            counts = [cut(b[q + 1] - b[q], c + 1) - cut(b[q + 1] - b[q], c) for q in range(P)]
-            send = cols.new_empty((sum(counts), dc))
-            off = 0
-            for q in range(P):
-                lo = b[q] + cut(b[q + 1] - b[q], c)
-                if run_rows(handle, cols, lo, lo + counts[q], send[off:off + counts[q]], kind=tag) is False:
-                    if pending:
-                        raise RuntimeError("reshard: backend refused a row range after accepting one")
-                    return None
-                off += counts[q]
-            m = cut(n_loc, c + 1) - cut(n_loc, c)
-            recv, work = self.comm.all_to_all_rows(send, counts, [m] * P)
-            pending.append((recv, work, m, send))  # `send` stays referenced until its exchange has been waited on
-        parts = []
-        for recv, work, m, _send in pending:
-            work.wait()
-            parts.append(recv.view(P, m, dc).permute(1, 0, 2).reshape(m, P * dc))
-        return torch.cat(parts, dim=0)
-
-    def _appnp_columns(self, direction, h, K, alpha):
-        out = self.backend.appnp(self._get_full("gcn")[direction], self._to_columns(h), K, alpha,
-                                 kind=f"dist_{direction}_appnp_colshard")
-        return self._to_rows(out)
-
     def appnp(self, h, K, alpha):
-        """K-step APPNP on the partitioned graph; `None` when the per-iteration path should be used."""
-        if self.comm.world > 1 and self.scheme(h.size(1)) == "reshard":
+        """K-step APPNP on the partitioned graph; `None` when the per-iteration path should be used. The
+        recurrence acts on every column independently, so under any column scheme the plain transpose (R = 1) with
+        all K steps between its two exchanges moves the fewest bytes: 2 all-to-alls instead of 2K."""
+        P = self.comm.world
+        if P > 1 and self.exchange != "halo" and h.size(1) % P == 0 and self.shape(h.size(1)) is not None:
             return _DistAPPNPColumns.apply(h, self, K, alpha)
         return None
 
     # ---- choice --------------------------------------------------------------------------------
-    def halo_rows(self):
-        """Rows this rank would receive per forward propagate under the halo scheme."""
-        if "halo_rows" not in self._choice:
-            src, dst = rewrite_global(self.edge_index, self.N_global, self.loops_mode)
+    # Cost model per propagate of width d (seconds; all ranks evaluate it on all-reduced inputs):
+    #   gather rate  : the aggregation kernels sustain ~6.5 TB/s of 128-byte lines on this chip at every width
+    #                  (DESIGN.md section 5: a row of <= 32 floats costs one line), so
+    #                  t_spmm = edges * ceil(4 * width / 128) * 128 B / 6.5e12
+    #   link rate    : RGBX_LINK_GBS (default 60) GB/s per direction per xGMI link, all P - 1 links concurrently
+    #   halo         : max(boundary bytes per link / rate, local-edge SpMM) + remote-edge SpMM
+    #   grid R x C   : n_local * d/C * 4 B inbound per link, SpMM of E'/R edges at width d/C,
+    #                  1/pieces of the outbound n_local * d/C * 4 B exposed
+    GATHER_BPS = 6.5e12
+
+    def _halo_stats(self):
+        """(boundary rows this rank receives per forward propagate, its local-source edges, its remote-source
+        edges) under the halo scheme."""
+        if "halo_stats" not in self._choice:
+            src, dst = rewrite_global(self._edges(), self.N_global, self.loops_mode)
             lo, hi = self.bounds[self.comm.rank], self.bounds[self.comm.rank + 1]
-            remote = (dst >= lo) & (dst < hi) & ((src < lo) | (src >= hi))
-            self._choice["halo_rows"] = int(torch.unique(src[remote]).numel())
-        return self._choice["halo_rows"]
+            mine = (dst >= lo) & (dst < hi)
+            remote = mine & ((src < lo) | (src >= hi))
+            n_rem = int(remote.sum())
+            self._choice["halo_stats"] = (int(torch.unique(src[remote]).numel()), int(mine.sum()) - n_rem, n_rem)
+        return self._choice["halo_stats"]
+
+    def halo_rows(self):
+        return self._halo_stats()[0]
+
+    def costs(self, d):
+        """{scheme name: modelled seconds per propagate of width d}, identical on every rank."""
+        key = ("costs", d)
+        if key in self._choice:
+            return self._choice[key]
+        import math
+        import os
+        P, N = self.comm.world, self.N_global
+        link = float(os.environ.get("RGBX_LINK_GBS", "60")) * 1e9
+        stats = torch.tensor([float(v) for v in self._halo_stats()], dtype=torch.float64,
+                             device=self._edges().device)
+        halo_rows, e_loc, e_rem = (self.comm.all_reduce_sum_(stats) / P).tolist()  # means over the ranks
+        line_s = lambda edges, width: edges * math.ceil(4 * width / 128) * 128 / self.GATHER_BPS
+        out = {}
+        if self.exchange == "auto":
+            out["halo"] = max(halo_rows * d * 4 / max(P - 1, 1) / link, line_s(e_loc, d)) + line_s(e_rem, d)
+        nnz = (e_loc + e_rem) * P
+        from .plan import grid_shapes
+        for R, C in grid_shapes(P):
+            if C == 1 or d % C:
+                continue  # C = 1 is the halo scheme with every remote row shipped
+            name = "reshard" if R == 1 else f"grid{R}x{C}"
+            per_link = (N / P) * (d / C) * 4 / link
+            out[name] = per_link + line_s(nnz / R, d // C) + per_link / self.pieces
+        self._choice[key] = out
+        return out
+
+    def shape(self, d):
+        """(R, C) of the grid scheme a propagate of width d uses, or None for the halo scheme."""
+        P = self.comm.world
+        if P == 1 or self.exchange == "halo":
+            return None
+        if self.exchange == "reshard":
+            return (1, P) if d % P == 0 else None
+        if "x" in self.exchange:  # explicit "RxC"
+            R, C = (int(v) for v in self.exchange.split("x"))
+            if R * C != P:
+                raise ValueError(f"exchange={self.exchange!r} does not factor the world size {P}")
+            return (R, C) if C > 1 and d % C == 0 else None
+        costs = self.costs(d)
+        best = min(costs, key=lambda k: (costs[k], k))
+        if best == "halo":
+            return None
+        if best == "reshard":
+            return (1, P)
+        R, C = (int(v) for v in best[4:].split("x"))
+        return (R, C)
 
     def scheme(self, d):
-        """'halo' or 'reshard' for feature width d (all ranks reach the same answer). Reshard needs
-        d divisible by the world size."""
-        P = self.comm.world
-        if P == 1 or d % P != 0 or self.exchange == "halo":
+        """'halo', 'reshard' (1 x P) or 'gridRxC' for feature width d (all ranks reach the same answer)."""
+        shape = self.shape(d)
+        if shape is None:
             return "halo"
-        if self.exchange == "reshard":
-            return "reshard"
-        key = ("scheme", d)
-        if key not in self._choice:
-            halo_bytes = torch.tensor([float(self.halo_rows()) * d * 4], dtype=torch.float64,
-                                      device=self.edge_index.device)
-            halo_bytes = self.comm.all_reduce_sum_(halo_bytes).item() / P  # mean over ranks
-            reshard_bytes = 2.0 * (self.N_global / P) * d * 4 * (P - 1) / P
-            self._choice[key] = "reshard" if reshard_bytes < halo_bytes else "halo"
-        return self._choice[key]
+        return "reshard" if shape[0] == 1 else f"grid{shape[0]}x{shape[1]}"
 
     def _run(self, kind, direction, x):
         if direction == "fwd" and self.is_resident(x):
             return self._run_resident(kind, x)
-        if self.comm.world > 1 and self.scheme(x.size(1)) == "reshard":
-            return self._run_reshard(kind, direction, x.contiguous())
+        shape = self.shape(x.size(1)) if self.comm.world > 1 else None
+        if shape is not None:
+            return self._run_grid(kind, direction, x.contiguous(), shape)
         return self._run_halo(kind, direction, x)
 
     def propagate(self, x, kind):
@@ -381,7 +468,7 @@ class DistGraph:
         transform is applied here, to local and halo rows alike."""
         st = self._kinds.get("gat")
         if st is None:
-            plan = PartitionPlan(self.edge_index, self.N_global, self.comm.world, self.comm.rank,
+            plan = PartitionPlan(self._edges(), self.N_global, self.comm.world, self.comm.rank,
                                  self.loops_mode, "sum")
             f = plan.fwd
             agg = torch.cat([f.loc_agg, f.rem_agg])
@@ -399,12 +486,12 @@ class DistGraph:
         return self.backend.gat(st["rect"], x_ext, att_src, att_dst, half.n_local, H, C, slope)
 
 
-def install(token_edge_index, n_local, edge_index, num_nodes, comm=None, backend=None, exchange="auto"):
+def install(token_edge_index, n_local, edge_index, num_nodes, comm=None, backend=None, exchange="auto", pieces=None):
     """Register DistGraphs so that conv layers called with (x_local, token_edge_index) aggregate over
     the partitioned global graph. Returns {loops_mode: DistGraph}."""
     graphs = {}
     for mode in (_graph.LOOPS_KEEP, _graph.LOOPS_ADD_REMAINING, _graph.LOOPS_REMOVE_ADD):
-        g = DistGraph(edge_index, num_nodes, mode, comm, backend, exchange)
+        g = DistGraph(edge_index, num_nodes, mode, comm, backend, exchange, pieces)
         _graph.register_graph(token_edge_index, n_local, mode, g)
         graphs[mode] = g
     return graphs

@@ -102,3 +102,75 @@ class PartitionPlan:
         self.bwd = HalfPlan(src, dst, w, num_nodes, world, rank)
         self.n_local = self.fwd.n_local
         self.nnz_local = int(self.fwd.loc_agg.numel() + self.fwd.rem_agg.numel())
+
+
+def grid_shapes(world):
+    """(R, C) factorisations of the world size: R row groups x C column slices."""
+    return [(world // c, c) for c in range(1, world + 1) if world % c == 0]
+
+
+class GridHalf:
+    """One direction of the row-group x column-slice scheme for one rank.
+
+    Rank p = r*C + c. Its ROW GROUP r is the union of the node ranges of ranks r*C .. r*C+C-1; its COLUMN SLICE c
+    is columns [c*d/C, (c+1)*d/C) of whatever feature width d is propagated. Per propagate the rank
+      1. receives column slice c of EVERY node's row (all-to-all, every peer sends its own rows),
+      2. aggregates into the rows of its row group from all N sources at width d/C,
+      3. returns to each rank of its row group that rank's rows (all-to-all inside the row group).
+    R = 1 is the plain transpose ("reshard"); R > 1 keeps d/C at a full 128-byte line for narrow d/P at the price
+    of a larger inbound exchange.
+
+    The group's rows are stored PIECE-MAJOR: piece k of every group member's block first (members in rank order),
+    then piece k+1, ... so that the rows one outbound all-to-all carries form ONE contiguous row range of the CSR,
+    already in send-buffer order. `pieces` is fixed here.
+    agg / gather: GLOBAL int64 index vectors of the rewritten edge list (aggregate-into, gather-from)."""
+
+    def __init__(self, agg, gather, weight, num_nodes, world, rank, C, pieces):
+        bounds = partition_bounds(num_nodes, world)
+        R = world // C
+        r, c = rank // C, rank % C
+        self.R, self.C, self.r, self.c, self.pieces = R, C, r, c, pieces
+        self.members = list(range(r * C, (r + 1) * C))  # ranks of my row group
+        glo, ghi = bounds[r * C], bounds[(r + 1) * C]
+        self.group_lo, self.n_group = glo, ghi - glo
+        self.n_local = bounds[rank + 1] - bounds[rank]
+        self.row_counts = [bounds[q + 1] - bounds[q] for q in range(world)]
+        dev = agg.device
+
+        cut = lambda n, k: (n * k) // pieces
+        # position of every group row in piece-major order, and per piece the rows each member receives
+        pos = torch.empty(self.n_group, dtype=torch.int64, device=dev)
+        self.piece_ptr = [0]
+        self.piece_counts = []  # [pieces][world] rows sent to every rank in piece k (0 outside the row group)
+        off = 0
+        for k in range(pieces):
+            counts = [0] * world
+            for q in self.members:
+                nq = bounds[q + 1] - bounds[q]
+                a, b = cut(nq, k), cut(nq, k + 1)
+                lo = bounds[q] - glo
+                pos[lo + a:lo + b] = torch.arange(off, off + (b - a), device=dev)
+                off += b - a
+                counts[q] = b - a
+            self.piece_counts.append(counts)
+            self.piece_ptr.append(off)
+        # rows of mine that piece k returns: [cut(n_local, k), cut(n_local, k+1))
+        self.my_piece = [(cut(self.n_local, k), cut(self.n_local, k + 1)) for k in range(pieces)]
+
+        mine = (agg >= glo) & (agg < ghi)
+        self.agg = pos[agg[mine] - glo]
+        self.gather = gather[mine]
+        self.w = None if weight is None else weight[mine]
+        self.nnz = int(self.agg.numel())
+
+
+class GridPlan:
+    """Forward + backward GridHalf for one (graph, rewrite mode, weighting kind, rank, C, pieces)."""
+
+    def __init__(self, edge_index, num_nodes, world, rank, loops_mode, kind, C, pieces):
+        src, dst = rewrite_global(edge_index, num_nodes, loops_mode)
+        w = edge_weights(src, dst, num_nodes, kind)
+        self.num_nodes, self.world, self.rank, self.kind = num_nodes, world, rank, kind
+        self.nnz_total = int(src.numel())
+        self.fwd = GridHalf(dst, src, w, num_nodes, world, rank, C, pieces)
+        self.bwd = GridHalf(src, dst, w, num_nodes, world, rank, C, pieces)

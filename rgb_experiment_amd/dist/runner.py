@@ -16,7 +16,8 @@ class DistRunner:
     rank keeps its node slice of x / y / masks and the whole edge list for index arithmetic."""
 
     def __init__(self, model, edge_index, x, y, masks, rank, world, device, lr=0.01, weight_decay=0.0,
-                 comm=None, backend=None, exchange="auto", resident_features=True):
+                 comm=None, backend=None, exchange="auto", resident_features=True, pieces=None,
+                 interleave_evals=True):
         self.comm = comm or Comm()
         self.rank, self.world, self.device = rank, world, device
         N = x.size(0)
@@ -25,10 +26,12 @@ class DistRunner:
         self.x = x[lo:hi].to(device).contiguous()
         self.y = y[lo:hi].to(device)
         self.masks = [m[lo:hi].to(device) for m in masks]
-        self.edge_index = edge_index.to(device)
-        # the conv layers see (x_local, token): the token's cache entries are the DistGraphs
+        # the conv layers see (x_local, token): the token's cache entries are the DistGraphs. The global edge list is
+        # on the device only until this rank's structures exist (release_edge_list)
         self.token = torch.zeros((2, 1), dtype=torch.int64, device=device)
-        self.graphs = install(self.token, hi - lo, self.edge_index, N, self.comm, backend, exchange)
+        self.graphs = install(self.token, hi - lo, edge_index.to(device), N, self.comm, backend, exchange, pieces)
+        self.interleave_evals = interleave_evals and world > 1
+        self._streams = None
         if resident_features:
             for g in self.graphs.values():
                 g.pin_resident(self.x)  # boundary rows of the static features are fetched once and kept
@@ -40,6 +43,12 @@ class DistRunner:
     # ---- statistics used by bench.py --------------------------------------------------------
     def plan(self, loops_mode, kind):
         return self.graphs[loops_mode].plan(kind)
+
+    def release_edge_list(self):
+        """Call after the first epoch (every structure the model uses has been built by then): the global int64
+        edge list leaves HBM; what stays is this rank's CSRs, exchange lists and resident boundary rows."""
+        for g in self.graphs.values():
+            g.release_edges()
 
     def _sync_grads(self):
         grads = [p.grad for p in self.model.parameters() if p.grad is not None]
@@ -92,14 +101,64 @@ class DistRunner:
         stats = (self.comm.all_reduce_sum_(stats) / self.mask_counts[which]).tolist()
         return stats[0], stats[1], res
 
+    def _interleaved_evals(self):
+        """The val and the test forward (itexperiments.py:464-473: two full eval forwards per epoch, both run here)
+        issued by two host threads that take turns at their exchange waits (comm.TakeTurns), each on its own HIP
+        stream: one forward's all-to-all is in flight while the other forward aggregates. Same kernels, same
+        numbers as two forwards in a row."""
+        import threading
+        from .comm import TakeTurns
+        cuda = self.device.type == "cuda"
+        if cuda and self._streams is None:
+            self._streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+        turns = TakeTurns(2)
+        out, err = [None, None], [None, None]
+        main = torch.cuda.current_stream(self.device) if cuda else None
+
+        def run(i):
+            turns.enter(i)
+            try:
+                if cuda:
+                    torch.cuda.set_device(self.device)
+                    self._streams[i].wait_stream(main)
+                    with torch.cuda.stream(self._streams[i]):
+                        out[i] = self.evaluate(1 + i, sync=False)[0]
+                else:
+                    out[i] = self.evaluate(1 + i, sync=False)[0]
+            except BaseException as exc:  # re-raised by the caller; the other thread must not wait for this one
+                err[i] = exc
+            finally:
+                turns.leave()
+
+        self.model.eval()
+        self.comm.turns = turns
+        try:
+            threads = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            self.comm.turns = None
+        for e in err:
+            if e is not None:
+                raise e
+        if cuda:
+            for s in self._streams:
+                main.wait_stream(s)
+        return out
+
     def epoch(self):
         """1 train forward+backward+Adam, then val and test forwards, as the reference loop body. The five
         numbers the reference reads with .item() along the way are only used after the epoch: they are reduced
         over the ranks in ONE all-reduce and read back in ONE copy, so the queues drain once per epoch, not three
         times."""
         tl = self.train_step(sync=False)
-        v, _ = self.evaluate(1, sync=False)
-        s, _ = self.evaluate(2, sync=False)
+        if self.interleave_evals:
+            v, s = self._interleaved_evals()
+        else:
+            v, _ = self.evaluate(1, sync=False)
+            s, _ = self.evaluate(2, sync=False)
         p = self.comm.all_reduce_sum_(torch.cat([tl, v, s])).tolist()
         cv, cs = self.mask_counts[1], self.mask_counts[2]
         return p[0], p[1] / cv, p[2] / cv, p[3] / cs, p[4] / cs

@@ -108,8 +108,8 @@ def propagate_worker(rank, world, port, out_dir, exchange="halo"):
     dist.destroy_process_group()
 
 
-def reshard_chunk_worker(rank, world, port, out_dir):
-    """The column-shard propagate with the outgoing transpose in 1, 3 (ragged) and 4 pieces: identical rows."""
+def reshard_chunk_worker(rank, world, port, out_dir, exchange="reshard"):
+    """The column-shard propagate with the outgoing exchange in 1, 3 (ragged) and 4 pieces: identical rows."""
     _init(rank, world, port)
     from rgb_experiment_amd.dist import Comm, DistGraph, partition_bounds
     ei, x, _, _ = make_problem(n=103, e=1200, f=12)
@@ -117,9 +117,8 @@ def reshard_chunk_worker(rank, world, port, out_dir):
     lo, hi = partition_bounds(n, world)[rank:rank + 2]
     outs = {}
     for chunks in (1, 3, 4):
-        dg = DistGraph(ei, n, 1, Comm(), OracleAggregator(), "reshard")
-        dg.reshard_chunks = chunks
-        assert dg.scheme(x.size(1)) == "reshard"
+        dg = DistGraph(ei, n, 1, Comm(), OracleAggregator(), exchange, pieces=chunks)
+        assert dg.scheme(x.size(1)) == ("reshard" if exchange == "reshard" else "grid" + exchange)
         xl = x[lo:hi].clone().requires_grad_(True)
         out = dg.propagate(xl, "gcn")
         out.sum().backward()
@@ -128,7 +127,7 @@ def reshard_chunk_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def runner_worker(rank, world, port, out_dir, model_name, exchange="halo"):
+def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", interleave=True, release=False):
     """Three epochs of DistRunner (train + evals) — compared by the test with single-process training."""
     _init(rank, world, port)
     from rgb_experiment_amd import models as M
@@ -137,8 +136,11 @@ def runner_worker(rank, world, port, out_dir, model_name, exchange="halo"):
     torch.manual_seed(14530529)
     model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
     r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
-                   backend=OracleAggregator(), exchange=exchange)
-    hist = [r.epoch() for _ in range(3)]
+                   backend=OracleAggregator(), exchange=exchange, interleave_evals=interleave)
+    hist = [r.epoch()]
+    if release:  # every structure exists after one epoch: the global edge list may go
+        r.release_edge_list()
+    hist += [r.epoch() for _ in range(2)]
     torch.save({"hist": hist, "logits_eval": r.logits(False), "lo": r.lo, "hi": r.hi,
                 "state": {k: v.clone() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"run_{model_name}_{rank}.pt"))
@@ -154,9 +156,9 @@ def exchange_count_worker(rank, world, port, out_dir, model_name, resident):
     class CountingComm(Comm):
         calls = 0
 
-        def all_to_all_rows(self, send, send_counts, recv_counts):
+        def all_to_all_rows(self, send, send_counts, recv_counts, tag=None):
             CountingComm.calls += 1
-            return super().all_to_all_rows(send, send_counts, recv_counts)
+            return super().all_to_all_rows(send, send_counts, recv_counts, tag)
 
     ei, x, y, masks = make_problem()
     torch.manual_seed(14530529)

@@ -48,7 +48,37 @@ def test_plan_is_consistent_and_covers_every_edge():
                     assert int(hp.loc_gather.max()) < hp.n_local
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "halo"), (3, "halo"), (2, "reshard"), (3, "reshard"), (3, "auto")])
+def test_grid_plan_covers_every_edge_once_and_orders_rows_piece_major():
+    """plan.GridHalf: the row groups partition the edges; the piece-major order is a permutation of the group's
+    rows in which piece k of every member's block is one contiguous range."""
+    from rgb_experiment_amd.dist.plan import GridPlan, grid_shapes, partition_bounds
+    ei, x, _, _ = W.make_problem()
+    n = x.size(0)
+    assert grid_shapes(8) == [(8, 1), (4, 2), (2, 4), (1, 8)]
+    for world, C, pieces in ((4, 2, 3), (6, 3, 2), (6, 2, 4), (4, 4, 1)):
+        b = partition_bounds(n, world)
+        plans = [GridPlan(ei, n, world, r, 1, "gcn", C, pieces) for r in range(world)]
+        for half in ("fwd", "bwd"):
+            hs = [getattr(p, half) for p in plans]
+            # ranks of one row group hold the same rows; over the R groups every rewritten edge appears once
+            assert sum(hs[r * C].nnz for r in range(world // C)) == plans[0].nnz_total
+            for p, h in enumerate(hs):
+                assert h.members == list(range((p // C) * C, (p // C + 1) * C))
+                assert h.n_group == b[(p // C + 1) * C] - b[(p // C) * C]
+                assert sorted(torch.unique(h.agg).tolist()) == sorted(set(h.agg.tolist())) and int(h.agg.max()) < h.n_group
+                assert h.piece_ptr[-1] == h.n_group and len(h.piece_ptr) == pieces + 1
+                for k in range(pieces):
+                    assert sum(h.piece_counts[k]) == h.piece_ptr[k + 1] - h.piece_ptr[k]
+                    assert all(h.piece_counts[k][q] == 0 for q in range(world) if q not in h.members)
+                # what the members send me in piece k is what I expect to receive
+                for k in range(pieces):
+                    a, e = h.my_piece[k]
+                    for q in h.members:
+                        assert hs[q].piece_counts[k][p] == e - a
+
+
+@pytest.mark.parametrize("world,exchange", [(2, "halo"), (3, "halo"), (2, "reshard"), (3, "reshard"), (3, "auto"),
+                                            (4, "2x2"), (6, "2x3"), (6, "3x2")])
 def test_distributed_propagate_matches_single_process(world, exchange, tmp_path):
     mp.spawn(W.propagate_worker, args=(world, _free_port(), str(tmp_path), exchange), nprocs=world, join=True)
     ei, x, _, _ = W.make_problem()
@@ -57,10 +87,12 @@ def test_distributed_propagate_matches_single_process(world, exchange, tmp_path)
     parts = [torch.load(os.path.join(tmp_path, f"prop_{r}.pt")) for r in range(world)]
     schemes = parts[0]["schemes"]
     assert all(p["schemes"] == schemes for p in parts)  # every rank takes the same branch
-    if exchange != "auto":
+    if exchange in ("halo", "reshard"):
         assert set(schemes) == {exchange}  # feature width 12 is divisible by 2 and 3
-    else:  # dense random graph: every remote row is a boundary row, so the transpose is cheaper
-        assert set(schemes) == {"reshard"}
+    elif "x" in exchange:
+        assert set(schemes) == {"grid" + exchange}
+    else:  # the cost model's pick: whatever it is, one of the known schemes (and the same on every rank)
+        assert set(schemes) <= {"halo", "reshard"}
     for mode, kind in ((1, "gcn"), (2, "mean"), (0, "mean"), (0, "sum")):
         rei, _ = O.rewrite_edges(ei, n, mode)
         xr = x.clone().requires_grad_(True)
@@ -122,14 +154,16 @@ def _single_process_reference(model_name):
 @pytest.mark.parametrize("model_name,world,exchange", [("gcn", 2, "halo"), ("gcn", 3, "halo"), ("graphsage", 2, "halo"),
                                                         ("graphsage2", 2, "halo"), ("appnpstack", 2, "halo"),
                                                         ("gcn", 2, "reshard"), ("graphsage2", 2, "auto"), ("gat", 2, "halo"),
-                                                        ("gat", 3, "auto"), ("appnpstack", 2, "reshard")])
+                                                        ("gat", 3, "auto"), ("appnpstack", 2, "reshard"),
+                                                        ("gcn", 4, "2x2"), ("graphsage", 4, "2x2"),
+                                                        ("appnpstack", 4, "2x2")])
 def test_dist_runner_training_matches_single_process(model_name, world, exchange, tmp_path):
     """Train-mode BatchNorm uses batch statistics in the oracle and reduced statistics in the runner, so
     train losses and trained WEIGHTS must agree; eval losses use running statistics, which the
     oracle's functional BN does not update, so they are compared in a separate running-stat-free way:
     every rank's trained parameters are identical and equal to the single-process ones."""
-    mp.spawn(W.runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange), nprocs=world,
-             join=True)
+    mp.spawn(W.runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, True, True),
+             nprocs=world, join=True)
     parts = [torch.load(os.path.join(tmp_path, f"run_{model_name}_{r}.pt")) for r in range(world)]
     hist, params = _single_process_reference(model_name)
     for r in range(1, world):  # replicated parameters stay bit-identical across ranks
@@ -171,12 +205,25 @@ def test_resident_input_features_remove_the_first_layer_exchange(model_name, wit
         assert abs(a[1] - b[1]) < 5e-3 and abs(a[3] - b[3]) < 5e-3, (a, b)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_pipelined_reshard_equals_the_single_exchange(world, tmp_path):
-    """DistGraph._reshard_pipelined (SpMM by pieces of every peer's row block, each piece's all-to-all in flight
-    while the next is aggregated) returns exactly the rows of the one-shot transpose, forward and backward, also
-    with ragged pieces (103 nodes, 3 pieces, 3 ranks; f = 12 columns, 4 per rank)."""
-    mp.spawn(W.reshard_chunk_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+def test_interleaved_eval_forwards_equal_sequential_ones(tmp_path):
+    """DistRunner._interleaved_evals (val and test forward issued by two host threads that take turns at their
+    exchange waits) gives the numbers of two forwards in a row, and the same on every rank."""
+    res = {}
+    for interleave in (True, False):
+        mp.spawn(W.runner_worker, args=(2, _free_port(), str(tmp_path), "gcn", "reshard", interleave), nprocs=2,
+                 join=True)
+        res[interleave] = [torch.load(os.path.join(tmp_path, f"run_gcn_{r}.pt")) for r in range(2)]
+    assert res[True][0]["hist"] == res[False][0]["hist"] == res[True][1]["hist"]
+    for k, v in res[True][0]["state"].items():
+        assert torch.equal(v, res[False][0]["state"][k]), k
+
+
+@pytest.mark.parametrize("world,exchange", [(2, "reshard"), (3, "reshard"), (4, "2x2")])
+def test_pipelined_reshard_equals_the_single_exchange(world, exchange, tmp_path):
+    """DistGraph._aggregate_and_return (the row group's rows in piece-major order, one SpMM per piece, each piece's
+    all-to-all in flight while the next is aggregated) returns exactly the rows of the one-shot exchange, forward
+    and backward, also with ragged pieces (103 nodes, 3 pieces, 3 ranks; f = 12 columns, 4 per rank)."""
+    mp.spawn(W.reshard_chunk_worker, args=(world, _free_port(), str(tmp_path), exchange), nprocs=world, join=True)
     for r in range(world):
         outs = torch.load(os.path.join(tmp_path, f"chunks_{r}.pt"))
         for chunks in (3, 4):
