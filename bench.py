@@ -16,14 +16,18 @@ Inputs are resident in HBM before the timed region.
 Metric (BASELINE.json): "aggregated edges/sec + training epochs/sec, full-graph GCN d=128".
   value            = edges aggregated per second over the WHOLE step = 7 * E' * steps / wall time
   epochs_per_s     = steps / wall time
-  spmm_edges_per_s = E' / mean SpMM kernel time (HIP events on the launch stream)
-  roofline         = algorithmic bytes of one SpMM / mean SpMM kernel time vs 8 TB/s HBM
+  spmm_edges_per_s = E' / mean aggregation kernel time (HIP events on the launch stream)
+  roofline         = algorithmic bytes of one aggregation launch / its mean duration vs 8 TB/s HBM
 
-Launch: `python bench.py [--gpus 1]`, or for N > 1 one rank per GPU under torch.distributed.run
-(RANK / LOCAL_RANK / WORLD_SIZE from the environment); the graph is then 1-D node-partitioned over the
-ranks with an RCCL all-to-all halo exchange per propagate (strong scaling: total work is fixed).
+Launch: `python bench.py [--gpus 1]`; `python bench.py --gpus N` starts N ranks (one per GPU) as child
+processes under torch.distributed.run; the driver's own `python -m torch.distributed.run ... bench.py --gpus N`
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment) runs the ranks directly. The graph is then 1-D
+node-partitioned over the ranks with RCCL all-to-all exchanges per propagate (strong scaling: total work fixed).
+`--emulate-rank P` runs exactly rank 0's kernel launches of a P-rank job on ONE GPU (exchanges replaced by
+stand-in rows) and reports its compute time per epoch next to the bytes every xGMI link would carry.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -39,11 +43,33 @@ import torch
 import torch.distributed as dist
 
 WORKLOADS = {
-    # BASELINE.json configs[1] / the north-star target size (S and L)
+    # BASELINE.json configs[1] / the north-star target size (S and L); T = the CLI test's toy size
+    "T": dict(N=3_000, E=40_000, d=32, name="toy |V|=3k |E|=40k d=32, 2-layer GCN"),
     "S": dict(N=200_000, E=4_000_000, d=128, name="synthetic |V|=200k |E|=4M d=128, 2-layer GCN"),
     "L": dict(N=2_000_000, E=60_000_000, d=128, name="synthetic |V|=2M |E|=60M d=128, 2-layer GCN"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+# event kind (ops._Timed) -> the HIP kernel that launch is
+KERNEL_OF_KIND = {
+    "gcn_linear_fwd": "spmm_linear_kernel", "mean_linear_fwd": "spmm_linear_kernel",
+    "gcn_linear_bwd": "spmm_linear_kernel", "mean_linear_bwd": "spmm_linear_kernel",
+    "gcn_fwd": "spmm_csr_kernel", "gcn_bwd": "spmm_csr_kernel", "mean_fwd": "spmm_csr_kernel",
+    "mean_bwd": "spmm_csr_kernel", "appnp_fwd": "spmm_csr_kernel (K launches)",
+    "appnp_bwd": "spmm_csr_kernel (K launches)", "gat_fwd": "gat_fwd_kernel", "gat_bwd_src": "gat_bwd_src_kernel",
+    "gat_bwd_prep": "gat_bwd_prep_kernel", "gat_bwd_segsum": "spmm_csr_kernel (width H)",
+    "dist_fwd_local": "spmm_csr_kernel", "dist_fwd_remote": "spmm_csr_kernel", "dist_bwd_local": "spmm_csr_kernel",
+    "dist_bwd_remote": "spmm_csr_kernel", "dist_fwd_resident": "spmm_csr_kernel",
+    "dist_fwd_colshard": "spmm_csr_kernel", "dist_bwd_colshard": "spmm_csr_kernel",
+    "dist_fwd_appnp_colshard": "spmm_csr_kernel (K launches)", "dist_bwd_appnp_colshard": "spmm_csr_kernel (K launches)",
+}
+AGG_KINDS = tuple(KERNEL_OF_KIND)
+KERNEL_SOURCES = {  # files whose text decides what the kernel does: a PMC figure is only valid for this hash
+    "spmm_linear_kernel": ("spmm_linear.hip", "spmm_internal.h", "rgbx_common.h"),
+    "spmm_csr_kernel": ("spmm.hip", "spmm_internal.h", "rgbx_common.h"),
+    "gat_fwd_kernel": ("gat.hip", "spmm_internal.h", "rgbx_common.h"),
+    "gat_bwd_src_kernel": ("gat.hip", "spmm_internal.h", "rgbx_common.h"),
+}
 
 
 def synth(N, E, d):
@@ -55,28 +81,43 @@ def synth(N, E, d):
     return ei, x, y
 
 
-def split_masks(N):
-    """6-2-2 split. The reference's get_whole_mask shuffles a Python list of N ints (seconds at 2M
-    nodes, outside the timed region either way); a seeded permutation gives the same row counts."""
-    perm = torch.randperm(N, generator=torch.Generator().manual_seed(123456789))
-    a, b = int(0.6 * N), int(0.6 * N) + int(0.2 * N)
-    masks = []
-    for part in (perm[:a], perm[a:b], perm[b:]):
-        m = torch.zeros(N, dtype=torch.bool)
-        m[part] = True
-        masks.append(m)
-    return masks
+def split_masks(y):
+    """The reference's default split: get_whole_mask(y, '6-2-2', 123456789) (itexperiments.py:47-49,215), the
+    product's bit-exact restatement (golden G4). Seconds at 2M nodes (a Python-list shuffle), outside the timing."""
+    from rgb_experiment_amd.utils import get_whole_mask
+    return list(get_whole_mask(y, "6-2-2", 123456789))
 
 
-def pmc_traffic(workload, world):
-    """HBM-side bytes per SpMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
-    WRITE_SIZE, gfx950 correction; profiles/pmc_traffic_<workload>.json). PMC counters cannot be read
-    from inside this process, so this is the last profiled value for the same kernel and workload, or None."""
-    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
-    if world != 1 or not os.path.exists(path):
+def kernel_source_hash(kernel):
+    base = kernel.split(" ")[0]
+    files = KERNEL_SOURCES.get(base)
+    if not files:
         return None
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "rgb_experiment_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload, model, kernel, world):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
+    WRITE_SIZE, gfx950 correction; profiles/pmc_traffic_<workload>_<model>.json, written by tools/profile_summary.py).
+    PMC counters cannot be read from inside this process, so this is the last profiled value — returned only when
+    the file was measured on the SAME kernel sources (hash stamp); otherwise None plus the reason."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}_{model}.json")
+    if world != 1:
+        return None, "single-GPU figure only"
+    if not os.path.exists(path):
+        return None, "no PMC pass committed for this workload / model"
     with open(path) as f:
-        return json.load(f)["traffic_bytes_per_launch"]
+        rec = json.load(f)
+    base = kernel.split(" ")[0]
+    if rec.get("kernel") != base:
+        return None, f"committed PMC pass is for {rec.get('kernel')}, the dominant kernel now is {base}"
+    if rec.get("source_hash") != kernel_source_hash(kernel):
+        return None, "kernel sources changed since the committed PMC pass (stale)"
+    return rec["traffic_bytes_per_launch"], f"rocprofv3 PMC, {rec.get('measured', '?')}"
 
 
 def gat_alg_bytes(n_rows, nnz, d, H=8):
@@ -93,6 +134,11 @@ def spmm_alg_bytes(n_rows, nnz, d):
     return nnz * (4 * d + 8) + n_rows * 4 * d + 4 * (n_rows + 1)
 
 
+def spmm_compulsory_bytes(n_rows, nnz, d):
+    """every feature row read once and written once, the CSR stream, rowptr."""
+    return 2 * n_rows * 4 * d + nnz * 8 + 4 * (n_rows + 1)
+
+
 def host_cores():
     """Cores this process may actually use: the cgroup CPU quota if there is one (a one-GPU box grants
     a share of the host, not all of os.cpu_count()), else the affinity mask."""
@@ -106,14 +152,36 @@ def host_cores():
     return n
 
 
-def cpu_baseline(ei, x, N, budget_s=20.0, hip_propagate=None):
+MODELS = {
+    # name: (constructor kwargs, propagates per epoch = 3 forwards + 1 backward, loops_mode, weighting kind)
+    # gcn: 2 + 2 + 2 forward SpMMs and ONE transposed SpMM (layer 2); layer 1's weight gradient is taken
+    # against A_hat x, so nothing flows back through A_hat^T there (nn/conv.py GCNConv)
+    "gcn": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 7, 1, "gcn"),
+    "graphsage": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 7, 2, "mean"),
+    "graphsage2": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 7, 0, "mean"),
+    "gat": (dict(num_layers=2, hidden_unit=16, heads=8, dropout_rate=0.5), 8, 2, "gat"),
+    "appnpstack": (dict(hidden_unit=64, K=10, alpha=0.1, dropout_rate=0.5), 40, 1, "gcn"),
+}
+
+
+def model_class(name):
+    from rgb_experiment_amd import models as M
+    return {"gcn": M.GCN, "graphsage": M.GraphSAGE, "graphsage2": M.GraphSAGE2, "gat": M.GAT,
+            "appnpstack": M.APPNPStack}[name]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU legs: the oracle as the checker of THIS run's results and as the timed CPU baseline (rank 0, one GPU only)
+
+def cpu_baseline(ei, x, N, budget_s=20.0, fused=None):
     """The oracle timed on the host cores, one GCN propagate at d = 128 (rank 0, N = 1 only).
     Primary: the C/OpenMP restatement (oracle/propagate_ref.c, per-target CSR sums over all host threads)
     on the WHOLE rewritten edge list — the strongest plain CPU form of the same arithmetic.
     Also reported: the PyG-style dataflow of the Python oracle (index_select -> multiply -> index_add_,
     which materialises [E, d]) on a bounded 8 M-edge sample, which is what the reference's CPU path does.
-    `hip_propagate` (the HIP kernel's result of the same propagate, on the host) is checked against the C result:
-    the full-size parity of this very run rides along on the line."""
+    `fused` = (out, W, b): the result of the TIMED kernel (ops.propagate_linear = rgbx_spmm_linear_f32: aggregate +
+    transform of the whole workload with the model's first-layer weights), checked here against the C restatement's
+    propagate followed by a CPU matmul: the full-size parity of this very run rides along on the line."""
     from oracle import ref_cpu as O
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -138,9 +206,15 @@ def cpu_baseline(ei, x, N, budget_s=20.0, hip_propagate=None):
         threads = min(O.c_threads(), cores)
         cpu_out = O.propagate_c_csr(rowptr, col, ws, x, "add", threads)  # warm-up (page faults, thread pool)
         parity = None
-        if hip_propagate is not None:
-            parity = {"max_abs_diff_hip_vs_cpu": (hip_propagate - cpu_out).abs().max().item(),
-                      "max_abs_value": cpu_out.abs().max().item(), "rows": N, "width": x.size(1)}
+        if fused is not None:
+            hip_out, W, b = fused
+            want = cpu_out @ W.t() + b
+            parity = {"kernel": "rgbx_spmm_linear_f32 (ops.propagate_linear, the launch the timed region makes)",
+                      "checker": "oracle_propagate_csr_f32 (C restatement) then a CPU matmul with the same weights",
+                      "max_abs_diff_hip_vs_cpu": (hip_out - want).abs().max().item(),
+                      "max_abs_value": want.abs().max().item(), "rows": N, "width_in": x.size(1),
+                      "width_out": W.size(0)}
+            del want
         del cpu_out
         t2 = []
         t_end = time.perf_counter() + budget_s / 2
@@ -159,22 +233,43 @@ def cpu_baseline(ei, x, N, budget_s=20.0, hip_propagate=None):
         return dataflow
 
 
-MODELS = {
-    # name: (constructor kwargs, propagates per epoch = 3 forwards + 1 backward, loops_mode, weighting kind)
-    # gcn: 2 + 2 + 2 forward SpMMs and ONE transposed SpMM (layer 2); layer 1's weight gradient is taken
-    # against A_hat x, so nothing flows back through A_hat^T there (nn/conv.py GCNConv)
-    "gcn": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 7, 1, "gcn"),
-    "graphsage": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 7, 2, "mean"),
-    "graphsage2": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 7, 0, "mean"),
-    "gat": (dict(num_layers=2, hidden_unit=16, heads=8, dropout_rate=0.5), 8, 2, "gat"),
-    "appnpstack": (dict(hidden_unit=64, K=10, alpha=0.1, dropout_rate=0.5), 40, 1, "gcn"),
-}
-AGG_KINDS = ("gcn_fwd", "gcn_bwd", "mean_fwd", "mean_bwd", "gcn_linear_fwd", "mean_linear_fwd", "gcn_linear_bwd",
-             "mean_linear_bwd", "appnp_fwd",
-             "appnp_bwd", "gat_fwd", "gat_bwd_prep", "gat_bwd_src", "gat_bwd_segsum", "dist_fwd_local", "dist_fwd_remote",
-             "dist_bwd_local", "dist_bwd_remote", "dist_fwd_resident",
-             "dist_fwd_colshard", "dist_bwd_colshard", "dist_fwd_appnp_colshard", "dist_bwd_appnp_colshard")
+def sampled_logit_parity(name, model, ei, x, x_d, ei_d, n_targets=None):
+    """Whole-model logits of this run's (trained) model at sampled target rows against the UNCHANGED oracle forward
+    on the targets' L-hop in-neighbourhood (oracle/sampled.py). APPNP: K = 10 hops cover the whole graph, so the
+    sampled check runs the same weights with K = 2 (the K = 10 recurrence itself is pinned by golden G3 and by the
+    linearity / adjoint tests at full size)."""
+    from oracle import sampled as S
+    kw = dict(MODELS[name][0])
+    kw.pop("dropout_rate", None)
+    kw.pop("hidden_unit", None)
+    N = x.size(0)
+    if n_targets is None:  # gcn_norm models complete the outer in-degrees with dummy edges: keep those bounded
+        n_targets = 96 if name in ("gcn", "appnpstack") else 768
+    targets = S.pick_targets(N, n_targets)
+    was_training = model.training
+    model.eval()
+    run = model
+    if name == "appnpstack":
+        kw["K"] = 2
+        run = model_class(name)(input_dim=x.size(1), output_dim=model.lin2.out_features, **{**MODELS[name][0], "K": 2})
+        run.load_state_dict(model.state_dict())
+        run.to(x_d.device).eval()
+    with torch.no_grad():
+        got = run(x_d, ei_d)["emb"][targets.to(x_d.device)].cpu()
+    model.train(was_training)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    t0 = time.perf_counter()
+    want, info = S.sampled_logits(name, sd, x, ei, targets, **kw)
+    info.update({"max_abs_diff_hip_vs_oracle": (got - want).abs().max().item(),
+                 "max_abs_logit": want.abs().max().item(), "tolerance": 1e-4, "oracle_seconds": time.perf_counter() - t0,
+                 "what": f"eval-mode {name} logits of {targets.numel()} sampled nodes: HIP forward over the whole graph vs "
+                         "oracle.ref_cpu forward on their in-neighbourhood" + (" (K=2 instance of the same weights)"
+                                                                                if name == "appnpstack" else "")})
+    return info
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# one-GPU step
 
 def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
     """One-GPU step function = the reference loop body (itexperiments.py:417-473): train forward +
@@ -224,7 +319,21 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
         return GraphedEpoch(model, gopt, {"x": x_d, "edge_index": ei_d}, y_d, (tm, vm, sm)).capture().run
 
     step.graphed = graphed
+    step.device_inputs = (x_d, ei_d)
     return step, nnz_total, alg
+
+
+def time_steps(step, steps, warmup, fence=None):
+    fence = fence or torch.cuda.synchronize
+    last = None
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    fence()
+    return time.perf_counter() - t0, last
 
 
 def time_graphed(step, steps, warmup):
@@ -232,55 +341,74 @@ def time_graphed(step, steps, warmup):
     loop, whose launches carry the per-kernel HIP events the roofline needs)."""
     try:
         run = step.graphed()
-        for _ in range(warmup):
-            run()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            run()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dt, _ = time_steps(run, steps, warmup)
         return {"ms_per_step": dt / steps * 1e3, "epochs_per_s": steps / dt}
     except Exception as exc:
         return {"error": repr(exc)}
 
 
-def secondary_config(dev, steps, warmup):
-    """BASELINE.json configs[1] (|V|=200k, |E|=4M, 2-layer GCN, one GPU) measured in the same process, so
-    that both readings of "the configuration the metric is quoted on" are on the line: the headline value
-    is the north-star target size L, this block is S. Note X (102 MB) sits in the 256 MiB Infinity Cache at
-    S, so its roofline fraction is cache-served (SURVEY §8d caveat)."""
-    from rgb_experiment_amd import models as M
+def gcn_block(name, ei, x, y, dev, steps, warmup, d, note=None, replay=True):
+    """A 2-layer GCN epoch on another graph in the same process (secondary blocks of the line)."""
     from rgb_experiment_amd import ops
     from rgb_experiment_amd.graph import clear_cache
-    wl = WORKLOADS["S"]
-    N, E, d = wl["N"], wl["E"], wl["d"]
-    ei, x, y = synth(N, E, d)
+    N = x.size(0)
     torch.manual_seed(14530529)
-    model = M.GCN(input_dim=d, output_dim=d, **MODELS["gcn"][0])
-    step, nnz, alg = build_single_gpu(model, ei, x, y, split_masks(N), dev, 1, "gcn", N, d)
+    model = model_class("gcn")(input_dim=d, output_dim=d, **MODELS["gcn"][0])
+    step, nnz, alg = build_single_gpu(model, ei, x, y, split_masks(y), dev, 1, "gcn", N, d)
     for _ in range(warmup):
         step()
     events = []
     ops.set_event_sink(events)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, _ = time_steps(step, steps, 0)
     ops.set_event_sink(None)
     n_prop = MODELS["gcn"][1]
-    kinds = ("gcn_fwd", "gcn_bwd", "gcn_linear_fwd", "gcn_linear_bwd")
-    spmm_s = sum(s.elapsed_time(e) for k, s, e in events if k in kinds) * 1e-3 / (n_prop * steps)
-    replay = time_graphed(step, steps, warmup)
+    spmm_s = sum(s.elapsed_time(e) for k, s, e in events if k in AGG_KINDS) * 1e-3 / (n_prop * steps)
+    out = {"workload": name, "edges_in": int(ei.size(1)), "edges_aggregated_per_propagate": nnz,
+           "value": n_prop * nnz * steps / elapsed, "unit": "edges/s", "ms_per_step": elapsed / steps * 1e3,
+           "epochs_per_s": steps / elapsed, "spmm_ms": spmm_s * 1e3,
+           "roofline_frac_algorithmic": alg / spmm_s / 1e9 / HBM_PEAK_GBS}
+    if replay:
+        out["hip_graph_replay"] = time_graphed(step, steps, warmup)
+    if note:
+        out["note"] = note
+    del step, model
     clear_cache()
-    return {"workload": wl["name"], "value": n_prop * nnz * steps / elapsed, "unit": "edges/s",
-            "ms_per_step": elapsed / steps * 1e3, "epochs_per_s": steps / elapsed, "spmm_ms": spmm_s * 1e3,
-            "hip_graph_replay": replay,
-            "roofline_frac_algorithmic": alg / spmm_s / 1e9 / HBM_PEAK_GBS,
-            "note": "X fits the Infinity Cache at this size: the fraction is cache-served, not HBM"}
+    torch.cuda.empty_cache()
+    return out
 
+
+def cora_shaped(dev, epochs=60):
+    """BASELINE.json configs[0] as SURVEY §8d states it (Cora itself is not shipped): N=2708, 5278 mirrored random
+    pairs, F=1433 bag-of-words rows (18 ones, row-normalised), C=7, 2-layer GCN hidden 64 — ms per epoch of the
+    reference loop body, eager and replayed as a hipGraph."""
+    n, pairs, f, c = 2708, 5278, 1433, 7
+    gen = torch.Generator().manual_seed(1234567)
+    a = torch.randint(0, n, (pairs,), generator=gen)
+    b = (a + 1 + torch.randint(0, n - 1, (pairs,), generator=gen)) % n
+    ei = torch.cat([torch.stack([a, b]), torch.stack([b, a])], dim=1)
+    x = torch.zeros(n, f)
+    x.scatter_(1, torch.randint(0, f, (n, 18), generator=gen), 1.0)
+    x = x / x.sum(1, keepdim=True)
+    y = torch.randint(0, c, (n,), generator=gen)
+    torch.manual_seed(14530529)
+    model = model_class("gcn")(input_dim=f, output_dim=c, num_layers=2, hidden_unit=64, dropout_rate=0.5)
+    step, _, _ = build_single_gpu(model, ei, x, y, split_masks(y), dev, 1, "gcn", n, c)
+    dt, _ = time_steps(step, epochs, 10)
+    out = {"workload": "Cora-shaped synthetic (N=2708, E=10556, F=1433, C=7), gcn num_layers=2 hidden_unit=64",
+           "eager_ms_per_epoch": dt / epochs * 1e3}
+    try:
+        run = step.graphed()
+        dt, _ = time_steps(run, epochs, 10)
+        out["hip_graph_ms_per_epoch"] = dt / epochs * 1e3
+    except Exception as exc:
+        out["hip_graph_error"] = repr(exc)
+    from rgb_experiment_amd.graph import clear_cache
+    clear_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N > 1
 
 def launch_ranks(n):
     """`python bench.py --gpus N` as typed: start N ranks (one per GPU) with torch.distributed.run as CHILD
@@ -298,6 +426,60 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def dist_alg_bytes(dgraph, kind, d, N, n_loc, world, K=10):
+    """Algorithmic bytes PER LAUNCH of every aggregation kind this rank can record (SURVEY 8d formula on the rows /
+    edges / width that launch covers)."""
+    out = {}
+    st = dgraph._kinds.get(kind)
+    if st is not None:
+        f, b = st["plan"].fwd, st["plan"].bwd
+        cnt = lambda t: 0 if t is None else int(t.numel())
+        nl, nr = cnt(f.loc_agg), cnt(f.rem_agg)
+        b_res = spmm_alg_bytes(n_loc, nl + nr, d)
+        out.update({"dist_fwd_resident": b_res, "gcn_linear_fwd": b_res, "mean_linear_fwd": b_res,
+                    "dist_fwd_local": spmm_alg_bytes(n_loc, nl, d),
+                    "dist_fwd_remote": spmm_alg_bytes(n_loc, nr, d) + n_loc * 4 * d,
+                    "dist_bwd_local": spmm_alg_bytes(n_loc, cnt(b.loc_agg), d),
+                    "dist_bwd_remote": spmm_alg_bytes(n_loc, cnt(b.rem_agg), d) + n_loc * 4 * d})
+    for (k, C, pieces), gst in dgraph._grid.items():
+        if k != kind:
+            continue
+        plan = gst["plan"]
+        dc = d // C
+        if pieces == 1 and C == world:  # the APPNP plan: K whole-graph launches at width d / P
+            per = K * (spmm_alg_bytes(N, plan.fwd.nnz, dc) + N * 4 * dc)
+            out.update({"dist_fwd_appnp_colshard": per, "dist_bwd_appnp_colshard": per})
+        else:
+            for direction, half in (("fwd", plan.fwd), ("bwd", plan.bwd)):
+                out[f"dist_{direction}_colshard"] = spmm_alg_bytes(half.n_group / pieces, half.nnz / pieces, dc)
+    return out
+
+
+def link_model(log, steps_logged, gbs=(50.0, 60.0, 76.8)):
+    """Link arithmetic on the emulated rank's exchange log: per epoch, the bytes the busiest link carries per
+    direction, summed over all exchanges (`serial`) and over those whose transfer nothing of the SAME propagate can
+    hide (`exposed`: the inbound exchange, the last outbound piece, halo / resident fetches)."""
+    tot = exp = 0
+    by_tag = {}
+    for tag, b_out, b_in in log:
+        b = max(b_out, b_in)
+        tot += b
+        t = (tag or "?")
+        by_tag.setdefault(t, [0, 0])
+        by_tag[t][0] += 1
+        by_tag[t][1] += b
+        last_piece = t.startswith("out") and t.split()[1].split("/")[0] == t.split()[1].split("/")[1]
+        if not t.startswith("out") or last_piece:
+            exp += b
+    per = lambda v: v / max(steps_logged, 1)
+    return {"link_bytes_per_epoch_serial": per(tot), "link_bytes_per_epoch_exposed": per(exp),
+            "exchanges_per_epoch": {t: {"n": c / max(steps_logged, 1), "link_bytes_each": b / c}
+                                    for t, (c, b) in sorted(by_tag.items())},
+            "exchange_ms_per_epoch": {f"{g:g} GB/s per link and direction": {"serial": per(tot) / g / 1e6,
+                                                                             "exposed": per(exp) / g / 1e6}
+                                      for g in gbs}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,10 +488,15 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="L")
     ap.add_argument("--model", choices=sorted(MODELS), default="gcn",
                     help="gcn is the BASELINE.json headline; the others are its configs 3-5")
-    ap.add_argument("--exchange", choices=["auto", "halo", "reshard"], default="auto")
+    ap.add_argument("--exchange", default="auto", help="auto | halo | reshard | RxC (row groups x column slices)")
+    ap.add_argument("--pieces", type=int, default=None, help="pieces of the outbound exchange (default 4)")
+    ap.add_argument("--no-interleave", action="store_true", help="val and test forward one after the other")
+    ap.add_argument("--emulate-rank", type=int, default=0, metavar="P",
+                    help="one GPU: rank 0's launches of a P-rank job, exchanges replaced by stand-in rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--primary-only", action="store_true",
-                    help="skip the secondary legs (hipGraph replay, configs[1] block): clean rocprofv3 runs")
+                    help="skip the secondary legs (hipGraph replay, configs[0]/[1] blocks, undirected run): clean "
+                         "rocprofv3 runs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -337,6 +524,7 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+    on_gpu = dev.type == "cuda"
     if world > 1:
         # RGBX_DIST_BACKEND=gloo rehearses the N>1 code path with several ranks on ONE GPU (host-staged
         # collectives) or on the CPU (above); the real runs use RCCL ("nccl").
@@ -345,60 +533,45 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from rgb_experiment_amd import models as M
     from rgb_experiment_amd import ops
 
     wl = WORKLOADS[args.workload]
     N, E, d = wl["N"], wl["E"], wl["d"]
     ei, x, y = synth(N, E, d)
-    train_mask, val_mask, test_mask = split_masks(N)
+    train_mask, val_mask, test_mask = split_masks(y)
     kwargs, n_prop, loops_mode, kind = MODELS[args.model]
-    cls = {"gcn": M.GCN, "graphsage": M.GraphSAGE, "graphsage2": M.GraphSAGE2, "gat": M.GAT,
-           "appnpstack": M.APPNPStack}[args.model]
 
     torch.manual_seed(14530529)  # the reference's reappear_seed (itexperiments.py:57)
-    model = cls(input_dim=d, output_dim=d, **kwargs)
+    model = model_class(args.model)(input_dim=d, output_dim=d, **kwargs)
     wl_name = wl["name"].replace("GCN", {"gcn": "GCN", "graphsage": "GraphSAGE", "graphsage2": "GraphSAGE2",
                                          "gat": "GAT 8 heads", "appnpstack": "APPNP K=10"}[args.model])
 
-    comm_mb, scheme, alg_by_kind = 0.0, "single GPU", None
-    if world > 1:
+    emu = args.emulate_rank if world == 1 else 0
+    parts = max(world, emu)  # ranks the graph is partitioned over
+    comm_obj = None
+    scheme, alg_by_kind, runner = "single GPU", None, None
+    if parts > 1:
         from rgb_experiment_amd.dist import DistRunner
-        runner = DistRunner(model, ei, x, y, (train_mask, val_mask, test_mask), rank, world, dev, lr=0.01,
-                            exchange=args.exchange)
+        from rgb_experiment_amd.dist.comm import Comm, EmulatedComm
+        comm_obj = EmulatedComm(emu, 0) if emu else Comm()
+        runner = DistRunner(model, ei, x, y, (train_mask, val_mask, test_mask), 0 if emu else rank, parts, dev,
+                            lr=0.01, comm=comm_obj, backend=test_backend, exchange=args.exchange, pieces=args.pieces,
+                            interleave_evals=not args.no_interleave)
         dgraph = runner.graphs[loops_mode]
         step = runner.epoch
         n_loc = runner.hi - runner.lo
+        step()  # builds every structure this model uses (outside the timing) ...
+        runner.release_edge_list()  # ... after which the global edge list leaves HBM
         scheme = dgraph.scheme(d) if kind != "gat" else "halo"
-        if kind == "gat":  # halo rows appended to the local rows, one rectangular CSR
-            model.eval()
-            with torch.no_grad():
-                model(runner.x, runner.token)  # builds the plan + rectangular CSRs once, outside the timing
+        if kind == "gat":
             plan = dgraph._kinds["gat"]["plan"]
             nnz_total = plan.nnz_total
             alg = gat_alg_bytes(n_loc, plan.nnz_local, d)
-            comm_mb = plan.fwd.n_halo * d * 4 / 1e6
         else:
-            # algorithmic bytes per launch of every aggregation kernel this rank runs (SURVEY 8d formula on the
-            # rows / edges / width that launch covers); the roofline line is total bytes / total kernel time
-            plan = dgraph.plan(kind)
-            nnz_total = plan.nnz_total
-            nnz_loc, nnz_rem = int(plan.fwd.loc_agg.numel()), int(plan.fwd.rem_agg.numel())
-            b_loc = spmm_alg_bytes(n_loc, nnz_loc, d)
-            b_rem = spmm_alg_bytes(n_loc, nnz_rem, d) + n_loc * 4 * d
-            b_col_full = spmm_alg_bytes(N, nnz_total, d // world)  # whole graph on this rank's d / P columns
-            # the column-shard SpMM runs as reshard_chunks * P launches (one per piece of every peer's row block,
-            # so that the transpose back overlaps it): bytes per launch accordingly
-            pieces = max(int(dgraph._chunks()), 1)
-            b_col = b_col_full / (pieces * world if pieces > 1 else 1)
-            b_res = spmm_alg_bytes(n_loc, nnz_loc + nnz_rem, d)  # first conv: resident [local; halo] features
-            alg_by_kind = {"dist_fwd_resident": b_res, "gcn_linear_fwd": b_res, "mean_linear_fwd": b_res,
-                           "dist_fwd_local": b_loc, "dist_bwd_local": b_loc, "dist_fwd_remote": b_rem,
-                           "dist_bwd_remote": b_rem, "dist_fwd_colshard": b_col, "dist_bwd_colshard": b_col,
-                           "dist_fwd_appnp_colshard": 10 * (b_col_full + N * 4 * (d // world)),
-                           "dist_bwd_appnp_colshard": 10 * (b_col_full + N * 4 * (d // world))}
-            alg = b_col_full if scheme == "reshard" else b_loc + b_rem
-            comm_mb = (2 * n_loc * d * 4 * (world - 1) / world if scheme == "reshard" else plan.fwd.n_halo * d * 4) / 1e6
+            plans = [st["plan"] for st in list(dgraph._kinds.values()) + list(dgraph._grid.values())]
+            nnz_total = plans[0].nnz_total
+            alg_by_kind = dist_alg_bytes(dgraph, kind, d, N, n_loc, parts, K=kwargs.get("K", 10))
+            alg = spmm_alg_bytes(n_loc, nnz_total / parts, d)  # an ideal 1/P share of one propagate
     else:
         step, nnz_total, alg = build_single_gpu(model, ei, x, y, (train_mask, val_mask, test_mask), dev, loops_mode,
                                                 kind, N, d)
@@ -406,37 +579,38 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     events = []
-    ops.set_event_sink(events)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    if on_gpu:
+        ops.set_event_sink(events)
+    if comm_obj is not None:
+        comm_obj.bytes_sent, comm_obj.exchanges = 0, 0
+        if emu:
+            comm_obj.log.clear()
+    elapsed, last = time_steps(step, args.steps, 0, fence)
     ops.set_event_sink(None)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    agg_total_ms = sum(s.elapsed_time(e) for k, s, e in events if k in AGG_KINDS)
-    agg_avg_s = agg_total_ms * 1e-3 / (n_prop * args.steps)  # aggregation kernel time per propagate (this rank)
-    achieved = alg / agg_avg_s / 1e9
-    if alg_by_kind:  # partitioned run: launches of different shapes, so sum bytes over the launches actually made
-        done = sum(alg_by_kind[k] for k, s, e in events if k in alg_by_kind)
-        achieved = done / (agg_total_ms * 1e-3) / 1e9
     by_kind = {}
     for k, s, e in events:
         by_kind.setdefault(k, []).append(s.elapsed_time(e))
+    agg_total_ms = sum(sum(v) for k, v in by_kind.items() if k in AGG_KINDS)
+    agg_avg_s = agg_total_ms * 1e-3 / (n_prop * args.steps)  # aggregation kernel time per propagate (this rank)
+    achieved = alg / agg_avg_s / 1e9 if agg_avg_s else None
+    if alg_by_kind and agg_total_ms:  # partitioned run: launches of different shapes, sum bytes over those made
+        done = sum(alg_by_kind[k] * len(v) for k, v in by_kind.items() if k in alg_by_kind)
+        achieved = done / (agg_total_ms * 1e-3) / 1e9
+    dominant = max((k for k in by_kind if k in AGG_KINDS), key=lambda k: sum(by_kind[k]), default=None)
+    kernel = KERNEL_OF_KIND.get(dominant, "none recorded")
     by_kind = {k: {"n": len(v), "avg_ms": sum(v) / len(v)} for k, v in sorted(by_kind.items())}
-    kernel = {"gat": "gat_fwd_kernel<4> / gat_bwd_src_kernel<4> (+ prep, segment sum)"}.get(
-        args.model, "spmm_linear_kernel<32,*,128,1> (aggregate + fp32 MFMA transform; forward, and backward on the transposed CSR)"
-        if scheme != "reshard" else f"spmm_csr_kernel at width {d // world}")
+    traffic, traffic_note = pmc_traffic(args.workload, args.model, kernel, parts)
 
     result = {
         "metric": "aggregated edges/sec (full-graph GCN d=128, reference epoch = train fwd+bwd+Adam + 2 eval fwd)"
@@ -454,35 +628,75 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl_name, "nodes": N, "edges_in": E, "edges_aggregated_per_propagate": nnz_total,
                    "width": d, "propagates_per_step": n_prop,
-                   "parallelism": "single GPU" if world == 1 else
-                   f"1-D node partition x{world}, RCCL all-to-all ({scheme} exchange; boundary rows of the static "
+                   "parallelism": "single GPU" if parts == 1 else
+                   f"1-D node partition x{parts}, RCCL all-to-all ({scheme} exchange; boundary rows of the static "
                    "input features resident in HBM)"},
         "epochs_per_s": args.steps / elapsed,
-        "spmm_edges_per_s": nnz_total / agg_avg_s if world == 1 else None,
+        "spmm_edges_per_s": nnz_total / agg_avg_s if parts == 1 and agg_avg_s else None,
         "spmm_ms": agg_avg_s * 1e3,
-        "exchange_mb_per_rank_per_propagate": comm_mb,
         "kernel_ms_by_kind": by_kind,
         "final_losses": {"train": last[0], "val": last[1], "test": last[3]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(args.workload, world) if args.model == "gcn" else None,
-                     "kernel": kernel, "algorithmic_bytes_per_launch": alg,
-                     "note": "rank 0's share of one propagate" if world > 1 else "whole graph, one propagate"},
+                     "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                     "traffic": traffic, "traffic_source": traffic_note,
+                     "kernel": kernel, "kernel_source_hash": kernel_source_hash(kernel),
+                     "algorithmic_bytes_per_launch": alg,
+                     "compulsory_bytes_per_launch": spmm_compulsory_bytes(N if parts == 1 else n_loc,
+                                                                          nnz_total / parts, d),
+                     "note": "an ideal 1/P share of one propagate" if parts > 1 else "whole graph, one propagate"},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from rgb_experiment_amd.graph import get_graph
-        with torch.no_grad():  # one GCN propagate of the whole workload by the HIP kernel, for the parity field
-            hip_out = ops.propagate_gcn(x.to(dev), get_graph(ei.to(dev), N, 1)).cpu()
-        result["cpu_baseline"] = cpu_baseline(ei, x, N, hip_propagate=hip_out)
-        del hip_out
-    if world == 1 and not args.primary_only:
+    if parts > 1:
+        mine = {"rank": rank, "scheme": scheme, "exchange_mb_per_step": comm_obj.bytes_sent / args.steps / 1e6,
+                "exchanges_per_step": comm_obj.exchanges / args.steps, "aggregation_ms_per_step": agg_total_ms / args.steps,
+                "rows": n_loc, "device": str(dev)}
+        per_rank = [mine]
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        result["ranks_seen"] = len(per_rank)
+        result["scheme"] = scheme
+        result["per_rank"] = per_rank
+        result["exchange_mb_per_rank_per_step"] = max(r["exchange_mb_per_step"] for r in per_rank)
+        result["modelled_seconds_per_propagate"] = dgraph._choice.get(("costs", d))
+    if emu:
+        result["n_gpus"] = 1
+        result["emulated"] = {"rank": 0, "of": emu, "scheme": scheme,
+                              "what": "rank 0's structures and kernel launches of the partitioned job on one GPU; every "
+                                      "exchange delivers stand-in rows, so ms_per_step is the rank's COMPUTE per epoch and "
+                                      "`value` is what the job would reach if the exchanges were free",
+                              **link_model(comm_obj.log, args.steps)}
+        result["metric"] = "EMULATED rank compute, not a benchmark value: " + result["metric"]
+    if rank == 0 and parts == 1 and on_gpu and not args.no_cpu_baseline:
+        x_d, ei_d = step.device_inputs
+        fused = None
+        if args.model == "gcn":  # the kernel the timed region launches, on the whole workload, model's first layer
+            from rgb_experiment_amd.graph import get_graph
+            conv = model.convs[0]
+            with torch.no_grad():
+                out = ops.propagate_linear(x_d, get_graph(ei_d, N, 1), "gcn", conv.lin.weight, conv.bias).cpu()
+            fused = (out, conv.lin.weight.detach().cpu(), conv.bias.detach().cpu())
+        result["parity"] = {"sampled_logits": sampled_logit_parity(args.model, model, ei, x, x_d, ei_d)}
+        result["cpu_baseline"] = cpu_baseline(ei, x, N, fused=fused)
+        del fused
+    if parts == 1 and on_gpu and not args.primary_only:
         result["hip_graph_replay"] = time_graphed(step, args.steps, args.warmup)
-    if world == 1 and args.workload == "L" and args.model == "gcn" and not args.primary_only:
+    if parts == 1 and on_gpu and args.workload == "L" and args.model == "gcn" and not args.primary_only:
         del step, model
         from rgb_experiment_amd.graph import clear_cache
+        from rgb_experiment_amd.utils import to_undirected
         clear_cache()
         torch.cuda.empty_cache()
-        result["configs_1_same_run"] = secondary_config(dev, args.steps, args.warmup)
+        # SURVEY 8d secondary run: the mirrored / coalesced variant of the same graph (itexperiments.py:235-238)
+        ei_u = to_undirected(ei.to(dev), N).cpu()
+        result["undirected_same_run"] = gcn_block(wl["name"] + ", to_undirected", ei_u, x, y, dev, args.steps, args.warmup,
+                                                  d, replay=False)
+        del ei_u
+        s = WORKLOADS["S"]
+        ei_s, x_s, y_s = synth(s["N"], s["E"], s["d"])
+        result["configs_1_same_run"] = gcn_block(
+            s["name"], ei_s, x_s, y_s, dev, args.steps, args.warmup, s["d"],
+            note="X fits the Infinity Cache at this size: the fraction is cache-served, not HBM")
+        result["configs_0_same_run"] = cora_shaped(dev)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

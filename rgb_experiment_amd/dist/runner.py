@@ -37,6 +37,10 @@ class DistRunner:
                 g.pin_resident(self.x)  # boundary rows of the static features are fetched once and kept
         self.model = DistBatchNorm1d.convert(model.to(device), self.comm)
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
+        for part, m in zip(("train", "val", "test"), self.masks):
+            sel = self.y[m]
+            if sel.numel() and int(sel.min()) < 0:  # NLLLoss on out[mask] raises on such rows in the reference
+                raise RuntimeError(f"{part} mask selects nodes with a negative label (unlabelled)")
         cnt = torch.tensor([float(m.sum()) for m in self.masks], dtype=torch.float64, device=device)
         self.mask_counts = self.comm.all_reduce_sum_(cnt).tolist()
 

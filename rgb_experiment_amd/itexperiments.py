@@ -265,6 +265,13 @@ def experiment(model_init_param: dict, *,
     y = data.y
     train_mask, val_mask, test_mask = (_as_bool_mask(m, data.num_nodes, device)
                                        for m in (data.train_mask, data.val_mask, data.test_mask))
+    # the reference's NLLLoss(out[mask], y[mask]) (:400,429) raises on a label outside [0, C); the masked loss kernels
+    # would skip such a row instead (different row set, different mean): refuse here, once, on the host
+    for part, m in (("train", train_mask), ("val", val_mask), ("test", test_mask)):
+        sel = y[m]
+        if sel.numel() and (int(sel.min()) < 0 or int(sel.max()) >= output_dim):
+            raise RuntimeError(f"{part}_mask selects nodes whose label is outside [0, {output_dim}) "
+                               "(e.g. -1 = unlabelled): the reference's NLLLoss would raise on them")
     is_pta = name == "pta"
     if is_pta:  # reference :351-374
         adj = normalized_adjacency(data.edge_index, data.num_nodes)

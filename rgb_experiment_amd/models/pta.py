@@ -36,9 +36,11 @@ class Linear(nn.Module):
     def __init__(self, in_features, out_features, dropout, bias=False):
         super().__init__()
         self.dropout, self.in_features, self.out_features = dropout, in_features, out_features
-        self.weight = nn.Parameter(torch.empty(in_features, out_features))
+        # torch.randn, as the reference allocates them (models/pta.py:19,21): the draws advance the global RNG before
+        # kaiming_uniform_ does, so a seeded run (need_to_reappear / reappear_seed) starts from the reference's weights
+        self.weight = nn.Parameter(torch.randn(in_features, out_features))
         if bias:
-            self.bias = nn.Parameter(torch.empty(out_features))
+            self.bias = nn.Parameter(torch.randn(out_features))
         else:
             self.register_parameter("bias", None)
         self.reset_parameters()

@@ -131,6 +131,31 @@ class _BNTrain(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
+class _AffineCols(torch.autograd.Function):
+    """y = x * scale + shift per column (rgbx_affine_cols_f32) WITH a backward: gx = gy * scale,
+    g_scale = sum_r gy * x, g_shift = sum_r gy. `scale` / `shift` are functions of the BatchNorm parameters
+    (eval_affine), so weight and bias receive their gradients through them."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        ctx.save_for_backward(x, scale)
+        return affine_cols(x, scale.detach().contiguous(), shift.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, scale = ctx.saved_tensors
+        gy = gy if gy.stride(-1) == 1 else gy.contiguous()
+        gx = g_scale = g_shift = None
+        if ctx.needs_input_grad[0]:
+            gx = affine_cols(gy, scale.detach().contiguous(), torch.zeros_like(scale))
+        if ctx.needs_input_grad[1]:
+            g_scale = (gy * x).sum(0)
+        if ctx.needs_input_grad[2]:
+            g_shift = gy.sum(0)
+        return gx, g_scale, g_shift
+
+
 class BatchNorm1d(nn.BatchNorm1d):
     """Drop-in for nn.BatchNorm1d on [N, d] inputs (affine, running statistics)."""
 
@@ -149,6 +174,10 @@ class BatchNorm1d(nn.BatchNorm1d):
             return super().forward(x)
         if not self.training:
             scale, shift = self.eval_affine()
+            if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad or self.bias.requires_grad):
+                # eval mode with autograd on (frozen-BN fine-tuning, saliency on the inputs): nn.BatchNorm1d is
+                # differentiable there, so this must be too — the raw kernel below has no autograd node
+                return _AffineCols.apply(x, scale, shift)
             return affine_cols(x if x.stride(-1) == 1 else x.contiguous(), scale.contiguous(), shift.contiguous())
         with torch.no_grad():
             self.num_batches_tracked += 1

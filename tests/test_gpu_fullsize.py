@@ -1,0 +1,113 @@
+"""Parity at the BASELINE sizes (S: |V|=200k |E|=4M, L: |V|=2M |E|=60M, d=128), on the kernels the benchmark times.
+
+The PyG-dataflow oracle cannot hold these graphs ([E', d] temporaries of 32 GB), so:
+  * the fused aggregate+transform kernel (rgbx_spmm_linear_f32, what bench.py's timed region launches) is
+    compared on the WHOLE graph with the C restatement's propagate (oracle/propagate_ref.c, per-target sums)
+    followed by a CPU matmul;
+  * whole-model logits of every BASELINE config (gcn / graphsage / graphsage2 / gat / appnpstack) are compared at
+    sampled target rows with the UNCHANGED oracle forward on the targets' in-neighbourhood (oracle/sampled.py).
+Tolerance: 1e-4 absolute on logits (north_star)."""
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from oracle import sampled as S
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+SIZES = {"S": (200_000, 4_000_000), "L": (2_000_000, 60_000_000)}
+_CACHE = {}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def workload(size):
+    """bench.py's synthetic graph of that size (same seeds), built once per module run."""
+    if size not in _CACHE:
+        _CACHE.clear()  # one size at a time in host memory
+        n, e = SIZES[size]
+        ei = torch.randint(0, n, (2, e), generator=torch.Generator().manual_seed(1234567), dtype=torch.int64)
+        x = torch.randn(n, 128, generator=torch.Generator().manual_seed(1234568))
+        y = torch.randint(0, 128, (n,), generator=torch.Generator().manual_seed(1234569))
+        _CACHE[size] = (ei, x, y)
+    return _CACHE[size]
+
+
+@pytest.mark.parametrize("size", ["S", "L"])
+def test_fused_aggregate_transform_on_the_whole_benchmark_graph(dev, size):
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import clear_cache, get_graph
+    ei, x, _ = workload(size)
+    n = x.size(0)
+    g = torch.Generator().manual_seed(7)
+    W = torch.randn(128, 128, generator=g) / 128 ** 0.5
+    Wr = torch.randn(128, 128, generator=g) / 128 ** 0.5
+    b = torch.randn(128, generator=g)
+    ei_d, x_d = ei.to(dev), x.to(dev)
+    threads = O.c_threads()
+    # GCN: A_hat x W^T + b
+    rei, w = O.gcn_norm(ei, None, n)
+    rowptr, col, perm = O.csr_from_edges(rei[1], rei[0], torch.arange(rei.size(1)), n)
+    want = O.propagate_c_csr(rowptr, col, w[perm.long()].contiguous(), x, "add", threads) @ W.t() + b
+    with torch.no_grad():
+        got = ops.propagate_linear(x_d, get_graph(ei_d, n, 1), "gcn", W.to(dev), b.to(dev)).cpu()
+    assert (got - want).abs().max().item() < TOL
+    del rei, w, rowptr, col, perm, want, got
+    # SAGEConv form: mean over the in-edges as given (no self-loops), root term in the same kernel
+    rowptr, col, _ = O.csr_from_edges(ei[1], ei[0], torch.arange(ei.size(1)), n)
+    want = O.propagate_c_csr(rowptr, col, None, x, "mean", threads) @ W.t() + b + x @ Wr.t()
+    with torch.no_grad():
+        got = ops.propagate_linear(x_d, get_graph(ei_d, n, 0), "mean", W.to(dev), b.to(dev), root_weight=Wr.to(dev)).cpu()
+    assert (got - want).abs().max().item() < TOL
+    clear_cache()
+
+
+MODEL_KW = {
+    "gcn": dict(num_layers=2, hidden_unit=128, dropout_rate=0.5),
+    "graphsage": dict(num_layers=2, hidden_unit=128, dropout_rate=0.5),
+    "graphsage2": dict(num_layers=2, hidden_unit=128, dropout_rate=0.5),
+    "gat": dict(num_layers=2, hidden_unit=16, heads=8, dropout_rate=0.5),
+    "appnpstack": dict(hidden_unit=64, K=2, alpha=0.1, dropout_rate=0.5),  # K = 2: see oracle/sampled.py
+}
+
+
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack"])
+@pytest.mark.parametrize("size", ["S", "L"])
+def test_model_logits_at_sampled_rows_of_the_benchmark_graph(dev, size, name):
+    """BASELINE configs 2-5 in their one-GPU form: two training steps (so that weights, BatchNorm running statistics
+    and biases are not at their initial values), then the eval-mode logits of sampled nodes against the oracle."""
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import clear_cache
+    ei, x, y = workload(size)
+    n = x.size(0)
+    cls = {"gcn": M.GCN, "graphsage": M.GraphSAGE, "graphsage2": M.GraphSAGE2, "gat": M.GAT,
+           "appnpstack": M.APPNPStack}[name]
+    torch.manual_seed(14530529)
+    model = cls(input_dim=128, output_dim=128, **MODEL_KW[name]).to(dev)
+    ei_d, x_d, y_d = ei.to(dev), x.to(dev), y.to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    mask = (torch.arange(n, device=dev) % 5) < 3
+    model.train()
+    for _ in range(2):
+        opt.zero_grad()
+        ops.masked_ce_loss(model(x_d, ei_d)["emb"], y_d, mask).backward()
+        opt.step()
+    model.eval()
+    n_targets = 96 if name in ("gcn", "appnpstack") else 512
+    targets = S.pick_targets(n, n_targets)
+    with torch.no_grad():
+        got = model(x_d, ei_d)["emb"][targets.to(dev)].cpu()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    kw = {k: v for k, v in MODEL_KW[name].items() if k not in ("hidden_unit", "dropout_rate")}
+    want, info = S.sampled_logits(name, sd, x, ei, targets, **kw)
+    err = (got - want).abs().max().item()
+    assert err < TOL, (name, size, err, info)
+    del model, opt
+    clear_cache()
+    torch.cuda.empty_cache()

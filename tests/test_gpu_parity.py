@@ -709,6 +709,91 @@ def test_experiment_cora_shaped_gcn(dev):
     assert (emb - O.gcn_forward(sd, xn, ei, 2, False)["emb"]).abs().max().item() < TOL
 
 
+@pytest.mark.slow
+def test_experiment_cora_shaped_gcn_300_epochs(dev):
+    """BASELINE config 1 at its stated length (epoch=300, lr 0.01, as examples/rd2pd_example.py:13-15) through
+    experiment(): the per-epoch training losses follow an oracle-autograd run of the same 300 Adam steps (same seed,
+    same split, CPU fp32), and the returned (best-validation) model's logits equal the oracle forward with its
+    weights. Rounding differences between the two runs are amplified step by step by Adam, so the curve tolerance
+    is looser than the per-forward one."""
+    import rgb_experiment_amd as R
+    from rgb_experiment_amd.models import GCN
+    from rgb_experiment_amd.utils import get_whole_mask
+    n, pairs, f, c = 2708, 5278, 1433, 7
+    gen = torch.Generator().manual_seed(1234567)
+    a = torch.randint(0, n, (pairs,), generator=gen)
+    b = (a + 1 + torch.randint(0, n - 1, (pairs,), generator=gen)) % n
+    ei = torch.cat([torch.stack([a, b]), torch.stack([b, a])], dim=1)
+    x = torch.zeros(n, f)
+    x.scatter_(1, torch.randint(0, f, (n, 18), generator=gen), 1.0)
+    y = torch.randint(0, c, (n,), generator=gen)
+    res = R.experiment({"num_layers": 2, "hidden_unit": 64, "dropout_rate": 0.5}, specify_data=True,
+                       data=R.Data(x=x, y=y, edge_index=ei), model_name="gcn", learning_rate=0.01, epoch=300,
+                       normalize_feature="row", need_to_reappear=True, print_print=False, return_model=True,
+                       implement_early_stopping=False)
+    hist = res["history"]
+    assert len(hist["train_loss"]) == 300
+    # the same 300 steps under the oracle's autograd
+    xn = x / x.sum(1, keepdim=True).clamp(min=1)
+    train_mask = get_whole_mask(y, "6-2-2", 123456789)[0]
+    torch.manual_seed(14530529)
+    ref = GCN(num_layers=2, hidden_unit=64, input_dim=f, output_dim=c, dropout_rate=0.5)
+    params = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in ref.state_dict().items()}
+    names = [k for k, _ in ref.named_parameters()]
+    opt = torch.optim.Adam([params[k] for k in names], lr=0.01)
+    losses = []
+    for _ in range(300):
+        opt.zero_grad()
+        out = O.gcn_forward(params, xn, ei, 2, training=True)["out"]
+        loss = torch.nn.functional.nll_loss(out[train_mask], y[train_mask])
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    diff = max(abs(p - q) for p, q in zip(hist["train_loss"], losses))
+    assert diff < 5e-3, diff
+    assert abs(hist["train_loss"][0] - losses[0]) < 1e-5 and hist["train_loss"][-1] < hist["train_loss"][0]
+    model = res["model"].eval()
+    with torch.no_grad():
+        emb = model(xn.to(dev), ei.to(dev))["emb"].cpu()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    assert (emb - O.gcn_forward(sd, xn, ei, 2, False)["emb"]).abs().max().item() < TOL
+
+
+def test_eval_mode_batchnorm_is_differentiable(dev):
+    """model.eval() with autograd on (frozen-BN fine-tuning, saliency): input, weight and bias gradients of the
+    eval-mode BatchNorm1d equal torch.nn.BatchNorm1d's on the CPU."""
+    from rgb_experiment_amd.nn import BatchNorm1d
+    torch.manual_seed(3)
+    ref = torch.nn.BatchNorm1d(24)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 2)
+        ref.bias.uniform_(-1, 1)
+        ref.running_mean.normal_()
+        ref.running_var.uniform_(0.5, 2)
+    mine = BatchNorm1d(24)
+    mine.load_state_dict(ref.state_dict())
+    mine.to(dev)
+    ref.eval(), mine.eval()
+    x = torch.randn(500, 24)
+    go = torch.randn(500, 24)
+    xa, xb = x.clone().requires_grad_(True), x.clone().to(dev).requires_grad_(True)
+    ref(xa).backward(go)
+    yb = mine(xb)
+    assert yb.requires_grad
+    yb.backward(go.to(dev))
+    assert torch.allclose(xb.grad.cpu(), xa.grad, atol=1e-5)
+    assert torch.allclose(mine.weight.grad.cpu(), ref.weight.grad, atol=1e-3, rtol=1e-4)
+    assert torch.allclose(mine.bias.grad.cpu(), ref.bias.grad, atol=1e-4, rtol=1e-5)
+    # and a conv stack in eval mode with grad on: the graph is not cut at the BatchNorm
+    from rgb_experiment_amd.models import GCN
+    ei = rand_graph(300, 2000, 1)
+    m = GCN(num_layers=2, hidden_unit=32, input_dim=16, output_dim=5, dropout_rate=0.5).to(dev).eval()
+    xin = torch.randn(300, 16, device=dev, requires_grad=True)
+    m(xin, ei.to(dev))["emb"].sum().backward()
+    assert xin.grad is not None and float(xin.grad.abs().sum()) > 0
+    assert m.convs[0].lin.weight.grad is not None and float(m.convs[0].lin.weight.grad.abs().sum()) > 0
+
+
 def test_index_arithmetic_beyond_2_31_elements(dev):
     """|V| = 17M, |E| = 300M, d = 128: N*d and E'*d exceed 2^31, so any 32-bit element offset in a kernel would
     wrap. Oracle-free properties: SpMM of ones = in-degree exactly; A_hat row sums; fused kernel = SpMM + GEMM; GAT of

@@ -214,6 +214,38 @@ def test_g7_pta_forward_and_loss(golden, mode):
     assert abs(model.loss_function(model(x), y_soft).item() - want) < 1e-6 * max(1.0, abs(want))
 
 
+def test_pta_seeded_initialisation_equals_the_reference(golden):
+    """The reference allocates PTA's Linear parameters with torch.randn (models/pta.py:19,21), which advances the
+    global RNG before kaiming_uniform_ draws: under the same seed the product must start from the same weights
+    (golden G7 was generated after torch.manual_seed(77), modes 0, 1, 2 built one after the other)."""
+    from rgb_experiment_amd.models import PTA
+    torch.manual_seed(77)
+    x = torch.from_numpy(golden["g7/x"])
+    for mode in (0, 1, 2):
+        model = PTA(nfeat=6, nhid=5, nclass=4, dropout=0.0, epsilon=100, K=3, alpha=0.1, mode=mode)
+        for k, v in model.state_dict().items():
+            assert torch.equal(v, torch.from_numpy(golden[f"g7/mode{mode}/state/{k}"])), (mode, k)
+        model.train()
+        model(x)  # the generator ran a training forward (dropout 0.0) between the constructions
+        model.eval()
+        model(x)
+
+
+def test_experiment_refuses_masks_that_select_unlabelled_nodes():
+    """A -1 label inside a mask: the reference's NLLLoss raises; the masked loss kernels would drop the row
+    silently, so experiment() refuses up front."""
+    d = _toy()
+    d.y[3] = -1
+    d.train_mask = torch.zeros(60, dtype=torch.bool)
+    d.train_mask[:30] = True
+    d.val_mask, d.test_mask = torch.zeros(60, dtype=torch.bool), torch.zeros(60, dtype=torch.bool)
+    d.val_mask[30:45] = True
+    d.test_mask[45:] = True
+    with pytest.raises(RuntimeError, match="label is outside"):
+        R.experiment({"num_layers": 2, "hidden_unit": 8, "dropout_rate": 0.5}, specify_data=True, data=d,
+                     model_name="MLP", epoch=2, use_cpu=True, print_print=False)
+
+
 def test_experiment_accepts_index_list_masks():
     """Masks given as node-index lists (reference :193-209) are honoured (MLP: runs on the CPU)."""
     d = _toy()
