@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define RGBX_VERSION 100 /* major*10000 + minor*100 + patch */
+#define RGBX_VERSION 200 /* major*10000 + minor*100 + patch */
 
 #define RGBX_OK 0
 #define RGBX_E_ARG (-1)    /* null pointer / negative size / bad enum */
@@ -194,13 +194,19 @@ int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const float* g_a_sr
  * pass the same pointer to rgbx_gat_bwd_prep_f32, which needs the bare aggregate.
  * `out_scale` ([H*C], optional, inference only): stored row = aggregate * out_scale + bias — an eval-mode
  * BatchNorm after the layer (models/gat.py:29) folded into the store (bias then = bias * scale + shift).
+ * `out_pos` ([N, H*C], dense) and `a_pos` ([N, H]) — both NULL (inference) or both set (a forward whose backward
+ * will be asked for): the part of the aggregate, and of the attention mass, carried by edges whose pre-activation
+ * score a_src[j] + a_dst[i] is positive,
+ *   out_pos[i,h,:] = sum_{p: s_p > 0} alpha_p * hfeat[col[p],h,:],   a_pos[i,h] = sum_{p: s_p > 0} alpha_p.
+ * LeakyReLU's derivative is 1 on those edges and `slope` on the others, which turns the target-side score
+ * gradient into a per-node expression (rgbx_gat_bwd_prep_f32): no per-edge tensor is written in the backward.
  * `split` (optional): hub targets are cut into chunks whose online-softmax states are merged in chunk
- * order; `split->partial` must hold n_chunks * (H*C + 2*H) floats. */
+ * order; `split->partial` must hold n_chunks * (H*C + 2*H) floats, or n_chunks * (2*H*C + 3*H) with out_pos. */
 int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                                int64_t ldh, const float* a_src, const float* att_src,
                                const float* a_dst, const float* out_scale, const float* bias, float* out,
-                               int64_t ldo, float* m, float* rden, int64_t N, int H, int C, float slope,
-                               const rgbx_row_split_t* split, rgbx_stream_t stream);
+                               int64_t ldo, float* m, float* rden, float* out_pos, float* a_pos, int64_t N, int H,
+                               int C, float slope, const rgbx_row_split_t* split, rgbx_stream_t stream);
 
 /* Backward, target side (same CSR as forward). Per target i, head h:
  *   dsum[i,h]    = <gout[i,h,:], out[i,h,:]>
@@ -215,10 +221,13 @@ int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, const float*
                          float slope, rgbx_stream_t stream);
 
 /* The per-target record alone (no neighbour loop, one streaming pass over out / gout):
- *   nodeq[i,h] = (a_dst[i,h], m[i,h] - log(rden[i,h]), <gout[i,h,:], out[i,h,:] - bias[h,:]>, 0)
- * (`bias` = the pointer given to the forward, or NULL). */
+ *   nodeq[i,h] = (a_dst[i,h], m[i,h] - log(rden[i,h]), dsum = <gout[i,h,:], out[i,h,:] - bias[h,:]>, 0)
+ * (`bias` = the pointer given to the forward, or NULL). With the forward's `out_pos` / `a_pos` (all three of
+ * out_pos, a_pos, g_a_dst set, or all NULL) also the target-side score gradient, with no pass over the edges:
+ *   g_a_dst[i,h] = sum_p alpha_p (<gout_i, h_j> - dsum) lrelu'(s_p) = (1 - slope) (<gout_i, out_pos_i> - dsum a_pos_i). */
 int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const float* rden, const float* out,
                           int64_t ldo, const float* bias, const float* gout, int64_t ldg, float* nodeq,
+                          const float* out_pos, const float* a_pos, float slope, float* g_a_dst,
                           int64_t N, int H, int C, rgbx_stream_t stream);
 
 /* Backward, source side, over the TRANSPOSED CSR (rows = sources j, col = targets i):

@@ -35,6 +35,8 @@ struct SplitDev {
   float* pacc;
   float* p0;
   float* p1;
+  float* pacc2;  // training forward: the positive-score part of the chunk's state, [n_chunks, F]
+  float* p2;     // and of its sum, [n_chunks, H]
 };
 
 template <int VEC>
@@ -202,15 +204,25 @@ gat_scores_bwd_finish_kernel(const float* __restrict__ part, int n_blocks, int F
 // Residency: 256-thread workgroups are admitted per CU by VGPRs (<= 64 for 8 waves per SIMD) AND by SGPRs (<= 80 for 8
 // workgroups; this kernel wanted 93 = 7): both are capped here — 16 scalars live in VGPR lanes instead, nothing goes
 // to scratch — which is worth 2.5 % on the H=8, C=16 forward (5.16 -> 5.03 ms at L).
-template <int VEC, bool CHUNK>
-__global__ void __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80)))
+// TRAIN: the launch also stores, per (target, head), the part of the aggregate and of the attention mass that comes
+// from edges with a POSITIVE pre-activation score s = a_src[j] + a_dst[i]:
+//   out_pos[i,h,:] = sum_{p: s_p > 0} alpha_p hfeat[col[p],h,:],   a_pos[i,h] = sum_{p: s_p > 0} alpha_p.
+// LeakyReLU's derivative takes two values, so the target-side score gradient of the backward,
+//   g_a_dst[i,h] = sum_p alpha_p (<gout_i, h_j> - <gout_i, out_i>) lrelu'(s_p)
+//                = (1 - slope) (<gout_i, out_pos_i> - <gout_i, out_i> a_pos_i)        (sum_p alpha_p = 1),
+// becomes a per-node expression (rgbx_gat_bwd_prep_f32) instead of a per-edge tensor ds[E', H] written by the
+// source-side pass and summed per target by another launch.
+template <int VEC, bool CHUNK, bool TRAIN>
+__global__ void __launch_bounds__(256, TRAIN ? 7 : 8) __attribute__((amdgpu_num_sgpr(80)))
 gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
                const float* __restrict__ att_src, const float* __restrict__ a_dst,
                const float* __restrict__ oscale, const float* __restrict__ bias, float* __restrict__ out,
                int64_t ldo,
-               float* __restrict__ m_out, float* __restrict__ rden_out, int N, float slope,
+               float* __restrict__ m_out, float* __restrict__ rden_out, float* __restrict__ opos_out,
+               float* __restrict__ apos_out, int N, float slope,
                const GatLayout L, const SplitDev sp) {
+  constexpr int U = TRAIN ? 3 : 4;  // neighbour rows in flight per lane group (TRAIN: VEC + 1 more accumulators)
   const int lane = threadIdx.x & 63;
   const int NG = kWave / L.G;
   const int g = lane / L.G;
@@ -245,8 +257,14 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
       if (att_src && active) load_vec<VEC>(att, att_src + cofs);
       float m = kNegBig, l = 0.f;
       float acc[VEC];
+      float lp = 0.f;
+      float accp[TRAIN ? VEC : 1];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      if constexpr (TRAIN) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) accp[i] = 0.f;
+      }
 
       for (int base = start; base < end; base += kWave) {
         const int n = min(kWave, end - base);
@@ -282,6 +300,12 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
             l = fmaf(l, sc, p);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = fmaf(acc[i], sc, p * v[u][i]);
+            if constexpr (TRAIN) {
+              const float pp = s > 0.f ? p : 0.f;
+              lp = fmaf(lp, sc, pp);
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) accp[i] = fmaf(accp[i], sc, pp * v[u][i]);
+            }
             m = mn;
           }
         }
@@ -298,14 +322,21 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
           const float a2 = __shfl_xor(acc[i], off);
           acc[i] = acc[i] * s1 + a2 * s2;
         }
+        if constexpr (TRAIN) {
+          lp = lp * s1 + __shfl_xor(lp, off) * s2;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) accp[i] = accp[i] * s1 + __shfl_xor(accp[i], off) * s2;
+        }
         m = mn;
       }
       if (g == 0 && active) {
         if constexpr (CHUNK) {  // un-normalised online-softmax state of this chunk
           store_vec<VEC>(sp.pacc + (int64_t)item * F + cofs, acc);
+          if constexpr (TRAIN) store_vec<VEC>(sp.pacc2 + (int64_t)item * F + cofs, accp);
           if (ch == 0) {
             sp.p0[(int64_t)item * L.H + head] = m;
             sp.p1[(int64_t)item * L.H + head] = l;
+            if constexpr (TRAIN) sp.p2[(int64_t)item * L.H + head] = lp;
           }
         } else {
           const float rd = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
@@ -317,9 +348,15 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
 #pragma unroll
           for (int i = 0; i < VEC; ++i) r[i] = acc[i] * rd * sv[i] + bv[i];
           store_vec<VEC>(out + (int64_t)row * ldo + cofs, r);
+          if constexpr (TRAIN) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) accp[i] *= rd;
+            store_vec<VEC>(opos_out + (int64_t)row * F + cofs, accp);
+          }
           if (ch == 0) {
             m_out[(int64_t)row * L.H + head] = l > 0.f ? m : 0.f;
             rden_out[(int64_t)row * L.H + head] = rd;
+            if constexpr (TRAIN) apos_out[(int64_t)row * L.H + head] = lp * rd;
           }
         }
       }
@@ -332,7 +369,8 @@ template <int VEC>
 __global__ void __launch_bounds__(256)
 gat_fwd_combine_kernel(int n_long, const int* __restrict__ long_row, const int* __restrict__ long_chunk_ptr,
                        const float* __restrict__ oscale, const float* __restrict__ bias, float* __restrict__ out, int64_t ldo, float* __restrict__ m_out,
-                       float* __restrict__ rden_out, const GatLayout L, const SplitDev sp) {
+                       float* __restrict__ rden_out, float* __restrict__ opos_out, float* __restrict__ apos_out,
+                       const GatLayout L, const SplitDev sp) {
   const int lane = threadIdx.x & 63;
   const int g = lane / L.G;
   const int t = lane % L.G;
@@ -348,10 +386,10 @@ gat_fwd_combine_kernel(int n_long, const int* __restrict__ long_row, const int* 
       const bool active = g == 0 && hl < L.HPC && head < L.H && ch < L.C;
       if (!active) continue;
       const int cofs = head * L.C + ch;
-      float m = kNegBig, l = 0.f;
-      float acc[VEC];
+      float m = kNegBig, l = 0.f, lp = 0.f;
+      float acc[VEC], accp[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      for (int i = 0; i < VEC; ++i) acc[i] = accp[i] = 0.f;
       for (int c = c0; c < c1; ++c) {
         const float m2 = sp.p0[(int64_t)c * L.H + head];
         const float l2 = sp.p1[(int64_t)c * L.H + head];
@@ -362,9 +400,21 @@ gat_fwd_combine_kernel(int n_long, const int* __restrict__ long_row, const int* 
         l = l * s1 + l2 * s2;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = acc[i] * s1 + a2[i] * s2;
+        if (opos_out) {
+          load_vec<VEC>(a2, sp.pacc2 + (int64_t)c * F + cofs);
+          lp = lp * s1 + sp.p2[(int64_t)c * L.H + head] * s2;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) accp[i] = accp[i] * s1 + a2[i] * s2;
+        }
         m = mn;
       }
       const float rd = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
+      if (opos_out) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) accp[i] *= rd;
+        store_vec<VEC>(opos_out + (int64_t)row * F + cofs, accp);
+        if (ch == 0) apos_out[(int64_t)row * L.H + head] = lp * rd;
+      }
       float bv[VEC], sv[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { bv[i] = 0.f; sv[i] = 1.f; }
@@ -472,7 +522,8 @@ __global__ void __launch_bounds__(256)
 gat_bwd_prep_kernel(const float* __restrict__ a_dst, const float* __restrict__ m_in,
                     const float* __restrict__ rden_in, const float* __restrict__ out, int64_t ldo,
                     const float* __restrict__ bias, const float* __restrict__ gout, int64_t ldg,
-                    float4* __restrict__ nodeq_out, int N, const GatLayout L) {
+                    float4* __restrict__ nodeq_out, const float* __restrict__ opos, const float* __restrict__ apos,
+                    float one_minus_slope, float* __restrict__ g_a_dst, int N, const GatLayout L) {
   const int lane = threadIdx.x & 63;
   const int t = lane % L.G;
   const int g = lane / L.G;
@@ -501,9 +552,18 @@ gat_bwd_prep_kernel(const float* __restrict__ a_dst, const float* __restrict__ m
         }
       }
       const float dsum = head_sum(dot_vec<VEC>(go, o), L.LPH);
+      float dpos = 0.f;
+      if (opos) {  // <gout_i, out_pos_i>: see gat_fwd_kernel<.., TRAIN>
+        float op[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) op[i] = 0.f;
+        if (active) load_vec<VEC>(op, opos + (int64_t)row * ((int64_t)L.H * L.C) + cofs);
+        dpos = head_sum(dot_vec<VEC>(go, op), L.LPH);
+      }
       if (active && ch == 0) {
         const int64_t q = (int64_t)row * L.H + head;
         nodeq_out[q] = make_float4(a_dst[q], softmax_shift(m_in[q], rden_in[q]), dsum, 0.f);
+        if (opos) g_a_dst[q] = one_minus_slope * (dpos - dsum * apos[q]);
       }
     }
   }
@@ -655,7 +715,7 @@ gat_bwd_src_combine_kernel(int n_long, const int* __restrict__ long_row, const i
 
 // ------------------------------------------------------------------------------------------
 int split_view(const rgbx_row_split_t* split, int H, int C, SplitDev* sd, const char* name) {
-  *sd = SplitDev{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  *sd = SplitDev{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (!split || split->threshold <= 0 || split->n_chunks <= 0) return RGBX_OK;
   if (split->n_long <= 0 || !split->chunk_row || !split->chunk_begin || !split->chunk_end || !split->long_row ||
       !split->long_chunk_ptr || !split->partial)
@@ -668,6 +728,8 @@ int split_view(const rgbx_row_split_t* split, int H, int C, SplitDev* sd, const 
   sd->pacc = split->partial;                                   // [n_chunks, F]
   sd->p0 = split->partial + (int64_t)split->n_chunks * F;      // [n_chunks, H]
   sd->p1 = sd->p0 + (int64_t)split->n_chunks * H;              // [n_chunks, H]
+  sd->pacc2 = sd->p1 + (int64_t)split->n_chunks * H;           // [n_chunks, F]   (training forward only: the caller
+  sd->p2 = sd->pacc2 + (int64_t)split->n_chunks * F;           // [n_chunks, H]    then provides 2F + 3H per chunk)
   return RGBX_OK;
 }
 
@@ -795,35 +857,45 @@ extern "C" int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const fl
 extern "C" int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                                           int64_t ldh, const float* a_src, const float* att_src,
                                           const float* a_dst, const float* out_scale, const float* bias,
-                                          float* out, int64_t ldo, float* m, float* rden, int64_t N, int H, int C,
+                                          float* out, int64_t ldo, float* m, float* rden, float* out_pos,
+                                          float* a_pos, int64_t N, int H, int C,
                                           float slope, const rgbx_row_split_t* split, rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_fwd")) return rc;
   if (N == 0) return RGBX_OK;
   if (!rowptr || !col || !hfeat || (!a_src && !att_src) || !a_dst || !out || !m || !rden)
     return fail(RGBX_E_ARG, "gat_fwd: null pointer");
+  if ((out_pos != nullptr) != (a_pos != nullptr)) return fail(RGBX_E_ARG, "gat_fwd: out_pos and a_pos go together");
   if (ldh < (int64_t)H * C || ldo < (int64_t)H * C) return fail(RGBX_E_ARG, "gat_fwd: leading dimension < H*C");
   SplitDev sd;
   if (int rc = split_view(split, H, C, &sd, "gat_fwd")) return rc;
-  const int vec = pick_vec(C, {hfeat, out, att_src, bias, out_scale, sd.pacc}, {ldh, ldo});
+  const int vec = pick_vec(C, {hfeat, out, att_src, bias, out_scale, sd.pacc, out_pos, sd.pacc2}, {ldh, ldo});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_fwd")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int grid = gat_grid(N);
-#define RGBX_GAT_FWD(V)                                                                                         \
+#define RGBX_GAT_FWD(V, T)                                                                                      \
   do {                                                                                                          \
-    gat_fwd_kernel<V, false><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out_scale,    \
-                                                  bias, out, ldo, m, rden, (int)N, slope, L, sd);               \
+    gat_fwd_kernel<V, false, T><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out_scale, \
+                                                     bias, out, ldo, m, rden, out_pos, a_pos, (int)N, slope, L, \
+                                                     sd);                                                       \
     if (sd.threshold > 0) {                                                                                     \
-      gat_fwd_kernel<V, true><<<gat_grid(split->n_chunks), 256, 0, s>>>(                                        \
-          rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out_scale, bias, out, ldo, m, rden, split->n_chunks,  \
-          slope, L, sd);                                                                                        \
+      gat_fwd_kernel<V, true, T><<<gat_grid(split->n_chunks), 256, 0, s>>>(                                     \
+          rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out_scale, bias, out, ldo, m, rden, out_pos, a_pos,   \
+          split->n_chunks, slope, L, sd);                                                                       \
       gat_fwd_combine_kernel<V><<<gat_grid(split->n_long), 256, 0, s>>>(                                        \
-          split->n_long, split->long_row, split->long_chunk_ptr, out_scale, bias, out, ldo, m, rden, L, sd);    \
+          split->n_long, split->long_row, split->long_chunk_ptr, out_scale, bias, out, ldo, m, rden, out_pos,   \
+          a_pos, L, sd);                                                                                        \
     }                                                                                                           \
   } while (0)
-  if (vec == 4) RGBX_GAT_FWD(4);
-  else if (vec == 2) RGBX_GAT_FWD(2);
-  else RGBX_GAT_FWD(1);
+  if (out_pos) {
+    if (vec == 4) RGBX_GAT_FWD(4, true);
+    else if (vec == 2) RGBX_GAT_FWD(2, true);
+    else RGBX_GAT_FWD(1, true);
+  } else {
+    if (vec == 4) RGBX_GAT_FWD(4, false);
+    else if (vec == 2) RGBX_GAT_FWD(2, false);
+    else RGBX_GAT_FWD(1, false);
+  }
 #undef RGBX_GAT_FWD
   RGBX_CHECK_LAUNCH("gat_fwd_kernel");
   return RGBX_OK;
@@ -859,21 +931,26 @@ extern "C" int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, c
 
 extern "C" int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const float* rden, const float* out,
                                      int64_t ldo, const float* bias, const float* gout, int64_t ldg, float* nodeq,
+                                     const float* out_pos, const float* a_pos, float slope, float* g_a_dst,
                                      int64_t N, int H, int C, rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_bwd_prep")) return rc;
   if (N == 0) return RGBX_OK;
   if (!a_dst || !m || !rden || !out || !gout || !nodeq) return fail(RGBX_E_ARG, "gat_bwd_prep: null pointer");
+  if ((out_pos != nullptr) != (a_pos != nullptr) || (out_pos != nullptr) != (g_a_dst != nullptr))
+    return fail(RGBX_E_ARG, "gat_bwd_prep: out_pos, a_pos and g_a_dst go together");
   const int64_t F = (int64_t)H * C;
   if (ldo < F || ldg < F) return fail(RGBX_E_ARG, "gat_bwd_prep: leading dimension < H*C");
   if (!aligned16(nodeq)) return fail(RGBX_E_ALIGN, "gat_bwd_prep: nodeq must be 16-byte aligned");
-  const int vec = pick_vec(C, {out, gout, bias}, {ldo, ldg});
+  const int vec = pick_vec(C, {out, gout, bias, out_pos}, {ldo, ldg});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_bwd_prep")) return rc;
   hipStream_t s = (hipStream_t)stream;
   int64_t b = cdiv(N, 4 * (kWave / L.G));
   const int grid = (int)(b < kMaxGrid ? b : kMaxGrid);
-#define RGBX_GAT_BP(V) \
-  gat_bwd_prep_kernel<V><<<grid, 256, 0, s>>>(a_dst, m, rden, out, ldo, bias, gout, ldg, reinterpret_cast<float4*>(nodeq), (int)N, L)
+#define RGBX_GAT_BP(V)                                                                                             \
+  gat_bwd_prep_kernel<V><<<grid, 256, 0, s>>>(a_dst, m, rden, out, ldo, bias, gout, ldg,                           \
+                                              reinterpret_cast<float4*>(nodeq), out_pos, a_pos, 1.0f - slope, g_a_dst, \
+                                              (int)N, L)
   if (vec == 4) RGBX_GAT_BP(4);
   else if (vec == 2) RGBX_GAT_BP(2);
   else RGBX_GAT_BP(1);

@@ -56,7 +56,8 @@ class HipAggregator:
 
     def gat(self, rect, x_ext, att_src, att_dst, n_tgt, H, C, slope):
         from .. import ops
-        return ops._GATAttend.apply(x_ext, att_src, att_dst, rect, H, C, slope)
+        want_grad = torch.is_grad_enabled() and (x_ext.requires_grad or att_src.requires_grad or att_dst.requires_grad)
+        return ops._GATAttend.apply(x_ext, att_src, att_dst, rect, H, C, slope, None, None, want_grad)
 
 
 class _ExtGraph:

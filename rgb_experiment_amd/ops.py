@@ -312,9 +312,10 @@ class _GATAggregate(torch.autograd.Function):
     """out[i,h,:] = sum_j softmax_j(leaky_relu(a_src[j,h] + a_dst[i,h])) * hfeat[j,h,:]."""
 
     @staticmethod
-    def forward(ctx, hfeat, a_src, a_dst, graph, H, C, slope, att_src=None):
+    def forward(ctx, hfeat, a_src, a_dst, graph, H, C, slope, att_src=None, want_grad=True):
         """`att_src` ([H, C], no gradient through this argument: the score path's gradient flows through
-        `a_src`) lets the kernel form the source scores from the rows it gathers anyway."""
+        `a_src`) lets the kernel form the source scores from the rows it gathers anyway. `want_grad`: a backward
+        will follow (the forward then also stores the positive-score parts the backward's prep pass needs)."""
         _lib.require_device(hfeat, a_src, a_dst, att_src)
         hfeat, a_src, a_dst = hfeat.contiguous(), a_src.contiguous(), a_dst.contiguous()
         att = None if att_src is None else att_src.detach().reshape(H, C).contiguous()
@@ -326,48 +327,62 @@ class _GATAggregate(torch.autograd.Function):
         ph, ldh = _lib.mat(hfeat, "hfeat")
         po, ldo = _lib.mat(out, "out")
         csr = graph.fwd
-        split, _scratch = csr.split_arg(H * C + 2 * H, dev)
+        opos, apos = _gat_train_extras(want_grad, N, H, C, dev)
+        split, _scratch = csr.split_arg((2 * H * C + 3 * H) if want_grad else (H * C + 2 * H), dev)
         with _Timed("gat_fwd"):
             _lib.check(
                 _lib.load().rgbx_gat_aggregate_fwd_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), ph, ldh,
                                                        _lib.ptr(a_src), _lib.ptr(att), _lib.ptr(a_dst), None, None,
-                                                       po, ldo, _lib.ptr(m), _lib.ptr(rden), N, H, C, float(slope),
+                                                       po, ldo, _lib.ptr(m), _lib.ptr(rden), _lib.ptr(opos),
+                                                       _lib.ptr(apos), N, H, C, float(slope),
                                                        None if split is None else ctypes.byref(split),
                                                        _lib.stream_ptr()), "rgbx_gat_aggregate_fwd_f32")
-        ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out)
+        ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out, opos, apos)
         ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, slope
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        """Three launches, one full gather pass: (1) per-target records nodeq = (a_dst, max, 1/sum,
-        <gout, out>) in a streaming pass; (2) the source-side pass over the transposed CSR gathers gout
-        rows + records, produces g_hfeat, g_a_src and the per-edge score gradient ds; (3) g_a_dst is the
-        width-H segment sum of ds over each target's in-edges (the SpMM kernel over the slot map)."""
-        hfeat, a_src, a_dst, m, rden, out = ctx.saved_tensors
+        """Two launches, one full gather pass: (1) per-target records nodeq = (a_dst, max - log(1/sum),
+        <gout, out>) and the target-side score gradient g_a_dst in a streaming pass; (2) the source-side pass
+        over the transposed CSR gathers gout rows + records and produces g_hfeat and g_a_src."""
+        hfeat, a_src, a_dst, m, rden, out, opos, apos = ctx.saved_tensors
         g_h, g_as, g_ad = _gat_backward_core(ctx.graph, hfeat, a_src, a_dst, m, rden, out, gout.contiguous(), ctx.H,
-                                             ctx.C, ctx.slope)
-        return g_h, g_as, g_ad, None, None, None, None, None
+                                             ctx.C, ctx.slope, opos=opos, apos=apos)
+        return g_h, g_as, g_ad, None, None, None, None, None, None
 
 
-def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope, bias=None):
+def _gat_train_extras(want_grad, N, H, C, dev):
+    """(out_pos [N, H*C], a_pos [N, H]) buffers of a forward whose backward will be asked for, else (None, None)."""
+    if not want_grad:
+        return None, None
+    return (torch.empty((N, H * C), dtype=torch.float32, device=dev),
+            torch.empty((N, H), dtype=torch.float32, device=dev))
+
+
+def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope, bias=None, opos=None, apos=None):
     """(g_hfeat through the aggregation, g_a_src [n_src, H], g_a_dst [n_tgt, H]). `bias`: the vector the
-    forward added to `out` in its store, if any."""
+    forward added to `out` in its store, if any. `opos` / `apos`: the positive-score parts the forward stored
+    (rgbx_gat_aggregate_fwd_f32 out_pos / a_pos): with them g_a_dst comes out of the streaming prep pass; without
+    them (a forward run without want_grad) the source-side pass also writes the per-edge score gradient ds [E', H]
+    and g_a_dst is its width-H segment sum over each target's in-edges."""
     N, n_src, dev = g.fwd.N, g.bwd.N, gout.device
     lib = _lib.load()
-    nodeq = torch.empty((N, H, 4), dtype=torch.float32, device=dev)  # (a_dst, max, 1/sum, dsum) records
+    nodeq = torch.empty((N, H, 4), dtype=torch.float32, device=dev)  # (a_dst, max - log(1/sum), dsum, -) records
     g_as = torch.empty((n_src, H), dtype=torch.float32, device=dev)
     g_h = torch.empty_like(hfeat)
     ph, ldh = _lib.mat(hfeat, "hfeat")
     po, ldo = _lib.mat(out, "out")
     pg, ldg = _lib.mat(gout, "gout")
     pgh, ldgh = _lib.mat(g_h, "g_hfeat")
-    seg = gat_segment_csr(g)
-    ds = torch.empty((max(g.bwd.nnz, 1), H), dtype=torch.float32, device=dev)
+    per_node = opos is not None
+    g_ad = torch.empty((N, H), dtype=torch.float32, device=dev) if per_node else None
+    ds = None if per_node else torch.empty((max(g.bwd.nnz, 1), H), dtype=torch.float32, device=dev)
     with _Timed("gat_bwd_prep"):
         _lib.check(
             lib.rgbx_gat_bwd_prep_f32(_lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, _lib.ptr(bias), pg, ldg,
-                                      _lib.ptr(nodeq), N, H, C, _lib.stream_ptr()), "rgbx_gat_bwd_prep_f32")
+                                      _lib.ptr(nodeq), _lib.ptr(opos), _lib.ptr(apos), float(slope), _lib.ptr(g_ad),
+                                      N, H, C, _lib.stream_ptr()), "rgbx_gat_bwd_prep_f32")
     split, _scratch = g.bwd.split_arg(H * C + 2 * H, dev)
     with _Timed("gat_bwd_src"):
         _lib.check(
@@ -375,7 +390,8 @@ def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope, 
                                      _lib.ptr(nodeq), pg, ldg, pgh, ldgh, _lib.ptr(g_as), _lib.ptr(ds), n_src, H,
                                      C, float(slope), None if split is None else ctypes.byref(split),
                                      _lib.stream_ptr()), "rgbx_gat_bwd_src_f32")
-    g_ad = spmm_raw(seg, None, None, ds, kind="gat_bwd_segsum")
+    if not per_node:
+        g_ad = spmm_raw(gat_segment_csr(g), None, None, ds, kind="gat_bwd_segsum")
     return g_h, g_as, g_ad
 
 
@@ -404,7 +420,8 @@ def gat_scores(hfeat, att_src, att_dst, H, C):
 
 
 def gat_aggregate(hfeat, a_src, a_dst, graph, H, C, slope=0.2, att_src=None):
-    return _GATAggregate.apply(hfeat, a_src, a_dst, graph, H, C, slope, att_src)
+    want_grad = torch.is_grad_enabled() and (hfeat.requires_grad or a_src.requires_grad or a_dst.requires_grad)
+    return _GATAggregate.apply(hfeat, a_src, a_dst, graph, H, C, slope, att_src, want_grad)
 
 
 class _GATAttend(torch.autograd.Function):
@@ -417,7 +434,7 @@ class _GATAttend(torch.autograd.Function):
     an eval-mode BatchNorm after the layer folded into the store."""
 
     @staticmethod
-    def forward(ctx, hfeat, att_src, att_dst, graph, H, C, slope, bias=None, out_scale=None):
+    def forward(ctx, hfeat, att_src, att_dst, graph, H, C, slope, bias=None, out_scale=None, want_grad=True):
         _lib.require_device(hfeat, att_src, att_dst, bias, out_scale)
         hfeat = hfeat.contiguous()
         b = None if bias is None else bias.detach().reshape(H * C).contiguous()
@@ -437,15 +454,18 @@ class _GATAttend(torch.autograd.Function):
         rden = torch.empty_like(m)
         po, ldo = _lib.mat(out, "out")
         att_k = att_s if _scores_in_kernel(C) else None
-        split, _scratch = graph.fwd.split_arg(H * C + 2 * H, dev)
+        want_grad = want_grad and sc is None
+        opos, apos = _gat_train_extras(want_grad, N, H, C, dev)
+        split, _scratch = graph.fwd.split_arg((2 * H * C + 3 * H) if want_grad else (H * C + 2 * H), dev)
         with _Timed("gat_fwd"):
             _lib.check(
                 lib.rgbx_gat_aggregate_fwd_f32(_lib.ptr(graph.fwd.rowptr), _lib.ptr(graph.fwd.col), ph, ldh,
                                                _lib.ptr(a_src), _lib.ptr(att_k), _lib.ptr(a_dst), _lib.ptr(sc),
-                                               _lib.ptr(b), po, ldo, _lib.ptr(m), _lib.ptr(rden), N, H, C, float(slope),
+                                               _lib.ptr(b), po, ldo, _lib.ptr(m), _lib.ptr(rden), _lib.ptr(opos),
+                                               _lib.ptr(apos), N, H, C, float(slope),
                                                None if split is None else ctypes.byref(split), _lib.stream_ptr()),
                 "rgbx_gat_aggregate_fwd_f32")
-        ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out, att_s, att_d, b)
+        ctx.save_for_backward(hfeat, a_src, a_dst, m, rden, out, att_s, att_d, b, opos, apos)
         ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, slope
         ctx.att_shapes = (att_src.shape, att_dst.shape)
         ctx.bias_shape = None if bias is None else bias.shape
@@ -455,10 +475,11 @@ class _GATAttend(torch.autograd.Function):
     def backward(ctx, gout):
         if ctx.inference_only:
             raise RuntimeError("gat_attend(out_scale=...) is an inference-only form (eval-mode BatchNorm fold)")
-        hfeat, a_src, a_dst, m, rden, out, att_s, att_d, b = ctx.saved_tensors
+        hfeat, a_src, a_dst, m, rden, out, att_s, att_d, b, opos, apos = ctx.saved_tensors
         H, C = ctx.H, ctx.C
         gout = gout.contiguous()
-        g_h, g_as, g_ad = _gat_backward_core(ctx.graph, hfeat, a_src, a_dst, m, rden, out, gout, H, C, ctx.slope, b)
+        g_h, g_as, g_ad = _gat_backward_core(ctx.graph, hfeat, a_src, a_dst, m, rden, out, gout, H, C, ctx.slope, b,
+                                             opos=opos, apos=apos)
         g_b = gout.sum(0).reshape(ctx.bias_shape) if b is not None and ctx.needs_input_grad[7] else None
         lib = _lib.load()
         n = hfeat.size(0)
@@ -477,7 +498,7 @@ class _GATAttend(torch.autograd.Function):
                                             _lib.ptr(scratch), n_scr.value, n, H, C, _lib.stream_ptr()),
                 "rgbx_gat_scores_bwd_f32")
         return (g_h, g_att_s.reshape(ctx.att_shapes[0]), g_att_d.reshape(ctx.att_shapes[1]), None, None, None, None, g_b,
-                None)
+                None, None)
 
 
 def gat_attend(h, att_src, att_dst, graph, H, C, slope=0.2, bias=None, out_scale=None):
@@ -490,7 +511,9 @@ def gat_attend(h, att_src, att_dst, graph, H, C, slope=0.2, bias=None, out_scale
         return out if bias is None else out + bias
     if out_scale is not None and torch.is_grad_enabled():
         raise RuntimeError("gat_attend(out_scale=...) is an inference-only form")
-    return _GATAttend.apply(h, att_src, att_dst, graph, H, C, slope, bias, out_scale)
+    want_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (h, att_src, att_dst, bias))
+    return _GATAttend.apply(h, att_src, att_dst, graph, H, C, slope, bias, out_scale, want_grad)
 
 
 def _scores_in_kernel(C):
