@@ -603,12 +603,20 @@ def main():
         by_kind.setdefault(k, []).append(s.elapsed_time(e))
     agg_total_ms = sum(sum(v) for k, v in by_kind.items() if k in AGG_KINDS)
     agg_avg_s = agg_total_ms * 1e-3 / (n_prop * args.steps)  # aggregation kernel time per propagate (this rank)
-    achieved = alg / agg_avg_s / 1e9 if agg_avg_s else None
+    dominant = max((k for k in by_kind if k in AGG_KINDS), key=lambda k: sum(by_kind[k]), default=None)
+    kernel = KERNEL_OF_KIND.get(dominant, "none recorded")
+    achieved = None
     if alg_by_kind and agg_total_ms:  # partitioned run: launches of different shapes, sum bytes over those made
         done = sum(alg_by_kind[k] * len(v) for k, v in by_kind.items() if k in alg_by_kind)
         achieved = done / (agg_total_ms * 1e-3) / 1e9
-    dominant = max((k for k in by_kind if k in AGG_KINDS), key=lambda k: sum(by_kind[k]), default=None)
-    kernel = KERNEL_OF_KIND.get(dominant, "none recorded")
+    elif dominant is not None:
+        # the DOMINANT kernel's own launches: its algorithmic bytes per launch / its mean launch duration
+        launches_per_event = kwargs.get("K", 1) if dominant.startswith("appnp") else 1
+        if dominant == "gat_fwd":
+            H = kwargs.get("heads", 8)
+            alg = nnz_total * (4 + 4 * H + 4 * d) + N * (8 * d + 12 * H) + 4 * (N + 1)
+        dom_s = sum(by_kind[dominant]) / len(by_kind[dominant]) / launches_per_event * 1e-3
+        achieved = alg / dom_s / 1e9
     by_kind = {k: {"n": len(v), "avg_ms": sum(v) / len(v)} for k, v in sorted(by_kind.items())}
     traffic, traffic_note = pmc_traffic(args.workload, args.model, kernel, parts)
 

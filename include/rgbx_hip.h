@@ -172,7 +172,8 @@ int rgbx_gat_scores_f32(const float* hfeat, int64_t ldh, const float* att_src,
 int rgbx_gat_scores_bwd_scratch_floats(int64_t n, int H, int C, int64_t* count);
 
 /* Backward of rgbx_gat_scores_f32, fused with the accumulation into the feature gradient:
- *   g_hfeat[r,h,:] += g_a_src[r,h] * att_src[h,:] + g_a_dst[r,h] * att_dst[h,:]   (in place)
+ *   g_hfeat[r,h,:] += g_a_src[r,h] * att_src[h,:] + g_a_dst[r,h] * att_dst[h,:]   (in place; skipped when
+ *                                                  g_hfeat is NULL: rgbx_gat_bwd_src_f32 can fold it into its store)
  *   g_att_src[h,:]  = sum_r g_a_src[r,h] * hfeat[r,h,:],   g_att_dst likewise
  * over rows r in [0, n); g_a_dst has n_dst <= n rows (rows beyond are zero: halo rows of a partitioned
  * run have no target role). Partial sums per workgroup are added in workgroup order (reproducible). */
@@ -190,6 +191,9 @@ int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const float* g_a_sr
  * Source scores: either `a_src` ([n_src, H], gathered per edge) or, when `att_src` ([H, C]) is not
  * NULL, recomputed inside the kernel from each gathered row as <hfeat[col[p],h,:], att_src[h,:]>
  * (saves one cache-line request per edge; `a_src` is then ignored and may be NULL).
+ * Target scores: `a_dst` ([N, H]) is an INPUT when `att_dst` is NULL. With `att_dst` ([H, C]) the kernel forms
+ * a_dst[i,h] = <hfeat[i,h,:], att_dst[h,:]> itself from the target's own row (targets are rows [0, N) of hfeat) and,
+ * if `a_dst` is not NULL, stores it there for the backward: rgbx_gat_scores_f32 is then not needed at all.
  * `bias` ([H*C], optional): added to every stored row (GATConv's `out + bias` with concat=True, or heads=1);
  * pass the same pointer to rgbx_gat_bwd_prep_f32, which needs the bare aggregate.
  * `out_scale` ([H*C], optional, inference only): stored row = aggregate * out_scale + bias — an eval-mode
@@ -204,9 +208,10 @@ int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const float* g_a_sr
  * order; `split->partial` must hold n_chunks * (H*C + 2*H) floats, or n_chunks * (2*H*C + 3*H) with out_pos. */
 int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                                int64_t ldh, const float* a_src, const float* att_src,
-                               const float* a_dst, const float* out_scale, const float* bias, float* out,
-                               int64_t ldo, float* m, float* rden, float* out_pos, float* a_pos, int64_t N, int H,
-                               int C, float slope, const rgbx_row_split_t* split, rgbx_stream_t stream);
+                               float* a_dst, const float* att_dst, const float* out_scale, const float* bias,
+                               float* out, int64_t ldo, float* m, float* rden, float* out_pos, float* a_pos,
+                               int64_t N, int H, int C, float slope, const rgbx_row_split_t* split,
+                               rgbx_stream_t stream);
 
 /* Backward, target side (same CSR as forward). Per target i, head h:
  *   dsum[i,h]    = <gout[i,h,:], out[i,h,:]>
@@ -237,11 +242,17 @@ int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const float* rden,
  * alpha is recomputed from a_src[j] and nodeq[i]. If `ds` is not NULL, ds_p is also stored at
  * ds[p, :] ([E', H] in transposed-slot order): g_a_dst[i,h] = sum of ds over the in-edges of i is then a
  * width-H segment sum (rgbx_spmm_csr_f32 over the forward rowptr with col = the forward-slot ->
- * transposed-slot map), which replaces the second full gather pass of rgbx_gat_bwd_dst_f32. */
+ * transposed-slot map), which replaces the second full gather pass of rgbx_gat_bwd_dst_f32.
+ * `a_src` NULL: the source's own score is formed from its row with att_src = att2[0], as the forward did.
+ * `att2` ([2, H, C] = [att_src; att_dst], optional) with `g_a_dst` ([N, H]: the target-side score gradient of every
+ * SOURCE row, zero for rows that are no target): the backward of the two score products is folded into the store,
+ *   g_hfeat[j,h,:] += g_a_src[j,h] * att_src[h,:] + g_a_dst[j,h] * att_dst[h,:]
+ * — rgbx_gat_scores_bwd_f32 then runs with g_hfeat = NULL (attention-vector gradients only). */
 int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const float* hfeat,
                          int64_t ldh, const float* a_src, const float* nodeq, const float* gout,
-                         int64_t ldg, float* g_hfeat, int64_t ldgh, float* g_a_src, float* ds, int64_t N,
-                         int H, int C, float slope, const rgbx_row_split_t* split, rgbx_stream_t stream);
+                         int64_t ldg, float* g_hfeat, int64_t ldgh, float* g_a_src, float* ds,
+                         const float* att2, const float* g_a_dst, int64_t N, int H, int C, float slope,
+                         const rgbx_row_split_t* split, rgbx_stream_t stream);
 
 /* ---- dense layers on the MFMA units -------------------------------------------------------- */
 

@@ -130,18 +130,22 @@ gat_scores_bwd_kernel(const float* __restrict__ hfeat, int64_t ldh, const float*
     for (int row0 = (blockIdx.x * wpb + wave) * NG; row0 < n; row0 += gridDim.x * wpb * NG) {
       const int row = row0 + g;
       if (lane_ok && row < n) {
-        float h[VEC], gh[VEC];
+        float h[VEC];
         load_vec<VEC>(h, hfeat + (int64_t)row * ldh + cofs);
-        load_vec<VEC>(gh, g_hfeat + (int64_t)row * ldgh + cofs);
         const float gs = g_a_src[(int64_t)row * L.H + head];
         const float gd = row < n_dst ? g_a_dst[(int64_t)row * L.H + head] : 0.f;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-          gh[i] = fmaf(gs, as[i], fmaf(gd, ad[i], gh[i]));
           ps[i] = fmaf(gs, h[i], ps[i]);
           pd[i] = fmaf(gd, h[i], pd[i]);
         }
-        store_vec<VEC>(g_hfeat + (int64_t)row * ldgh + cofs, gh);
+        if (g_hfeat) {  // NULL: rgbx_gat_bwd_src_f32 already folded the score terms into its store
+          float gh[VEC];
+          load_vec<VEC>(gh, g_hfeat + (int64_t)row * ldgh + cofs);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) gh[i] = fmaf(gs, as[i], fmaf(gd, ad[i], gh[i]));
+          store_vec<VEC>(g_hfeat + (int64_t)row * ldgh + cofs, gh);
+        }
       }
     }
     // fold the NG row groups, then the block's waves (fixed order), then one partial record per block
@@ -216,7 +220,8 @@ template <int VEC, bool CHUNK, bool TRAIN>
 __global__ void __launch_bounds__(256, TRAIN ? 7 : 8) __attribute__((amdgpu_num_sgpr(80)))
 gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
-               const float* __restrict__ att_src, const float* __restrict__ a_dst,
+               const float* __restrict__ att_src, float* __restrict__ a_dst,
+               const float* __restrict__ att_dst,
                const float* __restrict__ oscale, const float* __restrict__ bias, float* __restrict__ out,
                int64_t ldo,
                float* __restrict__ m_out, float* __restrict__ rden_out, float* __restrict__ opos_out,
@@ -248,7 +253,23 @@ gat_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
       const int head = hbase + hl;
       const bool active = hl < L.HPC && head < L.H && ch < L.C;
       const int cofs = head * L.C + ch;
-      const float ad = active ? a_dst[(int64_t)row * L.H + head] : 0.f;
+      // With att_dst given, the target's own score <h_i, att_dst> is formed here from its row (one more row next to
+      // the ~30 gathered ones) instead of by a pass of its own over hfeat (gat_scores_kernel); a forward that
+      // prepares a backward stores it for the per-target records.
+      float ad = 0.f;
+      if (att_dst) {
+        float hi[VEC], atd[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) hi[i] = atd[i] = 0.f;
+        if (active) {
+          load_vec<VEC>(hi, hfeat + (int64_t)row * ldh + cofs);
+          load_vec<VEC>(atd, att_dst + cofs);
+        }
+        ad = head_sum(dot_vec<VEC>(hi, atd), L.LPH);
+        if (a_dst && active && ch == 0 && g == 0) a_dst[(int64_t)row * L.H + head] = ad;  // a_dst: output here
+      } else if (active) {
+        ad = a_dst[(int64_t)row * L.H + head];
+      }
       // With att_src given, the source score <h_j, att_src> is formed from the gathered row itself (a few
       // cross-lane adds) instead of a fifth cache-line request per edge for a_src[j].
       float att[VEC];
@@ -581,7 +602,8 @@ gat_bwd_src_kernel(const int* __restrict__ rowptr_t, const int* __restrict__ col
                    const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
                    const float4* __restrict__ nodeq, const float* __restrict__ gout, int64_t ldg,
                    float* __restrict__ g_hfeat,
-                   int64_t ldgh, float* __restrict__ g_a_src, float* __restrict__ ds_out, int N, float slope,
+                   int64_t ldgh, float* __restrict__ g_a_src, float* __restrict__ ds_out,
+                   const float* __restrict__ att2, const float* __restrict__ g_a_dst, int N, float slope,
                    const GatLayout L, const SplitDev sp) {
   constexpr int U = 3;  // neighbour rows in flight per lane group: 3 x 8 waves per SIMD beat 4 x 7 (registers)
   const int lane = threadIdx.x & 63;
@@ -615,7 +637,14 @@ gat_bwd_src_kernel(const int* __restrict__ rowptr_t, const int* __restrict__ col
       float as = 0.f;
       if (active) {
         load_vec<VEC>(hj, hfeat + (int64_t)row * ldh + cofs);
-        as = a_src[(int64_t)row * L.H + head];
+        if (a_src) as = a_src[(int64_t)row * L.H + head];
+      }
+      if (!a_src) {  // the source's own score from the row it holds anyway (the forward formed it the same way)
+        float ats[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) ats[i] = 0.f;
+        if (active) load_vec<VEC>(ats, att2 + cofs);
+        as = head_sum(dot_vec<VEC>(hj, ats), L.LPH);
       }
       float acc_as = 0.f;
 
@@ -668,6 +697,16 @@ gat_bwd_src_kernel(const int* __restrict__ rowptr_t, const int* __restrict__ col
           store_vec<VEC>(sp.pacc + (int64_t)item * F + cofs, acc);
           if (ch == 0) sp.p0[(int64_t)item * L.H + head] = acc_as;
         } else {
+          if (g_a_dst) {
+            // backward of the scores a_src = <h, att_src>, a_dst = <h, att_dst>, folded into this store:
+            //   g_hfeat[j,h,:] += g_a_src[j,h] att_src[h,:] + g_a_dst[j,h] att_dst[h,:]     (att2 = [att_src; att_dst])
+            float ats[VEC], atd[VEC];
+            load_vec<VEC>(ats, att2 + cofs);
+            load_vec<VEC>(atd, att2 + F + cofs);
+            const float gd = g_a_dst[(int64_t)row * L.H + head];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(acc_as, ats[i], fmaf(gd, atd[i], acc[i]));
+          }
           store_vec<VEC>(g_hfeat + (int64_t)row * ldgh + cofs, acc);
           if (ch == 0) g_a_src[(int64_t)row * L.H + head] = acc_as;
         }
@@ -681,7 +720,8 @@ template <int VEC>
 __global__ void __launch_bounds__(256)
 gat_bwd_src_combine_kernel(int n_long, const int* __restrict__ long_row, const int* __restrict__ long_chunk_ptr,
                            float* __restrict__ g_hfeat, int64_t ldgh, float* __restrict__ g_a_src,
-                           const GatLayout L, const SplitDev sp) {
+                           const float* __restrict__ att2, const float* __restrict__ g_a_dst, const GatLayout L,
+                           const SplitDev sp) {
   const int lane = threadIdx.x & 63;
   const int g = lane / L.G;
   const int t = lane % L.G;
@@ -706,6 +746,14 @@ gat_bwd_src_combine_kernel(int n_long, const int* __restrict__ long_row, const i
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] += a2[i];
         as += sp.p0[(int64_t)c * L.H + head];
+      }
+      if (g_a_dst) {
+        float ats[VEC], atd[VEC];
+        load_vec<VEC>(ats, att2 + cofs);
+        load_vec<VEC>(atd, att2 + F + cofs);
+        const float gd = g_a_dst[(int64_t)row * L.H + head];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(as, ats[i], fmaf(gd, atd[i], acc[i]));
       }
       store_vec<VEC>(g_hfeat + (int64_t)row * ldgh + cofs, acc);
       if (ch == 0) g_a_src[(int64_t)row * L.H + head] = as;
@@ -829,10 +877,10 @@ extern "C" int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const fl
     RGBX_HIP(hipMemsetAsync(g_att_dst, 0, F * sizeof(float), s));
     return RGBX_OK;
   }
-  if (!hfeat || !g_a_src || !g_a_dst || !att_src || !att_dst || !g_hfeat || !scratch)
+  if (!hfeat || !g_a_src || !g_a_dst || !att_src || !att_dst || !scratch)
     return fail(RGBX_E_ARG, "gat_scores_bwd: null pointer");
   if (n_dst < 0 || n_dst > n) return fail(RGBX_E_ARG, "gat_scores_bwd: n_dst outside [0, n]");
-  if (ldh < F || ldgh < F) return fail(RGBX_E_ARG, "gat_scores_bwd: leading dimension < H*C");
+  if (ldh < F || (g_hfeat && ldgh < F)) return fail(RGBX_E_ARG, "gat_scores_bwd: leading dimension < H*C");
   const int vec = pick_vec(C, {hfeat, g_hfeat, att_src, att_dst}, {ldh, ldgh});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_scores_bwd")) return rc;
@@ -856,32 +904,33 @@ extern "C" int rgbx_gat_scores_bwd_f32(const float* hfeat, int64_t ldh, const fl
 
 extern "C" int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
                                           int64_t ldh, const float* a_src, const float* att_src,
-                                          const float* a_dst, const float* out_scale, const float* bias,
+                                          float* a_dst, const float* att_dst, const float* out_scale,
+                                          const float* bias,
                                           float* out, int64_t ldo, float* m, float* rden, float* out_pos,
                                           float* a_pos, int64_t N, int H, int C,
                                           float slope, const rgbx_row_split_t* split, rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_fwd")) return rc;
   if (N == 0) return RGBX_OK;
-  if (!rowptr || !col || !hfeat || (!a_src && !att_src) || !a_dst || !out || !m || !rden)
+  if (!rowptr || !col || !hfeat || (!a_src && !att_src) || (!a_dst && !att_dst) || !out || !m || !rden)
     return fail(RGBX_E_ARG, "gat_fwd: null pointer");
   if ((out_pos != nullptr) != (a_pos != nullptr)) return fail(RGBX_E_ARG, "gat_fwd: out_pos and a_pos go together");
   if (ldh < (int64_t)H * C || ldo < (int64_t)H * C) return fail(RGBX_E_ARG, "gat_fwd: leading dimension < H*C");
   SplitDev sd;
   if (int rc = split_view(split, H, C, &sd, "gat_fwd")) return rc;
-  const int vec = pick_vec(C, {hfeat, out, att_src, bias, out_scale, sd.pacc, out_pos, sd.pacc2}, {ldh, ldo});
+  const int vec = pick_vec(C, {hfeat, out, att_src, att_dst, bias, out_scale, sd.pacc, out_pos, sd.pacc2}, {ldh, ldo});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_fwd")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int grid = gat_grid(N);
 #define RGBX_GAT_FWD(V, T)                                                                                      \
   do {                                                                                                          \
-    gat_fwd_kernel<V, false, T><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out_scale, \
-                                                     bias, out, ldo, m, rden, out_pos, a_pos, (int)N, slope, L, \
-                                                     sd);                                                       \
+    gat_fwd_kernel<V, false, T><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, att_src, a_dst, att_dst,  \
+                                                     out_scale, bias, out, ldo, m, rden, out_pos, a_pos,        \
+                                                     (int)N, slope, L, sd);                                     \
     if (sd.threshold > 0) {                                                                                     \
       gat_fwd_kernel<V, true, T><<<gat_grid(split->n_chunks), 256, 0, s>>>(                                     \
-          rowptr, col, hfeat, ldh, a_src, att_src, a_dst, out_scale, bias, out, ldo, m, rden, out_pos, a_pos,   \
-          split->n_chunks, slope, L, sd);                                                                       \
+          rowptr, col, hfeat, ldh, a_src, att_src, a_dst, att_dst, out_scale, bias, out, ldo, m, rden, out_pos, \
+          a_pos, split->n_chunks, slope, L, sd);                                                                \
       gat_fwd_combine_kernel<V><<<gat_grid(split->n_long), 256, 0, s>>>(                                        \
           split->n_long, split->long_row, split->long_chunk_ptr, out_scale, bias, out, ldo, m, rden, out_pos,   \
           a_pos, L, sd);                                                                                        \
@@ -962,18 +1011,19 @@ extern "C" int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const f
 extern "C" int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_t, const float* hfeat,
                                     int64_t ldh, const float* a_src, const float* nodeq, const float* gout,
                                     int64_t ldg, float* g_hfeat, int64_t ldgh, float* g_a_src, float* ds,
-                                    int64_t N, int H, int C, float slope, const rgbx_row_split_t* split,
-                                    rgbx_stream_t stream) {
+                                    const float* att2, const float* g_a_dst, int64_t N, int H, int C,
+                                    float slope, const rgbx_row_split_t* split, rgbx_stream_t stream) {
   if (int rc = check_common(N, H, C, "gat_bwd_src")) return rc;
   if (N == 0) return RGBX_OK;
-  if (!rowptr_t || !col_t || !hfeat || !a_src || !nodeq || !gout || !g_hfeat || !g_a_src)
+  if (!rowptr_t || !col_t || !hfeat || (!a_src && !att2) || !nodeq || !gout || !g_hfeat || !g_a_src)
     return fail(RGBX_E_ARG, "gat_bwd_src: null pointer");
+  if (g_a_dst && !att2) return fail(RGBX_E_ARG, "gat_bwd_src: folding the score gradients needs att2");
   if (!aligned16(nodeq)) return fail(RGBX_E_ALIGN, "gat_bwd_src: nodeq must be 16-byte aligned");
   const int64_t F = (int64_t)H * C;
   if (ldh < F || ldg < F || ldgh < F) return fail(RGBX_E_ARG, "gat_bwd_src: leading dimension < H*C");
   SplitDev sd;
   if (int rc = split_view(split, H, C, &sd, "gat_bwd_src")) return rc;
-  const int vec = pick_vec(C, {hfeat, gout, g_hfeat, sd.pacc}, {ldh, ldg, ldgh});
+  const int vec = pick_vec(C, {hfeat, gout, g_hfeat, sd.pacc, att2}, {ldh, ldg, ldgh});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_bwd_src")) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -983,21 +1033,19 @@ extern "C" int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_
 #define RGBX_GAT_BS(V)                                                                                          \
   do {                                                                                                          \
     if (idx32)                                                                                                  \
-      gat_bwd_src_kernel<V, false, uint32_t><<<grid, 256, 0, s>>>(rowptr_t, col_t, hfeat, ldh, a_src,           \
-                                                                reinterpret_cast<const float4*>(nodeq), gout,   \
-                                                                ldg, g_hfeat, ldgh, g_a_src, ds, (int)N, slope, \
-                                                                L, sd);                                         \
+      gat_bwd_src_kernel<V, false, uint32_t><<<grid, 256, 0, s>>>(                                              \
+          rowptr_t, col_t, hfeat, ldh, a_src, reinterpret_cast<const float4*>(nodeq), gout, ldg, g_hfeat, ldgh, \
+          g_a_src, ds, att2, g_a_dst, (int)N, slope, L, sd);                                                    \
     else                                                                                                        \
-      gat_bwd_src_kernel<V, false, int64_t><<<grid, 256, 0, s>>>(rowptr_t, col_t, hfeat, ldh, a_src,            \
-                                                               reinterpret_cast<const float4*>(nodeq), gout,    \
-                                                               ldg, g_hfeat, ldgh, g_a_src, ds, (int)N, slope,  \
-                                                               L, sd);                                          \
+      gat_bwd_src_kernel<V, false, int64_t><<<grid, 256, 0, s>>>(                                               \
+          rowptr_t, col_t, hfeat, ldh, a_src, reinterpret_cast<const float4*>(nodeq), gout, ldg, g_hfeat, ldgh, \
+          g_a_src, ds, att2, g_a_dst, (int)N, slope, L, sd);                                                    \
     if (sd.threshold > 0) {                                                                                     \
       gat_bwd_src_kernel<V, true, int64_t><<<gat_grid(split->n_chunks), 256, 0, s>>>(                           \
           rowptr_t, col_t, hfeat, ldh, a_src, reinterpret_cast<const float4*>(nodeq), gout, ldg, g_hfeat, ldgh, \
-          g_a_src, ds, split->n_chunks, slope, L, sd);                                                          \
+          g_a_src, ds, att2, g_a_dst, split->n_chunks, slope, L, sd);                                           \
       gat_bwd_src_combine_kernel<V><<<gat_grid(split->n_long), 256, 0, s>>>(                                    \
-          split->n_long, split->long_row, split->long_chunk_ptr, g_hfeat, ldgh, g_a_src, L, sd);                \
+          split->n_long, split->long_row, split->long_chunk_ptr, g_hfeat, ldgh, g_a_src, att2, g_a_dst, L, sd); \
     }                                                                                                           \
   } while (0)
   if (vec == 4) RGBX_GAT_BS(4);

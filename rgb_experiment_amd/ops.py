@@ -332,7 +332,7 @@ class _GATAggregate(torch.autograd.Function):
         with _Timed("gat_fwd"):
             _lib.check(
                 _lib.load().rgbx_gat_aggregate_fwd_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), ph, ldh,
-                                                       _lib.ptr(a_src), _lib.ptr(att), _lib.ptr(a_dst), None, None,
+                                                       _lib.ptr(a_src), _lib.ptr(att), _lib.ptr(a_dst), None, None, None,
                                                        po, ldo, _lib.ptr(m), _lib.ptr(rden), _lib.ptr(opos),
                                                        _lib.ptr(apos), N, H, C, float(slope),
                                                        None if split is None else ctypes.byref(split),
@@ -360,12 +360,15 @@ def _gat_train_extras(want_grad, N, H, C, dev):
             torch.empty((N, H), dtype=torch.float32, device=dev))
 
 
-def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope, bias=None, opos=None, apos=None):
+def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope, bias=None, opos=None, apos=None,
+                       att=None):
     """(g_hfeat through the aggregation, g_a_src [n_src, H], g_a_dst [n_tgt, H]). `bias`: the vector the
     forward added to `out` in its store, if any. `opos` / `apos`: the positive-score parts the forward stored
     (rgbx_gat_aggregate_fwd_f32 out_pos / a_pos): with them g_a_dst comes out of the streaming prep pass; without
     them (a forward run without want_grad) the source-side pass also writes the per-edge score gradient ds [E', H]
-    and g_a_dst is its width-H segment sum over each target's in-edges."""
+    and g_a_dst is its width-H segment sum over each target's in-edges. `att` = (att_src, att_dst) [H, C] (needs
+    opos / apos): the scores are products of hfeat with these vectors, so the source pass folds their backward into
+    its g_hfeat store (and forms the source's own score from its row when `a_src` is None)."""
     N, n_src, dev = g.fwd.N, g.bwd.N, gout.device
     lib = _lib.load()
     nodeq = torch.empty((N, H, 4), dtype=torch.float32, device=dev)  # (a_dst, max - log(1/sum), dsum, -) records
@@ -376,7 +379,15 @@ def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope, 
     pg, ldg = _lib.mat(gout, "gout")
     pgh, ldgh = _lib.mat(g_h, "g_hfeat")
     per_node = opos is not None
-    g_ad = torch.empty((N, H), dtype=torch.float32, device=dev) if per_node else None
+    fold = per_node and att is not None
+    if a_src is None and not fold:
+        raise RuntimeError("gat backward: a_src may only be left to the kernel together with the folded score backward")
+    g_ad = None
+    if per_node:  # the fold reads g_a_dst by SOURCE row: rows that are no target (halo rows of a partitioned run) are 0
+        g_ad_full = (torch.zeros if fold and n_src > N else torch.empty)((max(n_src, N) if fold else N, H),
+                                                                         dtype=torch.float32, device=dev)
+        g_ad = g_ad_full[:N]
+    att2 = torch.cat([att[0].reshape(1, H, C), att[1].reshape(1, H, C)]).contiguous() if fold else None
     ds = None if per_node else torch.empty((max(g.bwd.nnz, 1), H), dtype=torch.float32, device=dev)
     with _Timed("gat_bwd_prep"):
         _lib.check(
@@ -387,9 +398,10 @@ def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope, 
     with _Timed("gat_bwd_src"):
         _lib.check(
             lib.rgbx_gat_bwd_src_f32(_lib.ptr(g.bwd.rowptr), _lib.ptr(g.bwd.col), ph, ldh, _lib.ptr(a_src),
-                                     _lib.ptr(nodeq), pg, ldg, pgh, ldgh, _lib.ptr(g_as), _lib.ptr(ds), n_src, H,
-                                     C, float(slope), None if split is None else ctypes.byref(split),
-                                     _lib.stream_ptr()), "rgbx_gat_bwd_src_f32")
+                                     _lib.ptr(nodeq), pg, ldg, pgh, ldgh, _lib.ptr(g_as), _lib.ptr(ds),
+                                     _lib.ptr(att2), _lib.ptr(g_ad_full) if fold else None, n_src, H, C, float(slope),
+                                     None if split is None else ctypes.byref(split), _lib.stream_ptr()),
+            "rgbx_gat_bwd_src_f32")
     if not per_node:
         g_ad = spmm_raw(gat_segment_csr(g), None, None, ds, kind="gat_bwd_segsum")
     return g_h, g_as, g_ad
@@ -444,23 +456,31 @@ class _GATAttend(torch.autograd.Function):
         att_d = att_dst.detach().reshape(H, C).contiguous()
         n_src, N, dev = hfeat.size(0), graph.fwd.N, hfeat.device
         lib = _lib.load()
-        a_src = torch.empty((n_src, H), dtype=torch.float32, device=dev)
-        a_dst = torch.empty_like(a_src)
         ph, ldh = _lib.mat(hfeat, "hfeat")
-        _lib.check(lib.rgbx_gat_scores_f32(ph, ldh, _lib.ptr(att_s), _lib.ptr(att_d), _lib.ptr(a_src), _lib.ptr(a_dst),
-                                           n_src, H, C, _lib.stream_ptr()), "rgbx_gat_scores_f32")
+        want_grad = want_grad and sc is None
+        in_kernel = _scores_in_kernel(C)
+        if in_kernel:
+            # heads spanning <= 8 lanes: both score products are formed inside the aggregation kernel from rows it
+            # holds anyway (the gathered row for a_src, the target's own row for a_dst): no scores pass over hfeat.
+            # a_dst is stored only for a backward (the per-target records need it)
+            a_src = None
+            a_dst = torch.empty((N, H), dtype=torch.float32, device=dev) if want_grad else None
+        else:
+            a_src = torch.empty((n_src, H), dtype=torch.float32, device=dev)
+            a_dst = torch.empty_like(a_src)
+            _lib.check(lib.rgbx_gat_scores_f32(ph, ldh, _lib.ptr(att_s), _lib.ptr(att_d), _lib.ptr(a_src),
+                                               _lib.ptr(a_dst), n_src, H, C, _lib.stream_ptr()), "rgbx_gat_scores_f32")
         out = torch.empty((N, H * C), dtype=torch.float32, device=dev)
         m = torch.empty((N, H), dtype=torch.float32, device=dev)
         rden = torch.empty_like(m)
         po, ldo = _lib.mat(out, "out")
-        att_k = att_s if _scores_in_kernel(C) else None
-        want_grad = want_grad and sc is None
         opos, apos = _gat_train_extras(want_grad, N, H, C, dev)
         split, _scratch = graph.fwd.split_arg((2 * H * C + 3 * H) if want_grad else (H * C + 2 * H), dev)
         with _Timed("gat_fwd"):
             _lib.check(
                 lib.rgbx_gat_aggregate_fwd_f32(_lib.ptr(graph.fwd.rowptr), _lib.ptr(graph.fwd.col), ph, ldh,
-                                               _lib.ptr(a_src), _lib.ptr(att_k), _lib.ptr(a_dst), _lib.ptr(sc),
+                                               _lib.ptr(a_src), _lib.ptr(att_s) if in_kernel else None,
+                                               _lib.ptr(a_dst), _lib.ptr(att_d) if in_kernel else None, _lib.ptr(sc),
                                                _lib.ptr(b), po, ldo, _lib.ptr(m), _lib.ptr(rden), _lib.ptr(opos),
                                                _lib.ptr(apos), N, H, C, float(slope),
                                                None if split is None else ctypes.byref(split), _lib.stream_ptr()),
@@ -478,8 +498,10 @@ class _GATAttend(torch.autograd.Function):
         hfeat, a_src, a_dst, m, rden, out, att_s, att_d, b, opos, apos = ctx.saved_tensors
         H, C = ctx.H, ctx.C
         gout = gout.contiguous()
+        if opos is None:
+            raise RuntimeError("gat_attend: backward asked of a forward that was run without want_grad")
         g_h, g_as, g_ad = _gat_backward_core(ctx.graph, hfeat, a_src, a_dst, m, rden, out, gout, H, C, ctx.slope, b,
-                                             opos=opos, apos=apos)
+                                             opos=opos, apos=apos, att=(att_s, att_d))
         g_b = gout.sum(0).reshape(ctx.bias_shape) if b is not None and ctx.needs_input_grad[7] else None
         lib = _lib.load()
         n = hfeat.size(0)
@@ -490,11 +512,10 @@ class _GATAttend(torch.autograd.Function):
         g_att_s = torch.empty((H, C), dtype=torch.float32, device=hfeat.device)
         g_att_d = torch.empty_like(g_att_s)
         ph, ldh = _lib.mat(hfeat, "hfeat")
-        pgh, ldgh = _lib.mat(g_h, "g_hfeat")
-        with _Timed("gat_scores_bwd"):
+        with _Timed("gat_scores_bwd"):  # the source pass folded the score terms into g_h: attention-vector sums only
             _lib.check(
                 lib.rgbx_gat_scores_bwd_f32(ph, ldh, _lib.ptr(g_as), _lib.ptr(g_ad), g_ad.size(0), _lib.ptr(att_s),
-                                            _lib.ptr(att_d), pgh, ldgh, _lib.ptr(g_att_s), _lib.ptr(g_att_d),
+                                            _lib.ptr(att_d), None, 0, _lib.ptr(g_att_s), _lib.ptr(g_att_d),
                                             _lib.ptr(scratch), n_scr.value, n, H, C, _lib.stream_ptr()),
                 "rgbx_gat_scores_bwd_f32")
         return (g_h, g_att_s.reshape(ctx.att_shapes[0]), g_att_d.reshape(ctx.att_shapes[1]), None, None, None, None, g_b,

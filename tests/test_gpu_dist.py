@@ -49,7 +49,9 @@ def _single_gpu(model_name):
                                                         ("appnpstack", 2, "halo"), ("gcn", 2, "reshard"),
                                                         ("appnpstack", 2, "reshard"), ("gcn", 4, "auto"), ("gat", 2, "auto"),
                                                         ("gat", 3, "auto"), ("gcn_wide", 2, "auto"),
-                                                        ("graphsage_wide", 3, "auto"), ("graphsage2_wide", 2, "halo")])
+                                                        ("graphsage_wide", 3, "auto"), ("graphsage2_wide", 2, "halo"),
+                                                        ("gcn_wide", 4, "2x2"), ("graphsage", 4, "2x2"),
+                                                        ("appnpstack", 4, "2x2")])
 def test_partitioned_hip_run_matches_single_gpu(model_name, world, exchange, tmp_path):
     mp.spawn(W.gpu_runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange), nprocs=world,
              join=True)
