@@ -147,12 +147,19 @@ int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w,
  * (rgbx_spmm_linear_supported); otherwise RGBX_E_SHAPE and the caller runs rgbx_spmm_csr_f32 + GEMMs.
  * `split` (optional): hub rows are aggregated first by the split-row kernels (chunk sums added in chunk order)
  * and the fused kernel copies their finished aggregates; `split->partial` must then hold
- * (n_chunks + n_long) * K floats. */
+ * (n_chunks + n_long) * K floats.
+ * `pre_scale`, `pre_shift` ([K]) and `pre_rowsum` ([N]) — all NULL or all set: the layer's input is the affinely
+ * mapped matrix x' = x * pre_scale + pre_shift (per column), which is never materialised: a training-mode
+ * BatchNorm1d in front of the conv layer (models/gcn.py:28 then :29). By linearity
+ *   z[i,:] = pre_scale * (rs[i] * sum_p w[p] x[col[p],:]) + pre_shift * pre_rowsum[i],
+ * pre_rowsum[i] = rs[i] * sum_{p in row i} w[p] (the caller's per-graph constant); the root rows get the map as
+ * they are loaded; z_out receives the mapped aggregate (what dW = dy^T z needs). */
 int rgbx_spmm_linear_supported(int64_t K, int64_t Nout, int has_root);
 int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
                          const float* x, int64_t ldx, const float* wt, const float* x_root, int64_t ldr,
                          const float* wt_root, const float* bias, float* out, int64_t ldo, float* z_out,
-                         int64_t ldz, int64_t N, int64_t K, int64_t Nout, const rgbx_row_split_t* split,
+                         int64_t ldz, const float* pre_scale, const float* pre_shift, const float* pre_rowsum,
+                         int64_t N, int64_t K, int64_t Nout, const rgbx_row_split_t* split,
                          rgbx_stream_t stream);
 
 /* z_0 = h;  z_{k+1} = (1-alpha) * A_hat z_k + alpha * h, k = 0..K-1; result in `out`.

@@ -41,6 +41,12 @@ struct FusedArgs {
   const float* zlong;
   int threshold, n_long;
   int N, K, Nout;
+  // optional per-column affine map of the GATHERED matrix, x' = x * pre_scale + pre_shift (a training-mode
+  // BatchNorm in front of this layer, never materialised): by linearity the aggregate of x' is
+  // pre_scale * aggregate(x) + pre_shift * pre_rowsum[row], pre_rowsum = the row's sum of aggregation weights
+  const float* pre_scale;
+  const float* pre_shift;
+  const float* pre_rowsum;
 };
 
 constexpr int TM = 32;       // destination rows per workgroup = one MFMA row tile; 4 waves aggregate 8 rows each
@@ -198,6 +204,14 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
       }
     }
     if (g == 0 && active) {
+      if (A.pre_scale && row < A.N) {
+        float ps[4], pt[4];
+        load_vec<4>(ps, A.pre_scale + c);
+        load_vec<4>(pt, A.pre_shift + c);
+        const float rsum = A.pre_rowsum[row];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(acc[i], ps[i], pt[i] * rsum);
+      }
       store_vec<4>(&zt[lr * ldz + c], acc);
       if (A.z_out && row < A.N) store_vec<4>(A.z_out + (int64_t)row * A.ldz + c, acc);
     }
@@ -224,7 +238,16 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
         const int row = row_base + r;
 #pragma unroll
         for (int i = 0; i < 4; ++i) rootv[j][i] = 0.f;
-        if (row < A.N) load_vec<4>(rootv[j], A.xr + (int64_t)row * A.ldr + c4);
+        if (row < A.N) {
+          load_vec<4>(rootv[j], A.xr + (int64_t)row * A.ldr + c4);
+          if (A.pre_scale) {  // the root rows are rows of the same affinely mapped matrix
+            float ps[4], pt[4];
+            load_vec<4>(ps, A.pre_scale + c4);
+            load_vec<4>(pt, A.pre_shift + c4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rootv[j][i] = fmaf(rootv[j][i], ps[i], pt[i]);
+          }
+        }
       }
     }
   }
@@ -276,7 +299,16 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
       const int r = idx / k4, c4 = (idx - r * k4) * 4;
       const int row = row_base + r;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (row < A.N) load_vec<4>(v, A.xr + (int64_t)row * A.ldr + c4);
+      if (row < A.N) {
+        load_vec<4>(v, A.xr + (int64_t)row * A.ldr + c4);
+        if (A.pre_scale) {
+          float ps[4], pt[4];
+          load_vec<4>(ps, A.pre_scale + c4);
+          load_vec<4>(pt, A.pre_shift + c4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fmaf(v[i], ps[i], pt[i]);
+        }
+      }
       store_vec<4>(&zt[r * ldz + c4], v);
     }
   }
@@ -325,7 +357,8 @@ extern "C" int rgbx_spmm_linear_supported(int64_t K, int64_t Nout, int has_root)
 extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
                                     const float* x, int64_t ldx, const float* wt, const float* x_root, int64_t ldr,
                                     const float* wt_root, const float* bias, float* out, int64_t ldo, float* z_out,
-                                    int64_t ldz, int64_t N, int64_t K, int64_t Nout,
+                                    int64_t ldz, const float* pre_scale, const float* pre_shift,
+                                    const float* pre_rowsum, int64_t N, int64_t K, int64_t Nout,
                                     const rgbx_row_split_t* split, rgbx_stream_t stream) {
   if (N < 0 || K <= 0 || Nout <= 0) return fail(RGBX_E_ARG, "spmm_linear: bad size");
   if (N == 0) return RGBX_OK;
@@ -333,6 +366,10 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
   if (N >= INT32_MAX) return fail(RGBX_E_RANGE, "spmm_linear: N exceeds int32");
   if ((x_root != nullptr) != (wt_root != nullptr))
     return fail(RGBX_E_ARG, "spmm_linear: x_root and wt_root go together");
+  if ((pre_scale != nullptr) != (pre_shift != nullptr) || (pre_scale != nullptr) != (pre_rowsum != nullptr))
+    return fail(RGBX_E_ARG, "spmm_linear: pre_scale, pre_shift and pre_rowsum go together");
+  if (pre_scale && (!aligned16(pre_scale) || !aligned16(pre_shift)))
+    return fail(RGBX_E_ALIGN, "spmm_linear: pre_scale / pre_shift must be 16-byte aligned");
   if (!rgbx_spmm_linear_supported(K, Nout, x_root != nullptr))
     return fail(RGBX_E_SHAPE,
                 "spmm_linear: needs K %% 4 == 0, K <= 256, Nout %% 32 == 0, Nout <= 256 with a root term (got K=%lld, "
@@ -356,7 +393,8 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
     n_long = split->n_long;
   }
   FusedArgs A{rowptr, col, w,  rs,  x,   wt,  x_root,   wt_root, bias,      out,    z_out,
-              ldx,    ldo, ldz, ldr, long_row, zlong, threshold, n_long,    (int)N, (int)K, (int)Nout};
+              ldx,    ldo, ldz, ldr, long_row, zlong, threshold, n_long,    (int)N, (int)K, (int)Nout,
+              pre_scale, pre_shift, pre_rowsum};
   if (K == 128) return launch<32, 128>(A, s);
   if (K == 64) return launch<16, 64>(A, s);
   if (K == 256) return launch<64, 256>(A, s);

@@ -162,6 +162,22 @@ class Graph:
                        "rgbx_inv_degree_f32")
         return self._inv_deg
 
+    def rowsum(self, kind):
+        """Sum of the aggregation weights of every row: sum_p w[p] ('gcn') or 1 / 0 for rows with / without
+        in-edges ('mean', whose weights 1/deg sum to 1). What a constant column contributes to the aggregate: the
+        fused kernel needs it to push an affine map of its input through the aggregation (ops.bn_propagate_linear)."""
+        cache = self.__dict__.setdefault("_rowsum", {})
+        if kind not in cache:
+            if kind == "gcn":
+                from . import ops
+                ones = torch.ones((self.N, 1), dtype=torch.float32, device=self.fwd.rowptr.device)
+                cache[kind] = ops.spmm_raw(self.fwd, self.w, None, ones, kind="rowsum").reshape(-1).contiguous()
+            elif kind == "mean":
+                cache[kind] = ((self.fwd.rowptr[1:] - self.fwd.rowptr[:-1]) > 0).to(torch.float32).contiguous()
+            else:
+                raise ValueError(kind)
+        return cache[kind]
+
     @property
     def w_mean_t(self):
         """Per transposed slot (j -> i): 1/deg(i), the weight of dY[i] in dX[j] for aggr='mean'."""

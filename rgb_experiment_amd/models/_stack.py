@@ -89,12 +89,26 @@ class ConvStack(nn.Module):
         self.bns = nn.ModuleList(BatchNorm1d(bn_width) for _ in range(num_layers - 1))
 
     def forward(self, x, edge_index):
+        """x = bns[i](convs[i](x)) ... convs[-1](x) (models/gcn.py:25-31). A BatchNorm is never a pass of its own
+        where a neighbouring conv can absorb it: under no_grad its eval-mode affine map goes into the PRECEDING conv's
+        weights; in a training forward it is handed to the FOLLOWING conv (forward_after_bn), whose fused kernel
+        applies it to the aggregate of the raw rows."""
         last = self.num_layers - 1
-        for conv, bn in zip(self.convs[:last], self.bns):
-            fold = getattr(bn, "eval_affine", None) if getattr(conv, "folds_post_affine", False) else None
-            affine = fold() if fold is not None and not torch.is_grad_enabled() else None
+        pending = None  # a BatchNorm whose output has not been formed yet
+        for i, conv in enumerate(self.convs):
+            bn = self.bns[i] if i < last else None
+            if pending is not None:
+                after = getattr(conv, "forward_after_bn", None)
+                if after is not None:
+                    x, pending = after(x, edge_index, pending), bn  # = conv(pending(x), edge_index)
+                    continue
+                x, pending = pending(x), None
+            affine = None
+            if bn is not None and getattr(conv, "folds_post_affine", False) and not torch.is_grad_enabled():
+                fold = getattr(bn, "eval_affine", None)
+                affine = fold() if fold is not None else None
             if affine is not None:  # eval forward: BatchNorm's affine map folded into the conv's weights
                 x = conv(x, edge_index, post_affine=affine)
             else:
-                x = bn(conv(x, edge_index))
-        return model_output(self.convs[last](x, edge_index))
+                x, pending = conv(x, edge_index), bn
+        return model_output(x)

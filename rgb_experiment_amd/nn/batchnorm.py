@@ -76,32 +76,7 @@ class _BNTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps, reduce, running):
         x = x if x.stride(-1) == 1 else x.contiguous()
-        d = x.size(1)
-        # the row count rides along as a device scalar made by a fill kernel (a host->device copy would break
-        # hipGraph capture)
-        count = torch.full((1,), float(x.size(0)), dtype=torch.float64, device=x.device)
-        packed = torch.cat([column_sums(x).reshape(-1), count])
-        packed = reduce(packed)  # identity on one GPU; all-reduce over the node partition otherwise
-        n = packed[2 * d:2 * d + 1]
-        if x.is_cuda:
-            mean, rstd, scale, shift = (torch.empty(d, dtype=torch.float32, device=x.device) for _ in range(4))
-            rm, rv, mom = running if running is not None else (None, None, 0.0)
-            _lib.check(_lib.load().rgbx_bn_finalize_f32(
-                _lib.ptr(packed), _lib.ptr(weight.detach().contiguous()), _lib.ptr(bias.detach().contiguous()),
-                float(eps), float(mom), _lib.ptr(rm), _lib.ptr(rv), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(scale),
-                _lib.ptr(shift), d, _lib.stream_ptr()), "rgbx_bn_finalize_f32")
-        else:
-            mean64 = packed[:d] / n
-            var64 = (packed[d:2 * d] / n - mean64 * mean64).clamp_(min=0.0)  # biased variance
-            mean, var = mean64.float(), var64.float()
-            rstd = torch.rsqrt(var + eps)
-            scale = weight.detach() * rstd
-            shift = bias.detach() - mean * scale
-            if running is not None:
-                rm, rv, mom = running
-                unbiased = var * (n / (n - 1).clamp(min=1)).float()
-                rm.mul_(1 - mom).add_(mean, alpha=mom)
-                rv.mul_(1 - mom).add_(unbiased, alpha=mom)
+        mean, rstd, scale, shift, n = train_statistics(x, weight, bias, eps, reduce, running)
         y = affine_cols(x, scale.contiguous(), shift.contiguous())
         ctx.save_for_backward(x, weight, mean, rstd, n)
         ctx.reduce = reduce
@@ -110,25 +85,63 @@ class _BNTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight, mean, rstd, n = ctx.saved_tensors
-        gy = gy if gy.stride(-1) == 1 else gy.contiguous()
-        d = x.size(1)
-        local = bwd_sums(gy, x, mean, rstd)            # [2, d]: sum gy, sum gy * xhat over the local rows
-        glob = ctx.reduce(local.reshape(-1).clone())
-        # parameter gradients are the LOCAL sums: a partitioned run all-reduces parameter gradients once
-        if gy.is_cuda:
-            ca, cb, ck, gw, gb = (torch.empty(d, dtype=torch.float32, device=gy.device) for _ in range(5))
-            _lib.check(_lib.load().rgbx_bn_bwd_finalize_f32(
-                _lib.ptr(glob), _lib.ptr(local), _lib.ptr(n), _lib.ptr(weight.detach().contiguous()), _lib.ptr(rstd),
-                _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(ck), _lib.ptr(gw), _lib.ptr(gb), d, _lib.stream_ptr()),
-                "rgbx_bn_bwd_finalize_f32")
-        else:
-            glob = glob.reshape(2, -1)
-            ca = (glob[0] / n).float().contiguous()
-            cb = (glob[1] / n).float().contiguous()
-            ck = (weight * rstd).contiguous()
-            gw, gb = local[1].float(), local[0].float()
-        gx = bwd_apply(gy, x, mean, rstd, ca, cb, ck)
+        gx, gw, gb = train_backward(gy, x, weight, mean, rstd, n, ctx.reduce)
         return gx, gw, gb, None, None, None
+
+
+def train_statistics(x, weight, bias, eps, reduce, running):
+    """Training-mode statistics of x [N, d] (row-contiguous): (mean, rstd, scale, shift, n) with
+    BN(x) = x * scale + shift, running statistics updated in place (`running` = (running_mean, running_var,
+    momentum) or None). Column sums -> [reduce over ranks] -> one finalize launch."""
+    d = x.size(1)
+    # the row count rides along as a device scalar made by a fill kernel (a host->device copy would break
+    # hipGraph capture)
+    count = torch.full((1,), float(x.size(0)), dtype=torch.float64, device=x.device)
+    packed = torch.cat([column_sums(x).reshape(-1), count])
+    packed = reduce(packed)  # identity on one GPU; all-reduce over the node partition otherwise
+    n = packed[2 * d:2 * d + 1]
+    if x.is_cuda:
+        mean, rstd, scale, shift = (torch.empty(d, dtype=torch.float32, device=x.device) for _ in range(4))
+        rm, rv, mom = running if running is not None else (None, None, 0.0)
+        _lib.check(_lib.load().rgbx_bn_finalize_f32(
+            _lib.ptr(packed), _lib.ptr(weight.detach().contiguous()), _lib.ptr(bias.detach().contiguous()),
+            float(eps), float(mom), _lib.ptr(rm), _lib.ptr(rv), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(scale),
+            _lib.ptr(shift), d, _lib.stream_ptr()), "rgbx_bn_finalize_f32")
+    else:
+        mean64 = packed[:d] / n
+        var64 = (packed[d:2 * d] / n - mean64 * mean64).clamp_(min=0.0)  # biased variance
+        mean, var = mean64.float(), var64.float()
+        rstd = torch.rsqrt(var + eps)
+        scale = weight.detach() * rstd
+        shift = bias.detach() - mean * scale
+        if running is not None:
+            rm, rv, mom = running
+            unbiased = var * (n / (n - 1).clamp(min=1)).float()
+            rm.mul_(1 - mom).add_(mean, alpha=mom)
+            rv.mul_(1 - mom).add_(unbiased, alpha=mom)
+    return mean, rstd, scale, shift, n
+
+
+def train_backward(gy, x, weight, mean, rstd, n, reduce):
+    """(gx, g_weight, g_bias) of training-mode BatchNorm given the gradient gy of its output."""
+    gy = gy if gy.stride(-1) == 1 else gy.contiguous()
+    d = x.size(1)
+    local = bwd_sums(gy, x, mean, rstd)            # [2, d]: sum gy, sum gy * xhat over the local rows
+    glob = reduce(local.reshape(-1).clone())
+    # parameter gradients are the LOCAL sums: a partitioned run all-reduces parameter gradients once
+    if gy.is_cuda:
+        ca, cb, ck, gw, gb = (torch.empty(d, dtype=torch.float32, device=gy.device) for _ in range(5))
+        _lib.check(_lib.load().rgbx_bn_bwd_finalize_f32(
+            _lib.ptr(glob), _lib.ptr(local), _lib.ptr(n), _lib.ptr(weight.detach().contiguous()), _lib.ptr(rstd),
+            _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(ck), _lib.ptr(gw), _lib.ptr(gb), d, _lib.stream_ptr()),
+            "rgbx_bn_bwd_finalize_f32")
+    else:
+        glob = glob.reshape(2, -1)
+        ca = (glob[0] / n).float().contiguous()
+        cb = (glob[1] / n).float().contiguous()
+        ck = (weight * rstd).contiguous()
+        gw, gb = local[1].float(), local[0].float()
+    return bwd_apply(gy, x, mean, rstd, ca, cb, ck), gw, gb
 
 
 class _AffineCols(torch.autograd.Function):
@@ -179,11 +192,22 @@ class BatchNorm1d(nn.BatchNorm1d):
                 # differentiable there, so this must be too — the raw kernel below has no autograd node
                 return _AffineCols.apply(x, scale, shift)
             return affine_cols(x if x.stride(-1) == 1 else x.contiguous(), scale.contiguous(), shift.contiguous())
+        return _BNTrain.apply(x, self.weight, self.bias, self.eps, self._reduce, self.begin_training_step())
+
+    def begin_training_step(self):
+        """What nn.BatchNorm1d does at the top of a training forward: count the batch, pick the momentum.
+        Returns the `running` triple (running_mean, running_var, momentum) for train_statistics."""
         with torch.no_grad():
             self.num_batches_tracked += 1
         if self.momentum is None:  # cumulative moving average: the factor depends on a device counter
             m = 1.0 / float(self.num_batches_tracked)
         else:
             m = self.momentum
-        return _BNTrain.apply(x, self.weight, self.bias, self.eps, self._reduce,
-                              (self.running_mean, self.running_var, m))
+        return self.running_mean, self.running_var, m
+
+    def folds_into_next_layer(self, x):
+        """Training forward on the GPU with the standard affine / running-statistics set-up: the normalised
+        matrix need not be written, the next conv layer can apply the affine map to its aggregate
+        (ops.bn_propagate_linear)."""
+        return (self.training and self.affine and self.track_running_stats and x.dim() == 2 and x.is_cuda
+                and torch.is_grad_enabled())

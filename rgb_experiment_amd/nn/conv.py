@@ -55,6 +55,16 @@ class GCNConv(nn.Module):
             weight, bias = weight * scale[:, None], bias * scale + shift
         return self._conv(x, edge_index, weight, bias)
 
+    def forward_after_bn(self, x, edge_index, bn):
+        """self(bn(x), edge_index) for the BatchNorm1d in front of this layer. In a training forward on one GPU the
+        normalised matrix is not written: the fused kernel gathers the raw rows and applies BatchNorm's affine map to
+        the aggregate (ops.bn_propagate_linear)."""
+        graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
+        if (bn.folds_into_next_layer(x) and not getattr(graph, "is_distributed", False)
+                and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x)):
+            return ops.bn_propagate_linear(x, bn, graph, "gcn", self.lin.weight, self.bias)
+        return self.forward(bn(x), edge_index)
+
     def _conv(self, x, edge_index, weight, bias):
         graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
         if ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x):
@@ -82,6 +92,15 @@ class SAGEConv(nn.Module):
         self.in_channels, self.out_channels = in_channels, out_channels
         self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
         self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward_after_bn(self, x, edge_index, bn):
+        """See GCNConv.forward_after_bn; the root term lin_r(bn(x)_i) gets the affine map as its rows are loaded."""
+        graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
+        if (bn.folds_into_next_layer(x) and not getattr(graph, "is_distributed", False)
+                and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x)):
+            return ops.bn_propagate_linear(x, bn, graph, "mean", self.lin_l.weight, self.lin_l.bias,
+                                           root_weight=self.lin_r.weight)
+        return self.forward(bn(x), edge_index)
 
     def forward(self, x, edge_index, post_affine=None):
         w_l, b_l, w_r = self.lin_l.weight, self.lin_l.bias, self.lin_r.weight
@@ -111,6 +130,16 @@ class MySAGEConv(nn.Module):
         self.add_self_loops = add_self_loops
         self.lin_l = nn.Linear(in_channels, out_channels)
         self.lin_r = nn.Linear(in_channels, out_channels)
+
+    def forward_after_bn(self, x, edge_index, bn):
+        """See GCNConv.forward_after_bn."""
+        if self.add_self_loops:
+            graph = get_graph(edge_index, x.size(0), LOOPS_REMOVE_ADD)
+            if (bn.folds_into_next_layer(x) and not getattr(graph, "is_distributed", False)
+                    and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x)):
+                return ops.bn_propagate_linear(x, bn, graph, "mean", self.lin_l.weight,
+                                               self.lin_l.bias + self.lin_r.bias, root_weight=self.lin_r.weight)
+        return self.forward(bn(x), edge_index)
 
     def forward(self, x, edge_index, post_affine=None):
         w_l, b_l, w_r, b_r = self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, self.lin_r.bias

@@ -140,10 +140,29 @@ def fused_linear_ok(graph, in_channels, out_channels, root=False, x=None):
     return bool(_lib.load().rgbx_spmm_linear_supported(in_channels, out_channels, int(root)))
 
 
-def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_root=None, kind="linear"):
+def weight_t(weight):
+    """W^T as the contiguous [K, Nout] operand rgbx_spmm_linear_f32 reads (its B fragments run along Nout). For an
+    nn.Parameter the transposed copy is kept on the parameter and reused until the parameter changes (in-place
+    version counter + storage address), instead of one `.t().contiguous()` per launch; temporaries (weights with a
+    folded BatchNorm) and launches being captured into a hipGraph (replays do not move version counters) always
+    transpose."""
+    w = weight.detach()
+    if not isinstance(weight, torch.nn.Parameter) or (w.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return w.t().contiguous()
+    tag = (weight._version, w.data_ptr(), tuple(w.shape))
+    cached = getattr(weight, "_rgbx_wt", None)
+    if cached is None or cached[0] != tag:
+        cached = (tag, w.t().contiguous())
+        weight._rgbx_wt = cached
+    return cached[1]
+
+
+def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_root=None, kind="linear", pre=None):
     """out = (rs * sum_p w_p x[col_p]) wt + bias (+ x_root wt_root) on rgbx_spmm_linear_f32; `wt` / `wt_root` are
-    [K, Nout] row-major. Returns (out, z) with z the stored aggregate [N, K] if `want_z`."""
+    [K, Nout] row-major. Returns (out, z) with z the stored aggregate [N, K] if `want_z`. `pre` = (scale [K],
+    shift [K], rowsum [N]): the gathered matrix (and the root rows) stand for x * scale + shift."""
     _lib.require_device(x, wt, bias, x_root, wt_root)
+    ps, pt, pr = (None, None, None) if pre is None else (t.contiguous() for t in pre)
     x = x if x.stride(-1) == 1 else x.contiguous()
     K, n_out = x.size(1), wt.size(1)
     wt = wt.contiguous()
@@ -160,8 +179,8 @@ def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_
             _lib.load().rgbx_spmm_linear_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
                                              _lib.ptr(x), x.stride(0), _lib.ptr(wt), _lib.ptr(xr), ldr or K,
                                              _lib.ptr(wtr), _lib.ptr(b), _lib.ptr(out), out.stride(0), _lib.ptr(z), K,
-                                             csr.N, K, n_out, None if split is None else ctypes.byref(split),
-                                             _lib.stream_ptr()),
+                                             _lib.ptr(ps), _lib.ptr(pt), _lib.ptr(pr), csr.N, K, n_out,
+                                             None if split is None else ctypes.byref(split), _lib.stream_ptr()),
             "rgbx_spmm_linear_f32")
     return out, z
 
@@ -181,9 +200,9 @@ class _PropagateLinear(torch.autograd.Function):
         x = x.contiguous()
         xr = x if x_root is None else x_root.contiguous()
         w, rs = (graph.w, None) if kind == "gcn" else (None, graph.inv_deg)
-        out, z = spmm_linear_raw(graph.fwd, w, rs, x, weight.detach().t(), None if bias is None else bias.detach(),
+        out, z = spmm_linear_raw(graph.fwd, w, rs, x, weight_t(weight), None if bias is None else bias.detach(),
                                  need_z, xr if root_weight is not None else None,
-                                 None if root_weight is None else root_weight.detach().t(), kind=f"{kind}_linear_fwd")
+                                 None if root_weight is None else weight_t(root_weight), kind=f"{kind}_linear_fwd")
         ctx.save_for_backward(z, weight, root_weight, xr if root_weight is not None else None)
         ctx.graph, ctx.kind, ctx.has_bias = graph, kind, bias is not None
         return out
@@ -205,21 +224,79 @@ class _PropagateLinear(torch.autograd.Function):
         if root_weight is not None and ctx.needs_input_grad[6]:
             gwr = gemm_tn(gy, x)
         if ctx.needs_input_grad[0]:
-            wt = g.w_t if kind == "gcn" else g.w_mean_t
-            n_out, n_in = weight.shape
-            if n_out <= n_in and _lib.load().rgbx_spmm_linear_supported(n_out, n_in, int(root_weight is not None)):
-                gx, _ = spmm_linear_raw(g.bwd, wt, None, gy, weight.detach(), None, False,
-                                        gy if root_weight is not None else None,
-                                        None if root_weight is None else root_weight.detach(),
-                                        kind=f"{kind}_linear_bwd")
-            else:
-                gz = gy @ weight
-                gr = gy @ root_weight if root_weight is not None else None
-                if gr is None:
-                    gx = spmm_raw(g.bwd, wt, None, gz, kind=f"{kind}_bwd")
-                else:
-                    gx = spmm_raw(g.bwd, wt, None, gz, y=gr, a=1.0, b=1.0, out=gr, kind=f"{kind}_bwd")
+            gx = _propagate_linear_input_grad(g, kind, gy, weight, root_weight)
         return gx, None, None, gw, gb, None, gwr, None
+
+
+def _propagate_linear_input_grad(g, kind, gy, weight, root_weight):
+    """dx = P^T (dy W) + dy Wr = (P^T dy) W + dy Wr: the fused kernel on the transposed CSR (W as stored is already
+    the [K, Nout] operand) when in == out, else GEMMs and the transposed SpMM with the root part as its additive
+    term."""
+    wt = g.w_t if kind == "gcn" else g.w_mean_t
+    n_out, n_in = weight.shape
+    if n_out <= n_in and _lib.load().rgbx_spmm_linear_supported(n_out, n_in, int(root_weight is not None)):
+        gx, _ = spmm_linear_raw(g.bwd, wt, None, gy, weight.detach().contiguous(), None, False,
+                                gy if root_weight is not None else None,
+                                None if root_weight is None else root_weight.detach().contiguous(),
+                                kind=f"{kind}_linear_bwd")
+        return gx
+    gz = gy @ weight
+    gr = gy @ root_weight if root_weight is not None else None
+    if gr is None:
+        return spmm_raw(g.bwd, wt, None, gz, kind=f"{kind}_bwd")
+    return spmm_raw(g.bwd, wt, None, gz, y=gr, a=1.0, b=1.0, out=gr, kind=f"{kind}_bwd")
+
+
+class _BNPropagateLinear(torch.autograd.Function):
+    """y = (P BN(x)) W^T + b (+ BN(x) Wr^T) for a TRAINING-mode BatchNorm1d in front of a conv layer
+    (models/gcn.py:28-29: x = bns[i](x); x = convs[i+1](x, edge_index)) without writing BN(x): the statistics pass
+    gives BN(x) = x * s + t per column, and rgbx_spmm_linear_f32 gathers the RAW rows and maps the aggregate,
+    s * (P x) + t * rowsum(P) (linearity of the aggregation), before the MFMA transform.
+    Backward = the two layers' own backward passes one after the other, unchanged: dW = dy^T z (z = the mapped
+    aggregate the forward stored), the gradient g_h of the BatchNorm output from the fused kernel on the transposed
+    CSR, then BatchNorm's backward (column sums of g_h and g_h * xhat, apply)."""
+
+    @staticmethod
+    def forward(ctx, x, bn_weight, bn_bias, graph, kind, weight, bias, root_weight, eps, reduce, running, need_z):
+        from .nn import batchnorm as B
+        x = x.contiguous()
+        mean, rstd, scale, shift, n = B.train_statistics(x, bn_weight, bn_bias, eps, reduce, running)
+        w, rs = (graph.w, None) if kind == "gcn" else (None, graph.inv_deg)
+        out, z = spmm_linear_raw(graph.fwd, w, rs, x, weight_t(weight), None if bias is None else bias.detach(), need_z,
+                                 x if root_weight is not None else None,
+                                 None if root_weight is None else weight_t(root_weight), kind=f"{kind}_linear_fwd",
+                                 pre=(scale, shift, graph.rowsum(kind)))
+        ctx.save_for_backward(x, bn_weight, mean, rstd, n, z, weight, root_weight, scale, shift)
+        ctx.graph, ctx.kind, ctx.has_bias, ctx.reduce = graph, kind, bias is not None, reduce
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .nn import batchnorm as B
+        x, bn_weight, mean, rstd, n, z, weight, root_weight, scale, shift = ctx.saved_tensors
+        g, kind = ctx.graph, ctx.kind
+        gy = gy.contiguous()
+        gw = gb = gwr = None
+        if ctx.needs_input_grad[5]:
+            gw, gcol = gemm_tn(gy, z, colsum=True)  # dy is read once for dW and the column sums
+            gb = gcol if ctx.has_bias and ctx.needs_input_grad[6] else None
+        else:
+            gcol = gy.sum(0)
+            gb = gcol if ctx.has_bias and ctx.needs_input_grad[6] else None
+        if root_weight is not None and ctx.needs_input_grad[7]:
+            # dWr = dy^T BN(x) = (dy^T x) diag(s) + colsum(dy) t^T
+            gwr = gemm_tn(gy, x) * scale + gcol[:, None] * shift
+        g_h = _propagate_linear_input_grad(g, kind, gy, weight, root_weight)
+        gx, g_bnw, g_bnb = B.train_backward(g_h, x, bn_weight, mean, rstd, n, ctx.reduce)
+        return gx, g_bnw, g_bnb, None, None, gw, gb, gwr, None, None, None, None
+
+
+def bn_propagate_linear(x, bn, graph, kind, weight, bias=None, root_weight=None):
+    """conv(bn(x)) for a training-mode BatchNorm1d `bn` and a conv layer whose propagate runs on the fused
+    aggregate+transform kernel (single-GPU graphs; the caller checked fused_linear_ok and bn.folds_into_next_layer)."""
+    need_z = weight.requires_grad
+    return _BNPropagateLinear.apply(x, bn.weight, bn.bias, graph, kind, weight, bias, root_weight, bn.eps, bn._reduce,
+                                    bn.begin_training_step(), need_z)
 
 
 def propagate_linear(x, graph, kind, weight, bias=None, root_weight=None):

@@ -348,6 +348,68 @@ def test_eval_batchnorm_folded_into_conv_weights(dev, name, f, hid):
     assert (folded.cpu() - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("name,f,hid", [("GCN", 64, 64), ("GCN", 32, 128), ("GraphSAGE", 64, 64), ("GraphSAGE2", 32, 96)])
+def test_training_batchnorm_folded_into_the_next_conv(dev, name, f, hid):
+    """Training forward of conv(bn(x)): the fused kernel gathers the RAW rows and maps the aggregate with BatchNorm's
+    affine (ops.bn_propagate_linear) — output, running statistics and EVERY gradient (input, BatchNorm weight / bias,
+    conv weights and biases) equal the oracle's bn -> conv under autograd, and the unfused product path."""
+    from rgb_experiment_amd import nn as RN
+    n = 1500
+    ei = rand_graph(n, 12000, 5, loops=7, dups=9)
+    ei[1, ei[1] == 3] = 4  # node 3 has no in-edges: its aggregate is 0, its mean-rowsum 0
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(n, f, generator=gen) * 2 + 0.5
+    go = torch.randn(n, hid, generator=gen)
+    torch.manual_seed(2)
+    conv = {"GCN": RN.GCNConv, "GraphSAGE": RN.MySAGEConv, "GraphSAGE2": RN.SAGEConv}[name](f, hid)
+    bn = RN.BatchNorm1d(f)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 2)
+        bn.bias.uniform_(-1, 1)
+        for p in conv.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.5, 0.5)
+    sd_bn = {k: v.detach().clone() for k, v in bn.state_dict().items()}
+    sd_cv = {k: v.detach().clone().requires_grad_(True) for k, v in conv.state_dict().items() if "lin_dst" not in k}
+    # oracle: torch BatchNorm (training) -> oracle conv, autograd
+    xr = x.clone().requires_grad_(True)
+    bnr = torch.nn.BatchNorm1d(f)
+    bnr.load_state_dict(sd_bn)
+    h = bnr(xr)
+    if name == "GCN":
+        want = O.gcn_conv(h, ei, sd_cv["lin.weight"], sd_cv["bias"])
+    elif name == "GraphSAGE":
+        want = O.my_sage_conv(h, ei, sd_cv["lin_l.weight"], sd_cv["lin_l.bias"], sd_cv["lin_r.weight"], sd_cv["lin_r.bias"])
+    else:
+        want = O.sage_conv(h, ei, sd_cv["lin_l.weight"], sd_cv["lin_l.bias"], sd_cv["lin_r.weight"])
+    want.backward(go)
+    conv.to(dev), bn.to(dev)
+    conv.train(), bn.train()
+    xg = x.to(dev).requires_grad_(True)
+    got = conv.forward_after_bn(xg, ei.to(dev), bn)
+    assert type(got.grad_fn).__name__ == "_BNPropagateLinearBackward"  # the folded path really ran
+    got.backward(go.to(dev))
+    tol = lambda t: 2e-4 * max(1.0, t.abs().max().item())
+    assert (got.detach().cpu() - want.detach()).abs().max().item() < tol(want)
+    assert (xg.grad.cpu() - xr.grad).abs().max().item() < tol(xr.grad)
+    assert (bn.weight.grad.cpu() - bnr.weight.grad).abs().max().item() < tol(bnr.weight.grad)
+    assert (bn.bias.grad.cpu() - bnr.bias.grad).abs().max().item() < tol(bnr.bias.grad)
+    assert torch.allclose(bn.running_mean.cpu(), bnr.running_mean, atol=1e-5)
+    assert torch.allclose(bn.running_var.cpu(), bnr.running_var, atol=1e-4)
+    assert int(bn.num_batches_tracked) == 1
+    for k, p in conv.named_parameters():
+        if "lin_dst" in k:
+            continue
+        assert (p.grad.cpu() - sd_cv[k].grad).abs().max().item() < tol(sd_cv[k].grad), k
+    # and the unfused product path (bn as a pass of its own) on the same device
+    conv.zero_grad(), bn.zero_grad()
+    xg2 = x.to(dev).requires_grad_(True)
+    ref = conv(bn(xg2), ei.to(dev))
+    ref.backward(go.to(dev))
+    assert (got.detach() - ref.detach()).abs().max().item() < 1e-4
+    assert (xg.grad - xg2.grad).abs().max().item() < tol(xr.grad)
+
+
 def test_spmm_epilogue_and_strides(dev):
     """a, b, y, row scale, and non-contiguous leading dimensions (column slices of wider matrices)."""
     from rgb_experiment_amd import ops
@@ -594,8 +656,8 @@ def test_gat_backward_two_implementations_agree(dev):
     lib = _lib.load()
     hd, asd, add = h.detach().contiguous(), a_s.detach().contiguous(), a_d.detach().contiguous()
     _lib.check(lib.rgbx_gat_aggregate_fwd_f32(g.fwd.rowptr.data_ptr(), g.fwd.col.data_ptr(), hd.data_ptr(), H * C,
-                                              asd.data_ptr(), None, add.data_ptr(), None, None, out2.data_ptr(), H * C,
-                                              m.data_ptr(), rden.data_ptr(), None, None, n, H, C, 0.2, None,
+                                              asd.data_ptr(), None, add.data_ptr(), None, None, None, out2.data_ptr(),
+                                              H * C, m.data_ptr(), rden.data_ptr(), None, None, n, H, C, 0.2, None,
                                               _lib.stream_ptr()), "fwd")
     nodeq = torch.empty(n, H, 4, device=dev)
     ref = torch.empty(n, H, device=dev)
