@@ -666,6 +666,7 @@ def main():
         result["per_rank"] = per_rank
         result["exchange_mb_per_rank_per_step"] = max(r["exchange_mb_per_step"] for r in per_rank)
         result["modelled_seconds_per_propagate"] = dgraph._choice.get(("costs", d))
+        result["link_gbs_measured"] = getattr(comm_obj, "link_gbs", None)  # 16 MB-per-peer all-to-all at start-up
     if emu:
         result["n_gpus"] = 1
         result["emulated"] = {"rank": 0, "of": emu, "scheme": scheme,

@@ -77,6 +77,7 @@ class Comm:
         self.turns = None  # a TakeTurns while two forwards are being interleaved
         self.bytes_sent = 0  # payload this rank handed to all-to-alls (rows * width * 4), for the bench line
         self.exchanges = 0
+        self.link_gbs = None  # measured by measure_link_gbs(); the cost model's link rate when set
 
     def _account(self, send, send_counts):
         own = send_counts[self.rank] if self.rank < len(send_counts) else 0
@@ -101,6 +102,31 @@ class Comm:
                                group=self.group)
         recv.copy_(host_recv)
         return recv, (_Done() if self.turns is None else _TurnWork(_Done(), self.turns))
+
+    def measure_link_gbs(self, device, mb_per_peer=16, reps=3):
+        """GB/s one xGMI link carries per direction under an all-to-all (every pair busy at once), measured: `reps`
+        timed all-to-alls of `mb_per_peer` MB per peer after two warm-ups; the slowest rank's time counts and all ranks
+        get the same figure (it feeds the exchange cost model, which must agree everywhere). RCCL only: None
+        otherwise (gloo rehearsals, one rank)."""
+        if self.world == 1 or self.backend != "nccl":
+            return None
+        import time
+        rows = mb_per_peer * 1024 * 1024 // (64 * 4)
+        send = torch.ones((rows * self.world, 64), dtype=torch.float32, device=device)
+        counts = [rows] * self.world
+        for _ in range(2):
+            self.all_to_all_rows(send, counts, counts)[1].wait()
+        torch.cuda.synchronize(device)
+        dist.barrier(group=self.group)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self.all_to_all_rows(send, counts, counts)[1].wait()
+        torch.cuda.synchronize(device)
+        dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=device)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=self.group)
+        self.bytes_sent, self.exchanges = 0, 0
+        self.link_gbs = rows * 64 * 4 / dt.item() / 1e9
+        return self.link_gbs
 
     def all_reduce_sum_(self, t):
         if self.world == 1:
@@ -133,6 +159,7 @@ class EmulatedComm(Comm):
         self.exchanges = 0
         self.log = []  # (tag, max bytes sent to one peer, max bytes received from one peer) per exchange
         self._pool = {}
+        self.link_gbs = None
 
     def all_to_all_rows(self, send, send_counts, recv_counts, tag=None):
         n_recv = int(sum(recv_counts))

@@ -374,7 +374,8 @@ class DistGraph:
     #   gather rate  : the aggregation kernels sustain ~6.5 TB/s of 128-byte lines on this chip at every width
     #                  (a row of <= 32 floats costs one line), so
     #                  t_spmm = edges * ceil(4 * width / 128) * 128 B / 6.5e12
-    #   link rate    : RGBX_LINK_GBS (default 60) GB/s per direction per xGMI link, all P - 1 links concurrently
+    #   link rate    : GB/s per direction per xGMI link, all P - 1 links concurrently: RGBX_LINK_GBS, else the rate
+    #                  DistRunner measured at start-up with a 16 MB-per-peer all-to-all, else 60
     #   halo         : max(boundary bytes per link / rate, local-edge SpMM) + remote-edge SpMM
     #   grid R x C   : n_local * d/C * 4 B inbound per link, SpMM of E'/R edges at width d/C,
     #                  1/pieces of the outbound n_local * d/C * 4 B exposed
@@ -403,7 +404,8 @@ class DistGraph:
         import math
         import os
         P, N = self.comm.world, self.N_global
-        link = float(os.environ.get("RGBX_LINK_GBS", "60")) * 1e9
+        # link rate: RGBX_LINK_GBS if set, else what Comm.measure_link_gbs() measured on this fabric, else 60 GB/s
+        link = float(os.environ.get("RGBX_LINK_GBS") or getattr(self.comm, "link_gbs", None) or 60.0) * 1e9
         stats = torch.tensor([float(v) for v in self._halo_stats()], dtype=torch.float64,
                              device=self._edges().device)
         halo_rows, e_loc, e_rem = (self.comm.all_reduce_sum_(stats) / P).tolist()  # means over the ranks

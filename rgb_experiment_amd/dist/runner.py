@@ -32,6 +32,8 @@ class DistRunner:
         self.graphs = install(self.token, hi - lo, edge_index.to(device), N, self.comm, backend, exchange, pieces)
         self.interleave_evals = interleave_evals and world > 1
         self._streams = None
+        if device.type == "cuda":  # one timed all-to-all: the exchange cost model then uses this fabric's link rate
+            self.link_gbs = self.comm.measure_link_gbs(device)
         if resident_features:
             for g in self.graphs.values():
                 g.pin_resident(self.x)  # boundary rows of the static features are fetched once and kept
