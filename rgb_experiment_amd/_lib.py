@@ -68,6 +68,20 @@ EXPORTS = ["rgbx_version", "rgbx_last_error_string"] + list(SIGNATURES)
 _lib = None
 
 
+def bind(path):
+    """ctypes handle of a build of the library with every entry point's signature declared."""
+    lib = ctypes.CDLL(path)
+    lib.rgbx_version.restype = _I
+    lib.rgbx_version.argtypes = []
+    lib.rgbx_last_error_string.restype = ctypes.c_char_p
+    lib.rgbx_last_error_string.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = _I
+        fn.argtypes = argtypes
+    return lib
+
+
 def load():
     """Load the library once; raise RuntimeError (never fall back) when it is not built."""
     global _lib
@@ -77,17 +91,14 @@ def load():
         raise RuntimeError(
             f"rgb_experiment_amd: {LIB_PATH} is not built — run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (or `make -C rgb_experiment_amd/csrc`). There is no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
-    lib.rgbx_version.restype = _I
-    lib.rgbx_version.argtypes = []
-    lib.rgbx_last_error_string.restype = ctypes.c_char_p
-    lib.rgbx_last_error_string.argtypes = []
-    for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)
-        fn.restype = _I
-        fn.argtypes = argtypes
+    _lib = bind(LIB_PATH)
+    return _lib
+
+
+def use(lib):
+    """Kernel A/B experiments (tools/ab_lib.py): route the calls through another build bound with `bind`."""
+    global _lib
     _lib = lib
-    return lib
 
 
 def check(rc, what):
