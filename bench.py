@@ -55,6 +55,7 @@ KERNEL_OF_KIND = {
     "gcn_linear_fwd": "spmm_linear_kernel", "mean_linear_fwd": "spmm_linear_kernel",
     "gcn_linear_bwd": "spmm_linear_kernel", "mean_linear_bwd": "spmm_linear_kernel",
     "gcn_fwd": "spmm_csr_kernel", "gcn_bwd": "spmm_csr_kernel", "mean_fwd": "spmm_csr_kernel",
+    "sum_fwd": "spmm_csr_kernel", "sum_bwd": "spmm_csr_kernel",
     "mean_bwd": "spmm_csr_kernel", "appnp_fwd": "spmm_csr_kernel (K launches)",
     "appnp_bwd": "spmm_csr_kernel (K launches)", "gat_fwd": "gat_fwd_kernel", "gat_bwd_src": "gat_bwd_src_kernel",
     "gat_bwd_prep": "gat_bwd_prep_kernel", "gat_bwd_segsum": "spmm_csr_kernel (width H)",
@@ -161,13 +162,22 @@ MODELS = {
     "graphsage2": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 7, 0, "mean"),
     "gat": (dict(num_layers=2, hidden_unit=16, heads=8, dropout_rate=0.5), 8, 2, "gat"),
     "appnpstack": (dict(hidden_unit=64, K=10, alpha=0.1, dropout_rate=0.5), 40, 1, "gcn"),
+    # SURVEY 8(f) "next" rows: callers of the same propagate kernels
+    # sgc: K = 2 propagates of the static features per forward, nothing flows back through them (cached=False: the
+    # reference's cached=True would leave an epoch without any propagate after the first)
+    "sgc": (dict(K=2, cached=False), 6, 1, "gcn"),
+    # gin: unweighted sum over the edges as given, 2 blocks per forward; layer 1's input needs no gradient
+    "gin": (dict(num_layers=2, hidden_unit=128, dropout_rate=0.5), 7, 0, "sum"),
+    # dagnn: K = 10 gcn-normalised hops of the MLP output per forward, all 10 transposed in the backward
+    "dagnn": (dict(hidden_dim=64, K=10, dropout_rate=0.5), 40, 1, "gcn"),
 }
+DEEP = {"appnpstack": 2, "dagnn": 2}  # K hops cover the whole graph: the sampled logit check runs these at K = 2
 
 
 def model_class(name):
     from rgb_experiment_amd import models as M
     return {"gcn": M.GCN, "graphsage": M.GraphSAGE, "graphsage2": M.GraphSAGE2, "gat": M.GAT,
-            "appnpstack": M.APPNPStack}[name]
+            "appnpstack": M.APPNPStack, "sgc": M.SGC, "gin": M.GIN, "dagnn": M.DAGNN}[name]
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -240,18 +250,19 @@ def sampled_logit_parity(name, model, ei, x, x_d, ei_d, n_targets=None):
     linearity / adjoint tests at full size)."""
     from oracle import sampled as S
     kw = dict(MODELS[name][0])
-    kw.pop("dropout_rate", None)
-    kw.pop("hidden_unit", None)
+    for k in ("dropout_rate", "hidden_unit", "hidden_dim", "cached"):
+        kw.pop(k, None)
     N = x.size(0)
     if n_targets is None:  # gcn_norm models complete the outer in-degrees with dummy edges: keep those bounded
-        n_targets = 96 if name in ("gcn", "appnpstack") else 768
+        n_targets = 96 if name in ("gcn", "appnpstack", "sgc", "dagnn") else 768
     targets = S.pick_targets(N, n_targets)
     was_training = model.training
     model.eval()
     run = model
-    if name == "appnpstack":
-        kw["K"] = 2
-        run = model_class(name)(input_dim=x.size(1), output_dim=model.lin2.out_features, **{**MODELS[name][0], "K": 2})
+    if name in DEEP:
+        kw["K"] = DEEP[name]
+        run = model_class(name)(input_dim=x.size(1), output_dim=model.lin2.out_features,
+                                **{**MODELS[name][0], "K": DEEP[name]})
         run.load_state_dict(model.state_dict())
         run.to(x_d.device).eval()
     with torch.no_grad():
@@ -264,7 +275,7 @@ def sampled_logit_parity(name, model, ei, x, x_d, ei_d, n_targets=None):
                  "max_abs_logit": want.abs().max().item(), "tolerance": 1e-4, "oracle_seconds": time.perf_counter() - t0,
                  "what": f"eval-mode {name} logits of {targets.numel()} sampled nodes: HIP forward over the whole graph vs "
                          "oracle.ref_cpu forward on their in-neighbourhood" + (" (K=2 instance of the same weights)"
-                                                                                if name == "appnpstack" else "")})
+                                                                                if name in DEEP else "")})
     return info
 
 
@@ -288,6 +299,8 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
     nnz_total = graph.fwd.nnz
     if kind == "gat":  # SURVEY §8d per-launch bytes, averaged over the 6 forward + 2 backward propagates
         alg = gat_alg_bytes(N, nnz_total, d)
+    elif kind == "sum":  # no per-edge weight
+        alg = spmm_alg_bytes(N, nnz_total, d) - 4 * nnz_total
     else:
         alg = spmm_alg_bytes(N, nnz_total, d)
 
@@ -543,8 +556,10 @@ def main():
 
     torch.manual_seed(14530529)  # the reference's reappear_seed (itexperiments.py:57)
     model = model_class(args.model)(input_dim=d, output_dim=d, **kwargs)
-    wl_name = wl["name"].replace("GCN", {"gcn": "GCN", "graphsage": "GraphSAGE", "graphsage2": "GraphSAGE2",
-                                         "gat": "GAT 8 heads", "appnpstack": "APPNP K=10"}[args.model])
+    wl_name = wl["name"].replace("2-layer GCN", {"gcn": "2-layer GCN", "graphsage": "2-layer GraphSAGE",
+                                                 "graphsage2": "2-layer GraphSAGE2", "gat": "2-layer GAT 8 heads",
+                                                 "appnpstack": "APPNP K=10", "sgc": "SGC K=2 (cached=False)",
+                                                 "gin": "2-block GIN", "dagnn": "DAGNN K=10"}[args.model])
 
     emu = args.emulate_rank if world == 1 else 0
     parts = max(world, emu)  # ranks the graph is partitioned over

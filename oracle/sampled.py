@@ -68,6 +68,12 @@ def _forward(name, sd, xs, sub, kw):
         return O.gat_forward(sd, xs, sub, kw["num_layers"], kw["heads"], training=False)
     if name == "appnpstack":
         return O.appnp_stack_forward(sd, xs, sub, kw["K"], kw["alpha"], training=False)
+    if name == "sgc":
+        return O.sgc_forward(sd, xs, sub, kw["K"])
+    if name == "gin":
+        return O.gin_forward(sd, xs, sub, kw["num_layers"], training=False)
+    if name == "dagnn":
+        return O.dagnn_forward(sd, xs, sub, kw["K"])
     raise KeyError(name)
 
 
@@ -75,8 +81,8 @@ def sampled_logits(name, state_dict, x, edge_index, targets, **kw):
     """Oracle logits [T, C] of `targets` for the model `name` with the product's `state_dict` (CPU tensors),
     eval mode. kw: num_layers (conv stacks), heads (gat), K / alpha (appnpstack: keep K small, the
     neighbourhood grows by the mean degree per hop)."""
-    hops = kw["K"] if name == "appnpstack" else kw["num_layers"]
-    needs_degree = name in ("gcn", "appnpstack")
+    hops = kw["K"] if name in ("appnpstack", "sgc", "dagnn") else kw["num_layers"]
+    needs_degree = name in ("gcn", "appnpstack", "sgc", "dagnn")
     sub, node_ids, tpos, n_total = khop_in_subgraph(edge_index, x.size(0), targets, hops, needs_degree)
     xs = _sub_features(x, node_ids, n_total)
     sd = {k: v for k, v in state_dict.items()}

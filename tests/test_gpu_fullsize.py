@@ -73,10 +73,14 @@ MODEL_KW = {
     "graphsage2": dict(num_layers=2, hidden_unit=128, dropout_rate=0.5),
     "gat": dict(num_layers=2, hidden_unit=16, heads=8, dropout_rate=0.5),
     "appnpstack": dict(hidden_unit=64, K=2, alpha=0.1, dropout_rate=0.5),  # K = 2: see oracle/sampled.py
+    # SURVEY 8(f) callers of the same kernels
+    "sgc": dict(K=2, cached=False),
+    "gin": dict(num_layers=2, hidden_unit=128, dropout_rate=0.0),
+    "dagnn": dict(hidden_dim=64, K=2, dropout_rate=0.0),
 }
 
 
-@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack"])
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack", "sgc", "gin", "dagnn"])
 @pytest.mark.parametrize("size", ["S", "L"])
 def test_model_logits_at_sampled_rows_of_the_benchmark_graph(dev, size, name):
     """BASELINE configs 2-5 in their one-GPU form: two training steps (so that weights, BatchNorm running statistics
@@ -87,7 +91,7 @@ def test_model_logits_at_sampled_rows_of_the_benchmark_graph(dev, size, name):
     ei, x, y = workload(size)
     n = x.size(0)
     cls = {"gcn": M.GCN, "graphsage": M.GraphSAGE, "graphsage2": M.GraphSAGE2, "gat": M.GAT,
-           "appnpstack": M.APPNPStack}[name]
+           "appnpstack": M.APPNPStack, "sgc": M.SGC, "gin": M.GIN, "dagnn": M.DAGNN}[name]
     torch.manual_seed(14530529)
     model = cls(input_dim=128, output_dim=128, **MODEL_KW[name]).to(dev)
     ei_d, x_d, y_d = ei.to(dev), x.to(dev), y.to(dev)
@@ -99,12 +103,12 @@ def test_model_logits_at_sampled_rows_of_the_benchmark_graph(dev, size, name):
         ops.masked_ce_loss(model(x_d, ei_d)["emb"], y_d, mask).backward()
         opt.step()
     model.eval()
-    n_targets = 96 if name in ("gcn", "appnpstack") else 512
+    n_targets = 96 if name in ("gcn", "appnpstack", "sgc", "dagnn") else 512
     targets = S.pick_targets(n, n_targets)
     with torch.no_grad():
         got = model(x_d, ei_d)["emb"][targets.to(dev)].cpu()
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    kw = {k: v for k, v in MODEL_KW[name].items() if k not in ("hidden_unit", "dropout_rate")}
+    kw = {k: v for k, v in MODEL_KW[name].items() if k not in ("hidden_unit", "hidden_dim", "dropout_rate", "cached")}
     want, info = S.sampled_logits(name, sd, x, ei, targets, **kw)
     err = (got - want).abs().max().item()
     assert err < TOL, (name, size, err, info)

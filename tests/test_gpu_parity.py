@@ -1130,6 +1130,39 @@ def test_hip_graph_epoch_equals_eager_loop(dev, name):
     assert abs(a["ACC"] - b["ACC"]) < 1e-9
 
 
+def test_transposed_weight_cache_follows_the_parameter(dev):
+    """ops.weight_t keeps W^T per parameter version: optimizer steps, load_state_dict, hipGraph replays (which do
+    not move version counters) and .to() must all invalidate it."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.epoch_graph import GraphedEpoch
+    from rgb_experiment_amd.models import GCN
+    torch.manual_seed(0)
+    n = 400
+    ei = rand_graph(n, 3000, 3).to(dev)
+    x = torch.randn(n, 32, device=dev)
+    y = torch.randint(0, 32, (n,), device=dev)
+    masks = tuple((torch.arange(n, device=dev) % 3) == k for k in range(3))
+    model = GCN(num_layers=2, hidden_unit=32, input_dim=32, output_dim=32, dropout_rate=0.5).to(dev)
+    w = model.convs[1].lin.weight
+    same = lambda: torch.equal(ops.weight_t(w), w.detach().t().contiguous())
+    assert same() and ops.weight_t(w) is ops.weight_t(w)  # cached
+    with torch.no_grad():
+        w.mul_(2.0)
+    assert same()
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+    ge = GraphedEpoch(model, opt, {"x": x, "edge_index": ei}, y, masks).capture()
+    assert same()
+    before = w.detach().clone()
+    ge.run()
+    ge.run()
+    assert not torch.equal(before, w.detach()) and same()  # replays moved the weights; the cache followed
+    model.eval()
+    with torch.no_grad():
+        eager = model(x, ei)["emb"]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    assert (eager.cpu() - O.gcn_forward(sd, x.cpu(), ei.cpu(), 2, False)["emb"]).abs().max().item() < TOL
+
+
 @pytest.mark.parametrize("graphed", [False, True])
 def test_shared_eval_forward_changes_nothing_but_the_forward_count(dev, graphed):
     """share_eval_forward=True: per-epoch test metrics from the val pass's outputs (the reference forwards a second

@@ -24,6 +24,12 @@ def _state(name, f, c):
         m = M.GAT(num_layers=2, hidden_unit=4, heads=3, input_dim=f, output_dim=c, dropout_rate=0.5)
     elif name == "appnpstack":
         m = M.APPNPStack(hidden_unit=16, input_dim=f, output_dim=c, K=2, alpha=0.1, dropout_rate=0.5)
+    elif name == "sgc":
+        m = M.SGC(input_dim=f, output_dim=c, K=2, cached=False)
+    elif name == "gin":
+        m = M.GIN(input_dim=f, output_dim=c, hidden_unit=16, num_layers=2, dropout_rate=0.5)
+    elif name == "dagnn":
+        m = M.DAGNN(input_dim=f, hidden_dim=16, output_dim=c, K=2, dropout_rate=0.5)
     else:
         cls = {"gcn": M.GCN, "graphsage": M.GraphSAGE, "graphsage2": M.GraphSAGE2}[name]
         m = cls(num_layers=2, hidden_unit=16, input_dim=f, output_dim=c, dropout_rate=0.5)
@@ -36,13 +42,14 @@ def _state(name, f, c):
     return sd
 
 
-@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack"])
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack", "sgc", "gin", "dagnn"])
 def test_sampled_subgraph_forward_equals_the_full_forward(name):
     ei, x = _graph()
     n, c = x.size(0), 5
     sd = _state(name, x.size(1), c)
     kw = {"gcn": dict(num_layers=2), "graphsage": dict(num_layers=2), "graphsage2": dict(num_layers=2),
-          "gat": dict(num_layers=2, heads=3), "appnpstack": dict(K=2, alpha=0.1)}[name]
+          "gat": dict(num_layers=2, heads=3), "appnpstack": dict(K=2, alpha=0.1), "sgc": dict(K=2),
+          "gin": dict(num_layers=2), "dagnn": dict(K=2)}[name]
     with torch.no_grad():
         full = S._forward(name, sd, x, ei, kw)["emb"]
     targets = torch.cat([S.pick_targets(n, 40), torch.tensor([7, 8])]).unique()
