@@ -19,18 +19,14 @@ class Prop(nn.Module):
         self.proj = nn.Linear(num_classes, 1)
 
     def forward(self, x, edge_index):
-        """The reference stacks the K + 1 hops into [N, K+1, C] (11 GB at |V| = 2M, C = 128, K = 10), projects the
-        stack and mixes it with a batched matmul (dagnn.py:46-55). Same values, hop by hop: the gate of hop k is
-        sigmoid(proj(pred_k)) and the output the running sum of gate_k * pred_k — no stacked copy exists."""
         graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
-        w, b = self.proj.weight.reshape(-1), self.proj.bias
-        out = None
-        for k in range(self.K + 1):
-            if k:
-                x = ops.propagate_gcn(x, graph)
-            gate = torch.sigmoid(torch.addmv(b, x, w)).unsqueeze(1)   # retain score of this hop, [N, 1]
-            out = gate * x if out is None else torch.addcmul(out, gate, x)
-        return out
+        preds = [x]
+        for _ in range(self.K):
+            x = ops.propagate_gcn(x, graph)
+            preds.append(x)
+        pps = torch.stack(preds, dim=1)                      # [N, K+1, C]
+        retain = torch.sigmoid(self.proj(pps).squeeze(-1))   # [N, K+1]
+        return torch.matmul(retain.unsqueeze(1), pps).squeeze(1)
 
     def reset_parameters(self):
         self.proj.reset_parameters()
