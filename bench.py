@@ -627,9 +627,10 @@ def main():
     elif dominant is not None:
         # the DOMINANT kernel's own launches: its algorithmic bytes per launch / its mean launch duration
         launches_per_event = kwargs.get("K", 1) if dominant.startswith("appnp") else 1
-        if dominant == "gat_fwd":
+        if dominant == "gat_fwd":  # forward launch alone (col + in-kernel scores + feature row per edge; out, m, 1/sum)
             H = kwargs.get("heads", 8)
-            alg = nnz_total * (4 + 4 * H + 4 * d) + N * (8 * d + 12 * H) + 4 * (N + 1)
+            rows_here, nnz_here = (N, nnz_total) if parts == 1 else (n_loc, plan.nnz_local)
+            alg = nnz_here * (4 + 4 * H + 4 * d) + rows_here * (8 * d + 12 * H) + 4 * (rows_here + 1)
         dom_s = sum(by_kind[dominant]) / len(by_kind[dominant]) / launches_per_event * 1e-3
         achieved = alg / dom_s / 1e9
     by_kind = {k: {"n": len(v), "avg_ms": sum(v) / len(v)} for k, v in sorted(by_kind.items())}

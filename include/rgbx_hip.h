@@ -153,12 +153,18 @@ int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w,
  * BatchNorm1d in front of the conv layer (models/gcn.py:28 then :29). By linearity
  *   z[i,:] = pre_scale * (rs[i] * sum_p w[p] x[col[p],:]) + pre_shift * pre_rowsum[i],
  * pre_rowsum[i] = rs[i] * sum_{p in row i} w[p] (the caller's per-graph constant); the root rows get the map as
- * they are loaded; z_out receives the mapped aggregate (what dW = dy^T z needs). */
+ * they are loaded; z_out receives the mapped aggregate (what dW = dy^T z needs).
+ * `out_colsums` ([2, Nout] doubles, optional): out_colsums[0,c] = sum_i out[i,c], [1,c] = sum_i out[i,c]^2 — the
+ * statistics of a training-mode BatchNorm1d that follows the layer (models/gcn.py:27 then :28), taken from the
+ * MFMA accumulators of the 32-row tiles (fp32 per tile, tiles added in fp64 in a fixed order) instead of a pass
+ * over `out`; needs `stats_ws` of rgbx_spmm_linear_stats_workspace_bytes(N, Nout) bytes (8-byte aligned). */
 int rgbx_spmm_linear_supported(int64_t K, int64_t Nout, int has_root);
+int rgbx_spmm_linear_stats_workspace_bytes(int64_t N, int64_t Nout, size_t* bytes);
 int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
                          const float* x, int64_t ldx, const float* wt, const float* x_root, int64_t ldr,
                          const float* wt_root, const float* bias, float* out, int64_t ldo, float* z_out,
                          int64_t ldz, const float* pre_scale, const float* pre_shift, const float* pre_rowsum,
+                         double* out_colsums, void* stats_ws, size_t stats_ws_bytes,
                          int64_t N, int64_t K, int64_t Nout, const rgbx_row_split_t* split,
                          rgbx_stream_t stream);
 

@@ -34,8 +34,9 @@ SIGNATURES = {
     "rgbx_inv_degree_f32": [_P, _I64, _P, _P],
     "rgbx_spmm_csr_f32": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _F, _F, _P, _P],
     "rgbx_spmm_linear_supported": [_I64, _I64, _I],
-    "rgbx_spmm_linear_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I64,
-                             _I64, _P, _P],
+    "rgbx_spmm_linear_stats_workspace_bytes": [_I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
+    "rgbx_spmm_linear_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P,
+                             ctypes.c_size_t, _I64, _I64, _I64, _P, _P],
     "rgbx_appnp_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _F, _P, _P],
     "rgbx_gat_scores_f32": [_P, _I64, _P, _P, _P, _P, _I64, _I, _I, _P],
     "rgbx_gat_scores_bwd_scratch_floats": [_I64, _I, _I, ctypes.POINTER(ctypes.c_int64)],

@@ -47,6 +47,10 @@ struct FusedArgs {
   const float* pre_scale;
   const float* pre_shift;
   const float* pre_rowsum;
+  // optional: per-workgroup column sums of the stored output tile, part[block][0][c] = sum_rows out, [1][c] = sum out^2
+  // (the statistics of the BatchNorm that follows the layer, taken from the MFMA accumulators instead of a pass
+  // over out)
+  float* stats_part;
 };
 
 constexpr int TM = 32;       // destination rows per workgroup = one MFMA row tile; 4 waves aggregate 8 rows each
@@ -109,14 +113,60 @@ __device__ __forceinline__ void tile_times_wt(f32x16& acc, const float* __restri
 // C/D layout of the 32x32 MFMA: column l&31, row (r&3) + 8*(r>>2) + 4*(l>>5)
 __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __restrict__ bias,
                                            float* __restrict__ out, int64_t ldo, int row_base, int N, int n0,
-                                           int kr, int cc) {
+                                           int kr, int cc, float* __restrict__ stats_part = nullptr, int Nout = 0) {
   const float bb = bias ? bias[n0 + cc] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * kr;
-    if (row < N) out[(int64_t)row * ldo + n0 + cc] = acc[r] + bb;
+    if (row < N) {
+      const float v = acc[r] + bb;
+      out[(int64_t)row * ldo + n0 + cc] = v;
+      s1 += v;
+      s2 = fmaf(v, v, s2);
+    }
+  }
+  if (stats_part) {  // lanes l and l + 32 hold the two row halves of column cc: one record per workgroup and column
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (kr == 0) {
+      float* rec = stats_part + (int64_t)blockIdx.x * 2 * Nout;
+      rec[n0 + cc] = s1;
+      rec[Nout + n0 + cc] = s2;
+    }
   }
 }
+
+// Second stage of the output statistics: workgroup g adds the per-tile records g, g + G, ... in fp64 (thread = column of
+// the [2, Nout] record), a third stage adds the G sums in order: fixed summation order, reproducible.
+__global__ void __launch_bounds__(256)
+tile_stats_gather_kernel(const float* __restrict__ part, int n_tiles, int width2, double* __restrict__ part2) {
+  for (int c = threadIdx.x; c < width2; c += 256) {
+    double s = 0.0;
+    for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) s += (double)part[(int64_t)b * width2 + c];
+    part2[(int64_t)blockIdx.x * width2 + c] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+tile_stats_finish_kernel(const double* __restrict__ part2, int G, int width2, double* __restrict__ sums) {
+  __shared__ double sh[32][8];
+  const int j = threadIdx.x & 7, q = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + j;
+  double s = 0.0;
+  if (c < width2)
+    for (int b = q; b < G; b += 32) s += part2[(int64_t)b * width2 + c];
+  sh[q][j] = s;
+  __syncthreads();
+  if (q == 0 && c < width2) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += sh[k][j];
+    sums[c] = t;
+  }
+}
+
+constexpr int kStatsGather = 256;  // workgroups of the second stage
 
 // KC = K when it is one of the common widths (the MFMA loop then unrolls fully), 0 = any supported K.
 template <int G, bool HAS_W, int KC, int NT>
@@ -262,7 +312,7 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       tile_times_wt<KC>(acc, zt, ldz, A.wt, K, A.Nout, n0, kr, cc);
-      store_tile(acc, A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc);
+      store_tile(acc, A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc, A.stats_part, A.Nout);
     }
     return;
   }
@@ -281,7 +331,7 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       const int n0 = wave * 32 + tt * 128;
-      if (n0 < A.Nout) store_tile(acc[tt], A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc);
+      if (n0 < A.Nout) store_tile(acc[tt], A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc, A.stats_part, A.Nout);
     }
     return;
   }
@@ -319,7 +369,7 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
     const int n0 = wave * 32 + tt * 128;
     if (n0 < A.Nout) {
       tile_times_wt<KC>(acc[tt], zt, ldz, A.wtr, K, A.Nout, n0, kr, cc);
-      store_tile(acc[tt], A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc);
+      store_tile(acc[tt], A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc, A.stats_part, A.Nout);
     }
   }
 }
@@ -358,7 +408,8 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
                                     const float* x, int64_t ldx, const float* wt, const float* x_root, int64_t ldr,
                                     const float* wt_root, const float* bias, float* out, int64_t ldo, float* z_out,
                                     int64_t ldz, const float* pre_scale, const float* pre_shift,
-                                    const float* pre_rowsum, int64_t N, int64_t K, int64_t Nout,
+                                    const float* pre_rowsum, double* out_colsums, void* stats_ws,
+                                    size_t stats_ws_bytes, int64_t N, int64_t K, int64_t Nout,
                                     const rgbx_row_split_t* split, rgbx_stream_t stream) {
   if (N < 0 || K <= 0 || Nout <= 0) return fail(RGBX_E_ARG, "spmm_linear: bad size");
   if (N == 0) return RGBX_OK;
@@ -378,6 +429,17 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
     return fail(RGBX_E_ARG, "spmm_linear: leading dimension too small");
   if (!aligned16(x) || ldx % 4 || (z_out && (!aligned16(z_out) || ldz % 4)) || (x_root && (!aligned16(x_root) || ldr % 4)))
     return fail(RGBX_E_ALIGN, "spmm_linear: x / x_root / z_out must be 16-byte aligned with ld %% 4 == 0");
+  float* stats_part = nullptr;
+  double* stats_part2 = nullptr;
+  if (out_colsums) {
+    size_t need = 0;
+    rgbx_spmm_linear_stats_workspace_bytes(N, Nout, &need);
+    if (!stats_ws || stats_ws_bytes < need)
+      return fail(RGBX_E_WS, "spmm_linear: statistics workspace %zu < %zu bytes", stats_ws_bytes, need);
+    if (reinterpret_cast<uintptr_t>(stats_ws) % 8) return fail(RGBX_E_ALIGN, "spmm_linear: stats_ws must be 8-byte aligned");
+    stats_part2 = static_cast<double*>(stats_ws);                            // [kStatsGather, 2 * Nout] doubles
+    stats_part = reinterpret_cast<float*>(stats_part2 + (size_t)kStatsGather * 2 * Nout);  // [tiles, 2 * Nout] floats
+  }
   hipStream_t s = (hipStream_t)stream;
   const int* long_row = nullptr;
   const float* zlong = nullptr;
@@ -394,16 +456,31 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
   }
   FusedArgs A{rowptr, col, w,  rs,  x,   wt,  x_root,   wt_root, bias,      out,    z_out,
               ldx,    ldo, ldz, ldr, long_row, zlong, threshold, n_long,    (int)N, (int)K, (int)Nout,
-              pre_scale, pre_shift, pre_rowsum};
-  if (K == 128) return launch<32, 128>(A, s);
-  if (K == 64) return launch<16, 64>(A, s);
-  if (K == 256) return launch<64, 256>(A, s);
+              pre_scale, pre_shift, pre_rowsum, stats_part};
   const int lanes = (int)(K / 4);
-  if (lanes <= 1) return launch<1, 0>(A, s);
-  if (lanes <= 2) return launch<2, 0>(A, s);
-  if (lanes <= 4) return launch<4, 0>(A, s);
-  if (lanes <= 8) return launch<8, 0>(A, s);
-  if (lanes <= 16) return launch<16, 0>(A, s);
-  if (lanes <= 32) return launch<32, 0>(A, s);
-  return launch<64, 0>(A, s);
+  int rc;
+  if (K == 128) rc = launch<32, 128>(A, s);
+  else if (K == 64) rc = launch<16, 64>(A, s);
+  else if (K == 256) rc = launch<64, 256>(A, s);
+  else if (lanes <= 1) rc = launch<1, 0>(A, s);
+  else if (lanes <= 2) rc = launch<2, 0>(A, s);
+  else if (lanes <= 4) rc = launch<4, 0>(A, s);
+  else if (lanes <= 8) rc = launch<8, 0>(A, s);
+  else if (lanes <= 16) rc = launch<16, 0>(A, s);
+  else if (lanes <= 32) rc = launch<32, 0>(A, s);
+  else rc = launch<64, 0>(A, s);
+  if (rc || !out_colsums) return rc;
+  const int tiles = (int)cdiv(N, TM), width2 = (int)(2 * Nout);
+  const int G = tiles < kStatsGather ? tiles : kStatsGather;
+  tile_stats_gather_kernel<<<G, 256, 0, s>>>(stats_part, tiles, width2, stats_part2);
+  RGBX_CHECK_LAUNCH("tile_stats_gather_kernel");
+  tile_stats_finish_kernel<<<(int)cdiv(width2, 8), 256, 0, s>>>(stats_part2, G, width2, out_colsums);
+  RGBX_CHECK_LAUNCH("tile_stats_finish_kernel");
+  return RGBX_OK;
+}
+
+extern "C" int rgbx_spmm_linear_stats_workspace_bytes(int64_t N, int64_t Nout, size_t* bytes) {
+  if (!bytes || N < 0 || Nout <= 0) return fail(RGBX_E_ARG, "spmm_linear_stats_workspace_bytes: bad argument");
+  *bytes = (size_t)kStatsGather * 2 * (size_t)Nout * sizeof(double) + (size_t)cdiv(N, TM) * 2 * (size_t)Nout * sizeof(float);
+  return RGBX_OK;
 }

@@ -257,7 +257,7 @@ class DistGraph:
         (csr, ws), half = self._ext_csr(kind)
         x_ext = self._resident_ext(x, half, kind)
         need_z = torch.is_grad_enabled() and weight.requires_grad
-        return ops._PropagateLinear.apply(x_ext, _ExtGraph(csr, ws), "gcn", weight, bias, need_z, root_weight, x)
+        return ops._PropagateLinear.apply(x_ext, _ExtGraph(csr, ws), "gcn", weight, bias, need_z, root_weight, x, False)
 
     def _run_halo(self, kind, direction, x):
         d = self._halo_csrs(kind, direction)

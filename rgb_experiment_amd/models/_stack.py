@@ -93,16 +93,24 @@ class ConvStack(nn.Module):
         where a neighbouring conv can absorb it: under no_grad its eval-mode affine map goes into the PRECEDING conv's
         weights; in a training forward it is handed to the FOLLOWING conv (forward_after_bn), whose fused kernel
         applies it to the aggregate of the raw rows."""
+        from .. import ops
         last = self.num_layers - 1
         pending = None  # a BatchNorm whose output has not been formed yet
         for i, conv in enumerate(self.convs):
             bn = self.bns[i] if i < last else None
+            # a training-mode BatchNorm follows a conv that can hand it its column sums (taken from the fused kernel's
+            # MFMA tiles): no statistics pass over the conv's output
+            extra = {}
+            if (bn is not None and bn.training and torch.is_grad_enabled() and getattr(conv, "emits_colsums", False)
+                    and hasattr(bn, "begin_training_step")):
+                extra["want_colsums"] = True
             if pending is not None:
+                sums = getattr(x, ops.COLSUMS, None)
                 after = getattr(conv, "forward_after_bn", None)
-                if after is not None:
-                    x, pending = after(x, edge_index, pending), bn  # = conv(pending(x), edge_index)
+                if after is not None:  # = conv(pending(x), edge_index)
+                    x, pending = after(x, edge_index, pending, colsums=sums, **extra), bn
                     continue
-                x, pending = pending(x), None
+                x, pending = (pending(x, colsums=sums) if sums is not None else pending(x)), None
             affine = None
             if bn is not None and getattr(conv, "folds_post_affine", False) and not torch.is_grad_enabled():
                 fold = getattr(bn, "eval_affine", None)
@@ -110,5 +118,5 @@ class ConvStack(nn.Module):
             if affine is not None:  # eval forward: BatchNorm's affine map folded into the conv's weights
                 x = conv(x, edge_index, post_affine=affine)
             else:
-                x, pending = conv(x, edge_index), bn
+                x, pending = conv(x, edge_index, **extra), bn
         return model_output(x)

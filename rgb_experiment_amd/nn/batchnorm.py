@@ -74,9 +74,9 @@ class _BNTrain(torch.autograd.Function):
     None; on host tensors (MLP on the CPU, gloo tests) the same arithmetic in plain torch."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, reduce, running):
+    def forward(ctx, x, weight, bias, eps, reduce, running, colsums=None):
         x = x if x.stride(-1) == 1 else x.contiguous()
-        mean, rstd, scale, shift, n = train_statistics(x, weight, bias, eps, reduce, running)
+        mean, rstd, scale, shift, n = train_statistics(x, weight, bias, eps, reduce, running, colsums)
         y = affine_cols(x, scale.contiguous(), shift.contiguous())
         ctx.save_for_backward(x, weight, mean, rstd, n)
         ctx.reduce = reduce
@@ -86,18 +86,21 @@ class _BNTrain(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight, mean, rstd, n = ctx.saved_tensors
         gx, gw, gb = train_backward(gy, x, weight, mean, rstd, n, ctx.reduce)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
-def train_statistics(x, weight, bias, eps, reduce, running):
+def train_statistics(x, weight, bias, eps, reduce, running, colsums=None):
     """Training-mode statistics of x [N, d] (row-contiguous): (mean, rstd, scale, shift, n) with
     BN(x) = x * scale + shift, running statistics updated in place (`running` = (running_mean, running_var,
-    momentum) or None). Column sums -> [reduce over ranks] -> one finalize launch."""
+    momentum) or None). Column sums -> [reduce over ranks] -> one finalize launch. `colsums` ([2, d] float64): the
+    column sums of x and x^2 when the kernel that produced x already took them (rgbx_spmm_linear_f32 out_colsums):
+    the pass over x is then skipped."""
     d = x.size(1)
     # the row count rides along as a device scalar made by a fill kernel (a host->device copy would break
     # hipGraph capture)
     count = torch.full((1,), float(x.size(0)), dtype=torch.float64, device=x.device)
-    packed = torch.cat([column_sums(x).reshape(-1), count])
+    sums = colsums if colsums is not None and tuple(colsums.shape) == (2, d) else column_sums(x)
+    packed = torch.cat([sums.reshape(-1), count])
     packed = reduce(packed)  # identity on one GPU; all-reduce over the node partition otherwise
     n = packed[2 * d:2 * d + 1]
     if x.is_cuda:
@@ -182,7 +185,8 @@ class BatchNorm1d(nn.BatchNorm1d):
         scale = self.weight * torch.rsqrt(self.running_var + self.eps)
         return scale, self.bias - self.running_mean * scale
 
-    def forward(self, x):
+    def forward(self, x, colsums=None):
+        """`colsums`: see train_statistics (training forwards only)."""
         if x.dim() != 2 or not self.affine or not self.track_running_stats:
             return super().forward(x)
         if not self.training:
@@ -192,7 +196,7 @@ class BatchNorm1d(nn.BatchNorm1d):
                 # differentiable there, so this must be too — the raw kernel below has no autograd node
                 return _AffineCols.apply(x, scale, shift)
             return affine_cols(x if x.stride(-1) == 1 else x.contiguous(), scale.contiguous(), shift.contiguous())
-        return _BNTrain.apply(x, self.weight, self.bias, self.eps, self._reduce, self.begin_training_step())
+        return _BNTrain.apply(x, self.weight, self.bias, self.eps, self._reduce, self.begin_training_step(), colsums)
 
     def begin_training_step(self):
         """What nn.BatchNorm1d does at the top of a training forward: count the batch, pick the momentum.

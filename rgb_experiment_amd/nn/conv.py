@@ -33,6 +33,7 @@ class GCNConv(nn.Module):
     Parameters: ``lin.weight`` [out, in] (glorot, no bias), ``bias`` [out] (zeros)."""
 
     folds_post_affine = True  # forward(..., post_affine=(scale, shift)): see models/_stack.py
+    emits_colsums = True      # forward(..., want_colsums=True): the output may carry its column sums (ops.COLSUMS)
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
@@ -45,32 +46,35 @@ class GCNConv(nn.Module):
         glorot_(self.lin.weight)
         nn.init.zeros_(self.bias)
 
-    def forward(self, x, edge_index, post_affine=None):
+    def forward(self, x, edge_index, post_affine=None, want_colsums=False):
         """`post_affine` = (scale, shift) of an eval-mode BatchNorm that follows this layer (no_grad only): a
         per-column affine map of a linear layer's output is the same layer with rows of W and b rescaled, so the
-        normalisation costs two [out]-sized vector ops instead of a pass over [N, out]."""
+        normalisation costs two [out]-sized vector ops instead of a pass over [N, out].
+        `want_colsums`: a training-mode BatchNorm follows; where the fused kernel runs, the output carries the column
+        sums that BatchNorm needs (attribute ops.COLSUMS), taken from the MFMA tiles instead of a pass over it."""
         weight, bias = self.lin.weight, self.bias
         if post_affine is not None:
             scale, shift = post_affine
             weight, bias = weight * scale[:, None], bias * scale + shift
-        return self._conv(x, edge_index, weight, bias)
+        return self._conv(x, edge_index, weight, bias, want_colsums)
 
-    def forward_after_bn(self, x, edge_index, bn):
+    def forward_after_bn(self, x, edge_index, bn, colsums=None, want_colsums=False):
         """self(bn(x), edge_index) for the BatchNorm1d in front of this layer. In a training forward on one GPU the
         normalised matrix is not written: the fused kernel gathers the raw rows and applies BatchNorm's affine map to
-        the aggregate (ops.bn_propagate_linear)."""
+        the aggregate (ops.bn_propagate_linear). `colsums`: the column sums of x if its producer took them."""
         graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
         if (bn.folds_into_next_layer(x) and not getattr(graph, "is_distributed", False)
                 and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x)):
-            return ops.bn_propagate_linear(x, bn, graph, "gcn", self.lin.weight, self.bias)
-        return self.forward(bn(x), edge_index)
+            return ops.bn_propagate_linear(x, bn, graph, "gcn", self.lin.weight, self.bias, colsums=colsums,
+                                           want_colsums=want_colsums)
+        return self.forward(bn(x, colsums=colsums), edge_index, want_colsums=want_colsums)
 
-    def _conv(self, x, edge_index, weight, bias):
+    def _conv(self, x, edge_index, weight, bias, want_colsums=False):
         graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
         if ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x):
             # A_hat (x W^T) + b = (A_hat x) W^T + b in one kernel: the aggregate stays in LDS and the GEMM
             # runs on the MFMA units underneath the gather (ops._PropagateLinear)
-            return ops.propagate_linear(x, graph, "gcn", weight, bias)
+            return ops.propagate_linear(x, graph, "gcn", weight, bias, want_colsums=want_colsums)
         if not x.requires_grad and self.in_channels <= self.out_channels:
             # Input layer (and every layer under no_grad): A_hat (x W^T) = (A_hat x) W^T. Aggregating first
             # costs the same forward (in <= out) and makes dW = dy^T (A_hat x) a plain weight-gradient GEMM: no
@@ -86,6 +90,7 @@ class SAGEConv(nn.Module):
     aggregate 0 [PyG SAGEConv defaults: aggr='mean', root_weight=True, lin_l bias, lin_r no bias]."""
 
     folds_post_affine = True  # forward(..., post_affine=(scale, shift)): see models/_stack.py
+    emits_colsums = True      # see GCNConv
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
@@ -93,16 +98,16 @@ class SAGEConv(nn.Module):
         self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
         self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
 
-    def forward_after_bn(self, x, edge_index, bn):
+    def forward_after_bn(self, x, edge_index, bn, colsums=None, want_colsums=False):
         """See GCNConv.forward_after_bn; the root term lin_r(bn(x)_i) gets the affine map as its rows are loaded."""
         graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
         if (bn.folds_into_next_layer(x) and not getattr(graph, "is_distributed", False)
                 and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x)):
             return ops.bn_propagate_linear(x, bn, graph, "mean", self.lin_l.weight, self.lin_l.bias,
-                                           root_weight=self.lin_r.weight)
-        return self.forward(bn(x), edge_index)
+                                           root_weight=self.lin_r.weight, colsums=colsums, want_colsums=want_colsums)
+        return self.forward(bn(x, colsums=colsums), edge_index, want_colsums=want_colsums)
 
-    def forward(self, x, edge_index, post_affine=None):
+    def forward(self, x, edge_index, post_affine=None, want_colsums=False):
         w_l, b_l, w_r = self.lin_l.weight, self.lin_l.bias, self.lin_r.weight
         if post_affine is not None:  # see GCNConv.forward
             scale, shift = post_affine
@@ -110,7 +115,7 @@ class SAGEConv(nn.Module):
         graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
         if ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x):
             # lin_l(mean_j x_j) + lin_r(x_i) in one kernel: both products accumulate in the same MFMA tile
-            return ops.propagate_linear(x, graph, "mean", w_l, b_l, root_weight=w_r)
+            return ops.propagate_linear(x, graph, "mean", w_l, b_l, root_weight=w_r, want_colsums=want_colsums)
         x_r = ops.linear(x, w_r)
         if ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x):
             return ops.propagate_linear(x, graph, "mean", w_l, b_l) + x_r
@@ -123,6 +128,7 @@ class MySAGEConv(nn.Module):
     remove_self_loops + add_self_loops, mean over N(i) ∪ {i} of x_l, then += x_r."""
 
     folds_post_affine = True  # forward(..., post_affine=(scale, shift)): see models/_stack.py
+    emits_colsums = True      # see GCNConv
 
     def __init__(self, in_channels, out_channels, add_self_loops=True):
         super().__init__()
@@ -131,33 +137,34 @@ class MySAGEConv(nn.Module):
         self.lin_l = nn.Linear(in_channels, out_channels)
         self.lin_r = nn.Linear(in_channels, out_channels)
 
-    def forward_after_bn(self, x, edge_index, bn):
+    def forward_after_bn(self, x, edge_index, bn, colsums=None, want_colsums=False):
         """See GCNConv.forward_after_bn."""
         if self.add_self_loops:
             graph = get_graph(edge_index, x.size(0), LOOPS_REMOVE_ADD)
             if (bn.folds_into_next_layer(x) and not getattr(graph, "is_distributed", False)
                     and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x)):
                 return ops.bn_propagate_linear(x, bn, graph, "mean", self.lin_l.weight,
-                                               self.lin_l.bias + self.lin_r.bias, root_weight=self.lin_r.weight)
-        return self.forward(bn(x), edge_index)
+                                               self.lin_l.bias + self.lin_r.bias, root_weight=self.lin_r.weight,
+                                               colsums=colsums, want_colsums=want_colsums)
+        return self.forward(bn(x, colsums=colsums), edge_index, want_colsums=want_colsums)
 
-    def forward(self, x, edge_index, post_affine=None):
+    def forward(self, x, edge_index, post_affine=None, want_colsums=False):
         w_l, b_l, w_r, b_r = self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, self.lin_r.bias
         if post_affine is not None and self.add_self_loops:  # see GCNConv.forward; the mean weights sum to 1
             scale, shift = post_affine
             w_l, b_l = w_l * scale[:, None], b_l * scale
             w_r, b_r = w_r * scale[:, None], b_r * scale + shift
-        out = self._conv(x, edge_index, w_l, b_l, w_r, b_r)
+        out = self._conv(x, edge_index, w_l, b_l, w_r, b_r, want_colsums)
         if post_affine is not None and not self.add_self_loops:
             out = out * post_affine[0] + post_affine[1]
         return out
 
-    def _conv(self, x, edge_index, w_l, b_l, w_r, b_r):
+    def _conv(self, x, edge_index, w_l, b_l, w_r, b_r, want_colsums=False):
         mode = LOOPS_REMOVE_ADD if self.add_self_loops else LOOPS_KEEP
         graph = get_graph(edge_index, x.size(0), mode)
         if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x):
             # mean_j(lin_l(x_j)) + lin_r(x_i) = (mean_j x_j) Wl^T + x_i Wr^T + (b_l + b_r), one kernel
-            return ops.propagate_linear(x, graph, "mean", w_l, b_l + b_r, root_weight=w_r)
+            return ops.propagate_linear(x, graph, "mean", w_l, b_l + b_r, root_weight=w_r, want_colsums=want_colsums)
         x_r = ops.linear(x, w_r, b_r)
         if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x):
             return ops.propagate_linear(x, graph, "mean", w_l, b_l) + x_r

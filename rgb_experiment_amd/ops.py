@@ -157,10 +157,12 @@ def weight_t(weight):
     return cached[1]
 
 
-def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_root=None, kind="linear", pre=None):
+def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_root=None, kind="linear", pre=None,
+                    want_colsums=False):
     """out = (rs * sum_p w_p x[col_p]) wt + bias (+ x_root wt_root) on rgbx_spmm_linear_f32; `wt` / `wt_root` are
     [K, Nout] row-major. Returns (out, z) with z the stored aggregate [N, K] if `want_z`. `pre` = (scale [K],
-    shift [K], rowsum [N]): the gathered matrix (and the root rows) stand for x * scale + shift."""
+    shift [K], rowsum [N]): the gathered matrix (and the root rows) stand for x * scale + shift. `want_colsums`:
+    returns (out, z, colsums) with colsums [2, Nout] float64 = column sums of out and out^2 from the MFMA tiles."""
     _lib.require_device(x, wt, bias, x_root, wt_root)
     ps, pt, pr = (None, None, None) if pre is None else (t.contiguous() for t in pre)
     x = x if x.stride(-1) == 1 else x.contiguous()
@@ -174,15 +176,26 @@ def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_
         ldr, wtr = xr.stride(0), wt_root.contiguous()
     b = None if bias is None else bias.contiguous()
     split, _scratch = csr.split_arg(K, x.device, hub_rows=True)
+    lib = _lib.load()
+    colsums = ws = None
+    ws_bytes = 0
+    if want_colsums:
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(lib.rgbx_spmm_linear_stats_workspace_bytes(csr.N, n_out, ctypes.byref(nbytes)),
+                   "rgbx_spmm_linear_stats_workspace_bytes")
+        ws_bytes = nbytes.value
+        ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=x.device)
+        colsums = torch.empty((2, n_out), dtype=torch.float64, device=x.device)
     with _Timed(kind):
         _lib.check(
-            _lib.load().rgbx_spmm_linear_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
-                                             _lib.ptr(x), x.stride(0), _lib.ptr(wt), _lib.ptr(xr), ldr or K,
-                                             _lib.ptr(wtr), _lib.ptr(b), _lib.ptr(out), out.stride(0), _lib.ptr(z), K,
-                                             _lib.ptr(ps), _lib.ptr(pt), _lib.ptr(pr), csr.N, K, n_out,
-                                             None if split is None else ctypes.byref(split), _lib.stream_ptr()),
+            lib.rgbx_spmm_linear_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
+                                     _lib.ptr(x), x.stride(0), _lib.ptr(wt), _lib.ptr(xr), ldr or K,
+                                     _lib.ptr(wtr), _lib.ptr(b), _lib.ptr(out), out.stride(0), _lib.ptr(z), K,
+                                     _lib.ptr(ps), _lib.ptr(pt), _lib.ptr(pr), _lib.ptr(colsums), _lib.ptr(ws), ws_bytes,
+                                     csr.N, K, n_out, None if split is None else ctypes.byref(split),
+                                     _lib.stream_ptr()),
             "rgbx_spmm_linear_f32")
-    return out, z
+    return (out, z, colsums) if want_colsums else (out, z)
 
 
 class _PropagateLinear(torch.autograd.Function):
@@ -194,21 +207,26 @@ class _PropagateLinear(torch.autograd.Function):
     root part as its additive term."""
 
     @staticmethod
-    def forward(ctx, x, graph, kind, weight, bias, need_z=True, root_weight=None, x_root=None):
+    def forward(ctx, x, graph, kind, weight, bias, need_z=True, root_weight=None, x_root=None, want_colsums=False):
         """`x_root`: the targets' own rows when they are not simply the first rows of `x` viewed as a separate
-        tensor (partitioned graph: x = [local; halo], x_root = local)."""
+        tensor (partitioned graph: x = [local; halo], x_root = local). `want_colsums`: returns (out, colsums)."""
         x = x.contiguous()
         xr = x if x_root is None else x_root.contiguous()
         w, rs = (graph.w, None) if kind == "gcn" else (None, graph.inv_deg)
-        out, z = spmm_linear_raw(graph.fwd, w, rs, x, weight_t(weight), None if bias is None else bias.detach(),
-                                 need_z, xr if root_weight is not None else None,
-                                 None if root_weight is None else weight_t(root_weight), kind=f"{kind}_linear_fwd")
+        res = spmm_linear_raw(graph.fwd, w, rs, x, weight_t(weight), None if bias is None else bias.detach(),
+                              need_z, xr if root_weight is not None else None,
+                              None if root_weight is None else weight_t(root_weight), kind=f"{kind}_linear_fwd",
+                              want_colsums=want_colsums)
+        out, z = res[0], res[1]
         ctx.save_for_backward(z, weight, root_weight, xr if root_weight is not None else None)
         ctx.graph, ctx.kind, ctx.has_bias = graph, kind, bias is not None
+        if want_colsums:
+            ctx.mark_non_differentiable(res[2])
+            return out, res[2]
         return out
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _g_colsums=None):
         z, weight, root_weight, x = ctx.saved_tensors
         g, kind = ctx.graph, ctx.kind
         gy = gy.contiguous()
@@ -225,7 +243,7 @@ class _PropagateLinear(torch.autograd.Function):
             gwr = gemm_tn(gy, x)
         if ctx.needs_input_grad[0]:
             gx = _propagate_linear_input_grad(g, kind, gy, weight, root_weight)
-        return gx, None, None, gw, gb, None, gwr, None
+        return gx, None, None, gw, gb, None, gwr, None, None
 
 
 def _propagate_linear_input_grad(g, kind, gy, weight, root_weight):
@@ -257,21 +275,26 @@ class _BNPropagateLinear(torch.autograd.Function):
     CSR, then BatchNorm's backward (column sums of g_h and g_h * xhat, apply)."""
 
     @staticmethod
-    def forward(ctx, x, bn_weight, bn_bias, graph, kind, weight, bias, root_weight, eps, reduce, running, need_z):
+    def forward(ctx, x, bn_weight, bn_bias, graph, kind, weight, bias, root_weight, eps, reduce, running, need_z,
+                colsums=None, want_colsums=False):
         from .nn import batchnorm as B
         x = x.contiguous()
-        mean, rstd, scale, shift, n = B.train_statistics(x, bn_weight, bn_bias, eps, reduce, running)
+        mean, rstd, scale, shift, n = B.train_statistics(x, bn_weight, bn_bias, eps, reduce, running, colsums)
         w, rs = (graph.w, None) if kind == "gcn" else (None, graph.inv_deg)
-        out, z = spmm_linear_raw(graph.fwd, w, rs, x, weight_t(weight), None if bias is None else bias.detach(), need_z,
-                                 x if root_weight is not None else None,
-                                 None if root_weight is None else weight_t(root_weight), kind=f"{kind}_linear_fwd",
-                                 pre=(scale, shift, graph.rowsum(kind)))
+        res = spmm_linear_raw(graph.fwd, w, rs, x, weight_t(weight), None if bias is None else bias.detach(), need_z,
+                              x if root_weight is not None else None,
+                              None if root_weight is None else weight_t(root_weight), kind=f"{kind}_linear_fwd",
+                              pre=(scale, shift, graph.rowsum(kind)), want_colsums=want_colsums)
+        out, z = res[0], res[1]
         ctx.save_for_backward(x, bn_weight, mean, rstd, n, z, weight, root_weight, scale, shift)
         ctx.graph, ctx.kind, ctx.has_bias, ctx.reduce = graph, kind, bias is not None, reduce
+        if want_colsums:
+            ctx.mark_non_differentiable(res[2])
+            return out, res[2]
         return out
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _g_colsums=None):
         from .nn import batchnorm as B
         x, bn_weight, mean, rstd, n, z, weight, root_weight, scale, shift = ctx.saved_tensors
         g, kind = ctx.graph, ctx.kind
@@ -288,24 +311,40 @@ class _BNPropagateLinear(torch.autograd.Function):
             gwr = gemm_tn(gy, x) * scale + gcol[:, None] * shift
         g_h = _propagate_linear_input_grad(g, kind, gy, weight, root_weight)
         gx, g_bnw, g_bnb = B.train_backward(g_h, x, bn_weight, mean, rstd, n, ctx.reduce)
-        return gx, g_bnw, g_bnb, None, None, gw, gb, gwr, None, None, None, None
+        return gx, g_bnw, g_bnb, None, None, gw, gb, gwr, None, None, None, None, None, None
 
 
-def bn_propagate_linear(x, bn, graph, kind, weight, bias=None, root_weight=None):
+def bn_propagate_linear(x, bn, graph, kind, weight, bias=None, root_weight=None, colsums=None, want_colsums=False):
     """conv(bn(x)) for a training-mode BatchNorm1d `bn` and a conv layer whose propagate runs on the fused
-    aggregate+transform kernel (single-GPU graphs; the caller checked fused_linear_ok and bn.folds_into_next_layer)."""
+    aggregate+transform kernel (single-GPU graphs; the caller checked fused_linear_ok and bn.folds_into_next_layer).
+    `colsums`: the [2, d] column sums of x and x^2 if the launch that produced x already took them."""
     need_z = weight.requires_grad
-    return _BNPropagateLinear.apply(x, bn.weight, bn.bias, graph, kind, weight, bias, root_weight, bn.eps, bn._reduce,
-                                    bn.begin_training_step(), need_z)
+    return _tag_colsums(_BNPropagateLinear.apply(x, bn.weight, bn.bias, graph, kind, weight, bias, root_weight, bn.eps,
+                                                 bn._reduce, bn.begin_training_step(), need_z, colsums, want_colsums),
+                        want_colsums)
 
 
-def propagate_linear(x, graph, kind, weight, bias=None, root_weight=None):
+COLSUMS = "_rgbx_colsums"  # attribute a conv output carries when the launch also produced its column sums
+
+
+def _tag_colsums(res, want_colsums):
+    """(out, colsums) of a Function -> out, with the [2, Nout] float64 column sums of out and out^2 riding on it as
+    an attribute for the BatchNorm that follows (models/_stack.ConvStack reads it right after the conv returns)."""
+    if not want_colsums:
+        return res
+    out, colsums = res
+    setattr(out, COLSUMS, colsums)
+    return out
+
+
+def propagate_linear(x, graph, kind, weight, bias=None, root_weight=None, want_colsums=False):
     if _is_dist(graph):  # resident input features of a partitioned graph (fused_linear_ok checked it)
         return graph.propagate_linear(x, kind, weight, bias, root_weight)
     # the aggregate is kept only when the weight gradient (dy^T (P x)) will be asked for; Function.forward
     # cannot see the caller's grad mode, so the decision is taken here
     need_z = torch.is_grad_enabled() and weight.requires_grad
-    return _PropagateLinear.apply(x, graph, kind, weight, bias, need_z, root_weight)
+    return _tag_colsums(_PropagateLinear.apply(x, graph, kind, weight, bias, need_z, root_weight, None, want_colsums),
+                        want_colsums)
 
 
 def appnp_raw(csr, w, h, K, alpha, kind="appnp"):

@@ -410,6 +410,35 @@ def test_training_batchnorm_folded_into_the_next_conv(dev, name, f, hid):
     assert (xg.grad - xg2.grad).abs().max().item() < tol(xr.grad)
 
 
+@pytest.mark.parametrize("name,f,hid,n", [("GCN", 64, 128, 5000), ("GCN", 32, 64, 33), ("GraphSAGE", 64, 64, 4097),
+                                          ("GraphSAGE2", 32, 160, 2500)])
+def test_fused_kernel_hands_the_batchnorm_its_column_sums(dev, name, f, hid, n):
+    """rgbx_spmm_linear_f32 out_colsums: the column sums of the layer's output and of its squares, taken from the MFMA
+    tiles (fp32 per 32-row tile, tiles added in fp64), equal fp64 sums over the stored output; a training BatchNorm
+    fed with them gives what it gives with its own statistics pass."""
+    from rgb_experiment_amd import nn as RN
+    from rgb_experiment_amd import ops
+    ei = rand_graph(n, 8 * n, 9, loops=3, dups=3).to(dev)
+    x = torch.randn(n, f, generator=torch.Generator().manual_seed(4)).to(dev)
+    torch.manual_seed(1)
+    conv = {"GCN": RN.GCNConv, "GraphSAGE": RN.MySAGEConv, "GraphSAGE2": RN.SAGEConv}[name](f, hid).to(dev)
+    with torch.no_grad():
+        for p in conv.parameters():
+            if p.dim() == 1:
+                p.uniform_(-1, 1)
+    out = conv(x, ei, want_colsums=True)
+    sums = getattr(out, ops.COLSUMS)
+    assert sums.shape == (2, hid) and sums.dtype == torch.float64
+    od = out.detach().double()
+    want = torch.stack([od.sum(0), (od * od).sum(0)])
+    assert (sums - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+    bn_a, bn_b = RN.BatchNorm1d(hid).to(dev), RN.BatchNorm1d(hid).to(dev)
+    ya, yb = bn_a(out.detach(), colsums=sums), bn_b(out.detach())
+    assert (ya - yb).abs().max().item() < 1e-5
+    assert torch.allclose(bn_a.running_var, bn_b.running_var, atol=1e-6)
+    assert getattr(conv(x, ei), ops.COLSUMS, None) is None  # only on request
+
+
 def test_spmm_epilogue_and_strides(dev):
     """a, b, y, row scale, and non-contiguous leading dimensions (column slices of wider matrices)."""
     from rgb_experiment_amd import ops
