@@ -141,10 +141,18 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __res
 // the [2, Nout] record), a third stage adds the G sums in order: fixed summation order, reproducible.
 __global__ void __launch_bounds__(256)
 tile_stats_gather_kernel(const float* __restrict__ part, int n_tiles, int width2, double* __restrict__ part2) {
+  const int G = gridDim.x;
   for (int c = threadIdx.x; c < width2; c += 256) {
-    double s = 0.0;
-    for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) s += (double)part[(int64_t)b * width2 + c];
-    part2[(int64_t)blockIdx.x * width2 + c] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains: the loads of a trip are all in flight
+    int b = blockIdx.x;
+    for (; b + 3 * G < n_tiles; b += 4 * G) {
+      s0 += (double)part[(int64_t)b * width2 + c];
+      s1 += (double)part[(int64_t)(b + G) * width2 + c];
+      s2 += (double)part[(int64_t)(b + 2 * G) * width2 + c];
+      s3 += (double)part[(int64_t)(b + 3 * G) * width2 + c];
+    }
+    for (; b < n_tiles; b += G) s0 += (double)part[(int64_t)b * width2 + c];
+    part2[(int64_t)blockIdx.x * width2 + c] = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -166,7 +174,7 @@ tile_stats_finish_kernel(const double* __restrict__ part2, int G, int width2, do
   }
 }
 
-constexpr int kStatsGather = 256;  // workgroups of the second stage
+constexpr int kStatsGather = 1024;  // workgroups of the second stage
 
 // KC = K when it is one of the common widths (the MFMA loop then unrolls fully), 0 = any supported K.
 template <int G, bool HAS_W, int KC, int NT>
