@@ -23,7 +23,8 @@ def _run(args, timeout=600):
     return proc
 
 
-@pytest.mark.parametrize("gpus,exchange,scheme", [(2, "reshard", "reshard"), (4, "2x2", "grid2x2"), (2, "halo", "halo")])
+@pytest.mark.parametrize("gpus,exchange,scheme", [(2, "reshard", "reshard"), (4, "2x2", "grid2x2"), (2, "halo", "halo"),
+                                                  (2, "auto", None)])
 def test_bench_gpus_n_launches_its_own_ranks(gpus, exchange, scheme):
     proc = _run(["--gpus", str(gpus), "--workload", "T", "--steps", "2", "--warmup", "1", "--exchange", exchange])
     assert proc.returncode == 0, proc.stderr[-3000:]
@@ -31,6 +32,9 @@ def test_bench_gpus_n_launches_its_own_ranks(gpus, exchange, scheme):
     assert len(lines) == 1, proc.stdout  # rank 0's line, once
     res = json.loads(lines[0])
     assert res["n_gpus"] == gpus and res["ranks_seen"] == gpus and res["steps"] == 2 and res["warmup"] == 1
+    if scheme is None:  # the cost model's pick (all ranks the same), with the modelled seconds on the line
+        scheme = res["scheme"]
+        assert scheme in ("halo", "reshard") and set(res["modelled_seconds_per_propagate"]) >= {"halo", "reshard"}
     assert res["scheme"] == scheme and res["scaling"] == "strong" and res["unit"] == "edges/s"
     assert sorted(r["rank"] for r in res["per_rank"]) == list(range(gpus))
     assert all(r["exchange_mb_per_step"] > 0 and r["scheme"] == scheme for r in res["per_rank"])
