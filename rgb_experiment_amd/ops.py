@@ -108,24 +108,46 @@ def _is_dist(graph):
     return getattr(graph, "is_distributed", False)
 
 
+def _pad4(x):
+    """Feature widths that are no multiple of 4 (C = 7 classes on Cora, 41 on Reddit, 47 on ogbn-products) run on
+    zero-padded rows: 16-byte aligned rows take the float4 gather path and straddle fewer 128-byte lines. Measured at
+    |V| = 2M, |E| = 60M: d = 7 1.22 ms vs 8 1.08 ms, 41 2.46 vs 44/48 2.21, 47 2.64 vs 48 2.21 (profiles/
+    r02_narrow_width_ms.txt); the pad copy is N x d floats against E' x d gathered. Returns (x or its padded copy,
+    original width); zero columns aggregate to zero columns, the caller slices them off (autograd pads the gradient)."""
+    d = x.size(1)
+    if d % 4 == 0 or not x.is_cuda:
+        return x, d
+    return torch.nn.functional.pad(x, (0, 4 - d % 4)), d
+
+
+def _pad4_vec(v, d_padded):
+    return v if v is None or v.numel() == d_padded else torch.nn.functional.pad(v, (0, d_padded - v.numel()))
+
+
 def propagate_gcn(x, graph, bias=None):
     """A_hat x (+ bias, fused into the kernel's store)."""
     if _is_dist(graph):
         out = graph.propagate(x, "gcn")
         return out if bias is None else out + bias
-    return _PropagateGCN.apply(x, graph, bias)
+    xp, d = _pad4(x)
+    out = _PropagateGCN.apply(xp, graph, _pad4_vec(bias, xp.size(1)))
+    return out if xp is x else out[:, :d]
 
 
 def propagate_mean(x, graph):
     if _is_dist(graph):
         return graph.propagate(x, "mean")
-    return _PropagateMean.apply(x, graph)
+    xp, d = _pad4(x)
+    out = _PropagateMean.apply(xp, graph)
+    return out if xp is x else out[:, :d]
 
 
 def propagate_sum(x, graph):
     if _is_dist(graph):
         return graph.propagate(x, "sum")
-    return _PropagateSum.apply(x, graph)
+    xp, d = _pad4(x)
+    out = _PropagateSum.apply(xp, graph)
+    return out if xp is x else out[:, :d]
 
 
 def fused_linear_ok(graph, in_channels, out_channels, root=False, x=None):
@@ -390,7 +412,9 @@ def appnp_propagate(h, graph, K, alpha):
         for _ in range(K):
             z = (1.0 - alpha) * graph.propagate(z, "gcn") + alpha * h
         return z
-    return _APPNP.apply(h, graph, K, alpha)
+    hp, d = _pad4(h)  # C = 7 classes: all K propagates on 8-float rows
+    out = _APPNP.apply(hp, graph, K, alpha)
+    return out if hp is h else out[:, :d]
 
 
 class _GATScores(torch.autograd.Function):
