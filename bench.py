@@ -9,7 +9,9 @@ BatchNorm and the loss. `value` counts the edges actually aggregated (7 * E' per
 of the transform-first formulation. Nothing of the epoch is skipped or cached across steps; two things are
 computed in a different FORM than the reference writes them, with the same values: the eval-mode BatchNorm is
 folded into the preceding layer's weights, and loss / accuracy / loss gradient are taken from the logits
-(cross-entropy = NLLLoss o log_softmax) so the log-probabilities are never written out.
+(cross-entropy = NLLLoss o log_softmax) so the log-probabilities are never written out — for the conv stacks inside
+the last layer's kernel, whose logits then go from the MFMA tiles into the loss (training: into the loss gradient) without a
+round trip through HBM.
 The five numbers the reference reads with .item() inside the loop body are read once, at the end of the step.
 Inputs are resident in HBM before the timed region.
 
@@ -304,12 +306,16 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
     else:
         alg = spmm_alg_bytes(N, nnz_total, d)
 
+    from rgb_experiment_amd.models._stack import masked_ce
+    fwd = {"x": x_d, "edge_index": ei_d}
+
     def evaluate(mask):
+        """An eval forward reduced to what the loop reads of it: device [nll sum, count, correct] = NLLLoss on
+        log_softmax(logits)[mask] + arg-max accuracy. The conv stacks take these inside the last layer's kernel (the
+        logits of an eval forward are read by nobody and are not written); other models from their logits."""
         model.eval()
         with torch.no_grad():
-            logits = model(x_d, ei_d)["emb"]
-        # device [nll sum, count, correct] = NLLLoss on log_softmax(logits)[mask] + arg-max accuracy, from the logits
-        return ops.masked_ce_accuracy(logits, y_d, mask)
+            return masked_ce(model, fwd, y_d, mask)[1]
 
     def step():
         """The numbers the reference reads with .item() at three points of the loop body (itexperiments.py:437,
@@ -317,7 +323,7 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
         ONE copy at the end, so the GPU queue does not drain three times per epoch."""
         model.train()
         opt.zero_grad()
-        loss = ops.masked_ce_loss(model(x_d, ei_d)["emb"], y_d, tm)  # = NLLLoss(log_softmax(.)[mask], y[mask])
+        loss = masked_ce(model, fwd, y_d, tm)[0]  # = NLLLoss(log_softmax(model(x)['emb'])[mask], y[mask])
         loss.backward()
         opt.step()
         val, tst = evaluate(vm), evaluate(sm)

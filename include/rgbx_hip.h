@@ -158,6 +158,23 @@ int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w,
  * statistics of a training-mode BatchNorm1d that follows the layer (models/gcn.py:27 then :28), taken from the
  * MFMA accumulators of the 32-row tiles (fp32 per tile, tiles added in fp64 in a fixed order) instead of a pass
  * over `out`; needs `stats_ws` of rgbx_spmm_linear_stats_workspace_bytes(N, Nout) bytes (8-byte aligned). */
+/* Optional cross-entropy epilogue of rgbx_spmm_linear_f32, for the model's LAST layer (models/gcn.py:29-31: the
+ * logits go straight into log_softmax + NLLLoss on out[mask], itexperiments.py:400,429, or into the arg-max /
+ * loss metrics of :624-626): the loss quantities come out of the 32 x Nout output tiles while they are in LDS.
+ *   stats[0] = sum over selected rows of logsumexp(out_i) - out[i, y_i], stats[1] = selected rows,
+ *   stats[2] = selected rows whose first arg-max equals y_i    (selection as rgbx_masked_ce_fwd_f32)
+ * grad_scale == NULL: statistics only, `out` is NOT written (may be NULL) — an eval forward whose logits nobody
+ * reads. grad_scale != NULL (device scalar): `out` receives grad_scale * (softmax(out_i) - onehot(y_i)) for selected
+ * rows, 0 otherwise: the gradient of grad_scale * stats[0] w.r.t. the logits (rgbx_masked_ce_bwd_f32), instead of
+ * the logits. scratch: ceil(N / 32) * 3 doubles. Needs Nout <= 128; excludes out_colsums. */
+typedef struct rgbx_ce_epilogue {
+  const int64_t* y;        /* [N] labels */
+  const uint8_t* mask;     /* [N] or NULL = all rows */
+  const float* grad_scale; /* device scalar or NULL */
+  double* stats;           /* [3] */
+  double* scratch;         /* [ceil(N / 32) * 3] */
+} rgbx_ce_epilogue_t;
+
 int rgbx_spmm_linear_supported(int64_t K, int64_t Nout, int has_root);
 int rgbx_spmm_linear_stats_workspace_bytes(int64_t N, int64_t Nout, size_t* bytes);
 int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
@@ -165,8 +182,8 @@ int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, const float*
                          const float* wt_root, const float* bias, float* out, int64_t ldo, float* z_out,
                          int64_t ldz, const float* pre_scale, const float* pre_shift, const float* pre_rowsum,
                          double* out_colsums, void* stats_ws, size_t stats_ws_bytes,
-                         int64_t N, int64_t K, int64_t Nout, const rgbx_row_split_t* split,
-                         rgbx_stream_t stream);
+                         const rgbx_ce_epilogue_t* ce, int64_t N, int64_t K, int64_t Nout,
+                         const rgbx_row_split_t* split, rgbx_stream_t stream);
 
 /* z_0 = h;  z_{k+1} = (1-alpha) * A_hat z_k + alpha * h, k = 0..K-1; result in `out`.
  * `tmp` is an [N, d] scratch (ld = ldo); h, out, tmp must not alias. K >= 0. */

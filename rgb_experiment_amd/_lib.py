@@ -25,6 +25,12 @@ class RowSplit(ctypes.Structure):
                 ("long_chunk_ptr", ctypes.c_void_p), ("partial", ctypes.c_void_p)]
 
 
+class CeEpilogue(ctypes.Structure):
+    """rgbx_ce_epilogue_t"""
+    _fields_ = [("y", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("grad_scale", ctypes.c_void_p),
+                ("stats", ctypes.c_void_p), ("scratch", ctypes.c_void_p)]
+
+
 # name -> argtypes, exactly the declarations of include/rgbx_hip.h
 SIGNATURES = {
     "rgbx_csr_workspace_bytes": [_I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
@@ -36,7 +42,7 @@ SIGNATURES = {
     "rgbx_spmm_linear_supported": [_I64, _I64, _I],
     "rgbx_spmm_linear_stats_workspace_bytes": [_I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
     "rgbx_spmm_linear_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P,
-                             ctypes.c_size_t, _I64, _I64, _I64, _P, _P],
+                             ctypes.c_size_t, _P, _I64, _I64, _I64, _P, _P],
     "rgbx_appnp_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _F, _P, _P],
     "rgbx_gat_scores_f32": [_P, _I64, _P, _P, _P, _P, _I64, _I, _I, _P],
     "rgbx_gat_scores_bwd_scratch_floats": [_I64, _I, _I, ctypes.POINTER(ctypes.c_int64)],

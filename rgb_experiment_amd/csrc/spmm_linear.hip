@@ -51,6 +51,14 @@ struct FusedArgs {
   // (the statistics of the BatchNorm that follows the layer, taken from the MFMA accumulators instead of a pass
   // over out)
   float* stats_part;
+  // optional cross-entropy epilogue (the layer is the model's last: models/gcn.py:29-31 followed by the loss of
+  // itexperiments.py:429 / the metrics of :624-626): per 32-row tile the masked NLL sum, row count and arg-max hits of
+  // softmax(out) go to ce_part[block][3]; `out` receives the loss gradient ce_scale * (softmax - onehot) when ce_scale
+  // is set, and is not written at all otherwise. Nout <= 128 only.
+  const int64_t* ce_y;
+  const uint8_t* ce_mask;
+  const float* ce_scale;
+  double* ce_part;
 };
 
 constexpr int TM = 32;       // destination rows per workgroup = one MFMA row tile; 4 waves aggregate 8 rows each
@@ -176,8 +184,96 @@ tile_stats_finish_kernel(const double* __restrict__ part2, int G, int width2, do
 
 constexpr int kStatsGather = 1024;  // workgroups of the second stage
 
+// Cross-entropy of the finished 32 x Nout tile (Nout <= 128), see FusedArgs::ce_part. The four waves park their 32 x 32
+// blocks in LDS (the aggregate tile is dead by now), then each wave takes 8 rows: a lane holds columns lane and
+// lane + 64, max / first arg-max / sum-exp go through the wave with shuffles. NLLLoss(log_softmax(z))_i = lse_i - z[i, y_i]
+// as rgbx_masked_ce_fwd_f32 computes it; the gradient as rgbx_masked_ce_bwd_f32.
+__device__ __forceinline__ void ce_epilogue(const FusedArgs& A, const f32x16& acc, float* __restrict__ ot, int row_base,
+                                            int wave, int lane) {
+  const int kr = lane >> 5, cc = lane & 31;
+  const int ldq = A.Nout + 4;
+  const int n0 = wave * 32;
+  __syncthreads();  // every wave is done reading the aggregate (or root) tile
+  if (n0 < A.Nout) {
+    const float bb = A.bias ? A.bias[n0 + cc] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2) + 4 * kr) * ldq + n0 + cc] = acc[r] + bb;
+  }
+  __syncthreads();
+  double nll = 0.0, cnt = 0.0, hit = 0.0;
+  const float sc = A.ce_scale ? A.ce_scale[0] : 0.f;
+  const bool c0 = lane < A.Nout, c1 = lane + 64 < A.Nout;
+  for (int rr = 0; rr < TM / 4; ++rr) {
+    const int rl = wave * (TM / 4) + rr;
+    const int row = row_base + rl;
+    if (row >= A.N) break;  // wave-uniform
+    int t = -1;
+    if (!A.ce_mask || A.ce_mask[row]) {
+      const int64_t ti = A.ce_y[row];
+      if (ti >= 0 && ti < A.Nout) t = (int)ti;
+    }
+    if (t < 0 && !A.ce_scale) continue;  // not selected, nothing to store: wave-uniform
+    const float v0 = c0 ? ot[rl * ldq + lane] : -INFINITY;
+    const float v1 = c1 ? ot[rl * ldq + lane + 64] : -INFINITY;
+    float best = v0;
+    int arg = c0 ? lane : INT32_MAX;
+    if (v1 > best) { best = v1; arg = lane + 64; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(best, off);
+      const int oa = __shfl_xor(arg, off);
+      if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    float se = (c0 ? expf(v0 - best) : 0.f) + (c1 ? expf(v1 - best) : 0.f);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off);
+    const float lse = best + logf(se);
+    if (t >= 0) {
+      nll += (double)(lse - ot[rl * ldq + t]);
+      cnt += 1.0;
+      hit += arg == t ? 1.0 : 0.0;
+    }
+    if (A.ce_scale) {
+      float* orow = A.out + (int64_t)row * A.ldo;
+      if (c0) orow[lane] = t >= 0 ? sc * (expf(v0 - lse) - (lane == t ? 1.f : 0.f)) : 0.f;
+      if (c1) orow[lane + 64] = t >= 0 ? sc * (expf(v1 - lse) - (lane + 64 == t ? 1.f : 0.f)) : 0.f;
+    }
+  }
+  __shared__ double cew[4][3];
+  if (lane == 0) {
+    cew[wave][0] = nll;
+    cew[wave][1] = cnt;
+    cew[wave][2] = hit;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    A.ce_part[(int64_t)blockIdx.x * 3 + k] = (cew[0][k] + cew[1][k]) + (cew[2][k] + cew[3][k]);
+  }
+}
+
+// stats[k] = sum over the tiles' records, one block, fixed order (as nll_finish_kernel of loss.hip)
+__global__ void __launch_bounds__(256)
+ce_tiles_finish_kernel(const double* __restrict__ part, int n_tiles, double* __restrict__ stats) {
+  __shared__ double sh[256];
+  for (int k = 0; k < 3; ++k) {
+    double v = 0.0;
+    for (int b = threadIdx.x; b < n_tiles; b += 256) v += part[(int64_t)b * 3 + k];
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) stats[k] = sh[0];
+    __syncthreads();
+  }
+}
+
 // KC = K when it is one of the common widths (the MFMA loop then unrolls fully), 0 = any supported K.
-template <int G, bool HAS_W, int KC, int NT>
+// CE: instantiated with the cross-entropy epilogue (NT == 1 only); a separate instantiation so that the epilogue's
+// registers are not the plain kernel's problem (as a run-time branch it cost the hot kernel a spill).
+template <int G, bool HAS_W, int KC, int NT, bool CE = false>
 __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const FusedArgs A) {
   constexpr int NG = kWave / G;
   constexpr int U = 4;
@@ -335,6 +431,10 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
       tile_times_wt<KC>(acc[tt], zt, ldz, A.wt, K, A.Nout, n0, kr, cc, pre && tt == 0 ? &bpre : nullptr);
   }
   if (!A.xr) {  // no root term (uniform): store and leave
+    if constexpr (CE) {
+      ce_epilogue(A, acc[0], zt, row_base, wave, lane);
+      return;
+    }
     if (wave >= 4) return;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -371,6 +471,11 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
     }
   }
   __syncthreads();
+  if constexpr (CE) {
+    if (wave * 32 < A.Nout) tile_times_wt<KC>(acc[0], zt, ldz, A.wtr, K, A.Nout, wave * 32, kr, cc);
+    ce_epilogue(A, acc[0], zt, row_base, wave, lane);
+    return;
+  }
   if (wave >= 4) return;
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
@@ -385,10 +490,17 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
 template <int G, int KC>
 int launch(const FusedArgs& A, hipStream_t s) {
   const int64_t blocks = cdiv(A.N, TM);
-  const size_t lds = (size_t)TM * (A.K + 4) * sizeof(float);
+  // the cross-entropy epilogue re-uses the tile as [TM][Nout + 4]
+  const size_t lds = (size_t)TM * ((A.ce_part && A.Nout > A.K ? A.Nout : A.K) + 4) * sizeof(float);
   // NT = 32-column tiles a wave keeps accumulators for (Nout <= 128: 1, <= 256: 2); 0 = any Nout, tile by tile
   const int nt = A.Nout <= 128 ? 1 : (A.Nout <= 128 * NT_ROOT ? NT_ROOT : 0);
 #define RGBX_FUSED(HW, NTV) spmm_linear_kernel<G, HW, KC, NTV><<<(int)blocks, 256, lds, s>>>(A)
+  if (A.ce_part) {  // nt == 1: the entry point checked Nout <= 128
+    if (A.w) spmm_linear_kernel<G, true, KC, 1, true><<<(int)blocks, 256, lds, s>>>(A);
+    else spmm_linear_kernel<G, false, KC, 1, true><<<(int)blocks, 256, lds, s>>>(A);
+    RGBX_CHECK_LAUNCH("spmm_linear_kernel (cross-entropy epilogue)");
+    return RGBX_OK;
+  }
   if (A.w) {
     if (nt == 0) RGBX_FUSED(true, 0);
     else if (nt == 1) RGBX_FUSED(true, 1);
@@ -417,11 +529,17 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
                                     const float* wt_root, const float* bias, float* out, int64_t ldo, float* z_out,
                                     int64_t ldz, const float* pre_scale, const float* pre_shift,
                                     const float* pre_rowsum, double* out_colsums, void* stats_ws,
-                                    size_t stats_ws_bytes, int64_t N, int64_t K, int64_t Nout,
-                                    const rgbx_row_split_t* split, rgbx_stream_t stream) {
+                                    size_t stats_ws_bytes, const rgbx_ce_epilogue_t* ce, int64_t N, int64_t K,
+                                    int64_t Nout, const rgbx_row_split_t* split, rgbx_stream_t stream) {
   if (N < 0 || K <= 0 || Nout <= 0) return fail(RGBX_E_ARG, "spmm_linear: bad size");
   if (N == 0) return RGBX_OK;
-  if (!rowptr || !col || !x || !wt || !out) return fail(RGBX_E_ARG, "spmm_linear: null pointer");
+  const bool stats_only = ce && !ce->grad_scale;  // the output matrix is then not written at all
+  if (!rowptr || !col || !x || !wt || (!out && !stats_only)) return fail(RGBX_E_ARG, "spmm_linear: null pointer");
+  if (ce) {
+    if (!ce->y || !ce->stats || !ce->scratch) return fail(RGBX_E_ARG, "spmm_linear: incomplete cross-entropy epilogue");
+    if (Nout > 128) return fail(RGBX_E_SHAPE, "spmm_linear: the cross-entropy epilogue needs Nout <= 128 (got %lld)", (long long)Nout);
+    if (out_colsums) return fail(RGBX_E_ARG, "spmm_linear: out_colsums and the cross-entropy epilogue exclude each other");
+  }
   if (N >= INT32_MAX) return fail(RGBX_E_RANGE, "spmm_linear: N exceeds int32");
   if ((x_root != nullptr) != (wt_root != nullptr))
     return fail(RGBX_E_ARG, "spmm_linear: x_root and wt_root go together");
@@ -433,7 +551,7 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
     return fail(RGBX_E_SHAPE,
                 "spmm_linear: needs K %% 4 == 0, K <= 256, Nout %% 32 == 0, Nout <= 256 with a root term (got K=%lld, "
                 "Nout=%lld)", (long long)K, (long long)Nout);
-  if (ldx < K || ldo < Nout || (z_out && ldz < K) || (x_root && ldr < K))
+  if (ldx < K || (out && ldo < Nout) || (z_out && ldz < K) || (x_root && ldr < K))
     return fail(RGBX_E_ARG, "spmm_linear: leading dimension too small");
   if (!aligned16(x) || ldx % 4 || (z_out && (!aligned16(z_out) || ldz % 4)) || (x_root && (!aligned16(x_root) || ldr % 4)))
     return fail(RGBX_E_ALIGN, "spmm_linear: x / x_root / z_out must be 16-byte aligned with ld %% 4 == 0");
@@ -464,7 +582,8 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
   }
   FusedArgs A{rowptr, col, w,  rs,  x,   wt,  x_root,   wt_root, bias,      out,    z_out,
               ldx,    ldo, ldz, ldr, long_row, zlong, threshold, n_long,    (int)N, (int)K, (int)Nout,
-              pre_scale, pre_shift, pre_rowsum, stats_part};
+              pre_scale, pre_shift, pre_rowsum, stats_part,
+              ce ? ce->y : nullptr, ce ? ce->mask : nullptr, ce ? ce->grad_scale : nullptr, ce ? ce->scratch : nullptr};
   const int lanes = (int)(K / 4);
   int rc;
   if (K == 128) rc = launch<32, 128>(A, s);
@@ -477,7 +596,12 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
   else if (lanes <= 16) rc = launch<16, 0>(A, s);
   else if (lanes <= 32) rc = launch<32, 0>(A, s);
   else rc = launch<64, 0>(A, s);
-  if (rc || !out_colsums) return rc;
+  if (rc) return rc;
+  if (ce) {
+    ce_tiles_finish_kernel<<<1, 256, 0, s>>>(ce->scratch, (int)cdiv(N, TM), ce->stats);
+    RGBX_CHECK_LAUNCH("ce_tiles_finish_kernel");
+  }
+  if (!out_colsums) return RGBX_OK;
   const int tiles = (int)cdiv(N, TM), width2 = (int)(2 * Nout);
   const int G = tiles < kStatsGather ? tiles : kStatsGather;
   tile_stats_gather_kernel<<<G, 256, 0, s>>>(stats_part, tiles, width2, stats_part2);

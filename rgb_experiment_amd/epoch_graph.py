@@ -28,27 +28,30 @@ class GraphedEpoch:
         self.train_mask, self.val_mask, self.test_mask = masks
         self.graph = None
         self.stats = None       # [3, 3] float64: rows train / val / test, columns (nll sum, count, correct)
-        self.train_out = None   # static log-probs of the training forward
-        self.eval_out = None    # static eval-mode outputs of the last (test) forward
+        self.train_out = None   # static training loss of the captured epoch
+        self.eval_out = None    # (kept for compatibility: the eval forwards no longer materialise outputs)
 
     def _epoch_body(self):
         net, y = self.net, self.y
+        from .models._stack import masked_ce
         net.train()
         self.opt.zero_grad(set_to_none=True)
-        out = net(**self.fwd)
-        # NLLLoss(log_softmax(emb)[mask], y[mask]) (reference :429) and the train accuracy (:434) in one pass
-        # over the logits; log-softmax itself is never written (models/_stack.ModelOutput)
-        loss, train_stats = ops.masked_ce_loss(out["emb"], y, self.train_mask, with_stats=True)
+        # NLLLoss(log_softmax(emb)[mask], y[mask]) (reference :429) and the train accuracy (:434) of the training
+        # forward; log-softmax is never written, and where the model's last conv can take the loss into its kernel
+        # (models/_stack.masked_ce) neither are the logits
+        loss, train_stats = masked_ce(net, self.fwd, y, self.train_mask)
         loss.backward()
         self.opt.step()
         net.eval()
         with torch.no_grad():
-            val_res = net(**self.fwd)
-            val_stats = ops.masked_ce_accuracy(val_res["emb"], y, self.val_mask)
-            # the reference runs a second, identical eval forward for the test mask (itexperiments.py:470)
-            test_res = val_res if self.share_eval_forward else net(**self.fwd)
-            test_stats = ops.masked_ce_accuracy(test_res["emb"], y, self.test_mask)
-        return out, test_res, torch.stack([train_stats, val_stats, test_stats])
+            if self.share_eval_forward:  # one eval forward, two masks: the logits are needed twice
+                res = net(**self.fwd)
+                val_stats = ops.masked_ce_accuracy(res["emb"], y, self.val_mask)
+                test_stats = ops.masked_ce_accuracy(res["emb"], y, self.test_mask)
+            else:  # the reference's two identical eval forwards (itexperiments.py:464,470)
+                val_stats = masked_ce(net, self.fwd, y, self.val_mask)[1]
+                test_stats = masked_ce(net, self.fwd, y, self.test_mask)[1]
+        return loss, None, torch.stack([train_stats, val_stats, test_stats])
 
     def capture(self, warmup=3):
         """Warm up on a side stream (allocator + lazily built CSRs), restore every piece of state the

@@ -323,13 +323,14 @@ def experiment(model_init_param: dict, *,
             return va, vl, None
         net.train()
         optimizer.zero_grad()
-        res = net(**fwd)
-        if res["emb"].is_cuda:
-            # NLLLoss on out[train_mask] (reference :429) and the train accuracy (:434) in one masked pass over
-            # the logits — the same kernels as the captured epoch, so both loops train bit-identically
-            loss, stats = ops.masked_ce_loss(res["emb"], y, train_mask, with_stats=True)
+        if device.type == "cuda":
+            # NLLLoss on out[train_mask] (reference :429) and the train accuracy (:434) of the training forward — the
+            # same kernels as the captured epoch (models/_stack.masked_ce), so both loops train bit-identically
+            from .models._stack import masked_ce
+            loss, stats = masked_ce(net, fwd, y, train_mask)
             hist["train_acc"].append((stats[2] / stats[1]).item())
         else:
+            res = net(**fwd)
             out = res["out"]
             loss = criterion(out[train_mask], y[train_mask])
             hist["train_acc"].append(compare_pred_label(out[train_mask].max(dim=1)[1], y[train_mask],

@@ -89,6 +89,16 @@ class ConvStack(nn.Module):
         self.bns = nn.ModuleList(BatchNorm1d(bn_width) for _ in range(num_layers - 1))
 
     def forward(self, x, edge_index):
+        return model_output(self._run(x, edge_index))
+
+    def masked_ce(self, x, edge_index, y, mask):
+        """(loss, stats) = NLLLoss(log_softmax(logits)[mask], y[mask]) and [nll sum, selected rows, correct] of this
+        model's logits — what the training loop and the metrics need of a forward (itexperiments.py:429,434,624-626) —
+        with the last conv taking the loss into its kernel where it can: the logits are then never written
+        (ops.propagate_linear_ce). Otherwise the same numbers from the materialised logits."""
+        return self._run(x, edge_index, ce=(y, mask))
+
+    def _run(self, x, edge_index, ce=None):
         """x = bns[i](convs[i](x)) ... convs[-1](x) (models/gcn.py:25-31). A BatchNorm is never a pass of its own
         where a neighbouring conv can absorb it: under no_grad its eval-mode affine map goes into the PRECEDING conv's
         weights; in a training forward it is handed to the FOLLOWING conv (forward_after_bn), whose fused kernel
@@ -104,6 +114,8 @@ class ConvStack(nn.Module):
             if (bn is not None and bn.training and torch.is_grad_enabled() and getattr(conv, "emits_colsums", False)
                     and hasattr(bn, "begin_training_step")):
                 extra["want_colsums"] = True
+            if i == last and ce is not None and getattr(conv, "accepts_ce", False):
+                extra["ce"] = ce  # the last conv returns (loss, stats) instead of the logits
             if pending is not None:
                 sums = getattr(x, ops.COLSUMS, None)
                 after = getattr(conv, "forward_after_bn", None)
@@ -119,4 +131,16 @@ class ConvStack(nn.Module):
                 x = conv(x, edge_index, post_affine=affine)
             else:
                 x, pending = conv(x, edge_index, **extra), bn
-        return model_output(x)
+        if ce is not None and not isinstance(x, tuple):  # a last conv without the loss epilogue (GATConv)
+            x = ops.ce_from_logits(x, ce[0], ce[1])
+        return x
+
+
+def masked_ce(model, fwd, y, mask):
+    """(loss, stats) of `model(**fwd)` on the masked rows, through model.masked_ce where the model has one (the conv
+    stacks: loss inside the last conv's kernel) and from the logits otherwise."""
+    from .. import ops
+    fn = getattr(model, "masked_ce", None)
+    if fn is not None and set(fwd) == {"x", "edge_index"} and fwd["x"].is_cuda:
+        return fn(fwd["x"], fwd["edge_index"], y, mask)
+    return ops.ce_from_logits(model(**fwd)["emb"], y, mask)

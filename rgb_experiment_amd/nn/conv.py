@@ -46,22 +46,42 @@ class GCNConv(nn.Module):
         glorot_(self.lin.weight)
         nn.init.zeros_(self.bias)
 
-    def forward(self, x, edge_index, post_affine=None, want_colsums=False):
+    accepts_ce = True         # forward(..., ce=(y, mask)): the model's last layer may take the loss into its kernel
+
+    def forward(self, x, edge_index, post_affine=None, want_colsums=False, ce=None):
         """`post_affine` = (scale, shift) of an eval-mode BatchNorm that follows this layer (no_grad only): a
         per-column affine map of a linear layer's output is the same layer with rows of W and b rescaled, so the
         normalisation costs two [out]-sized vector ops instead of a pass over [N, out].
         `want_colsums`: a training-mode BatchNorm follows; where the fused kernel runs, the output carries the column
-        sums that BatchNorm needs (attribute ops.COLSUMS), taken from the MFMA tiles instead of a pass over it."""
+        sums that BatchNorm needs (attribute ops.COLSUMS), taken from the MFMA tiles instead of a pass over it.
+        `ce` = (y, mask): this is the model's last layer and the caller wants the masked cross-entropy of its logits,
+        not the logits: returns (loss, stats [nll sum, selected rows, correct]); where the fused kernel runs the loss
+        is taken from the output tiles and the logits are never written (ops.propagate_linear_ce)."""
+        if ce is not None:
+            return self._ce(x, edge_index, ce, None, None)
         weight, bias = self.lin.weight, self.bias
         if post_affine is not None:
             scale, shift = post_affine
             weight, bias = weight * scale[:, None], bias * scale + shift
         return self._conv(x, edge_index, weight, bias, want_colsums)
 
-    def forward_after_bn(self, x, edge_index, bn, colsums=None, want_colsums=False):
+    def _ce(self, x, edge_index, ce, bn, colsums):
+        y, mask = ce
+        graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
+        hand_over = bn is not None and bn.folds_into_next_layer(x)
+        if ops.fused_ce_ok(graph, self.in_channels, self.out_channels, False, x, y) and (bn is None or hand_over):
+            return ops.propagate_linear_ce(x, graph, "gcn", self.lin.weight, self.bias, None, y, mask, bn=bn,
+                                           colsums=colsums)
+        if bn is not None:
+            x = bn(x, colsums=colsums)
+        return ops.ce_from_logits(self.forward(x, edge_index), y, mask)
+
+    def forward_after_bn(self, x, edge_index, bn, colsums=None, want_colsums=False, ce=None):
         """self(bn(x), edge_index) for the BatchNorm1d in front of this layer. In a training forward on one GPU the
         normalised matrix is not written: the fused kernel gathers the raw rows and applies BatchNorm's affine map to
         the aggregate (ops.bn_propagate_linear). `colsums`: the column sums of x if its producer took them."""
+        if ce is not None:
+            return self._ce(x, edge_index, ce, bn, colsums)
         graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
         if (bn.folds_into_next_layer(x) and not getattr(graph, "is_distributed", False)
                 and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x)):
@@ -98,8 +118,23 @@ class SAGEConv(nn.Module):
         self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
         self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
 
-    def forward_after_bn(self, x, edge_index, bn, colsums=None, want_colsums=False):
+    accepts_ce = True         # see GCNConv
+
+    def _ce(self, x, edge_index, ce, bn, colsums):
+        y, mask = ce
+        graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
+        hand_over = bn is not None and bn.folds_into_next_layer(x)
+        if ops.fused_ce_ok(graph, self.in_channels, self.out_channels, True, x, y) and (bn is None or hand_over):
+            return ops.propagate_linear_ce(x, graph, "mean", self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, y,
+                                           mask, bn=bn, colsums=colsums)
+        if bn is not None:
+            x = bn(x, colsums=colsums)
+        return ops.ce_from_logits(self.forward(x, edge_index), y, mask)
+
+    def forward_after_bn(self, x, edge_index, bn, colsums=None, want_colsums=False, ce=None):
         """See GCNConv.forward_after_bn; the root term lin_r(bn(x)_i) gets the affine map as its rows are loaded."""
+        if ce is not None:
+            return self._ce(x, edge_index, ce, bn, colsums)
         graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
         if (bn.folds_into_next_layer(x) and not getattr(graph, "is_distributed", False)
                 and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x)):
@@ -107,7 +142,9 @@ class SAGEConv(nn.Module):
                                            root_weight=self.lin_r.weight, colsums=colsums, want_colsums=want_colsums)
         return self.forward(bn(x, colsums=colsums), edge_index, want_colsums=want_colsums)
 
-    def forward(self, x, edge_index, post_affine=None, want_colsums=False):
+    def forward(self, x, edge_index, post_affine=None, want_colsums=False, ce=None):
+        if ce is not None:
+            return self._ce(x, edge_index, ce, None, None)
         w_l, b_l, w_r = self.lin_l.weight, self.lin_l.bias, self.lin_r.weight
         if post_affine is not None:  # see GCNConv.forward
             scale, shift = post_affine
@@ -137,8 +174,24 @@ class MySAGEConv(nn.Module):
         self.lin_l = nn.Linear(in_channels, out_channels)
         self.lin_r = nn.Linear(in_channels, out_channels)
 
-    def forward_after_bn(self, x, edge_index, bn, colsums=None, want_colsums=False):
+    accepts_ce = True         # see GCNConv
+
+    def _ce(self, x, edge_index, ce, bn, colsums):
+        y, mask = ce
+        if self.add_self_loops:
+            graph = get_graph(edge_index, x.size(0), LOOPS_REMOVE_ADD)
+            hand_over = bn is not None and bn.folds_into_next_layer(x)
+            if ops.fused_ce_ok(graph, self.in_channels, self.out_channels, True, x, y) and (bn is None or hand_over):
+                return ops.propagate_linear_ce(x, graph, "mean", self.lin_l.weight, self.lin_l.bias + self.lin_r.bias,
+                                               self.lin_r.weight, y, mask, bn=bn, colsums=colsums)
+        if bn is not None:
+            x = bn(x, colsums=colsums)
+        return ops.ce_from_logits(self.forward(x, edge_index), y, mask)
+
+    def forward_after_bn(self, x, edge_index, bn, colsums=None, want_colsums=False, ce=None):
         """See GCNConv.forward_after_bn."""
+        if ce is not None:
+            return self._ce(x, edge_index, ce, bn, colsums)
         if self.add_self_loops:
             graph = get_graph(edge_index, x.size(0), LOOPS_REMOVE_ADD)
             if (bn.folds_into_next_layer(x) and not getattr(graph, "is_distributed", False)
@@ -148,7 +201,9 @@ class MySAGEConv(nn.Module):
                                                colsums=colsums, want_colsums=want_colsums)
         return self.forward(bn(x, colsums=colsums), edge_index, want_colsums=want_colsums)
 
-    def forward(self, x, edge_index, post_affine=None, want_colsums=False):
+    def forward(self, x, edge_index, post_affine=None, want_colsums=False, ce=None):
+        if ce is not None:
+            return self._ce(x, edge_index, ce, None, None)
         w_l, b_l, w_r, b_r = self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, self.lin_r.bias
         if post_affine is not None and self.add_self_loops:  # see GCNConv.forward; the mean weights sum to 1
             scale, shift = post_affine

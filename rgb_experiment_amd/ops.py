@@ -180,17 +180,38 @@ def weight_t(weight):
 
 
 def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_root=None, kind="linear", pre=None,
-                    want_colsums=False):
+                    want_colsums=False, ce=None):
     """out = (rs * sum_p w_p x[col_p]) wt + bias (+ x_root wt_root) on rgbx_spmm_linear_f32; `wt` / `wt_root` are
     [K, Nout] row-major. Returns (out, z) with z the stored aggregate [N, K] if `want_z`. `pre` = (scale [K],
     shift [K], rowsum [N]): the gathered matrix (and the root rows) stand for x * scale + shift. `want_colsums`:
-    returns (out, z, colsums) with colsums [2, Nout] float64 = column sums of out and out^2 from the MFMA tiles."""
+    returns (out, z, colsums) with colsums [2, Nout] float64 = column sums of out and out^2 from the MFMA tiles.
+    `ce` = (y, mask, grad_scale): the layer is the model's last and its logits go straight into the masked
+    cross-entropy (rgbx_ce_epilogue_t): returns (out, z, stats) with stats [3] float64 = (nll sum, selected rows,
+    correct); out = the loss gradient grad_scale * (softmax - onehot) when grad_scale is a device scalar, None (nothing
+    written) when it is None."""
     _lib.require_device(x, wt, bias, x_root, wt_root)
     ps, pt, pr = (None, None, None) if pre is None else (t.contiguous() for t in pre)
     x = x if x.stride(-1) == 1 else x.contiguous()
     K, n_out = x.size(1), wt.size(1)
     wt = wt.contiguous()
-    out = torch.empty((csr.N, n_out), dtype=torch.float32, device=x.device)
+    ce_arg = ce_stats = None
+    if ce is not None:
+        y, mask, grad_scale = ce
+        _lib.require_device(y, mask, grad_scale)
+        if y.dtype != torch.int64:
+            raise RuntimeError(f"labels must be int64, got {y.dtype}")
+        if mask is not None and mask.dtype not in (torch.bool, torch.uint8):
+            raise RuntimeError(f"mask must be bool, got {mask.dtype}")
+        y = y.contiguous()
+        mask = None if mask is None else mask.contiguous()
+        ce_stats = torch.empty(3, dtype=torch.float64, device=x.device)
+        ce_scratch = torch.empty(3 * ((csr.N + 31) // 32), dtype=torch.float64, device=x.device)
+        ce_arg = _lib.CeEpilogue(_lib.ptr(y), _lib.ptr(mask), _lib.ptr(grad_scale), _lib.ptr(ce_stats),
+                                 _lib.ptr(ce_scratch))
+    if ce is not None and ce[2] is None:
+        out = None  # statistics only: the logits are never written
+    else:
+        out = torch.empty((csr.N, n_out), dtype=torch.float32, device=x.device)
     z = torch.empty((csr.N, K), dtype=torch.float32, device=x.device) if want_z else None
     xr = ldr = wtr = None
     if wt_root is not None:
@@ -212,11 +233,14 @@ def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_
         _lib.check(
             lib.rgbx_spmm_linear_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
                                      _lib.ptr(x), x.stride(0), _lib.ptr(wt), _lib.ptr(xr), ldr or K,
-                                     _lib.ptr(wtr), _lib.ptr(b), _lib.ptr(out), out.stride(0), _lib.ptr(z), K,
-                                     _lib.ptr(ps), _lib.ptr(pt), _lib.ptr(pr), _lib.ptr(colsums), _lib.ptr(ws), ws_bytes,
+                                     _lib.ptr(wtr), _lib.ptr(b), _lib.ptr(out), n_out if out is None else out.stride(0),
+                                     _lib.ptr(z), K, _lib.ptr(ps), _lib.ptr(pt), _lib.ptr(pr), _lib.ptr(colsums),
+                                     _lib.ptr(ws), ws_bytes, None if ce_arg is None else ctypes.byref(ce_arg),
                                      csr.N, K, n_out, None if split is None else ctypes.byref(split),
                                      _lib.stream_ptr()),
             "rgbx_spmm_linear_f32")
+    if ce is not None:
+        return out, z, ce_stats
     return (out, z, colsums) if want_colsums else (out, z)
 
 
@@ -334,6 +358,120 @@ class _BNPropagateLinear(torch.autograd.Function):
         g_h = _propagate_linear_input_grad(g, kind, gy, weight, root_weight)
         gx, g_bnw, g_bnb = B.train_backward(g_h, x, bn_weight, mean, rstd, n, ctx.reduce)
         return gx, g_bnw, g_bnb, None, None, gw, gb, gwr, None, None, None, None, None, None
+
+
+_SCALE_CACHE = {}
+
+
+def mask_scale(y, mask, C):
+    """Device scalar 1 / (number of rows the masked cross-entropy selects): rows with mask set (all if None) and a
+    label in [0, C). A mask is fixed for a run, so the count is taken once per (labels, mask) pair — the fused loss
+    epilogue needs the mean's divisor BEFORE the launch that produces the logits."""
+    key = (y.data_ptr(), y._version, y.numel(), None if mask is None else (mask.data_ptr(), mask._version), int(C))
+    hit = _SCALE_CACHE.get(key)
+    if hit is None:
+        sel = (y >= 0) & (y < C)
+        if mask is not None:
+            sel = sel & mask.bool()
+        hit = ((1.0 / sel.sum().double()).float().reshape(1), y, mask)  # the tensors stay alive with their addresses
+        _SCALE_CACHE[key] = hit
+        while len(_SCALE_CACHE) > 32:
+            _SCALE_CACHE.pop(next(iter(_SCALE_CACHE)))
+    return hit[0]
+
+
+def ce_from_logits(logits, y, mask):
+    """(loss, stats) of the masked cross-entropy taken from materialised logits: the unfused route of the *_ce
+    entry points. loss = NLLLoss(log_softmax(logits)[mask], y[mask]); stats = [nll sum, selected rows, correct]."""
+    if torch.is_grad_enabled() and logits.requires_grad:
+        return masked_ce_loss(logits, y, mask, with_stats=True)
+    stats = masked_ce_accuracy(logits, y, mask)
+    return (stats[0] / stats[1]).float(), stats
+
+
+def fused_ce_ok(graph, in_channels, out_channels, root, x, y):
+    """The model's last conv can take the loss into its kernel: fused aggregate+transform applies, at most 128
+    classes, single-GPU graph, device labels."""
+    return (not _is_dist(graph) and out_channels <= 128 and y is not None and y.is_cuda and y.dtype == torch.int64
+            and fused_linear_ok(graph, in_channels, out_channels, root=root, x=x))
+
+
+class _PropagateLinearCE(torch.autograd.Function):
+    """loss = masked cross-entropy of ((P x') W^T + b (+ x' Wr^T)) with x' = BN(x) (training BatchNorm handed over as
+    in _BNPropagateLinear) or x itself — the model's last conv with the loss taken inside the kernel
+    (rgbx_ce_epilogue_t): the logits are never written. A forward that prepares a backward stores the loss gradient
+    w.r.t. the logits instead (scaled by 1 / selected rows); the backward is then _PropagateLinear's / _BNPropagateLinear's
+    with that matrix as dy and the incoming scalar folded into the small operands (W, Wr, dW, db)."""
+
+    @staticmethod
+    def forward(ctx, x, graph, kind, weight, bias, root_weight, y, mask, want_grad, bn_weight, bn_bias, bn_args):
+        from .nn import batchnorm as B
+        x = x.contiguous()
+        pre = None
+        if bn_weight is not None:
+            eps, reduce, running, colsums = bn_args
+            mean, rstd, scale, shift, n = B.train_statistics(x, bn_weight, bn_bias, eps, reduce, running, colsums)
+            pre = (scale, shift, graph.rowsum(kind))
+        w, rs = (graph.w, None) if kind == "gcn" else (None, graph.inv_deg)
+        grad_scale = mask_scale(y, mask, weight.size(0)) if want_grad else None
+        dlogits, z, stats = spmm_linear_raw(
+            graph.fwd, w, rs, x, weight_t(weight), None if bias is None else bias.detach(),
+            want_grad and weight.requires_grad, x if root_weight is not None else None,
+            None if root_weight is None else weight_t(root_weight), kind=f"{kind}_linear_fwd", pre=pre,
+            ce=(y, mask, grad_scale))
+        ctx.graph, ctx.kind, ctx.has_bias, ctx.has_bn = graph, kind, bias is not None, bn_weight is not None
+        if want_grad:
+            if ctx.has_bn:
+                ctx.save_for_backward(dlogits, z, weight, root_weight, x, bn_weight, mean, rstd, n, scale, shift)
+                ctx.reduce = bn_args[1]
+            else:
+                ctx.save_for_backward(dlogits, z, weight, root_weight, x if root_weight is not None else None)
+        ctx.mark_non_differentiable(stats)
+        return (stats[0] / stats[1]).float(), stats
+
+    @staticmethod
+    def backward(ctx, g, _g_stats):
+        from .nn import batchnorm as B
+        saved = ctx.saved_tensors
+        if ctx.has_bn:
+            gy, z, weight, root_weight, x, bn_weight, mean, rstd, n, scale, shift = saved
+        else:
+            gy, z, weight, root_weight, x = saved
+        graph, kind = ctx.graph, ctx.kind
+        g = g.reshape(()).float()
+        gw = gb = gwr = gx = g_bnw = g_bnb = None
+        gcol = None
+        if ctx.needs_input_grad[3]:
+            gw, gcol = gemm_tn(gy, z, colsum=True)
+            gw = gw * g
+        if ctx.has_bias and ctx.needs_input_grad[4]:
+            gb = (gcol if gcol is not None else gy.sum(0)) * g
+        if root_weight is not None and ctx.needs_input_grad[5]:
+            if ctx.has_bn:  # dWr = dy^T BN(x) = (dy^T x) diag(s) + colsum(dy) t^T
+                gcol = gcol if gcol is not None else gy.sum(0)
+                gwr = (gemm_tn(gy, x) * scale + gcol[:, None] * shift) * g
+            else:
+                gwr = gemm_tn(gy, x) * g
+        if ctx.has_bn or ctx.needs_input_grad[0]:
+            g_h = _propagate_linear_input_grad(graph, kind, gy, weight.detach() * g,
+                                               None if root_weight is None else root_weight.detach() * g)
+            if ctx.has_bn:
+                gx, g_bnw, g_bnb = B.train_backward(g_h, x, bn_weight, mean, rstd, n, ctx.reduce)
+            else:
+                gx = g_h
+        return gx, None, None, gw, gb, gwr, None, None, None, g_bnw, g_bnb, None
+
+
+def propagate_linear_ce(x, graph, kind, weight, bias, root_weight, y, mask, bn=None, colsums=None):
+    """(loss, stats) = masked cross-entropy of the last conv's logits, taken inside rgbx_spmm_linear_f32 (the
+    caller checked fused_ce_ok, and bn.folds_into_next_layer when a training BatchNorm `bn` is handed over)."""
+    want_grad = torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad or
+                                             (bn is not None and bn.weight.requires_grad))
+    if bn is not None:
+        bn_args = (bn.eps, bn._reduce, bn.begin_training_step(), colsums)
+        return _PropagateLinearCE.apply(x, graph, kind, weight, bias, root_weight, y, mask, want_grad, bn.weight, bn.bias,
+                                        bn_args)
+    return _PropagateLinearCE.apply(x, graph, kind, weight, bias, root_weight, y, mask, want_grad, None, None, None)
 
 
 def bn_propagate_linear(x, bn, graph, kind, weight, bias=None, root_weight=None, colsums=None, want_colsums=False):

@@ -61,18 +61,24 @@ def test_shape_and_alignment_errors_of_the_fused_and_dense_entry_points():
     assert not ok(130, 128, 0) and not ok(260, 128, 0) and not ok(128, 100, 0) and not ok(64, 512, 1) and not ok(0, 32, 0)
     call = lambda K, n_out, x=p, ldx=None, root=None: lib.rgbx_spmm_linear_f32(
         p, p, None, None, x, K if ldx is None else ldx, p, root, K, root, None, p, n_out, None, K, None, None, None, None,
-        None, 0, 10, K, n_out, None, None)
+        None, 0, None, 10, K, n_out, None, None)
     assert call(5, 32) == -5 and b"K" in lib.rgbx_last_error_string()          # RGBX_E_SHAPE
     assert call(128, 100) == -5
     assert call(64, 512, root=p) == -5                                           # root term: Nout <= 256
     assert call(128, 128, x=p + 4) == -3                                         # RGBX_E_ALIGN
     assert call(128, 128, ldx=64) == -1                                          # leading dimension < K
     assert lib.rgbx_spmm_linear_f32(p, p, None, None, p, 128, p, p, 128, None, None, p, 128, None, 128, None, None, None,
-                                    None, None, 0, 10, 128, 128, None, None) == -1   # x_root without wt_root
+                                    None, None, 0, None, 10, 128, 128, None, None) == -1   # x_root without wt_root
     assert lib.rgbx_spmm_linear_f32(p, p, None, None, p, 128, p, None, 128, None, None, p, 128, None, 128, p, None, None,
-                                    None, None, 0, 10, 128, 128, None, None) == -1   # pre_scale without shift / rowsum
+                                    None, None, 0, None, 10, 128, 128, None, None) == -1   # pre_scale without shift / rowsum
     assert lib.rgbx_spmm_linear_f32(p, p, None, None, p, 128, p, None, 128, None, None, p, 128, None, 128, None, None, None,
-                                    p, p, 16, 10, 128, 128, None, None) == -4        # statistics workspace too small
+                                    p, p, 16, None, 10, 128, 128, None, None) == -4        # statistics workspace too small
+    ce = _lib.CeEpilogue(p, None, None, p, p)
+    assert lib.rgbx_spmm_linear_f32(p, p, None, None, p, 128, p, None, 128, None, None, None, 256, None, 128, None, None,
+                                    None, None, None, 0, ctypes.byref(ce), 10, 128, 256, None, None) == -5  # Nout > 128
+    assert lib.rgbx_spmm_linear_f32(p, p, None, None, p, 128, p, None, 128, None, None, None, 128, None, 128, None, None,
+                                    None, None, None, 0, ctypes.byref(_lib.CeEpilogue(None, None, None, p, p)), 10, 128,
+                                    128, None, None) == -1                                   # epilogue without labels
     # weight-gradient GEMM: workspace too small / leading dimension
     n = ctypes.c_size_t(0)
     assert lib.rgbx_gemm_tn_workspace_bytes(1000, 128, 128, ctypes.byref(n)) == 0 and n.value >= 128 * 128 * 4

@@ -439,6 +439,64 @@ def test_fused_kernel_hands_the_batchnorm_its_column_sums(dev, name, f, hid, n):
     assert getattr(conv(x, ei), ops.COLSUMS, None) is None  # only on request
 
 
+@pytest.mark.parametrize("name,C", [("GCN", 128), ("GCN", 32), ("GraphSAGE", 64), ("GraphSAGE2", 96), ("GraphSAGE2", 128)])
+def test_last_layer_takes_the_cross_entropy_into_its_kernel(dev, name, C):
+    """model.masked_ce: the last conv's fused kernel turns its output tiles into the masked NLL sum / count / arg-max hits
+    (and, for a training forward, writes the loss gradient instead of the logits). Loss, statistics and every
+    parameter gradient equal the route over materialised logits and the oracle under autograd; the no_grad form writes
+    no logits at all and gives the same statistics."""
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd import ops
+    n, f, hid = 2100, 48, 64
+    ei = rand_graph(n, 16000, 21, loops=5, dups=6)
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(n, f, generator=gen)
+    y = torch.randint(0, C, (n,), generator=gen)
+    y[17] = -1  # an unlabelled node inside the mask: skipped by the loss kernels (experiment() refuses such masks)
+    mask = torch.rand(n, generator=gen) < 0.6
+    torch.manual_seed(4)
+    model = {"GCN": M.GCN, "GraphSAGE": M.GraphSAGE, "GraphSAGE2": M.GraphSAGE2}[name](
+        num_layers=2, hidden_unit=hid, input_dim=f, output_dim=C, dropout_rate=0.5)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.5, 0.5) if "bns" not in k or "bias" in k else p.uniform_(0.5, 1.5)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    # oracle: training forward under autograd
+    params = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd0.items()}
+    fwd_o = {"GCN": O.gcn_forward, "GraphSAGE": O.graphsage_forward, "GraphSAGE2": O.graphsage2_forward}[name]
+    out_o = fwd_o(params, x, ei, 2, training=True)["out"]
+    sel = mask & (y >= 0)
+    loss_o = torch.nn.functional.nll_loss(out_o[sel], y[sel])
+    loss_o.backward()
+    model.to(dev).train()
+    xd, eid, yd, md = x.to(dev), ei.to(dev), y.to(dev), mask.to(dev)
+    loss_f, stats_f = model.masked_ce(xd, eid, yd, md)
+    assert type(loss_f.grad_fn).__name__ == "_PropagateLinearCEBackward"  # the loss really came out of the kernel
+    loss_f.backward()
+    grads_f = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    assert abs(loss_f.item() - loss_o.item()) < 1e-5
+    assert int(stats_f[1].item()) == int(sel.sum()) and abs(stats_f[0].item() / stats_f[1].item() - loss_o.item()) < 1e-5
+    assert int(stats_f[2].item()) == int((out_o[sel].argmax(1) == y[sel]).sum())
+    for k, g in grads_f.items():
+        want = params[k].grad
+        assert (g.cpu() - want).abs().max().item() < 2e-4 * max(1.0, want.abs().max().item()), k
+    # the route over materialised logits (same model state)
+    model.load_state_dict(sd0)
+    model.zero_grad()
+    loss_u, stats_u = ops.masked_ce_loss(model(xd, eid)["emb"], yd, md, with_stats=True)
+    loss_u.backward()
+    assert abs(loss_u.item() - loss_f.item()) < 1e-6 and torch.equal(stats_u[1:], stats_f[1:])
+    for k, p in model.named_parameters():
+        assert (p.grad - grads_f[k]).abs().max().item() < 1e-5 * max(1.0, grads_f[k].abs().max().item()), k
+    # eval / no_grad: statistics only, against the logits route
+    model.eval()
+    with torch.no_grad():
+        _, stats_e = model.masked_ce(xd, eid, yd, md)
+        want_e = ops.masked_ce_accuracy(model(xd, eid)["emb"], yd, md)
+    assert torch.equal(stats_e[1:], want_e[1:]) and abs(stats_e[0].item() - want_e[0].item()) < 1e-6 * want_e[0].item()
+
+
 def test_spmm_epilogue_and_strides(dev):
     """a, b, y, row scale, and non-contiguous leading dimensions (column slices of wider matrices)."""
     from rgb_experiment_amd import ops
