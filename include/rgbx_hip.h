@@ -166,13 +166,13 @@ int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w,
  * grad_scale == NULL: statistics only, `out` is NOT written (may be NULL) — an eval forward whose logits nobody
  * reads. grad_scale != NULL (device scalar): `out` receives grad_scale * (softmax(out_i) - onehot(y_i)) for selected
  * rows, 0 otherwise: the gradient of grad_scale * stats[0] w.r.t. the logits (rgbx_masked_ce_bwd_f32), instead of
- * the logits. scratch: ceil(N / 32) * 3 doubles. Needs Nout <= 128; excludes out_colsums. */
+ * the logits. scratch: (ceil(N / 32) + 64) * 3 doubles. Needs Nout <= 128; excludes out_colsums. */
 typedef struct rgbx_ce_epilogue {
   const int64_t* y;        /* [N] labels */
   const uint8_t* mask;     /* [N] or NULL = all rows */
   const float* grad_scale; /* device scalar or NULL */
   double* stats;           /* [3] */
-  double* scratch;         /* [ceil(N / 32) * 3] */
+  double* scratch;         /* [(ceil(N / 32) + 64) * 3] */
 } rgbx_ce_epilogue_t;
 
 int rgbx_spmm_linear_supported(int64_t K, int64_t Nout, int has_root);

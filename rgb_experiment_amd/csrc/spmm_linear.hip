@@ -252,21 +252,41 @@ __device__ __forceinline__ void ce_epilogue(const FusedArgs& A, const f32x16& ac
   }
 }
 
-// stats[k] = sum over the tiles' records, one block, fixed order (as nll_finish_kernel of loss.hip)
+// stats[k] = sum over the tiles' records in a fixed order, two stages: kCeGather workgroups add a contiguous slice of
+// the records each (thread-strided, then a block tree), one workgroup adds their sums.
+constexpr int kCeGather = 64;
+
+__device__ __forceinline__ double block_tree_sum(double v, double* sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
 __global__ void __launch_bounds__(256)
-ce_tiles_finish_kernel(const double* __restrict__ part, int n_tiles, double* __restrict__ stats) {
+ce_tiles_gather_kernel(const double* __restrict__ part, int n_tiles, double* __restrict__ part2) {
   __shared__ double sh[256];
+  const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const int b0 = blockIdx.x * per, b1 = min(n_tiles, b0 + per);
   for (int k = 0; k < 3; ++k) {
     double v = 0.0;
-    for (int b = threadIdx.x; b < n_tiles; b += 256) v += part[(int64_t)b * 3 + k];
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) stats[k] = sh[0];
-    __syncthreads();
+    for (int b = b0 + threadIdx.x; b < b1; b += 256) v += part[(int64_t)b * 3 + k];
+    v = block_tree_sum(v, sh);
+    if (threadIdx.x == 0) part2[blockIdx.x * 3 + k] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+ce_tiles_finish_kernel(const double* __restrict__ part2, int n, double* __restrict__ stats) {
+  __shared__ double sh[256];
+  for (int k = 0; k < 3; ++k) {
+    const double v = block_tree_sum((int)threadIdx.x < n ? part2[threadIdx.x * 3 + k] : 0.0, sh);
+    if (threadIdx.x == 0) stats[k] = v;
   }
 }
 
@@ -598,7 +618,11 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
   else rc = launch<64, 0>(A, s);
   if (rc) return rc;
   if (ce) {
-    ce_tiles_finish_kernel<<<1, 256, 0, s>>>(ce->scratch, (int)cdiv(N, TM), ce->stats);
+    const int tiles = (int)cdiv(N, TM);
+    double* part2 = ce->scratch + (size_t)tiles * 3;  // [kCeGather, 3] behind the tile records
+    ce_tiles_gather_kernel<<<kCeGather, 256, 0, s>>>(ce->scratch, tiles, part2);
+    RGBX_CHECK_LAUNCH("ce_tiles_gather_kernel");
+    ce_tiles_finish_kernel<<<1, 256, 0, s>>>(part2, kCeGather, ce->stats);
     RGBX_CHECK_LAUNCH("ce_tiles_finish_kernel");
   }
   if (!out_colsums) return RGBX_OK;

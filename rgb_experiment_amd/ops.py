@@ -205,7 +205,7 @@ def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_
         y = y.contiguous()
         mask = None if mask is None else mask.contiguous()
         ce_stats = torch.empty(3, dtype=torch.float64, device=x.device)
-        ce_scratch = torch.empty(3 * ((csr.N + 31) // 32), dtype=torch.float64, device=x.device)
+        ce_scratch = torch.empty(3 * ((csr.N + 31) // 32 + 64), dtype=torch.float64, device=x.device)
         ce_arg = _lib.CeEpilogue(_lib.ptr(y), _lib.ptr(mask), _lib.ptr(grad_scale), _lib.ptr(ce_stats),
                                  _lib.ptr(ce_scratch))
     if ce is not None and ce[2] is None:
