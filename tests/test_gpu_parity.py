@@ -1192,15 +1192,21 @@ def test_correct_and_smooth(dev, autoscale):
     assert (got.max(dim=1)[1] == want.max(dim=1)[1]).float().mean().item() > 0.999
 
 
-@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack", "gin"])
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack", "gin", "gcn_wide", "graphsage_wide"])
 def test_hip_graph_epoch_equals_eager_loop(dev, name):
-    """The captured-and-replayed epoch reproduces the eager loop: same losses, same trained weights."""
+    """The captured-and-replayed epoch reproduces the eager loop: same losses, same trained weights. The *_wide cases
+    (32 classes, hidden 32) put every layer on the fused kernel: BatchNorm handed to the next conv, its statistics
+    from the MFMA tiles, the loss inside the last conv's kernel — all inside the captured graph."""
     import rgb_experiment_amd as R
-    n, f, c = 1500, 40, 5
+    wide = name.endswith("_wide")
+    name = name.replace("_wide", "")
+    n, f, c = 1500, (32 if wide else 40), (32 if wide else 5)
     gen = torch.Generator().manual_seed(11)
     ei = rand_graph(n, 9000, 13, loops=4, dups=4)
     data = R.Data(x=torch.randn(n, f, generator=gen), y=torch.randint(0, c, (n,), generator=gen), edge_index=ei)
     params = R.InitialParameters.defaults_for(name)
+    if wide:
+        params["hidden_unit"] = 32
     params["dropout_rate"] = 0.0 if name == "gin" else params["dropout_rate"]
     runs = []
     for graphed in (False, True):
