@@ -56,6 +56,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 KERNEL_OF_KIND = {
     "gcn_linear_fwd": "spmm_linear_kernel", "mean_linear_fwd": "spmm_linear_kernel",
     "gcn_linear_bwd": "spmm_linear_kernel", "mean_linear_bwd": "spmm_linear_kernel",
+    "sum_linear_fwd": "spmm_linear_kernel", "sum_linear_bwd": "spmm_linear_kernel",
     "gcn_fwd": "spmm_csr_kernel", "gcn_bwd": "spmm_csr_kernel", "mean_fwd": "spmm_csr_kernel",
     "sum_fwd": "spmm_csr_kernel", "sum_bwd": "spmm_csr_kernel",
     "mean_bwd": "spmm_csr_kernel", "appnp_fwd": "spmm_csr_kernel (K launches)",

@@ -17,6 +17,7 @@
  *                         norm * x_j (models/dagnn.py:34-36,46,57-59; models/graphsage.py:58).
  *   rgbx_appnp_f32        APPNP.forward's K-step recurrence (models/appnp_stack.py:29),
  *                         restated in-repo by models/pta.py:79-84.
+ *   rgbx_dagnn_gate_*     Prop.forward's sigmoid-gated mix of the K+1 hops (models/dagnn.py:49-55) and its backward.
  *   rgbx_gat_*            GATConv.forward/message + segment softmax (models/gat.py:28,30) [PyG].
  *   rgbx_gemm_tn_f32      dW = dY^T X of the nn.Linear / conv.lin layers under loss.backward()
  *                         (itexperiments.py:439; layers at models/gcn.py:18-21, appnp_stack.py:19-20).
@@ -190,6 +191,29 @@ int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, const float*
 int rgbx_appnp_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* h,
                    int64_t ldh, float* out, float* tmp, int64_t ldo, int64_t N, int64_t d, int K,
                    float alpha, const rgbx_row_split_t* split, rgbx_stream_t stream);
+
+/* ---- DAGNN: adaptive mix of the K+1 hops (reference models/dagnn.py:49-55) ---------------- */
+
+/* Hop 0 is the layer input h0 [N, d] (ld0); hops 1..K are K matrices [N, d] (ldh) `hop_stride` floats apart,
+ * written there by K calls of rgbx_spmm_csr_f32.  s [d] / b [1] = weight / bias of Prop.proj = Linear(C, 1),
+ * both on the device.   retain[i,k] = sigmoid(<hop_k[i,:], s> + b);   out[i,:] = sum_k retain[i,k] * hop_k[i,:]
+ * (the stack / proj / sigmoid / matmul of dagnn.py:51-54 in one pass over the hops).  d % 4 == 0, d <= 256,
+ * 16-byte aligned rows. */
+int rgbx_dagnn_gate_fwd_f32(const float* h0, int64_t ld0, const float* hops, int64_t hop_stride, int64_t ldh,
+                            const float* s, const float* b, float* out, int64_t ldo, int64_t N, int64_t d, int K,
+                            rgbx_stream_t stream);
+
+/* Backward of the mix for gout = dL/dout [N, d]: per hop the DIRECT part of that hop's gradient,
+ *   direct_k[i,:] = retain[i,k] * gout[i,:] + c[i,k] * s,   c[i,k] = <gout_i, hop_k[i]> retain (1 - retain),
+ * written to d0 (hop 0) and dk + (k-1) * d_stride (hops 1..K) — the `y` operands of the Horner chain
+ * G_k = A_hat^T G_{k+1} + direct_k run with rgbx_spmm_csr_f32 on the transposed CSR — and the gradients of the
+ * projection, g_s[d] = sum_ik c[i,k] hop_k[i,:], g_b[1] = sum_ik c[i,k] (g_b may be NULL).  `ws`: scratch of
+ * rgbx_dagnn_gate_bwd_workspace_bytes(d) bytes (per-block partial sums, added in block order). */
+int rgbx_dagnn_gate_bwd_workspace_bytes(int64_t d, size_t* bytes);
+int rgbx_dagnn_gate_bwd_f32(const float* h0, int64_t ld0, const float* hops, int64_t hop_stride, int64_t ldh,
+                            const float* s, const float* b, const float* gout, int64_t ldg, float* d0,
+                            int64_t ldd0, float* dk, int64_t d_stride, int64_t ldd, float* g_s, float* g_b,
+                            void* ws, size_t ws_bytes, int64_t N, int64_t d, int K, rgbx_stream_t stream);
 
 /* ---- GAT: fused score + edge-softmax + aggregate ------------------------------------------ */
 

@@ -44,6 +44,10 @@ SIGNATURES = {
     "rgbx_spmm_linear_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P,
                              ctypes.c_size_t, _P, _I64, _I64, _I64, _P, _P],
     "rgbx_appnp_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _F, _P, _P],
+    "rgbx_dagnn_gate_fwd_f32": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _P],
+    "rgbx_dagnn_gate_bwd_workspace_bytes": [_I64, ctypes.POINTER(ctypes.c_size_t)],
+    "rgbx_dagnn_gate_bwd_f32": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I64, _P, _P, _P,
+                                ctypes.c_size_t, _I64, _I64, _I, _P],
     "rgbx_gat_scores_f32": [_P, _I64, _P, _P, _P, _P, _I64, _I, _I, _P],
     "rgbx_gat_scores_bwd_scratch_floats": [_I64, _I, _I, ctypes.POINTER(ctypes.c_int64)],
     "rgbx_gat_scores_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I, _I, _P],

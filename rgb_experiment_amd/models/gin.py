@@ -3,12 +3,12 @@ train_eps=True), then lin1 -> ReLU -> dropout -> lin2."""
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..nn import BatchNorm1d, GINConv
+from ..nn import BatchNorm1d, GINConv, Linear
 from ._stack import model_output
 
 
 def _block(fan_in, width):
-    return nn.Sequential(nn.Linear(fan_in, width), nn.ReLU(), nn.Linear(width, width), nn.ReLU(),
+    return nn.Sequential(Linear(fan_in, width), nn.ReLU(), Linear(width, width), nn.ReLU(),
                          BatchNorm1d(width))
 
 
@@ -19,8 +19,8 @@ class GIN(nn.Module):
         self.conv1 = GINConv(_block(input_dim, hidden_unit), train_eps=True)
         self.convs = nn.ModuleList(GINConv(_block(hidden_unit, hidden_unit), train_eps=True)
                                    for _ in range(num_layers - 1))
-        self.lin1 = nn.Linear(hidden_unit, hidden_unit)
-        self.lin2 = nn.Linear(hidden_unit, output_dim)
+        self.lin1 = Linear(hidden_unit, hidden_unit)
+        self.lin2 = Linear(hidden_unit, output_dim)
 
     def forward(self, x, edge_index):
         x = self.conv1(x, edge_index)

@@ -3,7 +3,7 @@ The reference builds one more BatchNorm1d (over output_dim) than it applies (mlp
 so that state_dict keys match."""
 import torch.nn as nn
 
-from ..nn import BatchNorm1d
+from ..nn import BatchNorm1d, Linear
 from ._stack import model_output
 
 
@@ -13,7 +13,7 @@ class MLP(nn.Module):
         self.num_layers = num_layers
         self.dropout_rate = dropout_rate
         widths = [input_dim] + [hidden_unit] * (num_layers - 1) + [output_dim]
-        self.lins = nn.ModuleList(nn.Linear(widths[i], widths[i + 1]) for i in range(num_layers))
+        self.lins = nn.ModuleList(Linear(widths[i], widths[i + 1]) for i in range(num_layers))
         self.bns = nn.ModuleList([BatchNorm1d(hidden_unit) for _ in range(num_layers - 1)] +
                                  [BatchNorm1d(output_dim)])
 

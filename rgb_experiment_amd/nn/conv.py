@@ -336,4 +336,15 @@ class GINConv(nn.Module):
 
     def forward(self, x, edge_index):
         graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
+        first = self.nn[0] if isinstance(self.nn, nn.Sequential) and len(self.nn) else None
+        if (isinstance(first, nn.Linear) and x.is_cuda
+                and ops.fused_linear_ok(graph, first.in_features, first.out_features, root=True, x=x)):
+            # nn's first Linear applied to (sum_j x_j + (1 + eps) x_i) = (sum_j x_j) W^T + x_i ((1 + eps) W)^T + b:
+            # aggregation, the root term and that Linear in one launch (rgbx_spmm_linear_f32), no [N, in] sum
+            # written, no scale / add passes; eps gets its gradient through the root operand
+            h = ops.propagate_linear(x, graph, "sum", first.weight, first.bias,
+                                     root_weight=(1 + self.eps) * first.weight)
+            for layer in list(self.nn)[1:]:
+                h = layer(h)
+            return h
         return self.nn(ops.propagate_sum(x, graph) + (1 + self.eps) * x)

@@ -245,7 +245,7 @@ def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_
 
 
 class _PropagateLinear(torch.autograd.Function):
-    """y = (P x) W^T + b (+ x Wr^T) with P = A_hat ('gcn') or the mean operator ('mean'), in one launch
+    """y = (P x) W^T + b (+ x Wr^T) with P = A_hat ('gcn'), the mean operator ('mean') or the plain edge sum ('sum'), in one launch
     (rgbx_spmm_linear_f32). Backward: dW = dy^T (P x) on the split-K MFMA kernel (P x was stored by the
     forward when a gradient is needed), db = column sums from the same pass, dWr = dy^T x, and — only if x
     needs a gradient — dx = P^T (dy W) + dy Wr = (P^T dy) W + dy Wr: the SAME fused kernel on the transposed CSR
@@ -258,7 +258,7 @@ class _PropagateLinear(torch.autograd.Function):
         tensor (partitioned graph: x = [local; halo], x_root = local). `want_colsums`: returns (out, colsums)."""
         x = x.contiguous()
         xr = x if x_root is None else x_root.contiguous()
-        w, rs = (graph.w, None) if kind == "gcn" else (None, graph.inv_deg)
+        w, rs = {"gcn": (graph.w, None), "mean": (None, graph.inv_deg), "sum": (None, None)}[kind]
         res = spmm_linear_raw(graph.fwd, w, rs, x, weight_t(weight), None if bias is None else bias.detach(),
                               need_z, xr if root_weight is not None else None,
                               None if root_weight is None else weight_t(root_weight), kind=f"{kind}_linear_fwd",
@@ -296,7 +296,7 @@ def _propagate_linear_input_grad(g, kind, gy, weight, root_weight):
     """dx = P^T (dy W) + dy Wr = (P^T dy) W + dy Wr: the fused kernel on the transposed CSR (W as stored is already
     the [K, Nout] operand) when in == out, else GEMMs and the transposed SpMM with the root part as its additive
     term."""
-    wt = g.w_t if kind == "gcn" else g.w_mean_t
+    wt = {"gcn": lambda: g.w_t, "mean": lambda: g.w_mean_t, "sum": lambda: None}[kind]()
     n_out, n_in = weight.shape
     if n_out <= n_in and _lib.load().rgbx_spmm_linear_supported(n_out, n_in, int(root_weight is not None)):
         gx, _ = spmm_linear_raw(g.bwd, wt, None, gy, weight.detach().contiguous(), None, False,
@@ -553,6 +553,81 @@ def appnp_propagate(h, graph, K, alpha):
     hp, d = _pad4(h)  # C = 7 classes: all K propagates on 8-float rows
     out = _APPNP.apply(hp, graph, K, alpha)
     return out if hp is h else out[:, :d]
+
+
+class _DAGNNProp(torch.autograd.Function):
+    """Prop.forward of DAGNN (reference models/dagnn.py:41-55): K gcn-normalised propagates, then
+    out = sum_k sigmoid(<hop_k, s> + b) * hop_k over the K+1 hops. The hops are written by the SpMM into one
+    [K, N, d] buffer and read once by rgbx_dagnn_gate_fwd_f32 — no stack, no [N, K+1, d] projection input.
+    Backward: one pass (rgbx_dagnn_gate_bwd_f32) writes every hop's direct gradient and reduces g_s / g_b; the
+    chain through the propagates is the Horner form G_k = A_hat^T G_{k+1} + direct_k, K transposed SpMMs that add
+    their `y` operand in the store."""
+
+    @staticmethod
+    def forward(ctx, x, graph, K, s, b):
+        lib = _lib.load()
+        N, d = x.shape
+        x = x.contiguous()
+        hops = torch.empty((K, N, d), dtype=torch.float32, device=x.device)
+        src = x
+        for k in range(K):
+            spmm_raw(graph.fwd, graph.w, None, src, out=hops[k], kind="gcn_fwd")
+            src = hops[k]
+        out = torch.empty_like(x)
+        sv = s.detach().reshape(-1).contiguous()
+        bv = None if b is None else b.detach().reshape(-1).contiguous()
+        with _Timed("dagnn_gate_fwd"):
+            _lib.check(lib.rgbx_dagnn_gate_fwd_f32(_lib.ptr(x), x.stride(0), _lib.ptr(hops), N * d, d, _lib.ptr(sv),
+                                                   _lib.ptr(bv), _lib.ptr(out), out.stride(0), N, d, K,
+                                                   _lib.stream_ptr()), "rgbx_dagnn_gate_fwd_f32")
+        ctx.graph, ctx.K, ctx.has_b = graph, K, b is not None
+        ctx.save_for_backward(x, hops, sv, bv)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        x, hops, sv, bv = ctx.saved_tensors
+        g, K = ctx.graph, ctx.K
+        N, d = x.shape
+        gout = gout.contiguous()
+        d0 = torch.empty_like(x)
+        dk = torch.empty((K, N, d), dtype=torch.float32, device=x.device)
+        g_s = torch.empty(d, dtype=torch.float32, device=x.device)
+        g_b = torch.empty(1, dtype=torch.float32, device=x.device) if ctx.has_b else None
+        need = ctypes.c_size_t(0)
+        _lib.check(lib.rgbx_dagnn_gate_bwd_workspace_bytes(d, ctypes.byref(need)), "rgbx_dagnn_gate_bwd_workspace_bytes")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
+        with _Timed("dagnn_gate_bwd"):
+            _lib.check(lib.rgbx_dagnn_gate_bwd_f32(_lib.ptr(x), x.stride(0), _lib.ptr(hops), N * d, d, _lib.ptr(sv),
+                                                   _lib.ptr(bv), _lib.ptr(gout), gout.stride(0), _lib.ptr(d0),
+                                                   d0.stride(0), _lib.ptr(dk), N * d, d, _lib.ptr(g_s), _lib.ptr(g_b),
+                                                   _lib.ptr(ws), need.value, N, d, K, _lib.stream_ptr()),
+                       "rgbx_dagnn_gate_bwd_f32")
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # G_K = direct_K; G_k = A_hat^T G_{k+1} + direct_k, each written over direct_k
+            cur = dk[K - 1] if K else d0
+            for k in range(K - 1, -1, -1):
+                dst = dk[k - 1] if k else d0
+                spmm_raw(g.bwd, g.w_t, None, cur, y=dst, a=1.0, b=1.0, out=dst, kind="gcn_bwd")
+                cur = dst
+            gx = d0
+        return gx, None, None, g_s, g_b
+
+
+def dagnn_prop(x, graph, K, proj_weight, proj_bias=None):
+    """DAGNN's propagate-and-mix (reference models/dagnn.py:41-55) on the HIP path; proj_weight [1, C], proj_bias [1].
+    Returns None when this shape is left to the caller's torch formulation (a partitioned graph, C > 256)."""
+    if _is_dist(graph) or x.size(1) > 256:
+        return None
+    _lib.require_device(x, proj_weight, proj_bias)
+    xp, d = _pad4(x)
+    s = proj_weight.reshape(-1)
+    if xp is not x:
+        s = torch.nn.functional.pad(s, (0, xp.size(1) - d))  # zero columns: no part in the scores or the mix
+    out = _DAGNNProp.apply(xp, graph, int(K), s, proj_bias)
+    return out if xp is x else out[:, :d]
 
 
 class _GATScores(torch.autograd.Function):

@@ -1175,6 +1175,49 @@ def test_next_row_models(dev):
     assert sgc.conv1._cached_x is not None  # cached=True keeps A_hat^K x after the first call
 
 
+@pytest.mark.parametrize("d,K", [(4, 1), (7, 3), (40, 2), (64, 10), (128, 4), (256, 2), (12, 0)])
+def test_dagnn_prop_forward_backward(dev, d, K):
+    """rgbx_dagnn_gate_* + the Horner chain of transposed SpMMs against the reference's own formulation
+    (models/dagnn.py:41-55: stack of the K+1 hops, proj, sigmoid, matmul) under CPU autograd — output and the
+    gradients of the input, of proj.weight and of proj.bias; hub rows included."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import LOOPS_ADD_REMAINING, get_graph
+    n = 900
+    gen = torch.Generator().manual_seed(d * 31 + K)
+    hub = torch.stack([torch.randint(0, n, (5000,), generator=gen), torch.full((5000,), 3)])  # one hub target
+    ei = torch.cat([rand_graph(n, 7000, 21 + d, loops=5, dups=5), hub], dim=1)
+    x = torch.randn(n, d, generator=gen)
+    pw = torch.randn(1, d, generator=gen) * 0.5
+    pb = torch.randn(1, generator=gen)
+    gout = torch.randn(n, d, generator=gen)
+    # oracle
+    xr, wr, br = x.clone().requires_grad_(), pw.clone().requires_grad_(), pb.clone().requires_grad_()
+    e2, norm = O.gcn_norm(ei, None, n)
+    preds, h = [xr], xr
+    for _ in range(K):
+        h = O.propagate(e2, h, n, norm)
+        preds.append(h)
+    pps = torch.stack(preds, dim=1)
+    retain = torch.sigmoid((pps @ wr.t() + br).squeeze(-1))
+    want = torch.matmul(retain.unsqueeze(1), pps).squeeze(1)
+    want.backward(gout)
+    # HIP
+    xd, wd, bd = x.to(dev).requires_grad_(), pw.to(dev).requires_grad_(), pb.to(dev).requires_grad_()
+    graph = get_graph(ei.to(dev), n, LOOPS_ADD_REMAINING)
+    got = ops.dagnn_prop(xd, graph, K, wd, bd)
+    assert type(got.grad_fn).__name__ in ("_DAGNNPropBackward", "SliceBackward0")
+    got.backward(gout.to(dev))
+    tol = lambda ref: 2e-5 * max(1.0, ref.abs().max().item())
+    assert (got.detach().cpu() - want.detach()).abs().max().item() < tol(want)
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() < tol(xr.grad)
+    assert (wd.grad.cpu() - wr.grad).abs().max().item() < 5 * tol(wr.grad)
+    assert (bd.grad.cpu() - br.grad).abs().max().item() < 5 * tol(br.grad)
+    # twice the same bits (block partials are added in a fixed order)
+    xd2, wd2, bd2 = x.to(dev).requires_grad_(), pw.to(dev).requires_grad_(), pb.to(dev).requires_grad_()
+    ops.dagnn_prop(xd2, graph, K, wd2, bd2).backward(gout.to(dev))
+    assert torch.equal(wd2.grad, wd.grad) and torch.equal(bd2.grad, bd.grad) and torch.equal(xd2.grad, xd.grad)
+
+
 @pytest.mark.parametrize("autoscale", [True, False])
 def test_correct_and_smooth(dev, autoscale):
     from rgb_experiment_amd.nn import CorrectAndSmooth
