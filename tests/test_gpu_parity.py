@@ -1235,7 +1235,8 @@ def test_correct_and_smooth(dev, autoscale):
     assert (got.max(dim=1)[1] == want.max(dim=1)[1]).float().mean().item() > 0.999
 
 
-@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack", "gin", "gcn_wide", "graphsage_wide"])
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack", "gin", "gcn_wide", "graphsage_wide",
+                                  "dagnn", "sgc"])
 def test_hip_graph_epoch_equals_eager_loop(dev, name):
     """The captured-and-replayed epoch reproduces the eager loop: same losses, same trained weights. The *_wide cases
     (32 classes, hidden 32) put every layer on the fused kernel: BatchNorm handed to the next conv, its statistics
@@ -1250,7 +1251,8 @@ def test_hip_graph_epoch_equals_eager_loop(dev, name):
     params = R.InitialParameters.defaults_for(name)
     if wide:
         params["hidden_unit"] = 32
-    params["dropout_rate"] = 0.0 if name == "gin" else params["dropout_rate"]
+    if name == "gin":
+        params["dropout_rate"] = 0.0
     runs = []
     for graphed in (False, True):
         res = R.experiment(params, specify_data=True, data=data, model_name=name, learning_rate=0.01, epoch=8,
