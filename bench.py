@@ -57,6 +57,10 @@ KERNEL_OF_KIND = {
     "gcn_linear_fwd": "spmm_linear_kernel", "mean_linear_fwd": "spmm_linear_kernel",
     "gcn_linear_bwd": "spmm_linear_kernel", "mean_linear_bwd": "spmm_linear_kernel",
     "sum_linear_fwd": "spmm_linear_kernel", "sum_linear_bwd": "spmm_linear_kernel",
+    # replicate scheme (dist.ReplicaGraph): first layer on all N rows, second on the [n_local x N] rectangular CSR
+    "replica_gcn_linear_fwd": "spmm_linear_kernel", "tail_gcn_linear_fwd": "spmm_linear_kernel",
+    "tail_gcn_linear_bwd": "spmm_linear_kernel", "tail_gcn_bwd": "spmm_csr_kernel", "replica_fwd": "spmm_csr_kernel",
+    "tail_fwd": "spmm_csr_kernel", "tail_bwd": "spmm_csr_kernel",
     "gcn_fwd": "spmm_csr_kernel", "gcn_bwd": "spmm_csr_kernel", "mean_fwd": "spmm_csr_kernel",
     "sum_fwd": "spmm_csr_kernel", "sum_bwd": "spmm_csr_kernel",
     "mean_bwd": "spmm_csr_kernel", "appnp_fwd": "spmm_csr_kernel (K launches)",
@@ -446,10 +450,17 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def dist_alg_bytes(dgraph, kind, d, N, n_loc, world, K=10):
+def dist_alg_bytes(dgraph, kind, d, N, n_loc, world, K=10, replica=None):
     """Algorithmic bytes PER LAUNCH of every aggregation kind this rank can record (SURVEY 8d formula on the rows /
     edges / width that launch covers)."""
     out = {}
+    rst = replica._st.get(kind) if replica is not None else None
+    if rst is not None:
+        full = spmm_alg_bytes(N, rst["nnz_total"], d)
+        tail = spmm_alg_bytes(n_loc, rst["nnz_tail"], d)
+        tail_t = spmm_alg_bytes(N, rst["nnz_tail"], d)  # transposed: a row per source
+        out.update({"replica_gcn_linear_fwd": full, "replica_fwd": full, "tail_gcn_linear_fwd": tail, "tail_fwd": tail,
+                    "tail_gcn_linear_bwd": tail_t, "tail_gcn_bwd": tail_t, "tail_bwd": tail_t})
     st = dgraph._kinds.get(kind)
     if st is not None:
         f, b = st["plan"].fwd, st["plan"].bwd
@@ -508,7 +519,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="L")
     ap.add_argument("--model", choices=sorted(MODELS), default="gcn",
                     help="gcn is the BASELINE.json headline; the others are its configs 3-5")
-    ap.add_argument("--exchange", default="auto", help="auto | halo | reshard | RxC (row groups x column slices)")
+    ap.add_argument("--exchange", default="auto",
+                    help="auto | halo | reshard | RxC (row groups x column slices) | replicate (first conv layer on all "
+                         "rows by every rank, no activation exchange)")
     ap.add_argument("--pieces", type=int, default=None, help="pieces of the outbound exchange (default 4)")
     ap.add_argument("--no-interleave", action="store_true", help="val and test forward one after the other")
     ap.add_argument("--emulate-rank", type=int, default=0, metavar="P",
@@ -584,8 +597,13 @@ def main():
         n_loc = runner.hi - runner.lo
         step()  # builds every structure this model uses (outside the timing) ...
         runner.release_edge_list()  # ... after which the global edge list leaves HBM
-        scheme = dgraph.scheme(d) if kind != "gat" else "halo"
-        if kind == "gat":
+        replica = runner.replicas[loops_mode] if runner.replicated else None
+        scheme = "replicate" if replica is not None else (dgraph.scheme(d) if kind != "gat" else "halo")
+        if replica is not None:
+            nnz_total = replica._st[kind]["nnz_total"]
+            alg_by_kind = dist_alg_bytes(dgraph, kind, d, N, n_loc, parts, K=kwargs.get("K", 10), replica=replica)
+            alg = spmm_alg_bytes(n_loc, nnz_total / parts, d)  # an ideal 1/P share of one propagate
+        elif kind == "gat":
             plan = dgraph._kinds["gat"]["plan"]
             nnz_total = plan.nnz_total
             alg = gat_alg_bytes(n_loc, plan.nnz_local, d)
@@ -660,6 +678,9 @@ def main():
         "config": {"workload": wl_name, "nodes": N, "edges_in": E, "edges_aggregated_per_propagate": nnz_total,
                    "width": d, "propagates_per_step": n_prop,
                    "parallelism": "single GPU" if parts == 1 else
+                   ("1-D node partition x%d, replicate scheme: first conv layer on all rows by every rank, second on "
+                    "its own targets, no activation exchange (RCCL all-reduces of loss / gradients only)" % parts)
+                   if scheme == "replicate" else
                    f"1-D node partition x{parts}, RCCL all-to-all ({scheme} exchange; boundary rows of the static "
                    "input features resident in HBM)"},
         "epochs_per_s": args.steps / elapsed,
@@ -688,7 +709,9 @@ def main():
         result["scheme"] = scheme
         result["per_rank"] = per_rank
         result["exchange_mb_per_rank_per_step"] = max(r["exchange_mb_per_step"] for r in per_rank)
-        result["modelled_seconds_per_propagate"] = dgraph._choice.get(("costs", d))
+        result["modelled_seconds_per_propagate"] = dgraph._choice.get(("costs", d)) or next(
+            (v for k, v in dgraph._choice.items() if isinstance(k, tuple) and k[0] == "costs"), None)
+        result["modelled_seconds_per_epoch_first_two_layers"] = getattr(runner, "replicate_costs", None)
         result["link_gbs_measured"] = getattr(comm_obj, "link_gbs", None)  # 16 MB-per-peer all-to-all at start-up
     if emu:
         result["n_gpus"] = 1

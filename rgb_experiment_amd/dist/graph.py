@@ -414,6 +414,7 @@ class DistGraph:
         if self.exchange == "auto":
             out["halo"] = max(halo_rows * d * 4 / max(P - 1, 1) / link, line_s(e_loc, d)) + line_s(e_rem, d)
         nnz = (e_loc + e_rem) * P
+        self._choice["nnz"] = nnz
         from .plan import grid_shapes
         for R, C in grid_shapes(P):
             if C == 1 or d % C:
@@ -423,6 +424,22 @@ class DistGraph:
             out[name] = per_link + line_s(nnz / R, d // C) + per_link / self.pieces
         self._choice[key] = out
         return out
+
+    def replicate_costs(self, d_in, d_h):
+        """Modelled seconds per EPOCH (training forward + backward, two eval forwards) of a model's first two conv
+        layers (input width d_in, hidden width d_h), identical on every rank: {"exchange": first layer on the resident
+        features at 1/P + the second layer's four exchanged propagates under the best scheme, "replicate": first layer
+        on all N rows by every rank + the second layer's rectangular aggregation without any exchange (ReplicaGraph)}.
+        The dense work on the hidden matrix (BatchNorm, weight gradients: ~10 passes per epoch at ~5 TB/s) is
+        counted at N rows vs N/P."""
+        import math
+        P, N = self.comm.world, self.N_global
+        best = min(self.costs(d_h).values())
+        nnz = self._choice["nnz"]
+        line_s = lambda edges, width: edges * math.ceil(4 * width / 128) * 128 / self.GATHER_BPS
+        dense = N * d_h * 4 * 10 / 5e12
+        return {"exchange": 3 * line_s(nnz / P, d_in) + 4 * best + dense / P,
+                "replicate": 3 * line_s(nnz, d_in) + 4 * line_s(nnz / P, d_h) + dense}
 
     def shape(self, d):
         """(R, C) of the grid scheme a propagate of width d uses, or None for the halo scheme."""
@@ -489,12 +506,145 @@ class DistGraph:
         return self.backend.gat(st["rect"], x_ext, att_src, att_dst, half.n_local, H, C, slope)
 
 
+class _TailGraph:
+    """What ops._PropagateLinear / spmm_raw read of the rectangular graph [this rank's targets x all N sources]."""
+    event_prefix = "tail_"
+
+    def __init__(self, fwd, bwd):
+        (self.fwd, self.w), (self.bwd, self.w_t) = fwd, bwd
+        self.inv_deg = None
+
+
+class _FullGraph:
+    event_prefix = "replica_"
+
+    def __init__(self, fwd):
+        self.fwd, self.w = fwd
+        self.inv_deg = None
+
+
+class _ReplicaPropagate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rgraph, kind, full):
+        ctx.rgraph, ctx.kind, ctx.full = rgraph, kind, full
+        st = rgraph._build(kind)
+        if full:
+            return rgraph.dg.backend.run(st["full"], x, kind="replica_fwd")
+        return rgraph.dg.backend.run(st["tail_fwd"], x.contiguous(), kind="tail_fwd")
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.full:
+            raise RuntimeError("ReplicaGraph: the replicated first layer aggregates the static input features, which "
+                               "take no gradient")
+        st = ctx.rgraph._build(ctx.kind)
+        return ctx.rgraph.dg.backend.run(st["tail_bwd"], gy.contiguous(), kind="tail_bwd"), None, None, None
+
+
+class ReplicaGraph:
+    """Exchange-free scheme for the first two conv layers ("replicate"): every rank holds the whole static feature
+    matrix and computes the FIRST conv layer (and the BatchNorm behind it) for ALL N nodes — the single-GPU work,
+    redundantly — and the SECOND conv layer only for its own targets, over a rectangular CSR [n_local x N] whose
+    sources are those replicated rows. No activation row ever crosses a link; the only collectives left are the
+    small all-reduces (loss, parameter gradients). Backward: the rectangular transposed SpMM gives every rank the
+    PARTIAL gradient of the replicated hidden rows that stems from its own targets; BatchNorm's and the first
+    layer's backward are linear in that gradient, so the partial parameter gradients add up to the true ones in the
+    gradient all-reduce that runs anyway (DistBatchNorm1d._reducer).
+
+    Costs (1 - 1/P) of the first layer's full-graph aggregation extra per forward and saves every exchange of the
+    second layer: the scheme of choice where the exchange is dearer than that — 2 GPUs (one xGMI link per pair), or
+    any world size when the measured link rate is low (DistGraph.replicate_pays). Registered for the conv layers
+    under (token, N_global rows); which of the two stages a call is follows from its input: the pinned feature
+    matrix itself -> first layer, any other N-row tensor -> second layer (so the first conv must aggregate the
+    features BEFORE transforming them: in_channels <= out_channels, which DistRunner checks)."""
+
+    is_distributed = True
+
+    def __init__(self, dgraph):
+        self.dg = dgraph
+        self.comm, self.backend = dgraph.comm, dgraph.backend
+        self._st = {}
+        self._x = None
+        self.lo = dgraph.bounds[dgraph.comm.rank]
+        self.hi = self.lo + dgraph.n_local
+
+    def pin_resident(self, x_full):
+        self._x = (x_full.data_ptr(), tuple(x_full.shape), x_full._version)
+
+    def is_resident(self, x):
+        return (self._x is not None and not x.requires_grad
+                and (x.data_ptr(), tuple(x.shape), x._version) == self._x)
+
+    def _build(self, kind):
+        st = self._st.get(kind)
+        if st is None:
+            dg = self.dg
+            src, dst = rewrite_global(dg._edges(), dg.N_global, dg.loops_mode)
+            from .plan import edge_weights
+            w = edge_weights(src, dst, dg.N_global, kind)
+            mine = (dst >= self.lo) & (dst < self.hi)
+            wm = None if w is None else w[mine]
+            be = dg.backend
+            st = {"full": be.prepare(dst, src, dg.N_global, w),
+                  "tail_fwd": be.prepare(dst[mine] - self.lo, src[mine], dg.n_local, wm),
+                  "tail_bwd": be.prepare(src[mine], dst[mine] - self.lo, dg.N_global, wm),
+                  "nnz_total": int(src.numel()), "nnz_tail": int(mine.sum())}
+            self._st[kind] = st
+        return st
+
+    def release_edges(self):
+        pass  # the edge list lives in the DistGraph this object was made from
+
+    def target_rows(self, x):
+        """Rows of a conv input that are targets of its aggregation: all N for the first stage, mine for the second."""
+        return x if self.is_resident(x) or x.size(0) != self.dg.N_global else x[self.lo:self.hi]
+
+    def propagate(self, x, kind):
+        return _ReplicaPropagate.apply(x, self, kind, self.is_resident(x))
+
+    def fused_resident_ok(self, x, in_channels, out_channels, root):
+        from .. import _lib
+        if not (x.is_cuda and isinstance(self.backend, HipAggregator)) or x.size(0) != self.dg.N_global:
+            return False
+        # the tail adds its root term outside the kernel (the targets' own rows are a row range of the sources)
+        return bool(_lib.load().rgbx_spmm_linear_supported(in_channels, out_channels,
+                                                           int(root and self.is_resident(x))))
+
+    def propagate_linear(self, x, kind, weight, bias, root_weight):
+        from .. import ops
+        st = self._build(kind)
+        need_z = torch.is_grad_enabled() and weight.requires_grad
+        if self.is_resident(x):  # first layer, all N rows: the single-GPU launch
+            return ops._PropagateLinear.apply(x, _FullGraph(st["full"]), "gcn", weight, bias, need_z, root_weight,
+                                              None, False)
+        out = ops._PropagateLinear.apply(x, _TailGraph(st["tail_fwd"], st["tail_bwd"]), "gcn", weight, bias, need_z,
+                                         None, None, False)
+        if root_weight is not None:
+            out = out + ops.linear(x[self.lo:self.hi], root_weight)
+        return out
+
+    def appnp(self, h, K, alpha):
+        raise RuntimeError("ReplicaGraph serves the conv-stack models only")
+
+
 def install(token_edge_index, n_local, edge_index, num_nodes, comm=None, backend=None, exchange="auto", pieces=None):
     """Register DistGraphs so that conv layers called with (x_local, token_edge_index) aggregate over
     the partitioned global graph. Returns {loops_mode: DistGraph}."""
     graphs = {}
     for mode in (_graph.LOOPS_KEEP, _graph.LOOPS_ADD_REMAINING, _graph.LOOPS_REMOVE_ADD):
-        g = DistGraph(edge_index, num_nodes, mode, comm, backend, exchange, pieces)
+        g = DistGraph(edge_index, num_nodes, mode, comm, backend, "auto" if exchange == "replicate" else exchange,
+                      pieces)
         _graph.register_graph(token_edge_index, n_local, mode, g)
         graphs[mode] = g
     return graphs
+
+
+def install_replicas(token_edge_index, graphs, num_nodes):
+    """Register a ReplicaGraph per rewrite mode for inputs of N_global rows (the replicate scheme). Returns
+    {loops_mode: ReplicaGraph}."""
+    out = {}
+    for mode, g in graphs.items():
+        r = ReplicaGraph(g)
+        _graph.register_graph(token_edge_index, num_nodes, mode, r)
+        out[mode] = r
+    return out

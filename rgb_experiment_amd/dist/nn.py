@@ -12,9 +12,19 @@ class DistBatchNorm1d(BatchNorm1d):
     def __init__(self, num_features, comm, **kw):
         super().__init__(num_features, **kw)
         self.comm = comm
+        self.replicated_rows = None  # row count of inputs EVERY rank holds in full (dist.ReplicaGraph): no reduction
 
     def _reduce(self, packed):
         return self.comm.all_reduce_sum_(packed)
+
+    def _reducer(self, x):
+        """An input with `replicated_rows` rows is the same matrix on every rank (the replicated first layer of
+        dist.ReplicaGraph): its local column sums ARE the global ones, and in backward every rank normalises its own
+        partial gradient — BatchNorm's backward is linear in the incoming gradient, so the partial results add up to
+        the true gradient in the parameter all-reduce."""
+        if self.replicated_rows is not None and x.size(0) == self.replicated_rows:
+            return lambda packed: packed
+        return self._reduce
 
     @classmethod
     def convert(cls, module, comm):

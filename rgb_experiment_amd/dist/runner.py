@@ -5,7 +5,7 @@ import torch
 import torch.nn.functional as F
 
 from .comm import Comm
-from .graph import install
+from .graph import install, install_replicas
 from .nn import DistBatchNorm1d
 from .plan import partition_bounds
 
@@ -34,10 +34,24 @@ class DistRunner:
         self._streams = None
         if device.type == "cuda":  # one timed all-to-all: the exchange cost model then uses this fabric's link rate
             self.link_gbs = self.comm.measure_link_gbs(device)
-        if resident_features:
+        # "replicate": every rank computes the first conv layer for all N nodes from the whole (static) feature
+        # matrix and the second one for its own targets, with no activation exchange at all (graph.ReplicaGraph);
+        # chosen by the cost model where the exchange would cost more than the redundant first layer
+        self.replicated = self._choose_replicate(model, exchange, world)
+        self.x_in = self.x  # what the model is called with
+        if self.replicated:
+            self.x_in = x.to(device).contiguous()
+            self.replicas = install_replicas(self.token, self.graphs, N)
+            for r in self.replicas.values():
+                r.pin_resident(self.x_in)
+        elif resident_features:
             for g in self.graphs.values():
                 g.pin_resident(self.x)  # boundary rows of the static features are fetched once and kept
         self.model = DistBatchNorm1d.convert(model.to(device), self.comm)
+        if self.replicated:
+            for m in self.model.modules():
+                if isinstance(m, DistBatchNorm1d):
+                    m.replicated_rows = N
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
         for part, m in zip(("train", "val", "test"), self.masks):
             sel = self.y[m]
@@ -45,6 +59,28 @@ class DistRunner:
                 raise RuntimeError(f"{part} mask selects nodes with a negative label (unlabelled)")
         cnt = torch.tensor([float(m.sum()) for m in self.masks], dtype=torch.float64, device=device)
         self.mask_counts = self.comm.all_reduce_sum_(cnt).tolist()
+
+    _REPLICABLE = {"GCNConv": 1, "SAGEConv": 0, "MySAGEConv": 2}  # conv class -> the loops mode its graph is keyed by
+
+    def _choose_replicate(self, model, exchange, world):
+        """True when the first two conv layers run under the replicate scheme: asked for (exchange="replicate") or,
+        under "auto", modelled cheaper per epoch than the best exchange scheme (DistGraph.replicate_costs — the same
+        inputs on every rank). Needs a conv stack whose first layer aggregates the input features before
+        transforming them (in_channels <= out_channels), so that a layer's stage follows from its input."""
+        convs = getattr(model, "convs", None)
+        ok = (world > 1 and convs is not None and len(convs) >= 2
+              and all(type(c).__name__ in self._REPLICABLE and getattr(c, "add_self_loops", True) for c in convs[:2])
+              and convs[0].in_channels <= convs[0].out_channels)
+        if exchange == "replicate":
+            if not ok:
+                raise RuntimeError("exchange='replicate' needs world > 1 and a GCN / GraphSAGE / GraphSAGE2 conv stack "
+                                   "whose first layer has in_channels <= out_channels")
+            return True
+        if exchange != "auto" or not ok:
+            return False
+        g = self.graphs[self._REPLICABLE[type(convs[0]).__name__]]
+        self.replicate_costs = g.replicate_costs(convs[0].in_channels, convs[0].out_channels)
+        return self.replicate_costs["replicate"] < self.replicate_costs["exchange"]
 
     # ---- statistics used by bench.py --------------------------------------------------------
     def plan(self, loops_mode, kind):
@@ -77,7 +113,7 @@ class DistRunner:
         (float64) instead of the all-reduced Python float — epoch() reduces everything once."""
         self.model.train()
         self.opt.zero_grad()
-        res = self.model(self.x, self.token)
+        res = self.model(self.x_in, self.token)
         m = self.masks[0]
         loss = self._nll_sum(res, m) / self.mask_counts[0]
         loss.backward()
@@ -93,7 +129,7 @@ class DistRunner:
         normalised Python floats (loss, accuracy, outputs); `sync=False`: the raw device tensor [2] and outputs."""
         self.model.eval()
         with torch.no_grad():
-            res = self.model(self.x, self.token)
+            res = self.model(self.x_in, self.token)
         m = self.masks[which]
         if res["emb"].is_cuda:
             from .. import ops
@@ -172,4 +208,4 @@ class DistRunner:
     def logits(self, training=False):
         self.model.train(training)
         with torch.no_grad():
-            return self.model(self.x, self.token)["emb"]
+            return self.model(self.x_in, self.token)["emb"]

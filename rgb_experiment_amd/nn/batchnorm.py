@@ -178,6 +178,11 @@ class BatchNorm1d(nn.BatchNorm1d):
     def _reduce(self, packed):
         return packed
 
+    def _reducer(self, x):
+        """The reduction of the raw column sums that goes with THIS input (dist.DistBatchNorm1d: all-reduce over the
+        node partition, or none when every rank holds all rows of x)."""
+        return self._reduce
+
     def eval_affine(self):
         """(scale, shift) with eval-mode BN(x) = x * scale + shift, or None when that form does not apply."""
         if self.training or not self.affine or not self.track_running_stats:
@@ -196,7 +201,7 @@ class BatchNorm1d(nn.BatchNorm1d):
                 # differentiable there, so this must be too — the raw kernel below has no autograd node
                 return _AffineCols.apply(x, scale, shift)
             return affine_cols(x if x.stride(-1) == 1 else x.contiguous(), scale.contiguous(), shift.contiguous())
-        return _BNTrain.apply(x, self.weight, self.bias, self.eps, self._reduce, self.begin_training_step(), colsums)
+        return _BNTrain.apply(x, self.weight, self.bias, self.eps, self._reducer(x), self.begin_training_step(), colsums)
 
     def begin_training_step(self):
         """What nn.BatchNorm1d does at the top of a training forward: count the batch, pick the momentum.

@@ -153,7 +153,7 @@ class SAGEConv(nn.Module):
         if ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x):
             # lin_l(mean_j x_j) + lin_r(x_i) in one kernel: both products accumulate in the same MFMA tile
             return ops.propagate_linear(x, graph, "mean", w_l, b_l, root_weight=w_r, want_colsums=want_colsums)
-        x_r = ops.linear(x, w_r)
+        x_r = ops.linear(ops.target_rows(x, graph), w_r)  # the targets' own rows (all of x except on a dist.ReplicaGraph)
         if ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x):
             return ops.propagate_linear(x, graph, "mean", w_l, b_l) + x_r
         agg = ops.propagate_mean(x, graph)
@@ -220,7 +220,7 @@ class MySAGEConv(nn.Module):
         if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x):
             # mean_j(lin_l(x_j)) + lin_r(x_i) = (mean_j x_j) Wl^T + x_i Wr^T + (b_l + b_r), one kernel
             return ops.propagate_linear(x, graph, "mean", w_l, b_l + b_r, root_weight=w_r, want_colsums=want_colsums)
-        x_r = ops.linear(x, w_r, b_r)
+        x_r = ops.linear(ops.target_rows(x, graph), w_r, b_r)
         if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x):
             return ops.propagate_linear(x, graph, "mean", w_l, b_l) + x_r
         if not x.requires_grad and self.add_self_loops and self.in_channels <= self.out_channels:

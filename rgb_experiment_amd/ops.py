@@ -108,6 +108,13 @@ def _is_dist(graph):
     return getattr(graph, "is_distributed", False)
 
 
+def target_rows(x, graph):
+    """The rows of `x` that are aggregation TARGETS of `graph`: all of them, except on a partitioned run's
+    rectangular second stage (dist.ReplicaGraph: sources = all N replicated rows, targets = this rank's)."""
+    fn = getattr(graph, "target_rows", None)
+    return x if fn is None else fn(x)
+
+
 def _pad4(x):
     """Feature widths that are no multiple of 4 (C = 7 classes on Cora, 41 on Reddit, 47 on ogbn-products) run on
     zero-padded rows: 16-byte aligned rows take the float4 gather path and straddle fewer 128-byte lines. Measured at
@@ -261,8 +268,8 @@ class _PropagateLinear(torch.autograd.Function):
         w, rs = {"gcn": (graph.w, None), "mean": (None, graph.inv_deg), "sum": (None, None)}[kind]
         res = spmm_linear_raw(graph.fwd, w, rs, x, weight_t(weight), None if bias is None else bias.detach(),
                               need_z, xr if root_weight is not None else None,
-                              None if root_weight is None else weight_t(root_weight), kind=f"{kind}_linear_fwd",
-                              want_colsums=want_colsums)
+                              None if root_weight is None else weight_t(root_weight),
+                              kind=f"{getattr(graph, 'event_prefix', '')}{kind}_linear_fwd", want_colsums=want_colsums)
         out, z = res[0], res[1]
         ctx.save_for_backward(z, weight, root_weight, xr if root_weight is not None else None)
         ctx.graph, ctx.kind, ctx.has_bias = graph, kind, bias is not None
@@ -297,18 +304,19 @@ def _propagate_linear_input_grad(g, kind, gy, weight, root_weight):
     the [K, Nout] operand) when in == out, else GEMMs and the transposed SpMM with the root part as its additive
     term."""
     wt = {"gcn": lambda: g.w_t, "mean": lambda: g.w_mean_t, "sum": lambda: None}[kind]()
+    prefix = getattr(g, "event_prefix", "")
     n_out, n_in = weight.shape
     if n_out <= n_in and _lib.load().rgbx_spmm_linear_supported(n_out, n_in, int(root_weight is not None)):
         gx, _ = spmm_linear_raw(g.bwd, wt, None, gy, weight.detach().contiguous(), None, False,
                                 gy if root_weight is not None else None,
                                 None if root_weight is None else root_weight.detach().contiguous(),
-                                kind=f"{kind}_linear_bwd")
+                                kind=f"{prefix}{kind}_linear_bwd")
         return gx
     gz = gy @ weight
     gr = gy @ root_weight if root_weight is not None else None
     if gr is None:
-        return spmm_raw(g.bwd, wt, None, gz, kind=f"{kind}_bwd")
-    return spmm_raw(g.bwd, wt, None, gz, y=gr, a=1.0, b=1.0, out=gr, kind=f"{kind}_bwd")
+        return spmm_raw(g.bwd, wt, None, gz, kind=f"{prefix}{kind}_bwd")
+    return spmm_raw(g.bwd, wt, None, gz, y=gr, a=1.0, b=1.0, out=gr, kind=f"{prefix}{kind}_bwd")
 
 
 class _BNPropagateLinear(torch.autograd.Function):

@@ -24,7 +24,7 @@ def _run(args, timeout=600):
 
 
 @pytest.mark.parametrize("gpus,exchange,scheme", [(2, "reshard", "reshard"), (4, "2x2", "grid2x2"), (2, "halo", "halo"),
-                                                  (2, "auto", None)])
+                                                  (2, "auto", None), (3, "replicate", "replicate")])
 def test_bench_gpus_n_launches_its_own_ranks(gpus, exchange, scheme):
     proc = _run(["--gpus", str(gpus), "--workload", "T", "--steps", "2", "--warmup", "1", "--exchange", exchange])
     assert proc.returncode == 0, proc.stderr[-3000:]
@@ -34,10 +34,14 @@ def test_bench_gpus_n_launches_its_own_ranks(gpus, exchange, scheme):
     assert res["n_gpus"] == gpus and res["ranks_seen"] == gpus and res["steps"] == 2 and res["warmup"] == 1
     if scheme is None:  # the cost model's pick (all ranks the same), with the modelled seconds on the line
         scheme = res["scheme"]
-        assert scheme in ("halo", "reshard") and set(res["modelled_seconds_per_propagate"]) >= {"halo", "reshard"}
+        assert scheme in ("halo", "reshard", "replicate")
+        assert set(res["modelled_seconds_per_propagate"]) >= {"halo", "reshard"}
+        assert set(res["modelled_seconds_per_epoch_first_two_layers"]) == {"exchange", "replicate"}
     assert res["scheme"] == scheme and res["scaling"] == "strong" and res["unit"] == "edges/s"
     assert sorted(r["rank"] for r in res["per_rank"]) == list(range(gpus))
-    assert all(r["exchange_mb_per_step"] > 0 and r["scheme"] == scheme for r in res["per_rank"])
+    assert all(r["scheme"] == scheme for r in res["per_rank"])
+    # the replicate scheme moves no activation rows at all; every other scheme does
+    assert all((r["exchange_mb_per_step"] == 0) == (scheme == "replicate") for r in res["per_rank"])
     assert res["value"] > 0 and res["ms_per_step"] > 0
     assert res["final_losses"]["train"] == res["final_losses"]["train"]  # not NaN
 

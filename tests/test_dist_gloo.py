@@ -125,6 +125,10 @@ def _single_process_reference(model_name):
     opt = torch.optim.Adam([params[k] for k in trainable], lr=0.01)
 
     def fwd(training):
+        if model_name.endswith("_wide"):
+            f = {"gcn_wide": O.gcn_forward, "graphsage_wide": O.graphsage_forward,
+                 "graphsage2_wide": O.graphsage2_forward}[model_name]
+            return f(params, x, ei, 2, training)
         if model_name == "gcn":
             return O.gcn_forward(params, x, ei, 3, training)
         if model_name == "graphsage":
@@ -156,7 +160,12 @@ def _single_process_reference(model_name):
                                                         ("gcn", 2, "reshard"), ("graphsage2", 2, "auto"), ("gat", 2, "halo"),
                                                         ("gat", 3, "auto"), ("appnpstack", 2, "reshard"),
                                                         ("gcn", 4, "2x2"), ("graphsage", 4, "2x2"),
-                                                        ("appnpstack", 4, "2x2")])
+                                                        ("appnpstack", 4, "2x2"),
+                                                        # first layer replicated, second on a rectangular CSR, no
+                                                        # activation exchange (dist.ReplicaGraph); "gcn" has a third
+                                                        # layer, which exchanges as usual
+                                                        ("gcn_wide", 2, "replicate"), ("graphsage_wide", 3, "replicate"),
+                                                        ("graphsage2_wide", 2, "replicate"), ("gcn", 3, "replicate")])
 def test_dist_runner_training_matches_single_process(model_name, world, exchange, tmp_path):
     """Train-mode BatchNorm uses batch statistics in the oracle and reduced statistics in the runner, so
     train losses and trained WEIGHTS must agree; eval losses use running statistics, which the
@@ -175,7 +184,8 @@ def test_dist_runner_training_matches_single_process(model_name, world, exchange
     # A bias added right before a BatchNorm has an exactly-zero true gradient (BN removes constant
     # shifts); Adam turns its rounding noise into +-lr steps, so those entries are not comparable.
     last = {"gcn": "convs.2.", "graphsage": "convs.1.", "graphsage2": "convs.1.", "appnpstack": "lin2.",
-            "gat": "convs.1."}[model_name]
+            "gat": "convs.1.", "gcn_wide": "convs.1.", "graphsage_wide": "convs.1.",
+            "graphsage2_wide": "convs.1."}[model_name]
     for k, v in params.items():
         pre_bn_bias = k.endswith("bias") and not k.startswith(("bns.", "bn.", last))
         if v.is_floating_point() and "running" not in k and not pre_bn_bias:

@@ -51,7 +51,11 @@ def _single_gpu(model_name):
                                                         ("gat", 3, "auto"), ("gcn_wide", 2, "auto"),
                                                         ("graphsage_wide", 3, "auto"), ("graphsage2_wide", 2, "halo"),
                                                         ("gcn_wide", 4, "2x2"), ("graphsage", 4, "2x2"),
-                                                        ("appnpstack", 4, "2x2")])
+                                                        ("appnpstack", 4, "2x2"),
+                                                        # dist.ReplicaGraph: first layer on all rows by every rank,
+                                                        # second on the rectangular CSR, fused kernels, no exchange
+                                                        ("gcn_wide", 2, "replicate"), ("graphsage_wide", 3, "replicate"),
+                                                        ("graphsage2_wide", 2, "replicate")])
 def test_partitioned_hip_run_matches_single_gpu(model_name, world, exchange, tmp_path):
     mp.spawn(W.gpu_runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange), nprocs=world,
              join=True)
