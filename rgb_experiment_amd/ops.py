@@ -265,7 +265,10 @@ class _PropagateLinear(torch.autograd.Function):
         tensor (partitioned graph: x = [local; halo], x_root = local). `want_colsums`: returns (out, colsums)."""
         x = x.contiguous()
         xr = x if x_root is None else x_root.contiguous()
-        w, rs = {"gcn": (graph.w, None), "mean": (None, graph.inv_deg), "sum": (None, None)}[kind]
+        w = graph.w if kind == "gcn" else None          # properties: each builds its vector on first use only
+        rs = graph.inv_deg if kind == "mean" else None  # ('sum': neither)
+        if kind not in ("gcn", "mean", "sum"):
+            raise ValueError(kind)
         res = spmm_linear_raw(graph.fwd, w, rs, x, weight_t(weight), None if bias is None else bias.detach(),
                               need_z, xr if root_weight is not None else None,
                               None if root_weight is None else weight_t(root_weight),
