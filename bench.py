@@ -80,10 +80,25 @@ KERNEL_SOURCES = {  # files whose text decides what the kernel does: a PMC figur
 }
 
 
-def synth(N, E, d):
+def powerlaw_endpoints(N, E, seed, exponent=2.0):
+    """E node ids with a Zipf-like popularity: id = perm[floor(N u^exponent)], u uniform — node k of the popularity
+    order is drawn with density ~ k^(1/exponent - 1) (exponent 2: the top node collects E / sqrt(N) entries, 42 k of
+    60 M at N = 2 M, the order of the hubs of ogbn-products / Reddit); `perm` scatters the popular nodes over the id
+    range as real datasets do."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(E, generator=g, dtype=torch.float64)
+    rank = (u.pow(exponent) * N).long().clamp_(max=N - 1)
+    return torch.randperm(N, generator=g)[rank]
+
+
+def synth(N, E, d, degree="uniform"):
     """directed iid-uniform endpoints (self-loops / duplicates left in), N(0,1) features,
-    uniform labels over d classes; fixed seeds."""
-    ei = torch.randint(0, N, (2, E), generator=torch.Generator().manual_seed(1234567), dtype=torch.int64)
+    uniform labels over d classes; fixed seeds. degree="powerlaw" (secondary runs, never the headline): sources AND
+    targets follow independent Zipf-like popularities, so both the forward and the transposed CSR have hub rows."""
+    if degree == "powerlaw":
+        ei = torch.stack([powerlaw_endpoints(N, E, 1234561), powerlaw_endpoints(N, E, 1234562)])
+    else:
+        ei = torch.randint(0, N, (2, E), generator=torch.Generator().manual_seed(1234567), dtype=torch.int64)
     x = torch.randn(N, d, generator=torch.Generator().manual_seed(1234568))
     y = torch.randint(0, d, (N,), generator=torch.Generator().manual_seed(1234569))
     return ei, x, y
@@ -526,6 +541,8 @@ def main():
     ap.add_argument("--no-interleave", action="store_true", help="val and test forward one after the other")
     ap.add_argument("--emulate-rank", type=int, default=0, metavar="P",
                     help="one GPU: rank 0's launches of a P-rank job, exchanges replaced by stand-in rows")
+    ap.add_argument("--degree", choices=("uniform", "powerlaw"), default="uniform",
+                    help="powerlaw: secondary run on a hub-heavy graph of the same size (row-split plans at work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--primary-only", action="store_true",
                     help="skip the secondary legs (hipGraph replay, configs[0]/[1] blocks, undirected run): clean "
@@ -570,7 +587,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     N, E, d = wl["N"], wl["E"], wl["d"]
-    ei, x, y = synth(N, E, d)
+    ei, x, y = synth(N, E, d, args.degree)
     train_mask, val_mask, test_mask = split_masks(y)
     kwargs, n_prop, loops_mode, kind = MODELS[args.model]
 
@@ -581,6 +598,8 @@ def main():
                                                  "appnpstack": "APPNP K=10", "sgc": "SGC K=2 (cached=False)",
                                                  "gin": "2-block GIN", "dagnn": "DAGNN K=10"}[args.model])
 
+    if args.degree != "uniform":
+        wl_name += " [SECONDARY: power-law in- and out-degree, same |V| and |E|]"
     emu = args.emulate_rank if world == 1 else 0
     parts = max(world, emu)  # ranks the graph is partitioned over
     comm_obj = None
@@ -660,6 +679,8 @@ def main():
         achieved = alg / dom_s / 1e9
     by_kind = {k: {"n": len(v), "avg_ms": sum(v) / len(v)} for k, v in sorted(by_kind.items())}
     traffic, traffic_note = pmc_traffic(args.workload, args.model, kernel, parts)
+    if args.degree != "uniform":
+        traffic, traffic_note = None, "the committed PMC passes were taken on the uniform graph"
 
     result = {
         "metric": "aggregated edges/sec (full-graph GCN d=128, reference epoch = train fwd+bwd+Adam + 2 eval fwd)"
