@@ -84,6 +84,15 @@ def test_shape_and_alignment_errors_of_the_fused_and_dense_entry_points():
     assert lib.rgbx_gemm_tn_workspace_bytes(1000, 128, 128, ctypes.byref(n)) == 0 and n.value >= 128 * 128 * 4
     assert lib.rgbx_gemm_tn_f32(p, 128, p, 128, p, 128, None, 1000, 128, 128, 1.0, p, 16, None) == -4   # RGBX_E_WS
     assert lib.rgbx_gemm_tn_f32(p, 64, p, 128, p, 128, None, 1000, 128, 128, 1.0, p, n.value, None) == -1
+    # DAGNN hop mix: width, alignment, workspace
+    assert lib.rgbx_dagnn_gate_fwd_f32(p, 6, p, 600, 6, p, None, p, 6, 100, 6, 2, None) == -5     # d % 4
+    assert lib.rgbx_dagnn_gate_fwd_f32(p, 260, p, 26000, 260, p, None, p, 260, 100, 260, 2, None) == -5  # d > 256
+    assert lib.rgbx_dagnn_gate_fwd_f32(p + 4, 8, p, 800, 8, p, None, p, 8, 100, 8, 2, None) == -3
+    assert lib.rgbx_dagnn_gate_fwd_f32(p, 8, None, 800, 8, p, None, p, 8, 100, 8, 2, None) == -1  # K > 0 without hops
+    assert lib.rgbx_dagnn_gate_fwd_f32(p, 8, p, 800, 8, p, None, None, 8, 100, 8, 2, None) == -1
+    assert lib.rgbx_dagnn_gate_bwd_workspace_bytes(128, ctypes.byref(n)) == 0 and n.value >= 2048 * 129 * 4
+    assert lib.rgbx_dagnn_gate_bwd_f32(p, 8, p, 800, 8, p, None, p, 8, p, 8, p, 800, 8, p, None, p, 16, 100, 8, 2,
+                                       None) == -4
     # GAT: a head wider than 64 lanes x 4 floats
     assert lib.rgbx_gat_scores_f32(p, 1000, p, p, p, p, 10, 1, 1000, None) == -5
 
