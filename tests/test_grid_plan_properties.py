@@ -2,6 +2,8 @@
 The plan is pure index arithmetic; what must hold is that an emulation of the whole exchange with plain tensors —
 column slices in, per-group aggregation in piece-major row order, pieces back to the row owners — reproduces the
 single-process propagate for every rank."""
+import os
+
 import torch
 from hypothesis import given, settings, strategies as st
 
@@ -54,3 +56,38 @@ def test_grid_exchange_emulated_with_tensors_equals_the_propagate(case):
                 off += cnt
             assert off == h.piece_ptr[k + 1]
     assert torch.allclose(out, want, atol=1e-5)
+
+
+def test_replicate_cost_model_follows_the_link_rate(monkeypatch):
+    """DistGraph.replicate_costs (what DistRunner's "auto" compares): with links that deliver nothing the replicated
+    first layer must win, with free links the exchange schemes must; both figures are positive and identical on every
+    rank by construction (inputs are all-reduced)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _dist_worker import OracleAggregator
+    from rgb_experiment_amd.dist.comm import EmulatedComm
+    from rgb_experiment_amd.dist.graph import DistGraph
+    g = torch.Generator().manual_seed(7)
+    n = 4000
+    ei = torch.randint(0, n, (2, 60000), generator=g)
+    picks = {}
+    for gbs in ("0.000001", "1000000"):
+        monkeypatch.setenv("RGBX_LINK_GBS", gbs)
+        for world in (2, 8):
+            dg = DistGraph(ei, n, 1, EmulatedComm(world, 0), OracleAggregator(), "auto")
+            c = dg.replicate_costs(128, 128)
+            assert set(c) == {"exchange", "replicate"} and min(c.values()) > 0
+            picks[(gbs, world)] = "replicate" if c["replicate"] < c["exchange"] else "exchange"
+    assert picks[("0.000001", 2)] == picks[("0.000001", 8)] == "replicate"
+    assert picks[("1000000", 2)] == picks[("1000000", 8)] == "exchange"
+
+
+def test_powerlaw_endpoints_are_skewed_and_in_range():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    ids = bench.powerlaw_endpoints(5000, 200000, 3)
+    assert ids.dtype == torch.int64 and int(ids.min()) >= 0 and int(ids.max()) < 5000
+    deg = torch.bincount(ids, minlength=5000)
+    assert int(deg.max()) > 20 * int(deg.float().median())  # a hub: 200000 / sqrt(5000) ~ 2800 against a median of ~20
+    assert torch.equal(ids, bench.powerlaw_endpoints(5000, 200000, 3))  # seeded
