@@ -1,0 +1,183 @@
+"""Seeded differential fuzz of the conv layers against the oracle: random layer kind, graph shape (single nodes,
+edgeless graphs, rows without in-edges, self-loops, duplicates, a hub), widths on both sides of every dispatch
+boundary (odd, < 4, not a multiple of 32, in > out, in <= out, > 128), with and without an input gradient, train
+and no_grad. Every case checks the output and every gradient. The parity tests proper pin chosen shapes; this walks
+the space between them."""
+import random
+
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+WIDTHS = [1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 32, 33, 40, 64, 96, 100, 128, 130, 160, 256]
+KINDS = ["gcn", "sage", "mysage", "gat", "appnp", "gin", "sgc", "dagnn"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda")
+
+
+def make_graph(rng, n):
+    g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+    style = rng.choice(["empty", "sparse", "dense", "hub", "loops"])
+    if style == "empty" or n == 0:
+        return torch.zeros((2, 0), dtype=torch.int64)
+    e = {"sparse": n // 2 + 1, "dense": 12 * n, "hub": 4 * n, "loops": 3 * n}[style]
+    ei = torch.randint(0, n, (2, e), generator=g)
+    if style == "hub":  # one target with most of the edges, one source likewise
+        k = 6 * n + 3000
+        ei = torch.cat([ei, torch.stack([torch.randint(0, n, (k,), generator=g), torch.full((k,), rng.randrange(n))]),
+                        torch.stack([torch.full((k // 2,), rng.randrange(n)), torch.randint(0, n, (k // 2,), generator=g)])],
+                       dim=1)
+    if style == "loops":
+        s = torch.randint(0, n, (n,), generator=g)
+        ei = torch.cat([ei, torch.stack([s, s]), ei[:, : max(1, e // 3)]], dim=1)
+    return ei[:, torch.randperm(ei.size(1), generator=g)]
+
+
+def tol(ref, base=2e-4):
+    return base * max(1.0, float(ref.detach().abs().max()) if ref.numel() else 1.0)
+
+
+def check(name, got, ref, base=2e-4):
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    if ref.numel():
+        err = (got.detach().cpu() - ref.detach()).abs().max().item()
+        assert err < tol(ref, base), (name, err, tol(ref, base))
+
+
+def run_case(dev, seed):
+    from rgb_experiment_amd import nn as RN
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import LOOPS_ADD_REMAINING, clear_cache, get_graph
+    rng = random.Random(seed)
+    kind = KINDS[seed % len(KINDS)]
+    n = rng.choice([1, 2, 3, 31, 32, 33, 64, 100, 257, 700])
+    f_in, f_out = rng.choice(WIDTHS), rng.choice(WIDTHS)
+    ei = make_graph(rng, n)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, f_in, generator=g)
+    need_xgrad = rng.random() < 0.6
+    no_grad = rng.random() < 0.15
+    torch.manual_seed(seed)
+    desc = f"seed={seed} kind={kind} n={n} E={ei.size(1)} in={f_in} out={f_out} xgrad={need_xgrad} no_grad={no_grad}"
+
+    if kind == "gcn":
+        conv = RN.GCNConv(f_in, f_out)
+        ref_fn = lambda sd, xc: O.gcn_conv(xc, ei, sd["lin.weight"], sd["bias"])
+    elif kind == "sage":
+        conv = RN.SAGEConv(f_in, f_out)
+        ref_fn = lambda sd, xc: O.sage_conv(xc, ei, sd["lin_l.weight"], sd["lin_l.bias"], sd["lin_r.weight"])
+    elif kind == "mysage":
+        conv = RN.MySAGEConv(f_in, f_out)
+        ref_fn = lambda sd, xc: O.my_sage_conv(xc, ei, sd["lin_l.weight"], sd["lin_l.bias"], sd["lin_r.weight"],
+                                               sd["lin_r.bias"])
+    elif kind == "gat":
+        H = rng.choice([1, 2, 3, 8])
+        C = rng.choice([1, 2, 5, 8, 16, 64, 128]) if H == 1 else rng.choice([1, 4, 7, 16, 32])
+        concat = rng.random() < 0.7
+        conv = RN.GATConv(f_in, C, H, concat=concat)
+        desc += f" H={H} C={C} concat={concat}"
+        ref_fn = lambda sd, xc: O.gat_conv(xc, ei, sd["lin_src.weight"], sd["att_src"], sd["att_dst"], sd["bias"], H,
+                                           concat)
+    elif kind == "appnp":
+        K, alpha = rng.choice([0, 1, 2, 5]), rng.choice([0.0, 0.1, 0.5])
+        conv = RN.APPNP(K, alpha)
+        desc += f" K={K} alpha={alpha}"
+        ref_fn = lambda sd, xc: O.appnp(xc, ei, K, alpha)
+    elif kind == "gin":
+        hid = rng.choice([8, 32, 64])
+        conv = RN.GINConv(torch.nn.Sequential(RN.Linear(f_in, hid), torch.nn.ReLU(), RN.Linear(hid, f_out)),
+                          train_eps=True)
+        with torch.no_grad():
+            conv.eps.fill_(rng.choice([0.0, 0.25, -0.5]))
+
+        def ref_fn(sd, xc):
+            agg = O.propagate(ei, xc, n, None, "add") + (1 + sd["eps"]) * xc
+            h = torch.relu(agg @ sd["nn.0.weight"].t() + sd["nn.0.bias"])
+            return h @ sd["nn.2.weight"].t() + sd["nn.2.bias"]
+    elif kind == "sgc":
+        K = rng.choice([1, 2, 3])
+        conv = RN.SGConv(f_in, f_out, K=K)
+        desc += f" K={K}"
+
+        def ref_fn(sd, xc):
+            e2, w = O.gcn_norm(ei, None, n)
+            h = xc
+            for _ in range(K):
+                h = O.propagate(e2, h, n, w, "add")
+            return h @ sd["lin.weight"].t() + sd["lin.bias"]
+    else:  # dagnn's Prop through ops.dagnn_prop
+        K = rng.choice([0, 1, 3, 6])
+        conv = torch.nn.Linear(f_in, 1)  # proj
+        desc += f" K={K}"
+
+        def ref_fn(sd, xc):
+            e2, w = O.gcn_norm(ei, None, n)
+            preds, h = [xc], xc
+            for _ in range(K):
+                h = O.propagate(e2, h, n, w, "add")
+                preds.append(h)
+            pps = torch.stack(preds, dim=1)
+            retain = torch.sigmoid((pps @ sd["weight"].t() + sd["bias"]).squeeze(-1))
+            return torch.matmul(retain.unsqueeze(1), pps).squeeze(1)
+
+    with torch.no_grad():  # biases start at zero in several layers: make them count
+        for p in conv.parameters():
+            if p.dim() == 1 and p.numel() > 1:
+                p.uniform_(-0.5, 0.5)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in conv.state_dict().items()
+          if "lin_dst" not in k}
+    conv.to(dev)
+    clear_cache()
+    xd = x.to(dev).requires_grad_(need_xgrad and not no_grad)
+    xc = x.clone().requires_grad_(need_xgrad and not no_grad)
+    eid = ei.to(dev)
+
+    def fwd():
+        if kind == "dagnn":
+            if f_in > 256:
+                return None
+            return ops.dagnn_prop(xd, get_graph(eid, n, LOOPS_ADD_REMAINING), K, conv.weight, conv.bias)
+        return conv(xd, eid)
+
+    try:
+        if no_grad:
+            with torch.no_grad():
+                got = fwd()
+        else:
+            got = fwd()
+        ref = ref_fn(sd, xc)
+        check("out", got, ref)
+        if no_grad or not ref.requires_grad:
+            return
+        go = torch.randn(ref.shape, generator=g)
+        got.backward(go.to(dev))
+        ref.backward(go)
+        if need_xgrad:
+            check("x.grad", xd.grad, xc.grad)
+        for name, p in conv.named_parameters():
+            if "lin_dst" in name or name not in sd:
+                continue
+            rg = sd[name].grad
+            if rg is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+                continue
+            assert p.grad is not None, name
+            check(name + ".grad", p.grad, rg, 4e-4)
+    except AssertionError as exc:
+        raise AssertionError(f"{desc}: {exc}") from exc
+    except RuntimeError as exc:
+        raise RuntimeError(f"{desc}: {exc}") from exc
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_conv_layers_against_the_oracle_on_random_shapes(dev, block):
+    for seed in range(block * 40, block * 40 + 40):
+        run_case(dev, 9000 + seed)
