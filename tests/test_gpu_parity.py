@@ -1269,6 +1269,26 @@ def test_hip_graph_epoch_equals_eager_loop(dev, name):
     assert abs(a["ACC"] - b["ACC"]) < 1e-9
 
 
+def test_hip_graph_capture_is_left_to_launch_bound_graphs(dev, monkeypatch):
+    """use_hip_graph=True captures only up to HIP_GRAPH_MAX_EDGES edges (beyond it the kernels set the epoch time and a
+    replay was measured slower); "always" forces the capture; the numbers do not depend on the choice."""
+    import rgb_experiment_amd as R
+    from rgb_experiment_amd import itexperiments
+    n, f, c = 600, 16, 4
+    gen = torch.Generator().manual_seed(5)
+    data = R.Data(x=torch.randn(n, f, generator=gen), y=torch.randint(0, c, (n,), generator=gen),
+                  edge_index=rand_graph(n, 4000, 3))
+    params = R.InitialParameters.defaults_for("gcn")
+    run = lambda mode: R.experiment(params, specify_data=True, data=data, model_name="gcn", epoch=4,
+                                    need_to_reappear=True, print_print=False, return_model=True, use_hip_graph=mode,
+                                    need_all_metrics=False)
+    assert run(True)["used_hip_graph"]
+    monkeypatch.setattr(itexperiments, "HIP_GRAPH_MAX_EDGES", 100)
+    eager, forced = run(True), run("always")
+    assert not eager["used_hip_graph"] and forced["used_hip_graph"]
+    assert np.allclose(eager["history"]["train_loss"], forced["history"]["train_loss"], rtol=0, atol=2e-6)
+
+
 def test_transposed_weight_cache_follows_the_parameter(dev):
     """ops.weight_t keeps W^T per parameter version: optimizer steps, load_state_dict, hipGraph replays (which do
     not move version counters) and .to() must all invalidate it."""
