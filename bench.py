@@ -350,6 +350,15 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
         s = torch.cat([loss.detach().double().reshape(1), val, tst]).tolist()  # the one host sync of the epoch
         return s[0], s[1] / s[2], s[3] / s[2], s[4] / s[5], s[6] / s[5]
 
+    def train_only():
+        """SURVEY 8d secondary number: the training step alone (forward + backward + Adam, itexperiments.py:427-440)."""
+        model.train()
+        opt.zero_grad()
+        loss = masked_ce(model, fwd, y_d, tm)[0]
+        loss.backward()
+        opt.step()
+        return loss.detach()  # not the loss itself: a kept autograd graph would outlive the step (and the later capture)
+
     def graphed():
         """The same epoch captured once as a hipGraph and replayed (rgb_experiment_amd.epoch_graph): needs a
         fresh capturable Adam; returns a run() callable."""
@@ -358,6 +367,7 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
         return GraphedEpoch(model, gopt, {"x": x_d, "edge_index": ei_d}, y_d, (tm, vm, sm)).capture().run
 
     step.graphed = graphed
+    step.train_only = train_only
     step.device_inputs = (x_d, ei_d)
     return step, nnz_total, alg
 
@@ -755,6 +765,11 @@ def main():
         result["cpu_baseline"] = cpu_baseline(ei, x, N, fused=fused)
         del fused
     if parts == 1 and on_gpu and not args.primary_only:
+        # SURVEY 8d secondary: the training step without the two eval forwards (after the headline: it moves the
+        # weights further, which the timed epochs above must not see)
+        t_train, _ = time_steps(step.train_only, args.steps, 1)
+        result["train_step_only"] = {"ms_per_step": t_train / args.steps * 1e3, "steps_per_s": args.steps / t_train,
+                                     "what": "train forward + backward + Adam, no eval forwards (itexperiments.py:427-440)"}
         result["hip_graph_replay"] = time_graphed(step, args.steps, args.warmup)
     if parts == 1 and on_gpu and args.workload == "L" and args.model == "gcn" and not args.primary_only:
         del step, model
