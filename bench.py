@@ -162,6 +162,17 @@ def spmm_compulsory_bytes(n_rows, nnz, d):
     return 2 * n_rows * 4 * d + nnz * 8 + 4 * (n_rows + 1)
 
 
+def cpu_model():
+    """Model name of the host CPU the baseline ran on (SURVEY 8d asks for it beside the core count)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def host_cores():
     """Cores this process may actually use: the cgroup CPU quota if there is one (a one-GPU box grants
     a share of the host, not all of os.cpu_count()), else the affinity mask."""
@@ -259,9 +270,11 @@ def cpu_baseline(ei, x, N, budget_s=20.0, fused=None):
         return {"value": rei.size(1) / m2, "unit": "edges/s", "cores": threads, "kind": "port",
                 "sample": f"oracle/propagate_ref.c oracle_propagate_csr_f32 (C + OpenMP, {threads} threads) over all "
                           f"{rei.size(1)} rewritten edges of one GCN propagate, d=128, median of {len(t2)} runs",
-                "seconds_per_run": m2, "pyg_dataflow_variant": dataflow, "parity_at_full_size": parity}
+                "seconds_per_run": m2, "cpu_model": cpu_model(), "pyg_dataflow_variant": dataflow,
+                "parity_at_full_size": parity}
     except Exception as exc:  # C restatement not built: fall back to the Python oracle's number
-        dataflow.update({"kind": "port", "sample": dataflow.pop("what"), "c_restatement_error": repr(exc)})
+        dataflow.update({"kind": "port", "sample": dataflow.pop("what"), "cpu_model": cpu_model(),
+                         "c_restatement_error": repr(exc)})
         return dataflow
 
 
