@@ -750,6 +750,11 @@ def main():
     if parts > 1:
         mine = {"rank": rank, "scheme": scheme, "exchange_mb_per_step": comm_obj.bytes_sent / args.steps / 1e6,
                 "exchanges_per_step": comm_obj.exchanges / args.steps, "aggregation_ms_per_step": agg_total_ms / args.steps,
+                # time the compute streams stood still in exchange waits (HIP events around every work.wait()): the
+                # exposed part of the exchanges, measured; RCCL runs only
+                "exposed_exchange_ms_per_step": (by_kind.get("exchange_wait", {"n": 0, "avg_ms": 0.0})["n"]
+                                                 * by_kind.get("exchange_wait", {"n": 0, "avg_ms": 0.0})["avg_ms"]
+                                                 / args.steps),
                 "rows": n_loc, "device": str(dev)}
         per_rank = [mine]
         if world > 1:
@@ -763,6 +768,7 @@ def main():
             (v for k, v in dgraph._choice.items() if isinstance(k, tuple) and k[0] == "costs"), None)
         result["modelled_seconds_per_epoch_first_two_layers"] = getattr(runner, "replicate_costs", None)
         result["link_gbs_measured"] = getattr(comm_obj, "link_gbs", None)  # 16 MB-per-peer all-to-all at start-up
+        result["small_all_to_all_us_measured"] = getattr(comm_obj, "link_latency_us", None)  # one row per peer
     if emu:
         result["n_gpus"] = 1
         result["emulated"] = {"rank": 0, "of": emu, "scheme": scheme,

@@ -57,6 +57,20 @@ class TakeTurns:
         self.local.me = None
 
 
+class _TimedWait:
+    """`work.wait()` bracketed by HIP events on the waiting stream when bench.py listens (ops.set_event_sink): the
+    elapsed time of an "exchange_wait" record is how long that stream stood still for the exchange — the EXPOSED part
+    of it, measured rather than modelled."""
+
+    def __init__(self, work):
+        self.work = work
+
+    def wait(self):
+        from .. import ops
+        with ops._Timed("exchange_wait"):
+            return self.work.wait()
+
+
 class _TurnWork:
     """`work.wait()` that first lets the other forward issue its share (TakeTurns)."""
 
@@ -78,6 +92,7 @@ class Comm:
         self.bytes_sent = 0  # payload this rank handed to all-to-alls (rows * width * 4), for the bench line
         self.exchanges = 0
         self.link_gbs = None  # measured by measure_link_gbs(); the cost model's link rate when set
+        self.link_latency_us = None
 
     def _account(self, send, send_counts):
         own = send_counts[self.rank] if self.rank < len(send_counts) else 0
@@ -96,12 +111,15 @@ class Comm:
         if self.backend == "nccl" or not send.is_cuda:
             work = dist.all_to_all_single(recv, send.contiguous(), list(recv_counts), list(send_counts),
                                           group=self.group, async_op=True)
+            if send.is_cuda:
+                work = _TimedWait(work)
             return recv, (work if self.turns is None else _TurnWork(work, self.turns))
         host_recv = torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_to_all_single(host_recv, send.cpu().contiguous(), list(recv_counts), list(send_counts),
                                group=self.group)
         recv.copy_(host_recv)
-        return recv, (_Done() if self.turns is None else _TurnWork(_Done(), self.turns))
+        done = _TimedWait(_Done()) if send.is_cuda else _Done()  # same wrappers as the RCCL path (rehearsals run them)
+        return recv, (done if self.turns is None else _TurnWork(done, self.turns))
 
     def measure_link_gbs(self, device, mb_per_peer=16, reps=3):
         """GB/s one xGMI link carries per direction under an all-to-all (every pair busy at once), measured: `reps`
@@ -124,8 +142,22 @@ class Comm:
         torch.cuda.synchronize(device)
         dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=device)
         dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=self.group)
-        self.bytes_sent, self.exchanges = 0, 0
         self.link_gbs = rows * 64 * 4 / dt.item() / 1e9
+        # and what one SMALL all-to-all costs end to end (one row per peer, issued and waited for back to back): the
+        # per-exchange latency a scheme with many pieces pays; reported on the bench line, not used by the cost model
+        tiny = torch.ones((self.world, 64), dtype=torch.float32, device=device)
+        ones = [1] * self.world
+        for _ in range(3):
+            self.all_to_all_rows(tiny, ones, ones)[1].wait()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            self.all_to_all_rows(tiny, ones, ones)[1].wait()
+        torch.cuda.synchronize(device)
+        lat = torch.tensor([(time.perf_counter() - t0) / 20], dtype=torch.float64, device=device)
+        dist.all_reduce(lat, op=dist.ReduceOp.MAX, group=self.group)
+        self.link_latency_us = lat.item() * 1e6
+        self.bytes_sent, self.exchanges = 0, 0
         return self.link_gbs
 
     def all_reduce_sum_(self, t):
@@ -160,6 +192,7 @@ class EmulatedComm(Comm):
         self.log = []  # (tag, max bytes sent to one peer, max bytes received from one peer) per exchange
         self._pool = {}
         self.link_gbs = None
+        self.link_latency_us = None
 
     def all_to_all_rows(self, send, send_counts, recv_counts, tag=None):
         n_recv = int(sum(recv_counts))
