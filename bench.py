@@ -686,6 +686,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    hbm_peak_gb = torch.cuda.max_memory_allocated(dev) / 1e9 if on_gpu else None  # structures + one epoch's tensors
     by_kind = {}
     for k, s, e in events:
         by_kind.setdefault(k, []).append(s.elapsed_time(e))
@@ -738,6 +739,7 @@ def main():
         "spmm_ms": agg_avg_s * 1e3,
         "kernel_ms_by_kind": by_kind,
         "final_losses": {"train": last[0], "val": last[1], "test": last[3]},
+        "hbm_allocated_peak_gb": hbm_peak_gb,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if achieved else None,
                      "traffic": traffic, "traffic_source": traffic_note,
