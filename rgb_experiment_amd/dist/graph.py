@@ -161,7 +161,9 @@ class DistGraph:
         self.row_counts = [b[q + 1] - b[q] for q in range(self.comm.world)]
         # pieces the outgoing exchange of the grid schemes is cut into: piece k's all-to-all is in flight while
         # piece k + 1 is aggregated (one SpMM launch per piece), so 1/pieces of it is exposed
+        # (given: fixed; else chosen per width by the cost model from the measured link rate and all-to-all latency)
         self.pieces = int(pieces) if pieces else 4
+        self._pieces_fixed = bool(pieces)
 
     def _edges(self):
         if self.edge_index is None:
@@ -297,7 +299,7 @@ class DistGraph:
         shape = self.shape(d)
         if shape is None:
             return None
-        return self._get_grid(kind, shape[1], self.pieces)["plan"], shape[0], shape[1]
+        return self._get_grid(kind, shape[1], self.pieces_for(d))["plan"], shape[0], shape[1]
 
     def _to_column_slice(self, x, R, C):
         """[n_local, d] row shard -> [N, d/C]: column slice c of EVERY node's row, c = this rank's slice. Every
@@ -344,7 +346,7 @@ class DistGraph:
 
     def _run_grid(self, kind, direction, x, shape):
         R, C = shape
-        half, handle = self._grid_half(kind, C, self.pieces, direction)
+        half, handle = self._grid_half(kind, C, self.pieces_for(x.size(1)), direction)
         cols = self._to_column_slice(x, R, C)
         return self._aggregate_and_return(half, handle, cols, f"dist_{direction}_colshard")
 
@@ -406,13 +408,17 @@ class DistGraph:
         P, N = self.comm.world, self.N_global
         # link rate: RGBX_LINK_GBS if set, else what Comm.measure_link_gbs() measured on this fabric, else 60 GB/s
         link = float(os.environ.get("RGBX_LINK_GBS") or getattr(self.comm, "link_gbs", None) or 60.0) * 1e9
+        # what one small all-to-all costs end to end (Comm.measure_link_gbs; RGBX_LINK_LATENCY_US overrides, 0 when
+        # nothing was measured): every exchange pays it once, so it decides how many pieces the outbound exchange is
+        # worth cutting into
+        lat = float(os.environ.get("RGBX_LINK_LATENCY_US") or getattr(self.comm, "link_latency_us", None) or 0.0) * 1e-6
         stats = torch.tensor([float(v) for v in self._halo_stats()], dtype=torch.float64,
                              device=self._edges().device)
         halo_rows, e_loc, e_rem = (self.comm.all_reduce_sum_(stats) / P).tolist()  # means over the ranks
         line_s = lambda edges, width: edges * math.ceil(4 * width / 128) * 128 / self.GATHER_BPS
         out = {}
         if self.exchange == "auto":
-            out["halo"] = max(halo_rows * d * 4 / max(P - 1, 1) / link, line_s(e_loc, d)) + line_s(e_rem, d)
+            out["halo"] = max(halo_rows * d * 4 / max(P - 1, 1) / link + lat, line_s(e_loc, d)) + line_s(e_rem, d)
         nnz = (e_loc + e_rem) * P
         self._choice["nnz"] = nnz
         from .plan import grid_shapes
@@ -421,7 +427,13 @@ class DistGraph:
                 continue  # C = 1 is the halo scheme with every remote row shipped
             name = "reshard" if R == 1 else f"grid{R}x{C}"
             per_link = (N / P) * (d / C) * 4 / link
-            out[name] = per_link + line_s(nnz / R, d // C) + per_link / self.pieces
+            # p pieces: 1/p of the outbound bytes exposed, one more all-to-all latency and one more SpMM launch +
+            # unpack copy (~20 us of rank compute) per piece
+            options = [self.pieces] if self._pieces_fixed else [1, 2, 4, 8]
+            tail = {p: per_link / p + (1 + p) * lat + 20e-6 * p for p in options}
+            best_p = min(tail, key=lambda p: (tail[p], p))
+            self._choice[("pieces", d, name)] = best_p
+            out[name] = per_link + line_s(nnz / R, d // C) + tail[best_p]
         self._choice[key] = out
         return out
 
@@ -440,6 +452,14 @@ class DistGraph:
         dense = N * d_h * 4 * 10 / 5e12
         return {"exchange": 3 * line_s(nnz / P, d_in) + 4 * best + dense / P,
                 "replicate": 3 * line_s(nnz, d_in) + 4 * line_s(nnz / P, d_h) + dense}
+
+    def pieces_for(self, d):
+        """Pieces the outbound exchange of a width-d propagate is cut into: the caller's, else the cost model's pick
+        for the scheme in use (identical on every rank)."""
+        if self._pieces_fixed or self.comm.world == 1 or self.exchange == "halo":
+            return self.pieces
+        self.costs(d)
+        return self._choice.get(("pieces", d, self.scheme(d)), self.pieces)
 
     def shape(self, d):
         """(R, C) of the grid scheme a propagate of width d uses, or None for the halo scheme."""

@@ -91,3 +91,24 @@ def test_powerlaw_endpoints_are_skewed_and_in_range():
     deg = torch.bincount(ids, minlength=5000)
     assert int(deg.max()) > 20 * int(deg.float().median())  # a hub: 200000 / sqrt(5000) ~ 2800 against a median of ~20
     assert torch.equal(ids, bench.powerlaw_endpoints(5000, 200000, 3))  # seeded
+
+
+def test_piece_count_follows_latency_and_link_rate(monkeypatch):
+    """Outbound pieces when the caller fixes none: slow links with free exchanges -> many pieces (less of the transfer
+    exposed), costly exchanges on fast links -> one; a caller's count is kept."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _dist_worker import OracleAggregator
+    from rgb_experiment_amd.dist.comm import EmulatedComm
+    from rgb_experiment_amd.dist.graph import DistGraph
+    g = torch.Generator().manual_seed(11)
+    n = 4000
+    ei = torch.randint(0, n, (2, 60000), generator=g)
+    mk = lambda **kw: DistGraph(ei, n, 1, EmulatedComm(8, 0), OracleAggregator(), "2x4", **kw)
+    monkeypatch.setenv("RGBX_LINK_GBS", "0.0001")
+    monkeypatch.setenv("RGBX_LINK_LATENCY_US", "0")
+    assert mk().pieces_for(128) == 8
+    monkeypatch.setenv("RGBX_LINK_GBS", "100000")
+    monkeypatch.setenv("RGBX_LINK_LATENCY_US", "500")
+    assert mk().pieces_for(128) == 1
+    assert mk(pieces=3).pieces_for(128) == 3
