@@ -144,7 +144,7 @@ class Comm:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=self.group)
         self.link_gbs = rows * 64 * 4 / dt.item() / 1e9
         # and what one SMALL all-to-all costs end to end (one row per peer, issued and waited for back to back): the
-        # per-exchange latency a scheme with many pieces pays; reported on the bench line, not used by the cost model
+        # per-exchange latency a scheme with many pieces pays; on the bench line and in DistGraph.costs (piece count)
         tiny = torch.ones((self.world, 64), dtype=torch.float32, device=device)
         ones = [1] * self.world
         for _ in range(3):
