@@ -65,7 +65,7 @@ KERNEL_OF_KIND = {
     "sum_fwd": "spmm_csr_kernel", "sum_bwd": "spmm_csr_kernel",
     "mean_bwd": "spmm_csr_kernel", "appnp_fwd": "spmm_csr_kernel (K launches)",
     "appnp_bwd": "spmm_csr_kernel (K launches)", "gat_fwd": "gat_fwd_kernel", "gat_bwd_src": "gat_bwd_src_kernel",
-    "gat_bwd_prep": "gat_bwd_prep_kernel", "gat_bwd_segsum": "spmm_csr_kernel (width H)",
+    "gat_bwd_prep": "gat_bwd_prep_kernel",
     "dist_fwd_local": "spmm_csr_kernel", "dist_fwd_remote": "spmm_csr_kernel", "dist_bwd_local": "spmm_csr_kernel",
     "dist_bwd_remote": "spmm_csr_kernel", "dist_fwd_resident": "spmm_csr_kernel",
     "dist_fwd_colshard": "spmm_csr_kernel", "dist_bwd_colshard": "spmm_csr_kernel",
@@ -149,13 +149,41 @@ def pmc_traffic(workload, model, kernel, world):
     return rec["traffic_bytes_per_launch"], f"rocprofv3 PMC, {rec.get('measured', '?')}"
 
 
+def gat_launch_bytes(n_rows, nnz, H, C):
+    """Algorithmic bytes per launch of the GAT kernels of ONE layer (H heads of C channels), from the passes that exist
+    (rgb_experiment_amd/ops.py _GATAttend, csrc/gat.hip): {"fwd_infer", "fwd_train", "bwd_src", "bwd_prep"}.
+    Heads spanning <= 8 lanes (ops._scores_in_kernel) form both score products inside the aggregation kernels from rows
+    they hold anyway; wider heads gather a_src[j] (4H bytes per edge) and read a_dst.
+      forward  : per edge col + the source row (+ a_src); per target the out row, max and 1/sum (+ its own row for
+                 a_dst in-kernel, else a_dst); the training form also stores out_pos [HC], a_pos [H] and a_dst [H]
+      bwd_src  : per edge col + the target's gout row + its 16-byte-per-head record (+ a_src); per source its own
+                 row, the g_hfeat row, g_a_src, g_a_dst
+      bwd_prep : streaming: out, gout, out_pos rows + (a_dst, max, 1/sum, a_pos) in, records + g_a_dst out
+    No per-edge tensor is written by any pass (round 2 removed the ds [E', H] store and its width-H segment sum)."""
+    from rgb_experiment_amd.ops import _scores_in_kernel
+    d = H * C
+    inside = _scores_in_kernel(C)
+    edge = nnz * (4 + 4 * d + (0 if inside else 4 * H))
+    fwd = edge + n_rows * (4 * d + 8 * H + (4 * d if inside else 4 * H)) + 4 * (n_rows + 1)
+    return {"fwd_infer": fwd, "fwd_train": fwd + n_rows * (4 * d + 8 * H),
+            "bwd_src": nnz * (4 + 4 * d + 16 * H + (0 if inside else 4 * H)) + n_rows * (8 * d + 8 * H)
+            + 4 * (n_rows + 1),
+            "bwd_prep": n_rows * (12 * d + 36 * H)}
+
+
 def gat_alg_bytes(n_rows, nnz, d, H=8):
-    """Forward: col + a_src[H] + feature row per edge, out + max + 1/sum per node. Backward: the source
-    pass (col + 16H-byte record + gout row per edge, ds store), the width-H segment sum, the streaming prep.
-    Returned: the mean over the 6 forward and 2 backward propagates of an epoch."""
-    fwd = nnz * (4 + 4 * H + 4 * d) + n_rows * (8 * d + 12 * H) + 4 * (n_rows + 1)
-    bwd = nnz * (4 + 16 * H + 4 * d) + nnz * 4 * H + nnz * (4 + 4 * H) + n_rows * (16 * d + 24 * H)
-    return (6 * fwd + 2 * bwd) / 8
+    """Mean algorithmic bytes per propagate of a 2-layer GAT epoch (layer 1: H heads of d/H channels, layer 2: one head
+    of d): 4 inference-form forwards (two eval forwards), 2 training-form forwards, 2 backward source passes with
+    their streaming prep pass — 8 propagates."""
+    l1, l2 = gat_launch_bytes(n_rows, nnz, H, d // H), gat_launch_bytes(n_rows, nnz, 1, d)
+    tot = sum(2 * l["fwd_infer"] + l["fwd_train"] + l["bwd_src"] + l["bwd_prep"] for l in (l1, l2))
+    return tot / 8
+
+
+def gat_fwd_launch_bytes(n_rows, nnz, d, H=8):
+    """Mean over the 6 forward launches of an epoch (per layer: 2 inference-form, 1 training-form)."""
+    l1, l2 = gat_launch_bytes(n_rows, nnz, H, d // H), gat_launch_bytes(n_rows, nnz, 1, d)
+    return sum(2 * l["fwd_infer"] + l["fwd_train"] for l in (l1, l2)) / 6
 
 
 def spmm_alg_bytes(n_rows, nnz, d):
@@ -391,17 +419,30 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
     return step, nnz_total, alg
 
 
-def time_steps(step, steps, warmup, fence=None):
+def time_steps(step, steps, warmup, fence=None, tick=None, per_step=True):
+    """(seconds for exactly `steps` steps between two fences, the last step's result, per-step milliseconds).
+    Every step ends with its own host read of the epoch's five numbers (one copy), so the wall clock between two
+    returns IS that step's duration: the per-step list costs no extra synchronisation."""
     fence = fence or torch.cuda.synchronize
     last = None
     for _ in range(warmup):
         step()
     fence()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    marks = [time.perf_counter()]
+    for i in range(steps):
         last = step()
+        marks.append(time.perf_counter())
+        if tick is not None:
+            tick(f"timed step {i + 1}/{steps}")
     fence()
-    return time.perf_counter() - t0, last
+    total = time.perf_counter() - marks[0]
+    return total, last, [(b - a) * 1e3 for a, b in zip(marks, marks[1:])]
+
+
+def median(v):
+    v = sorted(v)
+    n = len(v)
+    return None if not n else (v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]))
 
 
 def time_graphed(step, steps, warmup):
@@ -409,8 +450,8 @@ def time_graphed(step, steps, warmup):
     loop, whose launches carry the per-kernel HIP events the roofline needs)."""
     try:
         run = step.graphed()
-        dt, _ = time_steps(run, steps, warmup)
-        return {"ms_per_step": dt / steps * 1e3, "epochs_per_s": steps / dt}
+        dt, _, per = time_steps(run, steps, warmup)
+        return {"ms_per_step": dt / steps * 1e3, "median_ms_per_step": median(per), "epochs_per_s": steps / dt}
     except Exception as exc:
         return {"error": repr(exc)}
 
@@ -427,13 +468,13 @@ def gcn_block(name, ei, x, y, dev, steps, warmup, d, note=None, replay=True):
         step()
     events = []
     ops.set_event_sink(events)
-    elapsed, _ = time_steps(step, steps, 0)
+    elapsed, _, per_step = time_steps(step, steps, 0)
     ops.set_event_sink(None)
     n_prop = MODELS["gcn"][1]
     spmm_s = sum(s.elapsed_time(e) for k, s, e in events if k in AGG_KINDS) * 1e-3 / (n_prop * steps)
     out = {"workload": name, "edges_in": int(ei.size(1)), "edges_aggregated_per_propagate": nnz,
            "value": n_prop * nnz * steps / elapsed, "unit": "edges/s", "ms_per_step": elapsed / steps * 1e3,
-           "epochs_per_s": steps / elapsed, "spmm_ms": spmm_s * 1e3,
+           "median_ms_per_step": median(per_step), "epochs_per_s": steps / elapsed, "spmm_ms": spmm_s * 1e3,
            "roofline_frac_algorithmic": alg / spmm_s / 1e9 / HBM_PEAK_GBS}
     if replay:
         out["hip_graph_replay"] = time_graphed(step, steps, warmup)
@@ -461,12 +502,12 @@ def cora_shaped(dev, epochs=60):
     torch.manual_seed(14530529)
     model = model_class("gcn")(input_dim=f, output_dim=c, num_layers=2, hidden_unit=64, dropout_rate=0.5)
     step, _, _ = build_single_gpu(model, ei, x, y, split_masks(y), dev, 1, "gcn", n, c)
-    dt, _ = time_steps(step, epochs, 10)
+    dt, _, _ = time_steps(step, epochs, 10)
     out = {"workload": "Cora-shaped synthetic (N=2708, E=10556, F=1433, C=7), gcn num_layers=2 hidden_unit=64",
            "eager_ms_per_epoch": dt / epochs * 1e3}
     try:
         run = step.graphed()
-        dt, _ = time_steps(run, epochs, 10)
+        dt, _, _ = time_steps(run, epochs, 10)
         out["hip_graph_ms_per_epoch"] = dt / epochs * 1e3
     except Exception as exc:
         out["hip_graph_error"] = repr(exc)
@@ -479,11 +520,15 @@ def cora_shaped(dev, epochs=60):
 # N > 1
 
 def launch_ranks(n):
-    """`python bench.py --gpus N` as typed: start N ranks (one per GPU) with torch.distributed.run as CHILD
-    processes and return their exit status. Rank 0 of the children prints the JSON line on the inherited stdout.
-    Called before anything in this process has touched the GPU; this process never execs."""
+    """`python bench.py --gpus N` as typed: start N rank processes (one per GPU) with torch.distributed.run as a CHILD
+    process group — exactly the command the driver would type — wait for it with a deadline, and return its exit
+    status. Each rank process supervises its own worker (rgb_experiment_amd/dist/supervise.py: heartbeats, a
+    deadline, fresh workers with more conservative flags when an attempt fails); rank 0's supervisor prints the JSON
+    line on the inherited stdout. Called before anything in this process has touched the GPU; this process never execs
+    and never makes a GPU call."""
     import socket
     import subprocess
+    from rgb_experiment_amd.dist import supervise as sv
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -491,7 +536,22 @@ def launch_ranks(n):
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    deadline_s = sv.limits()[0]
+    attempts = int(os.environ.get("RGBX_LAUNCH_ATTEMPTS", len(sv.ATTEMPTS)))
+    total = attempts * (deadline_s + 90) + 120  # backstop only: the supervisors keep their own, tighter limits
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=total)
+    except subprocess.TimeoutExpired:
+        sv.kill_group(proc)
+        print(json.dumps({"metric": "aggregated edges/sec (multi-GPU run killed by the launcher)", "value": None,
+                          "unit": "edges/s", "n_gpus": n, "higher_is_better": True,
+                          "error": f"the ranks did not finish within {total:g} s",
+                          "launcher": {"supervised": True, "attempts_allowed": attempts}}), flush=True)
+        return 1
+    except KeyboardInterrupt:
+        sv.kill_group(proc)
+        raise
 
 
 def dist_alg_bytes(dgraph, kind, d, N, n_loc, world, K=10, replica=None):
@@ -587,6 +647,14 @@ def main():
         sys.exit(launch_ranks(args.gpus))
     if args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    from rgb_experiment_amd.dist import supervise as sv
+    if world > 1 and not os.environ.get("RGBX_SUPERVISED") and os.environ.get("RGBX_NO_SUPERVISOR") != "1":
+        # a rank process as torch.distributed.run (ours or the driver's) started it: it makes no GPU call, runs the
+        # actual worker as a child and watches it (deadline, heartbeats, fresh workers with conservative flags on
+        # failure) — so that a hang or an error in one rank ends in a JSON line, not in silence
+        sys.exit(sv.supervise(os.path.abspath(__file__), sys.argv[1:], rank, world))
+    t_start = time.perf_counter()
+    sv.beat("worker started, torch imported")
     backend = os.environ.get("RGBX_DIST_BACKEND", "nccl")
     test_backend = None
     if backend == "gloo" and not torch.cuda.is_available():
@@ -611,13 +679,19 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        sv.beat("process group up")
 
     from rgb_experiment_amd import ops
 
     wl = WORKLOADS[args.workload]
     N, E, d = wl["N"], wl["E"], wl["d"]
+    setup = {"imports_and_process_group_s": time.perf_counter() - t_start}
+    t_mark = time.perf_counter()
     ei, x, y = synth(N, E, d, args.degree)
+    sv.beat("synthetic graph drawn")
     train_mask, val_mask, test_mask = split_masks(y)
+    sv.beat("masks split")
+    setup["synthetic_graph_and_masks_s"] = time.perf_counter() - t_mark
     kwargs, n_prop, loops_mode, kind = MODELS[args.model]
 
     torch.manual_seed(14530529)  # the reference's reappear_seed (itexperiments.py:57)
@@ -637,13 +711,22 @@ def main():
         from rgb_experiment_amd.dist import DistRunner
         from rgb_experiment_amd.dist.comm import Comm, EmulatedComm
         comm_obj = EmulatedComm(emu, 0) if emu else Comm()
+        t_mark = time.perf_counter()
         runner = DistRunner(model, ei, x, y, (train_mask, val_mask, test_mask), 0 if emu else rank, parts, dev,
                             lr=0.01, comm=comm_obj, backend=test_backend, exchange=args.exchange, pieces=args.pieces,
                             interleave_evals=not args.no_interleave)
         dgraph = runner.graphs[loops_mode]
         step = runner.epoch
         n_loc = runner.hi - runner.lo
+        sv.beat("runner built (link rate measured)")
+        setup["runner_and_link_probe_s"] = time.perf_counter() - t_mark
+        t_mark = time.perf_counter()
+        sv.test_fault("first_epoch", rank)
         step()  # builds every structure this model uses (outside the timing) ...
+        if on_gpu:
+            torch.cuda.synchronize()
+        setup["first_epoch_plans_and_csr_build_s"] = time.perf_counter() - t_mark
+        sv.beat("first epoch done: plans and CSRs built")
         runner.release_edge_list()  # ... after which the global edge list leaves HBM
         replica = runner.replicas[loops_mode] if runner.replicated else None
         scheme = "replicate" if replica is not None else (dgraph.scheme(d) if kind != "gat" else "halo")
@@ -670,8 +753,11 @@ def main():
         if on_gpu:
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    tick = sv.Ticker()
+    for i in range(args.warmup):
         step()
+        tick(f"warm-up step {i + 1}/{args.warmup}")
+    sv.test_fault("timed_region", rank)
     events = []
     if on_gpu:
         ops.set_event_sink(events)
@@ -679,8 +765,9 @@ def main():
         comm_obj.bytes_sent, comm_obj.exchanges = 0, 0
         if emu:
             comm_obj.log.clear()
-    elapsed, last = time_steps(step, args.steps, 0, fence)
+    elapsed, last, step_ms = time_steps(step, args.steps, 0, fence, tick=tick)
     ops.set_event_sink(None)
+    sv.beat("timed region done")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -701,10 +788,9 @@ def main():
     elif dominant is not None:
         # the DOMINANT kernel's own launches: its algorithmic bytes per launch / its mean launch duration
         launches_per_event = kwargs.get("K", 1) if dominant.startswith("appnp") else 1
-        if dominant == "gat_fwd":  # forward launch alone (col + in-kernel scores + feature row per edge; out, m, 1/sum)
-            H = kwargs.get("heads", 8)
+        if dominant == "gat_fwd":  # the forward launches alone, both layers, inference and training form
             rows_here, nnz_here = (N, nnz_total) if parts == 1 else (n_loc, plan.nnz_local)
-            alg = nnz_here * (4 + 4 * H + 4 * d) + rows_here * (8 * d + 12 * H) + 4 * (rows_here + 1)
+            alg = gat_fwd_launch_bytes(rows_here, nnz_here, d, kwargs.get("heads", 8))
         dom_s = sum(by_kind[dominant]) / len(by_kind[dominant]) / launches_per_event * 1e-3
         achieved = alg / dom_s / 1e9
     by_kind = {k: {"n": len(v), "avg_ms": sum(v) / len(v)} for k, v in sorted(by_kind.items())}
@@ -721,6 +807,10 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        # median of the per-step times beside the mean (`value` and ms_per_step stay the contract's
+        # total-time figures); a step ends with its own host read, so these cost no extra synchronisation
+        "median_ms_per_step": median(step_ms),
+        "min_ms_per_step": min(step_ms) if step_ms else None,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -747,7 +837,11 @@ def main():
                      "algorithmic_bytes_per_launch": alg,
                      "compulsory_bytes_per_launch": spmm_compulsory_bytes(N if parts == 1 else n_loc,
                                                                           nnz_total / parts, d),
-                     "note": "an ideal 1/P share of one propagate" if parts > 1 else "whole graph, one propagate"},
+                     "note": ("an ideal 1/P share of one propagate" if parts > 1 else "whole graph, one propagate")
+                     + "; `achieved` = ALGORITHMIC bytes (SURVEY 8d formula, every gathered row counted once per edge) / "
+                     "mean launch duration, `frac` = that over the 8 TB/s spec peak. It is not an HBM-pin fraction: "
+                     "FETCH_SIZE counts at the L2's fabric side, and about a quarter of the gathered rows of a 1 GB "
+                     "table are served by the 256 MiB Infinity Cache (at workload S all of them)"},
     }
     if parts > 1:
         mine = {"rank": rank, "scheme": scheme, "exchange_mb_per_step": comm_obj.bytes_sent / args.steps / 1e6,
@@ -757,7 +851,10 @@ def main():
                 "exposed_exchange_ms_per_step": (by_kind.get("exchange_wait", {"n": 0, "avg_ms": 0.0})["n"]
                                                  * by_kind.get("exchange_wait", {"n": 0, "avg_ms": 0.0})["avg_ms"]
                                                  / args.steps),
-                "rows": n_loc, "device": str(dev)}
+                "rows": n_loc, "device": str(dev),
+                # where this rank's time went BEFORE the timed region (seconds): the partition plans are index arithmetic
+                # over the global edge list on every rank, the CSRs come from rgbx_csr_build
+                "setup_s": {k: round(v, 3) for k, v in setup.items()}}
         per_rank = [mine]
         if world > 1:
             per_rank = [None] * world
@@ -810,7 +907,7 @@ def main():
         # SURVEY 8d secondary: the training step without the two eval forwards (after the headline: it moves the
         # weights further, which the timed epochs above must not see)
         def train_only_leg():
-            t_train, _ = time_steps(step.train_only, args.steps, 1)
+            t_train, _, _ = time_steps(step.train_only, args.steps, 1)
             return {"ms_per_step": t_train / args.steps * 1e3, "steps_per_s": args.steps / t_train,
                     "what": "train forward + backward + Adam, no eval forwards (itexperiments.py:427-440)"}
         secondary("train_step_only", train_only_leg)

@@ -175,6 +175,22 @@ class Comm:
         if self.world > 1:
             dist.barrier(group=self.group)
 
+    def abort(self, exc, where=""):
+        """An error on this rank that its peers cannot see (raised on a helper thread, or between two collectives
+        the peers are already waiting in): end the process NOW with the traceback on stderr, so that the launcher
+        (torch.distributed.run / bench.py's supervisors) ends the peers, instead of a job-wide hang. No-op for a
+        one-process run, where the caller re-raises."""
+        if self.world == 1 or not dist.is_initialized():
+            return
+        import os
+        import sys
+        import traceback
+        sys.stderr.write(f"[rgb_experiment_amd.dist rank {self.rank}] fatal error in {where}: ending the process so that "
+                         "the peers do not wait in a collective\n")
+        traceback.print_exception(type(exc), exc, exc.__traceback__)
+        sys.stderr.flush()
+        os._exit(70)
+
 
 class EmulatedComm(Comm):
     """ONE process standing in for rank `rank` of a `world`-rank job (bench.py --emulate-rank): every structure
@@ -218,3 +234,6 @@ class EmulatedComm(Comm):
 
     def barrier(self):
         pass
+
+    def abort(self, exc, where=""):
+        pass  # one process: the caller re-raises

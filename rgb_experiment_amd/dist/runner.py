@@ -32,6 +32,7 @@ class DistRunner:
         self.graphs = install(self.token, hi - lo, edge_index.to(device), N, self.comm, backend, exchange, pieces)
         self.interleave_evals = interleave_evals and world > 1
         self._streams = None
+        self._epochs_done = 0
         if device.type == "cuda":  # one timed all-to-all: the exchange cost model then uses this fabric's link rate
             self.link_gbs = self.comm.measure_link_gbs(device)
         # "replicate": every rank computes the first conv layer for all N nodes from the whole (static) feature
@@ -167,8 +168,13 @@ class DistRunner:
                         out[i] = self.evaluate(1 + i, sync=False)[0]
                 else:
                     out[i] = self.evaluate(1 + i, sync=False)[0]
-            except BaseException as exc:  # re-raised by the caller; the other thread must not wait for this one
+            except BaseException as exc:
+                # This rank's other forward and every peer would wait for ever in the next all-to-all for the
+                # collectives this forward no longer issues: in a real multi-rank job the error ends the PROCESS at once
+                # (Comm.abort: traceback, exit status 70; the launcher then ends the peers), it is not carried to a join
+                # that might never return. One-process runs (emulated rank, world 1) re-raise it in the caller.
                 err[i] = exc
+                self.comm.abort(exc, f"eval forward {i} of the interleaved pair")
             finally:
                 turns.leave()
 
@@ -196,12 +202,16 @@ class DistRunner:
         over the ranks in ONE all-reduce and read back in ONE copy, so the queues drain once per epoch, not three
         times."""
         tl = self.train_step(sync=False)
-        if self.interleave_evals:
+        # the first epoch builds what the eval forwards use lazily (cost tables, plans / CSRs of widths only the
+        # no_grad path aggregates at) — on the MAIN stream, one forward after the other, so that no structure is
+        # produced on one of the two eval streams and consumed on the other; interleaving starts with the second epoch
+        if self.interleave_evals and self._epochs_done > 0:
             v, s = self._interleaved_evals()
         else:
             v, _ = self.evaluate(1, sync=False)
             s, _ = self.evaluate(2, sync=False)
         p = self.comm.all_reduce_sum_(torch.cat([tl, v, s])).tolist()
+        self._epochs_done += 1
         cv, cs = self.mask_counts[1], self.mask_counts[2]
         return p[0], p[1] / cv, p[2] / cv, p[3] / cs, p[4] / cs
 

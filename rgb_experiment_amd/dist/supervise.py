@@ -1,0 +1,270 @@
+"""Supervision of the ranks of a multi-GPU benchmark run (bench.py --gpus N; new capability — the reference is
+single-device, itexperiments.py:246, so there is nothing of it to mirror here).
+
+Every rank process that torch.distributed.run starts is a SUPERVISOR: it makes no GPU call, starts the actual worker
+(the same script with RGBX_SUPERVISED=1) as a child in its own process group, and watches it:
+
+  * the worker touches a heartbeat file at every milestone (imports done, process group up, graph built, each step);
+    a worker that stays silent longer than the stall limit, or runs past the deadline, is killed with its group;
+  * a supervisor whose worker failed says so in a file of the run's shared directory (/tmp, one node); every other
+    supervisor that sees the file kills its own worker at once, so one rank's error ends the attempt for all ranks
+    instead of leaving the peers waiting in a collective;
+  * then all supervisors start a FRESH set of workers with the next, more conservative set of flags (ATTEMPTS) on a
+    fresh rendezvous port chosen by rank 0's supervisor. A process that has touched the GPU is never re-executed
+    or reused: each attempt is new processes;
+  * rank 0's supervisor relays the surviving JSON line with a "launcher" object naming the attempt that produced it
+    and, if it was not the first, what failed before it.
+
+stdlib only: importing this module must not initialise anything."""
+import glob
+import json
+import os
+import signal
+import socket
+import subprocess
+import sys
+import tempfile
+import time
+
+# flags appended to the command line as typed (argparse: the last occurrence wins), most ambitious first
+ATTEMPTS = [
+    ("as asked", []),
+    ("conservative: val and test forward one after the other, one-piece transpose exchange",
+     ["--no-interleave", "--pieces", "1", "--exchange", "reshard"]),
+    ("halo exchange, sequential evals", ["--no-interleave", "--pieces", "1", "--exchange", "halo"]),
+    ("replicate: no activation exchange, all-reduces only", ["--no-interleave", "--exchange", "replicate"]),
+]
+
+
+def _env_s(name, default):
+    try:
+        return float(os.environ.get(name, default))
+    except ValueError:
+        return float(default)
+
+
+def limits():
+    """(deadline per attempt, stall limit once the worker has reported in, limit for the first report) in seconds.
+    The first `import torch` on a fresh box can take two minutes, hence the separate first limit."""
+    return (_env_s("RGBX_LAUNCH_DEADLINE_S", 900), _env_s("RGBX_LAUNCH_STALL_S", 180),
+            _env_s("RGBX_LAUNCH_IMPORT_S", 360))
+
+
+def run_key():
+    """Identifies this run on this node: all rank processes are children of the one torch.distributed.run agent."""
+    ppid = os.getppid()
+    start = "0"
+    try:
+        with open(f"/proc/{ppid}/stat") as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]  # field 22: start time of the agent
+    except (OSError, IndexError):
+        pass
+    return f"{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}"
+
+
+def shared_dir():
+    d = os.path.join(tempfile.gettempdir(), "rgbx_bench_" + run_key())
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _write(path, text):
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def _wait_for(paths, timeout):
+    """First existing path of `paths` (glob patterns allowed) within `timeout` seconds, else None."""
+    t_end = time.monotonic() + timeout
+    while True:
+        for p in paths:
+            hit = glob.glob(p)
+            if hit:
+                return hit[0]
+        if time.monotonic() > t_end:
+            return None
+        time.sleep(0.05)
+
+
+def kill_group(proc, grace=5.0):
+    """SIGTERM to the child's process group, SIGKILL after `grace` seconds."""
+    if proc.poll() is not None:
+        return
+    for sig, wait in ((signal.SIGTERM, grace), (signal.SIGKILL, 5.0)):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            proc.wait(timeout=wait)
+            return
+        except subprocess.TimeoutExpired:
+            continue
+
+
+def beat(phase):
+    """Worker side: report a milestone (no-op outside a supervised run)."""
+    path = os.environ.get("RGBX_HEARTBEAT")
+    if path:
+        try:
+            _write(path, f"{phase}\n")
+        except OSError:
+            pass
+
+
+class Ticker:
+    """Worker side: beat() from inside a hot loop at most once per `every` seconds (the file write is ~20 us; a step
+    of the timed region must not pay for it every time)."""
+
+    def __init__(self, every=1.0):
+        self.every, self.last = every, 0.0
+        self.on = bool(os.environ.get("RGBX_HEARTBEAT"))
+
+    def __call__(self, phase):
+        if self.on:
+            now = time.monotonic()
+            if now - self.last >= self.every:
+                self.last = now
+                beat(phase)
+
+
+def test_fault(point, rank):
+    """Test hook (tests/test_bench_cli.py): RGBX_TEST_FAULT="stall|raise:<rank>:<attempt>:<point>" makes that rank
+    of that attempt hang or fail at the named point, to exercise the supervision end to end."""
+    spec = os.environ.get("RGBX_TEST_FAULT")
+    if not spec:
+        return
+    kind, r, attempt, where = spec.split(":")
+    if int(r) == rank and attempt in ("*", os.environ.get("RGBX_ATTEMPT", "0")) and where == point:
+        if kind == "stall":
+            while True:
+                time.sleep(3600)
+        raise RuntimeError(f"injected test fault at {point} on rank {rank}")
+
+
+def _last_json_line(path):
+    text = _read(path) or ""
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    if not lines:
+        return None
+    try:
+        return json.loads(lines[-1])
+    except ValueError:
+        return None
+
+
+def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
+    """Run the worker for this rank under the rules above; returns the exit status of this rank process."""
+    attempts = ATTEMPTS if attempts is None else attempts
+    max_attempts = int(_env_s("RGBX_LAUNCH_ATTEMPTS", len(attempts)))
+    attempts = attempts[:max(1, max_attempts)]
+    deadline_s, stall_s, import_s = limits()
+    d = shared_dir()
+    child = [None]
+
+    def on_signal(signum, _frame):  # the agent (or the driver above it) ends the run: take the worker along
+        if child[0] is not None:
+            kill_group(child[0], grace=2.0)
+        sys.exit(128 + signum)
+
+    for s in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(s, on_signal)
+
+    history = []
+    for k, (name, flags) in enumerate(attempts):
+        port_file = os.path.join(d, f"attempt{k}.port")
+        if rank == 0:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            _write(port_file, str(port))
+        elif _wait_for([port_file, os.path.join(d, "gave_up")], 180) != port_file:
+            print(f"[bench supervisor rank {rank}] no rendezvous port for attempt {k}: leaving", file=sys.stderr)
+            return 1
+        port = int(_read(port_file))
+        hb = os.path.join(d, f"attempt{k}.hb.{rank}")
+        out_path = os.path.join(d, f"attempt{k}.out.{rank}")
+        env = dict(os.environ)
+        env.update({"MASTER_PORT": str(port), "RGBX_SUPERVISED": "1", "RGBX_ATTEMPT": str(k), "RGBX_HEARTBEAT": hb})
+        # the workers rendezvous among themselves on the attempt's own port (rank 0's worker hosts the store): the
+        # agent's store belongs to the supervisors' generation and must not be joined by a second one
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        t0 = time.monotonic()
+        with open(out_path, "w") as fout:
+            proc = subprocess.Popen([sys.executable, script] + list(argv) + flags, env=env, stdout=fout,
+                                    start_new_session=True)
+        child[0] = proc
+        failed_glob = os.path.join(d, f"attempt{k}.failed.*")
+        ok_file = os.path.join(d, f"attempt{k}.ok")
+        reason = None
+        while True:
+            rc = proc.poll()
+            if rc is not None:
+                break
+            now = time.monotonic()
+            peer = glob.glob(failed_glob)
+            if peer:
+                reason = f"a peer failed first ({os.path.basename(peer[0])}: {(_read(peer[0]) or '').strip()[:200]})"
+            elif now - t0 > deadline_s:
+                reason = f"deadline of {deadline_s:g} s passed (last milestone: {(_read(hb) or 'none').strip()})"
+            else:
+                try:  # heartbeat files carry wall-clock mtimes
+                    quiet, limit = time.time() - os.stat(hb).st_mtime, stall_s
+                except OSError:  # the worker has not reported in yet (interpreter start, `import torch`)
+                    quiet, limit = now - t0, import_s
+                if quiet > limit:
+                    reason = f"no milestone for {quiet:.0f} s (last: {(_read(hb) or 'none').strip()})"
+            if reason:
+                kill_group(proc)
+                rc = proc.returncode
+                break
+            time.sleep(0.1)
+        child[0] = None
+        line = _last_json_line(out_path) if rank == 0 else None
+        good = reason is None and rc == 0 and (rank != 0 or line is not None)
+        if good and rank != 0:
+            # my worker is through; the attempt counts if rank 0 got its line (a peer may still have failed)
+            hit = _wait_for([ok_file, os.path.join(d, f"attempt{k}.failed.0"), os.path.join(d, f"attempt{k + 1}.port")], 120)
+            if hit == ok_file or hit is None:
+                return 0
+            history.append({"attempt": k, "flags": flags, "reason": "rank 0 did not get its line"})
+            continue
+        if good:
+            _write(ok_file, "ok")
+            line["launcher"] = {"attempt": k, "settings": name, "extra_flags": flags, "attempts_made": k + 1,
+                                "supervised": True, "wall_s": time.monotonic() - t0,
+                                "fallback": None if not history else {"from": attempts[0][0], "failed": history}}
+            print(json.dumps(line), file=out, flush=True)
+            return 0
+        if os.path.exists(ok_file):  # rank 0 has the line: what happened to this rank afterwards changes nothing
+            return 0
+        reason = reason or (f"worker exited with status {rc}" if rc != 0 else "worker printed no JSON line")
+        history.append({"attempt": k, "settings": name, "extra_flags": flags, "reason": reason})
+        _write(os.path.join(d, f"attempt{k}.failed.{rank}"), reason)
+        print(f"[bench supervisor rank {rank}] attempt {k} ({name}) failed: {reason}", file=sys.stderr, flush=True)
+        if rank != 0:  # rank 0 decides: its line (-> done) or the next attempt's port (-> again)
+            hit = _wait_for([ok_file, os.path.join(d, f"attempt{k + 1}.port"), os.path.join(d, "gave_up")],
+                            deadline_s + 60)
+            if hit == ok_file:
+                return 0
+            if hit is None or hit.endswith("gave_up"):
+                return 1
+    if rank == 0:
+        _write(os.path.join(d, "gave_up"), "1")
+        print(json.dumps({"metric": "aggregated edges/sec (multi-GPU run failed in every attempt)", "value": None,
+                          "unit": "edges/s", "n_gpus": world, "higher_is_better": True,
+                          "error": "no attempt produced a benchmark line",
+                          "launcher": {"attempts_made": len(attempts), "supervised": True, "failed": history}}),
+              file=out, flush=True)
+    return 1
+

@@ -452,7 +452,7 @@ class _PropagateLinearCE(torch.autograd.Function):
         g = g.reshape(()).float()
         gw = gb = gwr = gx = g_bnw = g_bnb = None
         gcol = None
-        if ctx.needs_input_grad[3]:
+        if ctx.needs_input_grad[3]:  # z was stored by the forward exactly when the weight wants a gradient
             gw, gcol = gemm_tn(gy, z, colsum=True)
             gw = gw * g
         if ctx.has_bias and ctx.needs_input_grad[4]:
@@ -463,7 +463,7 @@ class _PropagateLinearCE(torch.autograd.Function):
                 gwr = (gemm_tn(gy, x) * scale + gcol[:, None] * shift) * g
             else:
                 gwr = gemm_tn(gy, x) * g
-        if ctx.has_bn or ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] or (ctx.has_bn and (ctx.needs_input_grad[9] or ctx.needs_input_grad[10])):
             g_h = _propagate_linear_input_grad(graph, kind, gy, weight.detach() * g,
                                                None if root_weight is None else root_weight.detach() * g)
             if ctx.has_bn:
@@ -476,8 +476,10 @@ class _PropagateLinearCE(torch.autograd.Function):
 def propagate_linear_ce(x, graph, kind, weight, bias, root_weight, y, mask, bn=None, colsums=None):
     """(loss, stats) = masked cross-entropy of the last conv's logits, taken inside rgbx_spmm_linear_f32 (the
     caller checked fused_ce_ok, and bn.folds_into_next_layer when a training BatchNorm `bn` is handed over)."""
-    want_grad = torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad or
-                                             (bn is not None and bn.weight.requires_grad))
+    # any operand a gradient can reach (frozen-weight fine-tuning: only a bias or the root weight may want one)
+    want_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad
+        for t in (weight, x, bias, root_weight) + ((bn.weight, bn.bias) if bn is not None else ()))
     if bn is not None:
         bn_args = (bn.eps, bn._reduce, bn.begin_training_step(), colsums)
         return _PropagateLinearCE.apply(x, graph, kind, weight, bias, root_weight, y, mask, want_grad, bn.weight, bn.bias,

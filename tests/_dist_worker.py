@@ -147,6 +147,35 @@ def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", inter
     dist.destroy_process_group()
 
 
+def failing_eval_worker(rank, world, port, out_dir):
+    """Rank 1 raises inside an eval forward of the second epoch (the interleaved pair, on a helper thread): the
+    process must END (Comm.abort), so that the job terminates instead of leaving rank 0 in an all-to-all."""
+    _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import Comm, DistRunner
+
+    class Failing(OracleAggregator):
+        armed = False
+
+        def run(self, handle, x, y=None, kind=None):
+            import threading
+            if Failing.armed and threading.current_thread() is not threading.main_thread():  # an eval thread
+                raise RuntimeError("injected: aggregation failed in an eval forward")
+            return super().run(handle, x, y, kind)
+
+    ei, x, y, masks = make_problem()
+    torch.manual_seed(14530529)
+    model = build_model(M, "gcn", x.size(1), int(y.max()) + 1)
+    r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
+                   backend=Failing(), exchange="reshard", interleave_evals=True)
+    r.epoch()  # the first epoch's evals run one after the other on the main thread
+    open(os.path.join(out_dir, f"first_epoch_done_{rank}"), "w").close()
+    Failing.armed = rank == 1
+    r.epoch()
+    open(os.path.join(out_dir, f"second_epoch_done_{rank}"), "w").close()  # must not be reached by rank 1
+    dist.destroy_process_group()
+
+
 def exchange_count_worker(rank, world, port, out_dir, model_name, resident):
     """Counts the row exchanges of one steady-state epoch, with and without resident input features."""
     _init(rank, world, port)

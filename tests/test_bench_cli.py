@@ -11,8 +11,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, timeout=600):
+def _run(args, timeout=600, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     env.update({"RGBX_DIST_BACKEND": "gloo", "RGBX_TEST_AGGREGATOR": "_dist_worker:OracleAggregator",
                 "PYTHONPATH": os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", ""),
                 "OMP_NUM_THREADS": "1", "CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
@@ -44,6 +45,49 @@ def test_bench_gpus_n_launches_its_own_ranks(gpus, exchange, scheme):
     assert all((r["exchange_mb_per_step"] == 0) == (scheme == "replicate") for r in res["per_rank"])
     assert res["value"] > 0 and res["ms_per_step"] > 0
     assert res["final_losses"]["train"] == res["final_losses"]["train"]  # not NaN
+    # the line names the attempt that produced it (first one here) and carries the per-rank set-up times
+    assert res["launcher"]["supervised"] and res["launcher"]["attempt"] == 0 and res["launcher"]["fallback"] is None
+    for r in res["per_rank"]:
+        assert set(r["setup_s"]) >= {"synthetic_graph_and_masks_s", "runner_and_link_probe_s",
+                                     "first_epoch_plans_and_csr_build_s"}
+        assert r["exposed_exchange_ms_per_step"] >= 0
+    assert "link_gbs_measured" in res and "small_all_to_all_us_measured" in res  # None on gloo, measured on RCCL
+    assert res["median_ms_per_step"] > 0
+
+
+@pytest.mark.parametrize("fault", ["stall:1:0:first_epoch", "raise:0:0:timed_region", "stall:0:0:timed_region"])
+def test_a_failing_or_stalled_rank_ends_in_a_line_from_fresh_conservative_ranks(fault):
+    """A rank of the first attempt hangs (no milestone within the stall limit) or raises: the supervisors kill that
+    attempt's workers and start FRESH ones with the conservative flags; the line that comes out says which attempt
+    produced it and why the first one was given up."""
+    proc = _run(["--gpus", "2", "--workload", "T", "--steps", "2", "--warmup", "1", "--exchange", "2x1"],
+                extra_env={"RGBX_TEST_FAULT": fault, "RGBX_LAUNCH_STALL_S": "8", "RGBX_LAUNCH_DEADLINE_S": "120"})
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    res = json.loads(lines[0])
+    la = res["launcher"]
+    assert la["attempt"] == 1 and la["extra_flags"] == ["--no-interleave", "--pieces", "1", "--exchange", "reshard"]
+    assert res["scheme"] == "reshard" and res["ranks_seen"] == 2 and res["value"] > 0
+    failed = la["fallback"]["failed"]
+    assert len(failed) == 1 and failed[0]["attempt"] == 0
+    if fault.startswith("stall:0"):
+        assert "no milestone" in failed[0]["reason"]
+    elif fault.startswith("raise"):
+        assert "status" in failed[0]["reason"]
+    else:  # rank 1 stalled: rank 0 either saw rank 1's failure file or ran into its own stall limit
+        assert "peer failed" in failed[0]["reason"] or "no milestone" in failed[0]["reason"]
+
+
+def test_every_attempt_failing_ends_in_a_diagnostic_line_and_a_nonzero_status():
+    proc = _run(["--gpus", "2", "--workload", "T", "--steps", "1", "--warmup", "0"],
+                extra_env={"RGBX_TEST_FAULT": "raise:1:*:first_epoch", "RGBX_LAUNCH_ATTEMPTS": "2",
+                           "RGBX_LAUNCH_STALL_S": "8", "RGBX_LAUNCH_DEADLINE_S": "120"})
+    assert proc.returncode != 0
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    res = json.loads(lines[0])
+    assert res["value"] is None and len(res["launcher"]["failed"]) == 2
 
 
 def test_bench_refuses_a_cpu_run_of_the_product_path():

@@ -228,6 +228,18 @@ def test_interleaved_eval_forwards_equal_sequential_ones(tmp_path):
         assert torch.equal(v, res[False][0]["state"][k]), k
 
 
+@pytest.mark.timeout(300)
+def test_an_error_inside_an_interleaved_eval_forward_ends_the_job(tmp_path):
+    """One rank's exception on an eval thread used to be carried to a join while its peers waited for ever in the next
+    all-to-all. Now the failing rank's process ends at once (Comm.abort, status 70) and the spawner ends the rest."""
+    with pytest.raises(Exception) as info:
+        mp.spawn(W.failing_eval_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert "70" in str(info.value) or "exit" in str(info.value).lower(), info.value
+    assert os.path.exists(os.path.join(tmp_path, "first_epoch_done_0"))
+    assert os.path.exists(os.path.join(tmp_path, "first_epoch_done_1"))
+    assert not os.path.exists(os.path.join(tmp_path, "second_epoch_done_1"))
+
+
 @pytest.mark.parametrize("world,exchange", [(2, "reshard"), (3, "reshard"), (4, "2x2")])
 def test_pipelined_reshard_equals_the_single_exchange(world, exchange, tmp_path):
     """DistGraph._aggregate_and_return (the row group's rows in piece-major order, one SpMM per piece, each piece's

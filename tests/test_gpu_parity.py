@@ -498,6 +498,44 @@ def test_last_layer_takes_the_cross_entropy_into_its_kernel(dev, name, C):
     assert torch.equal(stats_e[1:], want_e[1:]) and abs(stats_e[0].item() - want_e[0].item()) < 1e-6 * want_e[0].item()
 
 
+@pytest.mark.parametrize("name", ["GCN", "GraphSAGE2"])
+def test_loss_epilogue_with_frozen_weights(dev, name):
+    """Frozen-weight fine-tuning: only the bias (and lin_r of SAGEConv) of the last layer takes a gradient. The fused
+    loss forward must still prepare its backward (it used to save nothing and then fail to unpack), and the gradients
+    that remain equal the oracle's."""
+    from rgb_experiment_amd import models as M
+    n, f, hid, C = 1500, 32, 32, 32
+    ei = rand_graph(n, 11000, 23, loops=3, dups=4)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(n, f, generator=gen)
+    y = torch.randint(0, C, (n,), generator=gen)
+    mask = torch.rand(n, generator=gen) < 0.5
+    torch.manual_seed(5)
+    model = {"GCN": M.GCN, "GraphSAGE2": M.GraphSAGE2}[name](num_layers=2, hidden_unit=hid, input_dim=f, output_dim=C,
+                                                             dropout_rate=0.5)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    # everything frozen but the LAST layer's bias (and SAGEConv's root weight): the last conv's input needs no gradient
+    frozen = lambda k: k not in ("convs.1.bias", "convs.1.lin_l.bias", "convs.1.lin_r.weight")
+    params = {k: v.clone().requires_grad_(v.is_floating_point() and not frozen(k) and "running" not in k)
+              for k, v in sd0.items()}
+    fwd_o = {"GCN": O.gcn_forward, "GraphSAGE2": O.graphsage2_forward}[name]
+    loss_o = torch.nn.functional.nll_loss(fwd_o(params, x, ei, 2, training=True)["out"][mask], y[mask])
+    loss_o.backward()
+    model.to(dev).train()
+    for k, p in model.named_parameters():
+        p.requires_grad_(not frozen(k))
+    loss, _ = model.masked_ce(x.to(dev), ei.to(dev), y.to(dev), mask.to(dev))
+    assert type(loss.grad_fn).__name__ == "_PropagateLinearCEBackward"
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) < 1e-5
+    for k, p in model.named_parameters():
+        if frozen(k):
+            assert p.grad is None, k
+        else:
+            want = params[k].grad
+            assert (p.grad.cpu() - want).abs().max().item() < 2e-4 * max(1.0, want.abs().max().item()), k
+
+
 def test_spmm_epilogue_and_strides(dev):
     """a, b, y, row scale, and non-contiguous leading dimensions (column slices of wider matrices)."""
     from rgb_experiment_amd import ops
