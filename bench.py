@@ -348,6 +348,35 @@ def sampled_logit_parity(name, model, ei, x, x_d, ei_d, n_targets=None):
     return info
 
 
+def appnp_full_graph_parity(model, ei, x, x_d, ei_d):
+    """BASELINE config 5 as stated (APPNP K = 10, alpha = 0.1): eval-mode logits of ALL nodes of this run's trained
+    APPNPStack against the same model on the CPU — dense layers in torch, the K propagates + teleport in the C
+    restatement (oracle/propagate_ref.c; recurrence: reference models/pta.py:79-84). Ten hops cover the whole graph, so
+    this check is on the whole graph, not on a sampled neighbourhood."""
+    from oracle import ref_cpu as O
+    N = x.size(0)
+    K, alpha = model.conv.K, model.conv.alpha
+    t0 = time.perf_counter()
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        got = model(x_d, ei_d)["emb"].cpu()
+    model.train(was_training)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rei, w = O.gcn_norm(ei, None, N)
+    rowptr, col, perm = O.csr_from_edges(rei[1], rei[0], torch.arange(rei.size(1)), N)
+    ws = w[perm.long()].contiguous()
+    threads = min(O.c_threads(), host_cores())
+    h = O.batch_norm(x @ sd["lin1.weight"].t() + sd["lin1.bias"], sd, "bn.", False) @ sd["lin2.weight"].t() + sd["lin2.bias"]
+    z = h
+    for _ in range(K):
+        z = (1 - alpha) * O.propagate_c_csr(rowptr, col, ws, z, "add", threads) + alpha * h
+    return {"max_abs_diff_hip_vs_cpu": (got - z).abs().max().item(), "max_abs_logit": z.abs().max().item(),
+            "tolerance": 1e-4, "K": K, "alpha": alpha, "rows": N, "cpu_seconds": time.perf_counter() - t0,
+            "what": f"eval-mode APPNPStack logits of all {N} nodes, K = {K}: rgbx_appnp_f32 vs {K} iterations of "
+                    "oracle_propagate_csr_f32 + teleport on the CPU"}
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # one-GPU step
 
@@ -901,6 +930,8 @@ def main():
             return out, conv.lin.weight.detach().cpu(), conv.bias.detach().cpu()
 
         secondary("parity", lambda: {"sampled_logits": sampled_logit_parity(args.model, model, ei, x, x_d, ei_d)})
+        if args.model == "appnpstack":
+            secondary("parity_k10_whole_graph", lambda: appnp_full_graph_parity(model, ei, x, x_d, ei_d))
         secondary("cpu_baseline", lambda: cpu_baseline(ei, x, N, fused=fused_output()))
 
     if parts == 1 and on_gpu and not args.primary_only:

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define RGBX_VERSION 200 /* major*10000 + minor*100 + patch */
+#define RGBX_VERSION 300 /* major*10000 + minor*100 + patch */
 
 #define RGBX_OK 0
 #define RGBX_E_ARG (-1)    /* null pointer / negative size / bad enum */
@@ -185,6 +185,59 @@ int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, const float*
                          double* out_colsums, void* stats_ws, size_t stats_ws_bytes,
                          const rgbx_ce_epilogue_t* ce, int64_t N, int64_t K, int64_t Nout,
                          const rgbx_row_split_t* split, rgbx_stream_t stream);
+
+/* The same layer with everything a NODE-PARTITIONED run needs of it (new capability: the reference is single-device,
+ * itexperiments.py:246; the layer arithmetic is unchanged: models/gcn.py:27-29, graphsage.py:49-62), all arguments in
+ * one struct. On top of rgbx_spmm_linear_f32:
+ *  - DENSE mode (rowptr == NULL): the 32-row tile is not aggregated here but LOADED — row i of the tile is row i of
+ *    `x` (after the optional pre-affine map, where pre_rowsum[i] multiplies pre_shift as above). This is the RETURN
+ *    stage of the row-group x column-slice exchange: another rank aggregated column slices of this rank's rows and
+ *    sent them back; transform, root term, statistics and the loss epilogue then run here without an unpack pass.
+ *    It is also the plain product x * wt (e.g. dy * W of the backward pass) with any of the stores below.
+ *  - BLOCKED layouts: a matrix whose columns are cut into blocks of `cols` columns, each block stored as its own
+ *    contiguous [N, cols] matrix, `stride` elements from one block to the next: element (i, c) lives at
+ *    base + (c / cols) * stride + i * cols + c % cols. cols == 0 means plain row-major with the leading dimension
+ *    given beside it. Column slices of the rows are what the exchange sends and receives, so a producer writes its
+ *    output blocked straight into the send buffer (out_blk; `out` row-major may be written as well, or be NULL) and a
+ *    consumer reads the received slices in place (x in DENSE mode, x_root always). cols % 4 == 0.
+ * Everything else (w, rs, root term, z_out, pre_*, out_colsums, ce, split) as rgbx_spmm_linear_f32. */
+typedef struct rgbx_fused_layer {
+  const int32_t* rowptr;   /* NULL = DENSE mode (col, w, rs, split ignored) */
+  const int32_t* col;
+  const float* w;
+  const float* rs;
+  const float* x;
+  int64_t ldx;
+  int64_t x_blk_cols, x_blk_stride;   /* DENSE mode only */
+  const float* wt;         /* [K, Nout] */
+  const float* x_root;     /* or NULL */
+  int64_t ldr;
+  int64_t xr_blk_cols, xr_blk_stride;
+  const float* wt_root;
+  const float* bias;
+  float* out;              /* row-major [N, Nout] (ldo), or NULL */
+  int64_t ldo;
+  float* out_blk;          /* blocked copy of the output, or NULL */
+  int64_t ob_cols, ob_stride;
+  float* z_out;            /* [N, K] (ldz) or NULL */
+  int64_t ldz;
+  const float* pre_scale;
+  const float* pre_shift;
+  const float* pre_rowsum;
+  double* out_colsums;
+  void* stats_ws;
+  size_t stats_ws_bytes;
+  const rgbx_ce_epilogue_t* ce;
+  int64_t N, K, Nout;
+  const rgbx_row_split_t* split;
+} rgbx_fused_layer_t;
+
+int rgbx_fused_layer_f32(const rgbx_fused_layer_t* layer, rgbx_stream_t stream);
+
+/* dst[i, c] (row-major, ldd) = src (blocked as above: blk_cols, blk_stride)[i, c] for i < n, c < d: the unpack of
+ * received column slices where a consumer wants plain rows (e.g. BatchNorm's backward kernels). */
+int rgbx_blocked_to_rows_f32(const float* src, int64_t blk_cols, int64_t blk_stride, float* dst, int64_t ldd,
+                             int64_t n, int64_t d, rgbx_stream_t stream);
 
 /* z_0 = h;  z_{k+1} = (1-alpha) * A_hat z_k + alpha * h, k = 0..K-1; result in `out`.
  * `tmp` is an [N, d] scratch (ld = ldo); h, out, tmp must not alias. K >= 0. */

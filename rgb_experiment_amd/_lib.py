@@ -31,6 +31,17 @@ class CeEpilogue(ctypes.Structure):
                 ("stats", ctypes.c_void_p), ("scratch", ctypes.c_void_p)]
 
 
+class FusedLayer(ctypes.Structure):
+    """rgbx_fused_layer_t"""
+    _fields_ = [("rowptr", _P), ("col", _P), ("w", _P), ("rs", _P), ("x", _P), ("ldx", _I64),
+                ("x_blk_cols", _I64), ("x_blk_stride", _I64), ("wt", _P), ("x_root", _P), ("ldr", _I64),
+                ("xr_blk_cols", _I64), ("xr_blk_stride", _I64), ("wt_root", _P), ("bias", _P), ("out", _P),
+                ("ldo", _I64), ("out_blk", _P), ("ob_cols", _I64), ("ob_stride", _I64), ("z_out", _P), ("ldz", _I64),
+                ("pre_scale", _P), ("pre_shift", _P), ("pre_rowsum", _P), ("out_colsums", _P), ("stats_ws", _P),
+                ("stats_ws_bytes", ctypes.c_size_t), ("ce", _P), ("N", _I64), ("K", _I64), ("Nout", _I64),
+                ("split", _P)]
+
+
 # name -> argtypes, exactly the declarations of include/rgbx_hip.h
 SIGNATURES = {
     "rgbx_csr_workspace_bytes": [_I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
@@ -43,6 +54,8 @@ SIGNATURES = {
     "rgbx_spmm_linear_stats_workspace_bytes": [_I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
     "rgbx_spmm_linear_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P,
                              ctypes.c_size_t, _P, _I64, _I64, _I64, _P, _P],
+    "rgbx_fused_layer_f32": [_P, _P],
+    "rgbx_blocked_to_rows_f32": [_P, _I64, _I64, _P, _I64, _I64, _I64, _P],
     "rgbx_appnp_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _F, _P, _P],
     "rgbx_dagnn_gate_fwd_f32": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _P],
     "rgbx_dagnn_gate_bwd_workspace_bytes": [_I64, ctypes.POINTER(ctypes.c_size_t)],

@@ -59,7 +59,19 @@ struct FusedArgs {
   const uint8_t* ce_mask;
   const float* ce_scale;
   double* ce_part;
+  // node-partitioned runs (rgbx_fused_layer_f32). Blocked layout: element (i, c) at base + (c / cols) * stride +
+  // i * cols + c % cols — column slices stored one after the other, the form the exchange sends and receives.
+  // x_bc / x_bs: layout of x in DENSE mode (0 = row-major ldx); xr_bc / xr_bs: of the root rows; out_blk: a blocked
+  // copy of the output (next to `out`, or instead of it when out == NULL).
+  int64_t x_bc, x_bs, xr_bc, xr_bs;
+  float* out_blk;
+  int64_t ob_c, ob_s;
 };
+
+__device__ __forceinline__ const float* blocked_at(const float* base, int64_t bc, int64_t bs, int64_t ld, int row,
+                                                   int c) {
+  return bc ? base + (int64_t)(c / (int)bc) * bs + (int64_t)row * bc + (c % (int)bc) : base + (int64_t)row * ld + c;
+}
 
 constexpr int TM = 32;       // destination rows per workgroup = one MFMA row tile; 4 waves aggregate 8 rows each
                             // (64- and 128-row tiles, one B fragment feeding 2-4 MFMAs, measured slower: DESIGN 3.2a)
@@ -119,17 +131,22 @@ __device__ __forceinline__ void tile_times_wt(f32x16& acc, const float* __restri
 }
 
 // C/D layout of the 32x32 MFMA: column l&31, row (r&3) + 8*(r>>2) + 4*(l>>5)
+template <bool BLK>
 __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __restrict__ bias,
                                            float* __restrict__ out, int64_t ldo, int row_base, int N, int n0,
-                                           int kr, int cc, float* __restrict__ stats_part = nullptr, int Nout = 0) {
+                                           int kr, int cc, float* __restrict__ stats_part = nullptr, int Nout = 0,
+                                           float* __restrict__ out_blk = nullptr, int64_t ob_c = 0, int64_t ob_s = 0) {
   const float bb = bias ? bias[n0 + cc] : 0.f;
   float s1 = 0.f, s2 = 0.f;
+  // blocked copy: this lane's column n0 + cc sits in block (n0 + cc) / ob_c at offset (n0 + cc) % ob_c
+  float* ob = BLK && out_blk ? out_blk + (int64_t)((n0 + cc) / (int)ob_c) * ob_s + ((n0 + cc) % (int)ob_c) : nullptr;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * kr;
     if (row < N) {
       const float v = acc[r] + bb;
-      out[(int64_t)row * ldo + n0 + cc] = v;
+      if (!BLK || out) out[(int64_t)row * ldo + n0 + cc] = v;
+      if constexpr (BLK) { if (ob) ob[(int64_t)row * ob_c] = v; }
       s1 += v;
       s2 = fmaf(v, v, s2);
     }
@@ -293,7 +310,11 @@ ce_tiles_finish_kernel(const double* __restrict__ part2, int n, double* __restri
 // KC = K when it is one of the common widths (the MFMA loop then unrolls fully), 0 = any supported K.
 // CE: instantiated with the cross-entropy epilogue (NT == 1 only); a separate instantiation so that the epilogue's
 // registers are not the plain kernel's problem (as a run-time branch it cost the hot kernel a spill).
-template <int G, bool HAS_W, int KC, int NT, bool CE = false>
+// DENSE: no aggregation — the tile's rows are rows of A.x (plain or blocked), mapped by the pre-affine if given: the
+// return stage of the partitioned run's exchange, or a plain x * wt product, with the same phase 2 and epilogues.
+// BLK: the blocked layouts of FusedArgs are honoured (partitioned runs); the single-GPU instantiations are compiled
+// without them, so their register budget (64 VGPRs, no SGPR spills in the gather loop) is what it was.
+template <int G, bool HAS_W, int KC, int NT, bool CE = false, bool DENSE = false, bool BLK = false>
 __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const FusedArgs A) {
   constexpr int NG = kWave / G;
   constexpr int U = 4;
@@ -309,9 +330,30 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
   // ---- phase 1: the 32 rows of the tile, handed to the waves one at a time from an LDS counter — a fixed 8 rows per
   // wave leaves three waves waiting at the barrier for the one with the longest rows (5.10 -> 5.07 ms at L)
   __shared__ int next_row;
-  if (threadIdx.x == 0) next_row = 0;
-  __syncthreads();
-  while (true) {
+  if constexpr (DENSE) {
+    const int k4 = K >> 2;
+    for (int idx = threadIdx.x; idx < TM * k4; idx += 256) {
+      const int r = idx / k4, c4 = (idx - r * k4) * 4;
+      const int row = row_base + r;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (row < A.N) {
+        load_vec<4>(v, blocked_at(A.x, BLK ? A.x_bc : 0, A.x_bs, A.ldx, row, c4));
+        if (A.pre_scale) {
+          float ps[4], pt[4];
+          load_vec<4>(ps, A.pre_scale + c4);
+          load_vec<4>(pt, A.pre_shift + c4);
+          const float rsum = A.pre_rowsum[row];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fmaf(v[i], ps[i], pt[i] * rsum);
+        }
+        if (A.z_out) store_vec<4>(A.z_out + (int64_t)row * A.ldz + c4, v);
+      }
+      store_vec<4>(&zt[r * ldz + c4], v);
+    }
+  }
+  if (!DENSE && threadIdx.x == 0) next_row = 0;
+  if constexpr (!DENSE) __syncthreads();
+  while (!DENSE) {
     int lr = 0;
     if (lane == 0) lr = atomicAdd(&next_row, 1);
     lr = __builtin_amdgcn_readfirstlane(lr);
@@ -413,7 +455,7 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
 #pragma unroll
         for (int i = 0; i < 4; ++i) rootv[j][i] = 0.f;
         if (row < A.N) {
-          load_vec<4>(rootv[j], A.xr + (int64_t)row * A.ldr + c4);
+          load_vec<4>(rootv[j], blocked_at(A.xr, BLK ? A.xr_bc : 0, A.xr_bs, A.ldr, row, c4));
           if (A.pre_scale) {  // the root rows are rows of the same affinely mapped matrix
             float ps[4], pt[4];
             load_vec<4>(ps, A.pre_scale + c4);
@@ -436,7 +478,7 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       tile_times_wt<KC>(acc, zt, ldz, A.wt, K, A.Nout, n0, kr, cc);
-      store_tile(acc, A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc, A.stats_part, A.Nout);
+      store_tile<BLK>(acc, A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc, A.stats_part, A.Nout, A.out_blk, A.ob_c, A.ob_s);
     }
     return;
   }
@@ -459,7 +501,8 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       const int n0 = wave * 32 + tt * 128;
-      if (n0 < A.Nout) store_tile(acc[tt], A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc, A.stats_part, A.Nout);
+      if (n0 < A.Nout) store_tile<BLK>(acc[tt], A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc, A.stats_part, A.Nout, A.out_blk,
+                                  A.ob_c, A.ob_s);
     }
     return;
   }
@@ -478,7 +521,7 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
       const int row = row_base + r;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (row < A.N) {
-        load_vec<4>(v, A.xr + (int64_t)row * A.ldr + c4);
+        load_vec<4>(v, blocked_at(A.xr, BLK ? A.xr_bc : 0, A.xr_bs, A.ldr, row, c4));
         if (A.pre_scale) {
           float ps[4], pt[4];
           load_vec<4>(ps, A.pre_scale + c4);
@@ -502,29 +545,37 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
     const int n0 = wave * 32 + tt * 128;
     if (n0 < A.Nout) {
       tile_times_wt<KC>(acc[tt], zt, ldz, A.wtr, K, A.Nout, n0, kr, cc);
-      store_tile(acc[tt], A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc, A.stats_part, A.Nout);
+      store_tile<BLK>(acc[tt], A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc, A.stats_part, A.Nout, A.out_blk,
+                                  A.ob_c, A.ob_s);
     }
   }
 }
 
-template <int G, int KC>
+template <int G, int KC, bool DENSE = false>
 int launch(const FusedArgs& A, hipStream_t s) {
   const int64_t blocks = cdiv(A.N, TM);
   // the cross-entropy epilogue re-uses the tile as [TM][Nout + 4]
   const size_t lds = (size_t)TM * ((A.ce_part && A.Nout > A.K ? A.Nout : A.K) + 4) * sizeof(float);
   // NT = 32-column tiles a wave keeps accumulators for (Nout <= 128: 1, <= 256: 2); 0 = any Nout, tile by tile
   const int nt = A.Nout <= 128 ? 1 : (A.Nout <= 128 * NT_ROOT ? NT_ROOT : 0);
-#define RGBX_FUSED(HW, NTV) spmm_linear_kernel<G, HW, KC, NTV><<<(int)blocks, 256, lds, s>>>(A)
-  if (A.ce_part) {  // nt == 1: the entry point checked Nout <= 128
-    if (A.w) spmm_linear_kernel<G, true, KC, 1, true><<<(int)blocks, 256, lds, s>>>(A);
-    else spmm_linear_kernel<G, false, KC, 1, true><<<(int)blocks, 256, lds, s>>>(A);
+  // blocked layouts in play (a partitioned run): the BLK instantiations; DENSE is always one of them
+  const bool blk = DENSE || A.out_blk || A.xr_bc;
+#define RGBX_FUSED(HW, NTV)                                                                      \
+  do {                                                                                           \
+    if (blk) spmm_linear_kernel<G, HW, KC, NTV, false, DENSE, true><<<(int)blocks, 256, lds, s>>>(A); \
+    else spmm_linear_kernel<G, HW, KC, NTV, false, DENSE, DENSE><<<(int)blocks, 256, lds, s>>>(A);   \
+  } while (0)
+  if (A.ce_part) {  // nt == 1: the entry point checked Nout <= 128; the loss epilogue has no blocked output
+    if (A.w && !DENSE) spmm_linear_kernel<G, !DENSE, KC, 1, true, DENSE, DENSE><<<(int)blocks, 256, lds, s>>>(A);
+    else if (blk) spmm_linear_kernel<G, false, KC, 1, true, DENSE, true><<<(int)blocks, 256, lds, s>>>(A);
+    else spmm_linear_kernel<G, false, KC, 1, true, DENSE, DENSE><<<(int)blocks, 256, lds, s>>>(A);
     RGBX_CHECK_LAUNCH("spmm_linear_kernel (cross-entropy epilogue)");
     return RGBX_OK;
   }
-  if (A.w) {
-    if (nt == 0) RGBX_FUSED(true, 0);
-    else if (nt == 1) RGBX_FUSED(true, 1);
-    else RGBX_FUSED(true, 2);
+  if (A.w && !DENSE) {
+    if (nt == 0) RGBX_FUSED(!DENSE, 0);
+    else if (nt == 1) RGBX_FUSED(!DENSE, 1);
+    else RGBX_FUSED(!DENSE, 2);
   } else {
     if (nt == 0) RGBX_FUSED(false, 0);
     else if (nt == 1) RGBX_FUSED(false, 1);
@@ -551,62 +602,97 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
                                     const float* pre_rowsum, double* out_colsums, void* stats_ws,
                                     size_t stats_ws_bytes, const rgbx_ce_epilogue_t* ce, int64_t N, int64_t K,
                                     int64_t Nout, const rgbx_row_split_t* split, rgbx_stream_t stream) {
+  if (!rowptr) return fail(RGBX_E_ARG, "spmm_linear: null pointer");
+  rgbx_fused_layer_t L{};
+  L.rowptr = rowptr; L.col = col; L.w = w; L.rs = rs; L.x = x; L.ldx = ldx; L.wt = wt;
+  L.x_root = x_root; L.ldr = ldr; L.wt_root = wt_root; L.bias = bias; L.out = out; L.ldo = ldo;
+  L.z_out = z_out; L.ldz = ldz; L.pre_scale = pre_scale; L.pre_shift = pre_shift; L.pre_rowsum = pre_rowsum;
+  L.out_colsums = out_colsums; L.stats_ws = stats_ws; L.stats_ws_bytes = stats_ws_bytes; L.ce = ce;
+  L.N = N; L.K = K; L.Nout = Nout; L.split = split;
+  return rgbx_fused_layer_f32(&L, stream);
+}
+
+extern "C" int rgbx_fused_layer_f32(const rgbx_fused_layer_t* Lp, rgbx_stream_t stream) {
+  if (!Lp) return fail(RGBX_E_ARG, "fused_layer: null pointer");
+  const rgbx_fused_layer_t& L = *Lp;
+  const int64_t N = L.N, K = L.K, Nout = L.Nout;
+  const rgbx_ce_epilogue_t* ce = L.ce;
+  const bool dense = L.rowptr == nullptr;
   if (N < 0 || K <= 0 || Nout <= 0) return fail(RGBX_E_ARG, "spmm_linear: bad size");
   if (N == 0) return RGBX_OK;
   const bool stats_only = ce && !ce->grad_scale;  // the output matrix is then not written at all
-  if (!rowptr || !col || !x || !wt || (!out && !stats_only)) return fail(RGBX_E_ARG, "spmm_linear: null pointer");
+  if ((!dense && !L.col) || !L.x || !L.wt || (!L.out && !L.out_blk && !stats_only))
+    return fail(RGBX_E_ARG, "spmm_linear: null pointer");
   if (ce) {
     if (!ce->y || !ce->stats || !ce->scratch) return fail(RGBX_E_ARG, "spmm_linear: incomplete cross-entropy epilogue");
     if (Nout > 128) return fail(RGBX_E_SHAPE, "spmm_linear: the cross-entropy epilogue needs Nout <= 128 (got %lld)", (long long)Nout);
-    if (out_colsums) return fail(RGBX_E_ARG, "spmm_linear: out_colsums and the cross-entropy epilogue exclude each other");
+    if (L.out_colsums) return fail(RGBX_E_ARG, "spmm_linear: out_colsums and the cross-entropy epilogue exclude each other");
+    if (L.out_blk) return fail(RGBX_E_ARG, "spmm_linear: a blocked output and the cross-entropy epilogue exclude each other");
+    if (ce->grad_scale && !L.out) return fail(RGBX_E_ARG, "spmm_linear: the loss gradient needs `out`");
   }
   if (N >= INT32_MAX) return fail(RGBX_E_RANGE, "spmm_linear: N exceeds int32");
-  if ((x_root != nullptr) != (wt_root != nullptr))
+  if ((L.x_root != nullptr) != (L.wt_root != nullptr))
     return fail(RGBX_E_ARG, "spmm_linear: x_root and wt_root go together");
-  if ((pre_scale != nullptr) != (pre_shift != nullptr) || (pre_scale != nullptr) != (pre_rowsum != nullptr))
+  if ((L.pre_scale != nullptr) != (L.pre_shift != nullptr) || (L.pre_scale != nullptr) != (L.pre_rowsum != nullptr))
     return fail(RGBX_E_ARG, "spmm_linear: pre_scale, pre_shift and pre_rowsum go together");
-  if (pre_scale && (!aligned16(pre_scale) || !aligned16(pre_shift)))
+  if (L.pre_scale && (!aligned16(L.pre_scale) || !aligned16(L.pre_shift)))
     return fail(RGBX_E_ALIGN, "spmm_linear: pre_scale / pre_shift must be 16-byte aligned");
-  if (!rgbx_spmm_linear_supported(K, Nout, x_root != nullptr))
+  if (!rgbx_spmm_linear_supported(K, Nout, L.x_root != nullptr))
     return fail(RGBX_E_SHAPE,
                 "spmm_linear: needs K %% 4 == 0, K <= 256, Nout %% 32 == 0, Nout <= 256 with a root term (got K=%lld, "
                 "Nout=%lld)", (long long)K, (long long)Nout);
-  if (ldx < K || (out && ldo < Nout) || (z_out && ldz < K) || (x_root && ldr < K))
+  const bool x_blk = dense && L.x_blk_cols > 0, xr_blk = L.x_root && L.xr_blk_cols > 0;
+  if (!dense && L.x_blk_cols) return fail(RGBX_E_ARG, "fused_layer: a blocked x needs DENSE mode (rowptr == NULL)");
+  if ((x_blk && (L.x_blk_cols % 4 || L.x_blk_stride % 4 || K % L.x_blk_cols)) ||
+      (xr_blk && (L.xr_blk_cols % 4 || L.xr_blk_stride % 4 || K % L.xr_blk_cols)) ||
+      (L.out_blk && (L.ob_cols <= 0 || Nout % L.ob_cols)))
+    return fail(RGBX_E_ARG, "fused_layer: block widths must divide the matrix width (inputs: multiples of 4)");
+  if ((!x_blk && L.ldx < K) || (L.out && L.ldo < Nout) || (L.z_out && L.ldz < K) || (L.x_root && !xr_blk && L.ldr < K))
     return fail(RGBX_E_ARG, "spmm_linear: leading dimension too small");
-  if (!aligned16(x) || ldx % 4 || (z_out && (!aligned16(z_out) || ldz % 4)) || (x_root && (!aligned16(x_root) || ldr % 4)))
+  if (!aligned16(L.x) || (!x_blk && L.ldx % 4) || (L.z_out && (!aligned16(L.z_out) || L.ldz % 4)) ||
+      (L.x_root && (!aligned16(L.x_root) || (!xr_blk && L.ldr % 4))))
     return fail(RGBX_E_ALIGN, "spmm_linear: x / x_root / z_out must be 16-byte aligned with ld %% 4 == 0");
   float* stats_part = nullptr;
   double* stats_part2 = nullptr;
-  if (out_colsums) {
+  if (L.out_colsums) {
     size_t need = 0;
     rgbx_spmm_linear_stats_workspace_bytes(N, Nout, &need);
-    if (!stats_ws || stats_ws_bytes < need)
-      return fail(RGBX_E_WS, "spmm_linear: statistics workspace %zu < %zu bytes", stats_ws_bytes, need);
-    if (reinterpret_cast<uintptr_t>(stats_ws) % 8) return fail(RGBX_E_ALIGN, "spmm_linear: stats_ws must be 8-byte aligned");
-    stats_part2 = static_cast<double*>(stats_ws);                            // [kStatsGather, 2 * Nout] doubles
+    if (!L.stats_ws || L.stats_ws_bytes < need)
+      return fail(RGBX_E_WS, "spmm_linear: statistics workspace %zu < %zu bytes", L.stats_ws_bytes, need);
+    if (reinterpret_cast<uintptr_t>(L.stats_ws) % 8) return fail(RGBX_E_ALIGN, "spmm_linear: stats_ws must be 8-byte aligned");
+    stats_part2 = static_cast<double*>(L.stats_ws);                            // [kStatsGather, 2 * Nout] doubles
     stats_part = reinterpret_cast<float*>(stats_part2 + (size_t)kStatsGather * 2 * Nout);  // [tiles, 2 * Nout] floats
   }
   hipStream_t s = (hipStream_t)stream;
   const int* long_row = nullptr;
   const float* zlong = nullptr;
   int threshold = 0, n_long = 0;
+  const rgbx_row_split_t* split = dense ? nullptr : L.split;
   if (split && split->threshold > 0 && split->n_chunks > 0) {
     // hub rows first: chunk sums + ordered combine into the tail of the caller's scratch, [n_long, K] after the
     // [n_chunks, K] partials
     float* zl = split->partial ? split->partial + (size_t)split->n_chunks * K : nullptr;
-    if (int rc = spmm_long_rows_compact(rowptr, col, w, rs, x, ldx, (int)K, split, zl, s)) return rc;
+    if (int rc = spmm_long_rows_compact(L.rowptr, L.col, L.w, L.rs, L.x, L.ldx, (int)K, split, zl, s)) return rc;
     long_row = split->long_row;
     zlong = zl;
     threshold = split->threshold;
     n_long = split->n_long;
   }
-  FusedArgs A{rowptr, col, w,  rs,  x,   wt,  x_root,   wt_root, bias,      out,    z_out,
-              ldx,    ldo, ldz, ldr, long_row, zlong, threshold, n_long,    (int)N, (int)K, (int)Nout,
-              pre_scale, pre_shift, pre_rowsum, stats_part,
-              ce ? ce->y : nullptr, ce ? ce->mask : nullptr, ce ? ce->grad_scale : nullptr, ce ? ce->scratch : nullptr};
+  FusedArgs A{L.rowptr, L.col, L.w, L.rs, L.x, L.wt, L.x_root, L.wt_root, L.bias, L.out, L.z_out,
+              L.ldx, L.ldo, L.ldz, L.ldr, long_row, zlong, threshold, n_long, (int)N, (int)K, (int)Nout,
+              L.pre_scale, L.pre_shift, L.pre_rowsum, stats_part,
+              ce ? ce->y : nullptr, ce ? ce->mask : nullptr, ce ? ce->grad_scale : nullptr, ce ? ce->scratch : nullptr,
+              x_blk ? L.x_blk_cols : 0, L.x_blk_stride, xr_blk ? L.xr_blk_cols : 0, L.xr_blk_stride,
+              L.out_blk, L.ob_cols, L.ob_stride};
   const int lanes = (int)(K / 4);
   int rc;
-  if (K == 128) rc = launch<32, 128>(A, s);
+  if (dense) {  // the lane grouping of the gather is irrelevant: one instantiation per unrolled width
+    if (K == 128) rc = launch<32, 128, true>(A, s);
+    else if (K == 64) rc = launch<16, 64, true>(A, s);
+    else if (K == 256) rc = launch<64, 256, true>(A, s);
+    else rc = launch<32, 0, true>(A, s);
+  }
+  else if (K == 128) rc = launch<32, 128>(A, s);
   else if (K == 64) rc = launch<16, 64>(A, s);
   else if (K == 256) rc = launch<64, 256>(A, s);
   else if (lanes <= 1) rc = launch<1, 0>(A, s);
@@ -625,12 +711,12 @@ extern "C" int rgbx_spmm_linear_f32(const int32_t* rowptr, const int32_t* col, c
     ce_tiles_finish_kernel<<<1, 256, 0, s>>>(part2, kCeGather, ce->stats);
     RGBX_CHECK_LAUNCH("ce_tiles_finish_kernel");
   }
-  if (!out_colsums) return RGBX_OK;
+  if (!L.out_colsums) return RGBX_OK;
   const int tiles = (int)cdiv(N, TM), width2 = (int)(2 * Nout);
   const int G = tiles < kStatsGather ? tiles : kStatsGather;
   tile_stats_gather_kernel<<<G, 256, 0, s>>>(stats_part, tiles, width2, stats_part2);
   RGBX_CHECK_LAUNCH("tile_stats_gather_kernel");
-  tile_stats_finish_kernel<<<(int)cdiv(width2, 8), 256, 0, s>>>(stats_part2, G, width2, out_colsums);
+  tile_stats_finish_kernel<<<(int)cdiv(width2, 8), 256, 0, s>>>(stats_part2, G, width2, L.out_colsums);
   RGBX_CHECK_LAUNCH("tile_stats_finish_kernel");
   return RGBX_OK;
 }

@@ -186,22 +186,73 @@ def weight_t(weight):
     return cached[1]
 
 
-def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_root=None, kind="linear", pre=None,
-                    want_colsums=False, ce=None):
-    """out = (rs * sum_p w_p x[col_p]) wt + bias (+ x_root wt_root) on rgbx_spmm_linear_f32; `wt` / `wt_root` are
-    [K, Nout] row-major. Returns (out, z) with z the stored aggregate [N, K] if `want_z`. `pre` = (scale [K],
-    shift [K], rowsum [N]): the gathered matrix (and the root rows) stand for x * scale + shift. `want_colsums`:
-    returns (out, z, colsums) with colsums [2, Nout] float64 = column sums of out and out^2 from the MFMA tiles.
-    `ce` = (y, mask, grad_scale): the layer is the model's last and its logits go straight into the masked
-    cross-entropy (rgbx_ce_epilogue_t): returns (out, z, stats) with stats [3] float64 = (nll sum, selected rows,
-    correct); out = the loss gradient grad_scale * (softmax - onehot) when grad_scale is a device scalar, None (nothing
-    written) when it is None."""
-    _lib.require_device(x, wt, bias, x_root, wt_root)
-    ps, pt, pr = (None, None, None) if pre is None else (t.contiguous() for t in pre)
-    x = x if x.stride(-1) == 1 else x.contiguous()
-    K, n_out = x.size(1), wt.size(1)
+def _blocked(t, what):
+    """(pointer, block columns, block stride) of a blocked matrix: a [B, n, cols] tensor whose blocks are contiguous
+    [n, cols] matrices (views over the row range of a bigger one keep the block stride of their base)."""
+    if t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != t.size(2):
+        raise RuntimeError(f"{what}: expected a float32 [blocks, rows, cols] tensor with contiguous blocks, got "
+                           f"{t.dtype} {tuple(t.shape)} strides {t.stride()}")
+    return t.data_ptr(), t.size(2), t.stride(0)
+
+
+def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_root=None, pre=None, want_out=True,
+                out_blocked=None, want_z=False, want_colsums=False, ce=None, kind="linear"):
+    """One conv layer's arithmetic on rgbx_fused_layer_f32 (no autograd):
+        z   = rs * sum_p w_p x[col_p]   over `csr`            (csr given: aggregate)
+            = x                                                 (csr None: DENSE mode, the rows are loaded)
+        z   = z * scale + shift * rowsum                        (`pre` = (scale [K], shift [K], rowsum [N]))
+        out = z wt + bias (+ x_root' wt_root),  x_root' = x_root * scale + shift
+    `x` is [n_src, K] row-major or, in DENSE mode, possibly BLOCKED ([B, N, K / B] — column slices as the exchange of
+    a partitioned run delivers them); `x_root` likewise. `out_blocked` ([B', N, Nout / B'], optional): the output is
+    (also) written there, in the layout the exchange sends from. `want_out=False`: no row-major output.
+    `want_z`: the (mapped) aggregate is stored. `want_colsums`: [2, Nout] float64 column sums of out and out^2.
+    `ce` = (y, mask, grad_scale): loss epilogue (see spmm_linear_raw). Returns (out, z, colsums or stats)."""
+    _lib.require_device(x, wt, bias, x_root, wt_root, out_blocked)
+    lib = _lib.load()
+    L = _lib.FusedLayer()
+    dense = csr is None
+    if x.dim() == 3:
+        if not dense:
+            raise RuntimeError("fused_layer: a blocked x needs DENSE mode (no csr)")
+        L.x, L.x_blk_cols, L.x_blk_stride = _blocked(x, "x")
+        n_rows, K = x.size(1), x.size(0) * x.size(2)
+    else:
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        L.x, L.ldx = x.data_ptr(), x.stride(0) if x.size(0) > 1 else x.size(1)
+        n_rows, K = x.size(0), x.size(1)
+    N = n_rows if dense else csr.N
     wt = wt.contiguous()
-    ce_arg = ce_stats = None
+    n_out = wt.size(1)
+    if wt.size(0) != K:
+        raise RuntimeError(f"fused_layer: wt is {tuple(wt.shape)}, the input width is {K}")
+    keep = [x, wt]
+    L.wt = wt.data_ptr()
+    if not dense:
+        L.rowptr, L.col, L.w, L.rs = _lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs)
+        split, _scratch = csr.split_arg(K, x.device, hub_rows=True)
+        keep.append(_scratch)
+        if split is not None:
+            keep.append(split)
+            L.split = ctypes.addressof(split)
+    if wt_root is not None:
+        wtr = wt_root.contiguous()
+        keep.append(wtr)
+        L.wt_root = wtr.data_ptr()
+        if x_root.dim() == 3:
+            L.x_root, L.xr_blk_cols, L.xr_blk_stride = _blocked(x_root, "x_root")
+        else:
+            xr = x_root if x_root.stride(-1) == 1 else x_root.contiguous()
+            keep.append(xr)
+            L.x_root, L.ldr = xr.data_ptr(), xr.stride(0) if xr.size(0) > 1 else xr.size(1)
+    if bias is not None:
+        b = bias.contiguous()
+        keep.append(b)
+        L.bias = b.data_ptr()
+    if pre is not None:
+        ps, pt, pr = (t.contiguous() for t in pre)
+        keep += [ps, pt, pr]
+        L.pre_scale, L.pre_shift, L.pre_rowsum = ps.data_ptr(), pt.data_ptr(), pr.data_ptr()
+    ce_stats = None
     if ce is not None:
         y, mask, grad_scale = ce
         _lib.require_device(y, mask, grad_scale)
@@ -212,43 +263,68 @@ def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_
         y = y.contiguous()
         mask = None if mask is None else mask.contiguous()
         ce_stats = torch.empty(3, dtype=torch.float64, device=x.device)
-        ce_scratch = torch.empty(3 * ((csr.N + 31) // 32 + 64), dtype=torch.float64, device=x.device)
+        ce_scratch = torch.empty(3 * ((N + 31) // 32 + 64), dtype=torch.float64, device=x.device)
         ce_arg = _lib.CeEpilogue(_lib.ptr(y), _lib.ptr(mask), _lib.ptr(grad_scale), _lib.ptr(ce_stats),
                                  _lib.ptr(ce_scratch))
-    if ce is not None and ce[2] is None:
-        out = None  # statistics only: the logits are never written
+        keep += [y, mask, ce_scratch, ce_arg]
+        L.ce = ctypes.addressof(ce_arg)
+        want_out = grad_scale is not None  # statistics only: the logits are never written
+    out = torch.empty((N, n_out), dtype=torch.float32, device=x.device) if want_out else None
+    if out is not None:
+        L.out, L.ldo = out.data_ptr(), out.stride(0)
     else:
-        out = torch.empty((csr.N, n_out), dtype=torch.float32, device=x.device)
-    z = torch.empty((csr.N, K), dtype=torch.float32, device=x.device) if want_z else None
-    xr = ldr = wtr = None
-    if wt_root is not None:
-        xr = x_root if x_root.stride(-1) == 1 else x_root.contiguous()
-        ldr, wtr = xr.stride(0), wt_root.contiguous()
-    b = None if bias is None else bias.contiguous()
-    split, _scratch = csr.split_arg(K, x.device, hub_rows=True)
-    lib = _lib.load()
-    colsums = ws = None
-    ws_bytes = 0
+        L.ldo = n_out
+    if out_blocked is not None:
+        L.out_blk, L.ob_cols, L.ob_stride = _blocked(out_blocked, "out_blocked")
+        if out_blocked.size(1) != N or out_blocked.size(0) * out_blocked.size(2) != n_out:
+            raise RuntimeError(f"fused_layer: out_blocked is {tuple(out_blocked.shape)} for a [{N}, {n_out}] output")
+    z = torch.empty((N, K), dtype=torch.float32, device=x.device) if want_z else None
+    if z is not None:
+        L.z_out = z.data_ptr()
+    L.ldz = K
+    colsums = None
     if want_colsums:
         nbytes = ctypes.c_size_t(0)
-        _lib.check(lib.rgbx_spmm_linear_stats_workspace_bytes(csr.N, n_out, ctypes.byref(nbytes)),
+        _lib.check(lib.rgbx_spmm_linear_stats_workspace_bytes(N, n_out, ctypes.byref(nbytes)),
                    "rgbx_spmm_linear_stats_workspace_bytes")
-        ws_bytes = nbytes.value
-        ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=x.device)
+        ws = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=x.device)
         colsums = torch.empty((2, n_out), dtype=torch.float64, device=x.device)
+        keep.append(ws)
+        L.out_colsums, L.stats_ws, L.stats_ws_bytes = colsums.data_ptr(), ws.data_ptr(), nbytes.value
+    L.N, L.K, L.Nout = N, K, n_out
     with _Timed(kind):
-        _lib.check(
-            lib.rgbx_spmm_linear_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs),
-                                     _lib.ptr(x), x.stride(0), _lib.ptr(wt), _lib.ptr(xr), ldr or K,
-                                     _lib.ptr(wtr), _lib.ptr(b), _lib.ptr(out), n_out if out is None else out.stride(0),
-                                     _lib.ptr(z), K, _lib.ptr(ps), _lib.ptr(pt), _lib.ptr(pr), _lib.ptr(colsums),
-                                     _lib.ptr(ws), ws_bytes, None if ce_arg is None else ctypes.byref(ce_arg),
-                                     csr.N, K, n_out, None if split is None else ctypes.byref(split),
-                                     _lib.stream_ptr()),
-            "rgbx_spmm_linear_f32")
-    if ce is not None:
-        return out, z, ce_stats
-    return (out, z, colsums) if want_colsums else (out, z)
+        _lib.check(lib.rgbx_fused_layer_f32(ctypes.byref(L), _lib.stream_ptr()), "rgbx_fused_layer_f32")
+    del keep
+    return out, z, (ce_stats if ce is not None else colsums)
+
+
+def blocked_to_rows(src, out=None):
+    """[B, n, cols] blocked -> [n, B * cols] row-major (rgbx_blocked_to_rows_f32)."""
+    _lib.require_device(src)
+    ptr, bc, bs = _blocked(src, "src")
+    n, d = src.size(1), src.size(0) * src.size(2)
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().rgbx_blocked_to_rows_f32(ptr, bc, bs, out.data_ptr(), out.stride(0), n, d, _lib.stream_ptr()),
+               "rgbx_blocked_to_rows_f32")
+    return out
+
+
+def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_root=None, kind="linear", pre=None,
+                    want_colsums=False, ce=None):
+    """out = (rs * sum_p w_p x[col_p]) wt + bias (+ x_root wt_root) on the fused aggregate+transform kernel; `wt` /
+    `wt_root` are [K, Nout] row-major. Returns (out, z) with z the stored aggregate [N, K] if `want_z`. `pre` = (scale
+    [K], shift [K], rowsum [N]): the gathered matrix (and the root rows) stand for x * scale + shift. `want_colsums`:
+    returns (out, z, colsums) with colsums [2, Nout] float64 = column sums of out and out^2 from the MFMA tiles.
+    `ce` = (y, mask, grad_scale): the layer is the model's last and its logits go straight into the masked
+    cross-entropy (rgbx_ce_epilogue_t): returns (out, z, stats) with stats [3] float64 = (nll sum, selected rows,
+    correct); out = the loss gradient grad_scale * (softmax - onehot) when grad_scale is a device scalar, None (nothing
+    written) when it is None."""
+    out, z, extra = fused_layer(x, wt, csr=csr, w=w, rs=rs, bias=bias, x_root=x_root if wt_root is not None else None,
+                                wt_root=wt_root, pre=pre, want_z=want_z, want_colsums=want_colsums, ce=ce, kind=kind)
+    if ce is not None or want_colsums:
+        return out, z, extra
+    return out, z
 
 
 class _PropagateLinear(torch.autograd.Function):

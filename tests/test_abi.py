@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in rgbx_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == declared_symbols()
-    assert lib.rgbx_version() == 200
+    assert lib.rgbx_version() == 300
 
 
 def test_argument_errors_do_not_need_a_gpu():
@@ -79,6 +79,27 @@ def test_shape_and_alignment_errors_of_the_fused_and_dense_entry_points():
     assert lib.rgbx_spmm_linear_f32(p, p, None, None, p, 128, p, None, 128, None, None, None, 128, None, 128, None, None,
                                     None, None, None, 0, ctypes.byref(_lib.CeEpilogue(None, None, None, p, p)), 10, 128,
                                     128, None, None) == -1                                   # epilogue without labels
+    # the struct form (partitioned runs): dense mode, blocked layouts
+    def layer(**kw):
+        L = _lib.FusedLayer()
+        base = dict(rowptr=None, x=p, ldx=128, wt=p, out=p, ldo=128, N=10, K=128, Nout=128)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(L, k, v)
+        return lib.rgbx_fused_layer_f32(ctypes.byref(L), None)
+    assert lib.rgbx_fused_layer_f32(None, None) == -1
+    assert layer(x=None) == -1
+    assert layer(out=None) == -1                                                  # nothing to write
+    assert layer(x_blk_cols=48, x_blk_stride=480) == -1                           # 48 does not divide K = 128
+    assert layer(x_blk_cols=32, x_blk_stride=322) == -1                           # stride % 4
+    assert layer(rowptr=p, col=p, x_blk_cols=32, x_blk_stride=320) == -1          # blocked x only in dense mode
+    assert layer(out=None, out_blk=p, ob_cols=48, ob_stride=480) == -1            # 48 does not divide Nout
+    assert layer(out_blk=p, ob_cols=32, ob_stride=320, ce=ctypes.addressof(ce)) == -1   # loss epilogue: no blocked output
+    assert layer(K=130) == -5
+    assert lib.rgbx_blocked_to_rows_f32(p, 32, 320, p, 128, 10, 100, None) == -1  # 32 does not divide d = 100
+    assert lib.rgbx_blocked_to_rows_f32(p, 32, 320, p, 64, 10, 128, None) == -1   # ldd < d
+    assert lib.rgbx_blocked_to_rows_f32(None, 32, 320, p, 128, 10, 128, None) == -1
+    assert lib.rgbx_blocked_to_rows_f32(p, 32, 320, p, 128, 0, 128, None) == 0    # nothing to do
     # weight-gradient GEMM: workspace too small / leading dimension
     n = ctypes.c_size_t(0)
     assert lib.rgbx_gemm_tn_workspace_bytes(1000, 128, 128, ctypes.byref(n)) == 0 and n.value >= 128 * 128 * 4

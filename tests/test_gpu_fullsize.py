@@ -5,7 +5,9 @@ The PyG-dataflow oracle cannot hold these graphs ([E', d] temporaries of 32 GB),
     compared on the WHOLE graph with the C restatement's propagate (oracle/propagate_ref.c, per-target sums)
     followed by a CPU matmul;
   * whole-model logits of every BASELINE config (gcn / graphsage / graphsage2 / gat / appnpstack) are compared at
-    sampled target rows with the UNCHANGED oracle forward on the targets' in-neighbourhood (oracle/sampled.py).
+    sampled target rows with the UNCHANGED oracle forward on the targets' in-neighbourhood (oracle/sampled.py);
+  * APPNP at its stated K = 10 (whose ten hops cover the whole graph, so no neighbourhood can be cut out) is compared
+    on ALL rows with ten iterations of the C restatement.
 Tolerance: 1e-4 absolute on logits (north_star)."""
 import pytest
 import torch
@@ -65,6 +67,63 @@ def test_fused_aggregate_transform_on_the_whole_benchmark_graph(dev, size):
         got = ops.propagate_linear(x_d, get_graph(ei_d, n, 0), "mean", W.to(dev), b.to(dev), root_weight=Wr.to(dev)).cpu()
     assert (got - want).abs().max().item() < TOL
     clear_cache()
+
+
+@pytest.mark.parametrize("size", ["S", "L"])
+def test_appnp_k10_on_the_whole_benchmark_graph(dev, size):
+    """BASELINE config 5 as stated: APPNP K = 10, alpha = 0.1, d = 128 over the WHOLE benchmark graph.
+    rgbx_appnp_f32 (ops.appnp_propagate: ten launches with the teleport in the store) against ten iterations of the C
+    restatement's propagate + teleport on the CPU (recurrence: reference models/pta.py:79-84, APPNP behind
+    models/appnp_stack.py:29); then the whole APPNPStack model with K = 10 — eval-mode logits of ALL nodes against the
+    same model evaluated on the CPU (dense layers in torch, the ten propagates in the C restatement). Tolerance 1e-4."""
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import clear_cache, get_graph
+    ei, x, y = workload(size)
+    n = x.size(0)
+    K, alpha = 10, 0.1
+    threads = O.c_threads()
+    rei, w = O.gcn_norm(ei, None, n)
+    rowptr, col, perm = O.csr_from_edges(rei[1], rei[0], torch.arange(rei.size(1)), n)
+    ws = w[perm.long()].contiguous()
+    del rei, w, perm
+
+    def appnp_cpu(h):
+        z = h
+        for _ in range(K):
+            z = (1 - alpha) * O.propagate_c_csr(rowptr, col, ws, z, "add", threads) + alpha * h
+        return z
+
+    ei_d, x_d = ei.to(dev), x.to(dev)
+    with torch.no_grad():
+        got = ops.appnp_propagate(x_d, get_graph(ei_d, n, 1), K, alpha).cpu()
+    want = appnp_cpu(x)
+    assert (got - want).abs().max().item() < TOL
+    del got, want
+    # the model of config 5: lin1 -> BatchNorm -> lin2 -> APPNP(K = 10), after two training steps
+    torch.manual_seed(14530529)
+    model = M.APPNPStack(input_dim=128, output_dim=128, hidden_unit=64, K=K, alpha=alpha, dropout_rate=0.5).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    y_d = y.to(dev)
+    mask = (torch.arange(n, device=dev) % 5) < 3
+    model.train()
+    for _ in range(2):
+        opt.zero_grad()
+        ops.masked_ce_loss(model(x_d, ei_d)["emb"], y_d, mask).backward()
+        opt.step()
+    model.eval()
+    with torch.no_grad():
+        got = model(x_d, ei_d)["emb"].cpu()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    h = x @ sd["lin1.weight"].t() + sd["lin1.bias"]
+    h = O.batch_norm(h, sd, "bn.", False)
+    h = h @ sd["lin2.weight"].t() + sd["lin2.bias"]
+    want = appnp_cpu(h)
+    err = (got - want).abs().max().item()
+    assert err < TOL, (size, err, want.abs().max().item())
+    del model, opt
+    clear_cache()
+    torch.cuda.empty_cache()
 
 
 MODEL_KW = {

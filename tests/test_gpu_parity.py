@@ -536,6 +536,102 @@ def test_loss_epilogue_with_frozen_weights(dev, name):
             assert (p.grad.cpu() - want).abs().max().item() < 2e-4 * max(1.0, want.abs().max().item()), k
 
 
+def _to_blocked(m, B):
+    """[n, d] -> [B, n, d / B]: column slices stored one after the other (the exchange layout of a partitioned run)."""
+    n, d = m.shape
+    return m.view(n, B, d // B).permute(1, 0, 2).contiguous()
+
+
+@pytest.mark.parametrize("K,n_out,B,Bo", [(128, 128, 4, 4), (128, 128, 8, 2), (64, 32, 2, 1), (48, 96, 1, 3),
+                                           (256, 256, 4, 8), (32, 160, 8, 5)])
+def test_dense_mode_and_blocked_layouts_of_the_fused_layer(dev, K, n_out, B, Bo):
+    """rgbx_fused_layer_f32 in DENSE mode (the return stage of the partitioned exchange: rows loaded, not aggregated):
+    blocked input, pre-affine with the row sums, root term from plain and from blocked rows, stored z, blocked output
+    copy, column sums and the loss epilogue — against the same arithmetic in torch (float64 accumulate)."""
+    from rgb_experiment_amd import ops
+    n = 1000 + 13  # no multiple of the 32-row tile
+    g = torch.Generator().manual_seed(K * 7 + n_out)
+    x = torch.randn(n, K, generator=g)
+    xr = torch.randn(n, K, generator=g)
+    W = torch.randn(n_out, K, generator=g) / K ** 0.5
+    Wr = torch.randn(n_out, K, generator=g) / K ** 0.5
+    b = torch.randn(n_out, generator=g)
+    s_, t_ = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    rowsum = torch.rand(n, generator=g)
+    z_want = x * s_ + t_ * rowsum[:, None]
+    root_want = xr * s_ + t_
+    out_want = (z_want.double() @ W.double().t() + b.double()).float()
+    out_root_want = (z_want.double() @ W.double().t() + root_want.double() @ Wr.double().t() + b.double()).float()
+    d = lambda t: t.to(dev)
+    xb = _to_blocked(d(x), B)
+    ob = torch.empty((Bo, n, n_out // Bo), device=dev)
+    out, z, cs = ops.fused_layer(xb, d(W).t().contiguous(), bias=d(b), pre=(d(s_), d(t_), d(rowsum)), want_z=True,
+                                 want_colsums=True, out_blocked=ob)
+    assert (out.cpu() - out_want).abs().max().item() < 1e-4
+    assert (z.cpu() - z_want).abs().max().item() < 1e-5
+    assert torch.equal(ob.permute(1, 0, 2).reshape(n, n_out), out)  # the blocked copy holds the same numbers
+    want_cs = torch.stack([out.double().sum(0), (out.double() ** 2).sum(0)]).cpu()
+    assert (cs.cpu() - want_cs).abs().max().item() < 1e-3 * max(1.0, want_cs.abs().max().item()) * 1e-2
+    assert torch.equal(ops.blocked_to_rows(ob), out)
+    # blocked output only, plain input, no pre-affine: the plain product (dy W of the backward pass)
+    ob2 = torch.empty_like(ob)
+    out2, z2, _ = ops.fused_layer(d(x), d(W).t().contiguous(), want_out=False, out_blocked=ob2)
+    assert out2 is None and z2 is None
+    want2 = (x.double() @ W.double().t()).float()
+    assert (ob2.permute(1, 0, 2).reshape(n, n_out).cpu() - want2).abs().max().item() < 1e-4
+    if n_out <= 256:  # root term, rows plain and blocked, same pre-affine
+        for xr_arg in (d(xr), _to_blocked(d(xr), B)):
+            out3, _, _ = ops.fused_layer(xb, d(W).t().contiguous(), bias=d(b), pre=(d(s_), d(t_), d(rowsum)),
+                                         x_root=xr_arg, wt_root=d(Wr).t().contiguous())
+            assert (out3.cpu() - out_root_want).abs().max().item() < 2e-4
+    if n_out <= 128:  # loss epilogue on the loaded tile
+        y = torch.randint(0, n_out, (n,), generator=g)
+        y[5] = -1
+        mask = torch.rand(n, generator=g) < 0.7
+        scale = ops.mask_scale(d(y), d(mask), n_out)
+        dl, _, stats = ops.fused_layer(xb, d(W).t().contiguous(), bias=d(b), pre=(d(s_), d(t_), d(rowsum)),
+                                       ce=(d(y), d(mask), scale))
+        logits = out.detach().clone().requires_grad_(True)
+        loss_u, stats_u = ops.masked_ce_loss(logits, d(y), d(mask), with_stats=True)
+        loss_u.backward()
+        assert torch.equal(stats[1:], stats_u[1:]) and abs(stats[0].item() - stats_u[0].item()) < 1e-6 * stats_u[0].item()
+        assert (dl - logits.grad).abs().max().item() < 1e-7
+        _, _, stats_e = ops.fused_layer(xb, d(W).t().contiguous(), bias=d(b), pre=(d(s_), d(t_), d(rowsum)),
+                                        ce=(d(y), d(mask), None))
+        assert torch.equal(stats_e, stats)
+
+
+@pytest.mark.parametrize("K,n_out,Bo,kind", [(128, 128, 4, "gcn"), (64, 64, 2, "mean"), (32, 96, 3, "sum")])
+def test_fused_aggregate_transform_writes_the_blocked_exchange_layout(dev, K, n_out, Bo, kind):
+    """The aggregating form with a blocked output (a partitioned run's producer writes straight into its send
+    buffer): same numbers as the row-major launch, with and without the row-major copy, root term from blocked rows."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n = 2000 + 7
+    ei = rand_graph(n, 24000, 31, loops=4, dups=5)
+    gph = Graph(ei.to(dev), n, {"gcn": 1, "mean": 2, "sum": 0}[kind])
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, K, generator=g).to(dev)
+    W = (torch.randn(n_out, K, generator=g) / K ** 0.5).to(dev)
+    Wr = (torch.randn(n_out, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(n_out, generator=g).to(dev)
+    w = gph.w if kind == "gcn" else None
+    rs = gph.inv_deg if kind == "mean" else None
+    ref, zref, csref = ops.spmm_linear_raw(gph.fwd, w, rs, x, W.t().contiguous(), b, True, x, Wr.t().contiguous(),
+                                           want_colsums=True)
+    ob = torch.empty((Bo, n, n_out // Bo), device=dev)
+    out, z, cs = ops.fused_layer(x, W.t().contiguous(), csr=gph.fwd, w=w, rs=rs, bias=b, x_root=_to_blocked(x, 4),
+                                 wt_root=Wr.t().contiguous(), want_z=True, want_colsums=True, out_blocked=ob)
+    assert torch.equal(out, ref) and torch.equal(z, zref) and torch.equal(cs, csref)
+    assert torch.equal(ob.permute(1, 0, 2).reshape(n, n_out), ref)
+    ob.zero_()
+    out, _, _ = ops.fused_layer(x, W.t().contiguous(), csr=gph.fwd, w=w, rs=rs, bias=b, x_root=x,
+                                wt_root=Wr.t().contiguous(), want_out=False, out_blocked=ob)
+    assert out is None and torch.equal(ob.permute(1, 0, 2).reshape(n, n_out), ref)
+    rows = ob[:, 100:900]  # a row range of the blocked matrix keeps the block stride of its base
+    assert torch.equal(ops.blocked_to_rows(rows), ref[100:900])
+
+
 def test_spmm_epilogue_and_strides(dev):
     """a, b, y, row scale, and non-contiguous leading dimensions (column slices of wider matrices)."""
     from rgb_experiment_amd import ops
