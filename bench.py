@@ -69,6 +69,7 @@ KERNEL_OF_KIND = {
     "dist_fwd_local": "spmm_csr_kernel", "dist_fwd_remote": "spmm_csr_kernel", "dist_bwd_local": "spmm_csr_kernel",
     "dist_bwd_remote": "spmm_csr_kernel", "dist_fwd_resident": "spmm_csr_kernel",
     "dist_fwd_colshard": "spmm_csr_kernel", "dist_bwd_colshard": "spmm_csr_kernel",
+    # fused per-rank schedule (dist/stack.py): the return stage's dense launches carry no aggregation bytes
     "dist_fwd_appnp_colshard": "spmm_csr_kernel (K launches)", "dist_bwd_appnp_colshard": "spmm_csr_kernel (K launches)",
 }
 AGG_KINDS = tuple(KERNEL_OF_KIND)
@@ -657,6 +658,10 @@ def main():
                          "rows by every rank, no activation exchange)")
     ap.add_argument("--pieces", type=int, default=None, help="pieces of the outbound exchange (default 4)")
     ap.add_argument("--no-interleave", action="store_true", help="val and test forward one after the other")
+    ap.add_argument("--no-fused", action="store_true",
+                    help="N > 1: conv stacks through the modules (separate pack / GEMM / BatchNorm / loss launches) instead "
+                         "of the fused per-rank schedule of rgb_experiment_amd/dist/stack.py — the conservative setting")
+    ap.add_argument("--pieces-in", type=int, default=1, help="pieces of the inbound exchange (fused schedule)")
     ap.add_argument("--emulate-rank", type=int, default=0, metavar="P",
                     help="one GPU: rank 0's launches of a P-rank job, exchanges replaced by stand-in rows")
     ap.add_argument("--degree", choices=("uniform", "powerlaw"), default="uniform",
@@ -743,7 +748,7 @@ def main():
         t_mark = time.perf_counter()
         runner = DistRunner(model, ei, x, y, (train_mask, val_mask, test_mask), 0 if emu else rank, parts, dev,
                             lr=0.01, comm=comm_obj, backend=test_backend, exchange=args.exchange, pieces=args.pieces,
-                            interleave_evals=not args.no_interleave)
+                            interleave_evals=not args.no_interleave, fused=not args.no_fused, pieces_in=args.pieces_in)
         dgraph = runner.graphs[loops_mode]
         step = runner.epoch
         n_loc = runner.hi - runner.lo
@@ -873,7 +878,8 @@ def main():
                      "table are served by the 256 MiB Infinity Cache (at workload S all of them)"},
     }
     if parts > 1:
-        mine = {"rank": rank, "scheme": scheme, "exchange_mb_per_step": comm_obj.bytes_sent / args.steps / 1e6,
+        mine = {"rank": rank, "scheme": scheme, "fused_schedule": runner.engine is not None,
+                "exchange_mb_per_step": comm_obj.bytes_sent / args.steps / 1e6,
                 "exchanges_per_step": comm_obj.exchanges / args.steps, "aggregation_ms_per_step": agg_total_ms / args.steps,
                 # time the compute streams stood still in exchange waits (HIP events around every work.wait()): the
                 # exposed part of the exchanges, measured; RCCL runs only
@@ -890,6 +896,7 @@ def main():
             dist.all_gather_object(per_rank, mine)
         result["ranks_seen"] = len(per_rank)
         result["scheme"] = scheme
+        result["fused_schedule"] = runner.engine is not None
         result["per_rank"] = per_rank
         result["exchange_mb_per_rank_per_step"] = max(r["exchange_mb_per_step"] for r in per_rank)
         result["modelled_seconds_per_propagate"] = dgraph._choice.get(("costs", d)) or next(

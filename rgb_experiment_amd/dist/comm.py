@@ -121,6 +121,40 @@ class Comm:
         done = _TimedWait(_Done()) if send.is_cuda else _Done()  # same wrappers as the RCCL path (rehearsals run them)
         return recv, (done if self.turns is None else _TurnWork(done, self.turns))
 
+    def all_to_all_views(self, send, recv, tag=None):
+        """All-to-all of tensors where they lie: `send[q]` (contiguous, possibly empty) goes to rank q, `recv[q]`
+        (contiguous view, possibly empty) is filled by rank q's `send[self.rank]`. The same tensor may stand in several
+        slots of `send` (a column slice that several ranks need is not duplicated) and the `recv` views may be row
+        ranges of one blocked buffer (received slices land where their consumer reads them: no unpack pass).
+        RCCL: one grouped send / recv (torch.distributed.all_to_all). gloo rehearsals (no list form there): the pieces
+        are staged through one buffer each way. Returns a work object; call .wait() before reading `recv`."""
+        if self.world == 1:
+            if recv[0].numel():
+                recv[0].copy_(send[0])
+            return _Done()
+        width = max((t.size(-1) for t in send if t.numel()), default=0)
+        self.bytes_sent += sum(t.numel() for q, t in enumerate(send) if q != self.rank) * 4
+        self.exchanges += 1
+        cuda = any(t.is_cuda for t in send) or any(t.is_cuda for t in recv)
+        if self.backend == "nccl":
+            work = dist.all_to_all(list(recv), list(send), group=self.group, async_op=True)
+            work = _TimedWait(work)
+            return work if self.turns is None else _TurnWork(work, self.turns)
+        # gloo: flatten, exchange, scatter back (host-staged for device tensors)
+        sc = [t.numel() for t in send]
+        rc = [t.numel() for t in recv]
+        flat = torch.cat([t.reshape(-1) for t in send]) if sum(sc) else send[0].new_empty(0)
+        host_recv = torch.empty(sum(rc), dtype=flat.dtype)
+        dist.all_to_all_single(host_recv, flat.cpu().contiguous(), rc, sc, group=self.group)
+        off = 0
+        for t, n in zip(recv, rc):
+            if n:
+                t.copy_(host_recv[off:off + n].view(t.shape))
+            off += n
+        del width
+        done = _TimedWait(_Done()) if cuda else _Done()
+        return done if self.turns is None else _TurnWork(done, self.turns)
+
     def measure_link_gbs(self, device, mb_per_peer=16, reps=3):
         """GB/s one xGMI link carries per direction under an all-to-all (every pair busy at once), measured: `reps`
         timed all-to-alls of `mb_per_peer` MB per peer after two warm-ups; the slowest rank's time counts and all ranks
@@ -228,6 +262,29 @@ class EmulatedComm(Comm):
             recv = (send if reps == 1 else send.repeat(reps, 1))[:n_recv].clone()
             self._pool[key] = recv
         return recv, (_Done() if self.turns is None else _TurnWork(_Done(), self.turns))
+
+    def all_to_all_views(self, send, recv, tag=None):
+        """Stand-in for the view exchange: the receive views are filled ONCE per (tag, shapes) with rows being sent
+        (ordinary activations, so the kernels that consume them see ordinary values) and the bytes the busiest link
+        would carry are logged; a real exchange lands the rows by DMA at no cost in kernel time."""
+        out_b = [t.numel() * 4 for q, t in enumerate(send) if q != self.rank]
+        in_b = [t.numel() * 4 for q, t in enumerate(recv) if q != self.rank]
+        self.bytes_sent += sum(out_b)
+        self.exchanges += 1
+        self.log.append((tag, max(out_b, default=0), max(in_b, default=0)))
+        key = ("views", tag, tuple(t.data_ptr() for t in recv if t.numel()),
+               getattr(self.turns, "local", None) and getattr(self.turns.local, "me", None))
+        if key not in self._pool:
+            src = next((t for t in send if t.numel()), None)
+            for t in recv:
+                if t.numel() and src is not None:
+                    flat = src.reshape(-1)
+                    reps = -(-t.numel() // flat.numel())
+                    t.copy_((flat if reps == 1 else flat.repeat(reps))[:t.numel()].view(t.shape))
+            self._pool[key] = True
+            if len(self._pool) > 4096:
+                self._pool.clear()
+        return _Done() if self.turns is None else _TurnWork(_Done(), self.turns)
 
     def all_reduce_sum_(self, t):
         return t.mul_(self.world)  # as if every rank had contributed this rank's share

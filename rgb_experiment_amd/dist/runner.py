@@ -17,7 +17,7 @@ class DistRunner:
 
     def __init__(self, model, edge_index, x, y, masks, rank, world, device, lr=0.01, weight_decay=0.0,
                  comm=None, backend=None, exchange="auto", resident_features=True, pieces=None,
-                 interleave_evals=True):
+                 interleave_evals=True, fused=True, pieces_in=1):
         self.comm = comm or Comm()
         self.rank, self.world, self.device = rank, world, device
         N = x.size(0)
@@ -60,6 +60,14 @@ class DistRunner:
                 raise RuntimeError(f"{part} mask selects nodes with a negative label (unlabelled)")
         cnt = torch.tensor([float(m.sum()) for m in self.masks], dtype=torch.float64, device=device)
         self.mask_counts = self.comm.all_reduce_sum_(cnt).tolist()
+        # conv stacks under a column-slice exchange scheme run on the fused per-rank schedule (dist/stack.py: layer
+        # outputs written straight into send buffers, BatchNorm / transform / loss in the return stage's kernel);
+        # everything else — and `fused=False`, the conservative setting — goes through the modules
+        self.engine = None
+        if fused and not self.replicated and resident_features and world > 1:
+            from .stack import GridStack
+            self.engine = GridStack.build(self.model, self.graphs, self.comm, backend or self.graphs[0].backend, self.x,
+                                          self.y, self.masks, self.mask_counts, pieces_in=pieces_in)
 
     _REPLICABLE = {"GCNConv": 1, "SAGEConv": 0, "MySAGEConv": 2}  # conv class -> the loops mode its graph is keyed by
 
@@ -114,13 +122,16 @@ class DistRunner:
         (float64) instead of the all-reduced Python float — epoch() reduces everything once."""
         self.model.train()
         self.opt.zero_grad()
-        res = self.model(self.x_in, self.token)
-        m = self.masks[0]
-        loss = self._nll_sum(res, m) / self.mask_counts[0]
-        loss.backward()
+        if self.engine is not None:
+            part = self.engine.train_step()  # forward + backward, every parameter's .grad set
+        else:
+            res = self.model(self.x_in, self.token)
+            m = self.masks[0]
+            loss = self._nll_sum(res, m) / self.mask_counts[0]
+            loss.backward()
+            part = loss.detach().double().reshape(1)
         self._sync_grads()
         self.opt.step()
-        part = loss.detach().double().reshape(1)
         if not sync:
             return part
         return self.comm.all_reduce_sum_(part.clone()).item()
@@ -129,6 +140,8 @@ class DistRunner:
         """Eval forward + (masked NLL sum, correct count) of this rank's rows. `sync=True`: all-reduced and
         normalised Python floats (loss, accuracy, outputs); `sync=False`: the raw device tensor [2] and outputs."""
         self.model.eval()
+        if self.engine is not None and not sync:
+            return self.engine.eval_stats(which), None  # loss statistics straight from the last layer's kernel
         with torch.no_grad():
             res = self.model(self.x_in, self.token)
         m = self.masks[which]

@@ -1,0 +1,328 @@
+"""Conv-stack models (GCN / GraphSAGE / GraphSAGE2: reference models/gcn.py:25-31, graphsage.py:26-32,
+graphsage2.py:27-33) on a node partition, with the single-GPU fusions carried over to the row-group x column-slice
+exchange (DistGraph "gridRxC" / "reshard"). New capability — the reference is single-device (itexperiments.py:246);
+the arithmetic of every layer is the one of rgb_experiment_amd.nn.conv / ops, only WHERE each piece runs differs.
+
+What a rank runs per training step of an L-layer stack (layer 0 on the resident input features, layers >= 1
+exchanged; no pack / unpack pass anywhere):
+
+  layer 0   ONE rgbx_fused_layer_f32 launch over the [local; halo] CSR: aggregate + transform (+ root term), the raw
+            output h_0 written row-major (BatchNorm's backward reads it) AND blocked — column slice by column slice —
+            straight into the send buffer of the next layer's exchange; the aggregate z_0 stored for dW_0; the column
+            sums of h_0 (BatchNorm statistics) from the MFMA tiles. The [2, d] sums are all-reduced, one finalize launch.
+  layer i   inbound all-to-all of the RAW slices (BatchNorm is applied by the consumer, by linearity of the
+            aggregation) -> one rgbx_spmm_csr_f32 launch per outbound piece over the row group's rows at slice
+            width, each into its send buffer, its all-to-all in flight while the next piece is aggregated; the pieces
+            land directly in a blocked [C, n_local, d/C] buffer ->
+            ONE rgbx_fused_layer_f32 launch in DENSE mode (the return stage): loads the 32-row tiles from the
+            received slices, applies z = s * u + t * rowsum(P) (BatchNorm of the layer's input), stores z_i (dW_i),
+            multiplies by W_i on the MFMA units, adds the root term from h_{i-1}, and — last layer — turns the
+            logits tile into the masked cross-entropy statistics and the loss gradient; middle layers write h_i
+            row-major + blocked and take its column sums.
+  backward  per exchanged layer: dW_i = dy^T z_i (+ column sums = db_i) on rgbx_gemm_tn_f32; q = dy W_i written blocked
+            into the send buffer by a DENSE launch; exchange + transposed SpMM pieces + return; the received slices are
+            turned into rows once (rgbx_blocked_to_rows_f32) for BatchNorm's backward kernels (all-reduce of [2, d]);
+            layer 0: dW_0 = g^T z_0.
+An eval forward folds every BatchNorm into the preceding layer's weights and writes no row-major activation at all
+(layer outputs exist only as send buffers); the last launch returns the loss statistics, no logits.
+
+Every exchange moves views (Comm.all_to_all_views: grouped send / recv of the slices where they lie), so the same
+slice buffer serves the R ranks that need it without being duplicated.
+"""
+import torch
+
+from ..nn import batchnorm as B
+from .plan import partition_bounds
+
+
+class HipStackBackend:
+    """Product compute backend of GridStack: rgbx_fused_layer_f32, rgbx_spmm_csr_f32, rgbx_gemm_tn_f32,
+    rgbx_blocked_to_rows_f32 (through rgb_experiment_amd.ops). `agg` = the HipAggregator the DistGraph was built with."""
+
+    def __init__(self, agg):
+        self.agg = agg
+
+    def layer(self, x, wt, handle=None, rows=None, **kw):
+        """ops.fused_layer with `handle` = (csr, per-slot weights) of DistGraph.backend.prepare; `rows` = (lo, hi)
+        restricts an aggregating launch to that row range of the CSR (the outputs then have hi - lo rows)."""
+        from .. import graph as G
+        from .. import ops
+        csr = w = None
+        if handle is not None:
+            csr, w = handle
+            if rows is not None:
+                if csr.split is not None:
+                    raise RuntimeError("row ranges of a CSR with a hub-row plan are not supported")
+                lo, hi = rows
+                csr = G.CSR(csr.rowptr[lo:hi + 1], csr.col, csr.perm, hi - lo, csr.nnz, None)
+        return ops.fused_layer(x, wt, csr=csr, w=w, **kw)
+
+    def run_rows(self, handle, x, lo, hi, out, kind):
+        return self.agg.run_rows(handle, x, lo, hi, out, kind=kind)
+
+    def run(self, handle, x, kind):
+        return self.agg.run(handle, x, kind=kind)
+
+    def gemm_tn(self, a, b, colsum=False):
+        from .. import ops
+        return ops.gemm_tn(a, b, colsum=colsum)
+
+    def blocked_to_rows(self, blk):
+        from .. import ops
+        return ops.blocked_to_rows(blk)
+
+
+class LayerSpec:
+    """What GridStack needs of one conv layer: aggregation kind, rewrite mode, the parameters and how they enter
+    out = (P x) W^T + sum(biases) (+ x Wr^T)."""
+
+    def __init__(self, conv):
+        from ..graph import LOOPS_ADD_REMAINING, LOOPS_KEEP, LOOPS_REMOVE_ADD
+        name = type(conv).__name__
+        self.d_in, self.d_out = conv.in_channels, conv.out_channels
+        if name == "GCNConv":
+            self.kind, self.mode = "gcn", LOOPS_ADD_REMAINING
+            self.W, self.biases, self.Wr = conv.lin.weight, [conv.bias], None
+        elif name == "SAGEConv":
+            self.kind, self.mode = "mean", LOOPS_KEEP
+            self.W, self.biases, self.Wr = conv.lin_l.weight, [conv.lin_l.bias], conv.lin_r.weight
+        elif name == "MySAGEConv" and conv.add_self_loops:
+            self.kind, self.mode = "mean", LOOPS_REMOVE_ADD
+            self.W, self.biases, self.Wr = conv.lin_l.weight, [conv.lin_l.bias, conv.lin_r.bias], conv.lin_r.weight
+        else:
+            raise TypeError(name)
+
+    def bias(self):
+        b = self.biases[0].detach()
+        for extra in self.biases[1:]:
+            b = b + extra.detach()
+        return b
+
+
+def _supported(K, n_out, root):
+    return K >= 4 and K % 4 == 0 and K <= 256 and n_out >= 32 and n_out % 32 == 0 and (not root or n_out <= 256)
+
+
+class GridStack:
+    """See the module docstring. Built by `GridStack.build` (None when the model / scheme / widths do not fit; the
+    caller then runs the generic module path, which is what every other model uses)."""
+
+    @classmethod
+    def build(cls, model, graphs, comm, backend, x_local, y, masks, mask_counts, pieces_in=1):
+        convs, bns = getattr(model, "convs", None), getattr(model, "bns", None)
+        if comm.world < 2 or convs is None or bns is None or len(convs) < 2 or len(bns) != len(convs) - 1:
+            return None
+        try:
+            specs = [LayerSpec(c) for c in convs]
+        except TypeError:
+            return None
+        if len({s.mode for s in specs}) != 1 or len({s.kind for s in specs}) != 1:
+            return None
+        from .nn import DistBatchNorm1d
+        if not all(isinstance(b, DistBatchNorm1d) and b.affine and b.track_running_stats for b in bns):
+            return None
+        stack_be = getattr(backend, "stack_backend", None)
+        if stack_be is None:
+            from .graph import HipAggregator
+            if not (isinstance(backend, HipAggregator) and x_local.is_cuda):
+                return None
+            stack_be = HipStackBackend(backend)
+        else:
+            stack_be = stack_be()
+        dg = graphs[specs[0].mode]
+        first = specs[0]
+        if not (dg.is_resident(x_local) and first.d_in <= first.d_out
+                and _supported(first.d_in, first.d_out, first.Wr is not None)):
+            return None
+        shapes = []
+        for i, s in enumerate(specs[1:], start=1):
+            shape = dg.shape(s.d_in)
+            if shape is None:  # halo scheme for this width
+                return None
+            dc = s.d_in // shape[1]
+            if s.d_in % shape[1] or dc % 4 or not _supported(s.d_in, s.d_out, s.Wr is not None):
+                return None
+            if not _supported(s.d_out, s.d_in, False):  # q = dy W of the backward pass, on the same kernel
+                return None
+            shapes.append(shape)
+        if specs[-1].d_out > 128:  # the loss epilogue's limit
+            return None
+        return cls(model, specs, bns, dg, shapes, comm, stack_be, x_local, y, masks, mask_counts, pieces_in)
+
+    def __init__(self, model, specs, bns, dg, shapes, comm, be, x_local, y, masks, mask_counts, pieces_in):
+        self.model, self.specs, self.bns, self.dg, self.comm, self.be = model, specs, list(bns), dg, comm, be
+        self.shapes = [None] + shapes  # per layer: (R, C) of its exchange
+        self.x, self.y, self.masks = x_local, y, masks
+        self.n_loc, self.N, self.P = dg.n_local, dg.N_global, comm.world
+        self.bounds = partition_bounds(self.N, self.P)
+        dev = x_local.device
+        self.grad_scale = torch.tensor([1.0 / mask_counts[0]], dtype=torch.float32, device=dev)
+        self.mask_counts = mask_counts
+        self.pieces_in = max(1, int(pieces_in))
+        self._rowsum = None
+
+    # ---- structures ------------------------------------------------------------------------------------------
+    def _first(self):
+        """([local; halo] CSR handle, the resident extended feature matrix) of layer 0."""
+        kind = self.specs[0].kind
+        handle, half = self.dg._ext_csr(kind)
+        return handle, self.dg._resident_ext(self.x, half, kind)
+
+    def rowsum(self):
+        """Per own target row the sum of its aggregation weights (what a constant column contributes to the
+        aggregate): the consumer needs it to push BatchNorm's shift through the aggregation."""
+        if self._rowsum is None:
+            handle, x_ext = self._first()
+            ones = torch.ones((x_ext.size(0), 1), dtype=torch.float32, device=x_ext.device)
+            self._rowsum = self.be.run(handle, ones, kind="rowsum").reshape(-1).contiguous()
+        return self._rowsum
+
+    def _blocked_buffer(self, i, rows=None):
+        """Send / receive buffer of layer i's exchange: [C, rows, d_in / C]."""
+        C = self.shapes[i][1]
+        return torch.empty((C, self.n_loc if rows is None else rows, self.specs[i].d_in // C), dtype=torch.float32,
+                           device=self.x.device)
+
+    # ---- the exchange ----------------------------------------------------------------------------------------
+    def _inbound(self, i, blk, lo=0, hi=None, cols=None):
+        """Column slice c of every node's rows [cut(n_q, lo piece), ...) -> `cols` [N, dc]; returns (cols, work)."""
+        R, C = self.shapes[i]
+        P, b = self.P, self.bounds
+        dc = blk.size(2)
+        if cols is None:
+            cols = torch.empty((self.N, dc), dtype=torch.float32, device=blk.device)
+        send = [blk[q % C] for q in range(P)]
+        recv = [cols[b[q]:b[q + 1]] for q in range(P)]
+        return cols, self.comm.all_to_all_views(send, recv, tag="in")
+
+    def _propagate(self, i, direction, blk):
+        """The exchanged aggregation of layer i: blocked rows of this rank in, blocked aggregated rows of this rank
+        out (u[c', r, :] = column slice c' of own row r of P x, or of P^T x for direction "bwd")."""
+        R, C = self.shapes[i]
+        d = self.specs[i].d_in
+        dg, P = self.dg, self.P
+        half, handle = dg._grid_half(self.specs[i].kind, C, dg.pieces_for(d), direction)
+        cols, work = self._inbound(i, blk)
+        work.wait()
+        dc = blk.size(2)
+        u = self._blocked_buffer(i)
+        empty = u[0, 0:0]
+        tag = f"dist_{direction}_colshard"
+        pending, full = [], None
+        for k in range(half.pieces):
+            lo, hi = half.piece_ptr[k], half.piece_ptr[k + 1]
+            send = None
+            if full is None:
+                send = cols.new_empty((hi - lo, dc))
+                if self.be.run_rows(handle, cols, lo, hi, send, tag) is False:
+                    if pending:
+                        raise RuntimeError("grid exchange: backend refused a row range after accepting one")
+                    send = None
+            if send is None:  # hub-row plan (row ids in it are absolute)
+                if full is None:
+                    full = self.be.run(handle, cols, tag)
+                send = full[lo:hi]
+            a, b = half.my_piece[k]
+            sv, rv, off = [], [], 0
+            for q in range(P):
+                cnt = half.piece_counts[k][q]
+                sv.append(send[off:off + cnt])
+                off += cnt
+                rv.append(u[q % C, a:b] if q in half.members else empty)
+            pending.append((self.comm.all_to_all_views(sv, rv, tag=f"out {k + 1}/{half.pieces}"), send))
+        for w, _send in pending:  # `_send` stays referenced until its exchange was waited on
+            w.wait()
+        return u
+
+    # ---- training step -----------------------------------------------------------------------------------------
+    def train_step(self):
+        """Forward + backward of one training step; leaves every parameter's .grad set (this rank's share) and
+        returns this rank's share of the loss as a float64 device tensor [1]."""
+        S, be = self.specs, self.be
+        L = len(S)
+        wt = lambda w: w.detach().t().contiguous()
+        handle, x_ext = self._first()
+        s0 = S[0]
+        blk = self._blocked_buffer(1)
+        h, z, cs = be.layer(x_ext, wt(s0.W), handle=handle, bias=s0.bias(), x_root=self.x if s0.Wr is not None else None,
+                            wt_root=None if s0.Wr is None else wt(s0.Wr), want_z=True, want_colsums=True,
+                            out_blocked=blk, kind=f"{s0.kind}_linear_fwd")
+        saved = [(z, None, None)]
+        dl = None
+        for i in range(1, L):
+            sp, bn = S[i], self.bns[i - 1]
+            stats = B.train_statistics(h, bn.weight, bn.bias, bn.eps, bn._reducer(h), bn.begin_training_step(), cs)
+            mean, rstd, scale, shift, n = stats
+            u = self._propagate(i, "fwd", blk)
+            pre = (scale, shift, self.rowsum())
+            root = dict(x_root=h, wt_root=wt(sp.Wr)) if sp.Wr is not None else {}
+            if i == L - 1:
+                dl, z, ce = be.layer(u, wt(sp.W), bias=sp.bias(), pre=pre, want_z=True,
+                                     ce=(self.y, self.masks[0], self.grad_scale), kind="return_linear_fwd", **root)
+                saved.append((z, h, stats))
+            else:
+                blk = self._blocked_buffer(i + 1)
+                h_next, z, cs = be.layer(u, wt(sp.W), bias=sp.bias(), pre=pre, want_z=True, want_colsums=True,
+                                         out_blocked=blk, kind="return_linear_fwd", **root)
+                saved.append((z, h, stats))
+                h = h_next
+        loss_part = (ce[0] / self.mask_counts[0]).reshape(1)
+        # ---- backward
+        dy = dl
+        for i in range(L - 1, 0, -1):
+            sp, bn = S[i], self.bns[i - 1]
+            z, h_prev, (mean, rstd, scale, shift, n) = saved[i]
+            gw, gcol = be.gemm_tn(dy, z, colsum=True)
+            sp.W.grad = gw
+            for b in sp.biases:
+                b.grad = gcol if b is sp.biases[0] else gcol.clone()
+            if sp.Wr is not None:  # dWr = dy^T BN(h) = (dy^T h) diag(s) + colsum(dy) t^T
+                sp.Wr.grad = be.gemm_tn(dy, h_prev) * scale + gcol[:, None] * shift
+            q = self._blocked_buffer(i)
+            be.layer(dy, sp.W.detach().contiguous(), want_out=False, out_blocked=q, kind="return_linear_bwd")
+            v = self._propagate(i, "bwd", q)
+            g_a = be.blocked_to_rows(v)
+            if sp.Wr is not None:
+                g_a.addmm_(dy, sp.Wr.detach())
+            dy, g_bnw, g_bnb = B.train_backward(g_a, h_prev, bn.weight, mean, rstd, n, bn._reducer(h_prev))
+            bn.weight.grad, bn.bias.grad = g_bnw, g_bnb
+        z0 = saved[0][0]
+        gw, gcol = be.gemm_tn(dy, z0, colsum=True)
+        s0.W.grad = gw
+        for b in s0.biases:
+            b.grad = gcol if b is s0.biases[0] else gcol.clone()
+        if s0.Wr is not None:
+            s0.Wr.grad = be.gemm_tn(dy, self.x)
+        return loss_part
+
+    # ---- eval forward ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def eval_stats(self, which):
+        """[masked NLL sum, correct count] (float64 device tensor) of this rank's rows under masks[which], eval mode:
+        every BatchNorm folded into the preceding layer's weights, no row-major activation written, no logits."""
+        S, be = self.specs, self.be
+        L = len(S)
+        handle, x_ext = self._first()
+        prev_blk = None
+        for i in range(L):
+            sp = S[i]
+            W, b, Wr = sp.W.detach(), sp.bias(), None if sp.Wr is None else sp.Wr.detach()
+            if i < L - 1:
+                scale, shift = self.bns[i].eval_affine()
+                W, b = W * scale[:, None], b * scale + shift
+                Wr = None if Wr is None else Wr * scale[:, None]
+            wt, wtr = W.t().contiguous(), None if Wr is None else Wr.t().contiguous()
+            if i == 0:
+                blk = self._blocked_buffer(1)
+                be.layer(x_ext, wt, handle=handle, bias=b, x_root=self.x if Wr is not None else None, wt_root=wtr,
+                         want_out=False, out_blocked=blk, kind=f"{sp.kind}_linear_fwd")
+                prev_blk = blk
+                continue
+            u = self._propagate(i, "fwd", prev_blk)
+            root = dict(x_root=prev_blk, wt_root=wtr) if Wr is not None else {}
+            if i == L - 1:
+                _, _, st = be.layer(u, wt, bias=b, ce=(self.y, self.masks[which], None), kind="return_linear_fwd", **root)
+                return st[[0, 2]]
+            blk = self._blocked_buffer(i + 1)
+            be.layer(u, wt, bias=b, want_out=False, out_blocked=blk, kind="return_linear_fwd", **root)
+            prev_blk = blk

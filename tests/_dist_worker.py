@@ -57,6 +57,86 @@ class OracleAggregator:
         return out.reshape(n_tgt, H * C)
 
 
+def _rows_of(blocked):
+    """[B, n, cols] blocked -> [n, B * cols]."""
+    return blocked.permute(1, 0, 2).reshape(blocked.size(1), -1)
+
+
+def _store_blocked(dst, rows):
+    B, n, c = dst.shape
+    dst.copy_(rows.view(n, B, c).permute(1, 0, 2))
+
+
+class TorchStackBackend:
+    """What dist.stack.HipStackBackend computes (rgbx_fused_layer_f32 & co.), in plain torch on the CPU, with the
+    aggregation from the oracle: the checker of GridStack's host logic (layouts, exchange views, manual backward)."""
+
+    def __init__(self, agg):
+        self.agg = agg
+
+    def layer(self, x, wt, handle=None, rows=None, bias=None, x_root=None, wt_root=None, pre=None, want_out=True,
+              out_blocked=None, want_z=False, want_colsums=False, ce=None, kind=None):
+        if x.dim() == 3:
+            assert handle is None
+            x = _rows_of(x)
+        z = x if handle is None else self.agg.run(handle, x)
+        if rows is not None:
+            z = z[rows[0]:rows[1]]
+        if pre is not None:
+            scale, shift, rowsum = pre
+            z = z * scale + shift * rowsum[:, None]
+        out = z @ wt
+        if bias is not None:
+            out = out + bias
+        if wt_root is not None:
+            xr = _rows_of(x_root) if x_root.dim() == 3 else x_root
+            if pre is not None:
+                xr = xr * pre[0] + pre[1]
+            out = out + xr @ wt_root
+        extra = None
+        if want_colsums:
+            od = out.double()
+            extra = torch.stack([od.sum(0), (od * od).sum(0)])
+        if out_blocked is not None:
+            _store_blocked(out_blocked, out)
+        if ce is not None:
+            y, mask, grad_scale = ce
+            sel = (y >= 0) & (y < out.size(1))
+            if mask is not None:
+                sel = sel & mask.bool()
+            logp = torch.log_softmax(out, dim=1)
+            nll = -logp[sel, y[sel]].double().sum()
+            hits = (out[sel].argmax(1) == y[sel]).sum().double()
+            extra = torch.stack([nll, sel.sum().double(), hits])
+            if grad_scale is None:
+                out = None
+            else:
+                g = torch.zeros_like(out)
+                g[sel] = (torch.softmax(out[sel], dim=1) - torch.nn.functional.one_hot(y[sel], out.size(1))) * grad_scale
+                out = g
+        return (out if want_out or ce is not None else None), (z.contiguous() if want_z else None), extra
+
+    def run_rows(self, handle, x, lo, hi, out, kind):
+        return self.agg.run_rows(handle, x, lo, hi, out, kind)
+
+    def run(self, handle, x, kind):
+        return self.agg.run(handle, x)
+
+    def gemm_tn(self, a, b, colsum=False):
+        out = a.t() @ b
+        return (out, a.sum(0)) if colsum else out
+
+    def blocked_to_rows(self, blk):
+        return _rows_of(blk).contiguous()
+
+
+def _stack_backend(self):
+    return TorchStackBackend(self)
+
+
+OracleAggregator.stack_backend = _stack_backend
+
+
 def make_problem(n=97, e=900, f=12, c=5, seed=0):
     g = torch.Generator().manual_seed(seed)
     ei = torch.randint(0, n, (2, e), generator=g)
@@ -127,7 +207,8 @@ def reshard_chunk_worker(rank, world, port, out_dir, exchange="reshard"):
     dist.destroy_process_group()
 
 
-def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", interleave=True, release=False):
+def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", interleave=True, release=False, fused=True,
+                  pieces=None):
     """Three epochs of DistRunner (train + evals) — compared by the test with single-process training."""
     _init(rank, world, port)
     from rgb_experiment_amd import models as M
@@ -136,12 +217,20 @@ def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", inter
     torch.manual_seed(14530529)
     model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
     r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
-                   backend=OracleAggregator(), exchange=exchange, interleave_evals=interleave)
+                   backend=OracleAggregator(), exchange=exchange, interleave_evals=interleave, fused=fused,
+                   pieces=pieces)
     hist = [r.epoch()]
     if release:  # every structure exists after one epoch: the global edge list may go
         r.release_edge_list()
     hist += [r.epoch() for _ in range(2)]
-    torch.save({"hist": hist, "logits_eval": r.logits(False), "lo": r.lo, "hi": r.hi,
+    both = None
+    if r.engine is not None:  # the same weights through the fused schedule and through the modules
+        eng = [r.engine.eval_stats(w) for w in (1, 2)]
+        engine, r.engine = r.engine, None
+        both = (eng, [r.evaluate(w, sync=False)[0] for w in (1, 2)])
+        r.engine = engine
+    torch.save({"hist": hist, "logits_eval": r.logits(False), "lo": r.lo, "hi": r.hi, "engine": r.engine is not None,
+                "eval_both": both,
                 "state": {k: v.clone() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"run_{model_name}_{rank}.pt"))
     dist.destroy_process_group()
@@ -206,6 +295,10 @@ def build_model(M, name, f, c):
     if name.endswith("_wide"):  # in <= hidden, hidden % 32 == 0: the first conv takes the fused / resident route
         cls = {"gcn_wide": M.GCN, "graphsage_wide": M.GraphSAGE, "graphsage2_wide": M.GraphSAGE2}[name]
         return cls(num_layers=2, hidden_unit=64, input_dim=f, output_dim=c, dropout_rate=0.5)
+    if name.endswith("_grid"):  # widths the fused per-rank schedule takes (dist/stack.py): hidden 96, 32 logits
+        cls, layers = {"gcn_grid": (M.GCN, 2), "gcn3_grid": (M.GCN, 3), "graphsage_grid": (M.GraphSAGE, 2),
+                       "graphsage2_grid": (M.GraphSAGE2, 3)}[name]
+        return cls(num_layers=layers, hidden_unit=96, input_dim=f, output_dim=32, dropout_rate=0.5)
     if name == "gcn":
         return M.GCN(num_layers=3, hidden_unit=16, input_dim=f, output_dim=c, dropout_rate=0.5)
     if name == "graphsage":
@@ -232,6 +325,7 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo"):
     r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm(), exchange=exchange)
     hist = [r.epoch() for _ in range(2)]
     torch.cuda.synchronize()
-    torch.save({"hist": hist, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi},
+    torch.save({"hist": hist, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi,
+                "engine": r.engine is not None},
                os.path.join(out_dir, f"gpu_{model_name}_{rank}.pt"))
     dist.destroy_process_group()

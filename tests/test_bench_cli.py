@@ -52,6 +52,8 @@ def test_bench_gpus_n_launches_its_own_ranks(gpus, exchange, scheme):
                                      "first_epoch_plans_and_csr_build_s"}
         assert r["exposed_exchange_ms_per_step"] >= 0
     assert "link_gbs_measured" in res and "small_all_to_all_us_measured" in res  # None on gloo, measured on RCCL
+    # conv stacks under a column-slice scheme run the fused per-rank schedule (dist/stack.py)
+    assert res["fused_schedule"] == (scheme in ("reshard", "grid2x2"))
     assert res["median_ms_per_step"] > 0
 
 
@@ -60,15 +62,15 @@ def test_a_failing_or_stalled_rank_ends_in_a_line_from_fresh_conservative_ranks(
     """A rank of the first attempt hangs (no milestone within the stall limit) or raises: the supervisors kill that
     attempt's workers and start FRESH ones with the conservative flags; the line that comes out says which attempt
     produced it and why the first one was given up."""
-    proc = _run(["--gpus", "2", "--workload", "T", "--steps", "2", "--warmup", "1", "--exchange", "2x1"],
+    proc = _run(["--gpus", "2", "--workload", "T", "--steps", "2", "--warmup", "1", "--exchange", "reshard"],
                 extra_env={"RGBX_TEST_FAULT": fault, "RGBX_LAUNCH_STALL_S": "8", "RGBX_LAUNCH_DEADLINE_S": "120"})
     assert proc.returncode == 0, proc.stderr[-3000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, proc.stdout
     res = json.loads(lines[0])
     la = res["launcher"]
-    assert la["attempt"] == 1 and la["extra_flags"] == ["--no-interleave", "--pieces", "1", "--exchange", "reshard"]
-    assert res["scheme"] == "reshard" and res["ranks_seen"] == 2 and res["value"] > 0
+    assert la["attempt"] == 1 and la["extra_flags"] == ["--no-fused", "--no-interleave", "--pieces", "1"]
+    assert res["scheme"] == "reshard" and res["ranks_seen"] == 2 and res["value"] > 0 and not res["fused_schedule"]
     failed = la["fallback"]["failed"]
     assert len(failed) == 1 and failed[0]["attempt"] == 0
     if fault.startswith("stall:0"):

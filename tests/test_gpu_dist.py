@@ -55,11 +55,19 @@ def _single_gpu(model_name):
                                                         # dist.ReplicaGraph: first layer on all rows by every rank,
                                                         # second on the rectangular CSR, fused kernels, no exchange
                                                         ("gcn_wide", 2, "replicate"), ("graphsage_wide", 3, "replicate"),
-                                                        ("graphsage2_wide", 2, "replicate")])
+                                                        ("graphsage2_wide", 2, "replicate"),
+                                                        # the fused per-rank schedule (dist/stack.py GridStack): layer
+                                                        # outputs blocked into the send buffers, BatchNorm / transform /
+                                                        # loss in the return stage's DENSE launch, manual backward
+                                                        ("gcn_grid", 2, "reshard"), ("gcn_grid", 4, "2x2"),
+                                                        ("gcn3_grid", 3, "reshard"), ("graphsage_grid", 4, "2x2"),
+                                                        ("graphsage2_grid", 2, "reshard"), ("gcn_grid", 4, "auto")])
 def test_partitioned_hip_run_matches_single_gpu(model_name, world, exchange, tmp_path):
     mp.spawn(W.gpu_runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange), nprocs=world,
              join=True)
     parts = [torch.load(os.path.join(tmp_path, f"gpu_{model_name}_{r}.pt")) for r in range(world)]
+    if model_name.endswith("_grid") and exchange != "auto":
+        assert all(p["engine"] for p in parts), "the fused schedule was not taken"
     hist, emb = _single_gpu(model_name)
     # Train-mode quantities (batch statistics) are well conditioned: compare tightly. Eval-mode ones
     # are not: a conv bias in front of a BatchNorm has a true gradient of exactly zero, Adam turns its
