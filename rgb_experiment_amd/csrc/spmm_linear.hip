@@ -135,7 +135,9 @@ template <bool BLK>
 __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __restrict__ bias,
                                            float* __restrict__ out, int64_t ldo, int row_base, int N, int n0,
                                            int kr, int cc, float* __restrict__ stats_part = nullptr, int Nout = 0,
-                                           float* __restrict__ out_blk = nullptr, int64_t ob_c = 0, int64_t ob_s = 0) {
+                                           float* __restrict__ out_blk = nullptr, int64_t ob_c = 0, int64_t ob_s = 0,
+                                           int tile = -1) {
+  if (tile < 0) tile = blockIdx.x;  // one tile per workgroup unless the caller walks several
   const float bb = bias ? bias[n0 + cc] : 0.f;
   float s1 = 0.f, s2 = 0.f;
   // blocked copy: this lane's column n0 + cc sits in block (n0 + cc) / ob_c at offset (n0 + cc) % ob_c
@@ -155,7 +157,7 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __res
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
     if (kr == 0) {
-      float* rec = stats_part + (int64_t)blockIdx.x * 2 * Nout;
+      float* rec = stats_part + (int64_t)tile * 2 * Nout;
       rec[n0 + cc] = s1;
       rec[Nout + n0 + cc] = s2;
     }
@@ -206,7 +208,8 @@ constexpr int kStatsGather = 1024;  // workgroups of the second stage
 // lane + 64, max / first arg-max / sum-exp go through the wave with shuffles. NLLLoss(log_softmax(z))_i = lse_i - z[i, y_i]
 // as rgbx_masked_ce_fwd_f32 computes it; the gradient as rgbx_masked_ce_bwd_f32.
 __device__ __forceinline__ void ce_epilogue(const FusedArgs& A, const f32x16& acc, float* __restrict__ ot, int row_base,
-                                            int wave, int lane) {
+                                            int wave, int lane, int tile = -1) {
+  if (tile < 0) tile = blockIdx.x;
   const int kr = lane >> 5, cc = lane & 31;
   const int ldq = A.Nout + 4;
   const int n0 = wave * 32;
@@ -265,7 +268,7 @@ __device__ __forceinline__ void ce_epilogue(const FusedArgs& A, const f32x16& ac
   __syncthreads();
   if (threadIdx.x < 3) {
     const int k = threadIdx.x;
-    A.ce_part[(int64_t)blockIdx.x * 3 + k] = (cew[0][k] + cew[1][k]) + (cew[2][k] + cew[3][k]);
+    A.ce_part[(int64_t)tile * 3 + k] = (cew[0][k] + cew[1][k]) + (cew[2][k] + cew[3][k]);
   }
 }
 
@@ -551,6 +554,127 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
   }
 }
 
+// The DENSE form for the widths a partitioned run lives on (K = 64 / 128), as a STREAMING kernel: a workgroup walks
+// many 32-row tiles and keeps its waves' W^T fragments in registers (K / 2 values per lane and 32-column tile; the
+// root term's Wr^T likewise), so W is read once per workgroup instead of once per tile — the per-tile 4-byte L2
+// fetches are what held the one-tile-per-workgroup form at 0.12-0.20 ms for 250 k rows against 0.05 ms of streaming.
+// Same tile loads, epilogues (blocked store, column sums, loss) and numbers as spmm_linear_kernel<.., DENSE>.
+template <int KC, int NT, bool CE, bool ROOT>
+__global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE ? 3 : 4)) dense_stream_kernel(const FusedArgs A, int tiles) {
+  extern __shared__ float zt[];  // [TM][KC + 4] (the loss epilogue re-uses it as [TM][Nout + 4])
+  constexpr int K = KC, ldz = KC + 4, k4 = KC / 4, S = KC / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kr = lane >> 5, cc = lane & 31;
+  float breg[NT][S];
+  float rreg[ROOT ? NT : 1][ROOT ? S : 1];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    const int n0 = wave * 32 + tt * 128;
+    if (n0 < A.Nout) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        breg[tt][i] = A.wt[(int64_t)(2 * i + kr) * A.Nout + n0 + cc];
+        if constexpr (ROOT) rreg[tt][i] = A.wtr[(int64_t)(2 * i + kr) * A.Nout + n0 + cc];
+      }
+    }
+  }
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int row_base = tile * TM;
+    for (int idx = threadIdx.x; idx < TM * k4; idx += 256) {
+      const int r = idx / k4, c4 = (idx - r * k4) * 4;
+      const int row = row_base + r;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (row < A.N) {
+        load_vec<4>(v, blocked_at(A.x, A.x_bc, A.x_bs, A.ldx, row, c4));
+        if (A.pre_scale) {
+          float ps[4], pt[4];
+          load_vec<4>(ps, A.pre_scale + c4);
+          load_vec<4>(pt, A.pre_shift + c4);
+          const float rsum = A.pre_rowsum[row];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fmaf(v[i], ps[i], pt[i] * rsum);
+        }
+        if (A.z_out) store_vec<4>(A.z_out + (int64_t)row * A.ldz + c4, v);
+      }
+      store_vec<4>(&zt[r * ldz + c4], v);
+    }
+    __syncthreads();
+    f32x16 acc[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+      if (wave * 32 + tt * 128 < A.Nout) {
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+          acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zt[cc * ldz + 2 * i + kr], breg[tt][i], acc[tt], 0, 0, 0);
+      }
+    }
+    if constexpr (ROOT) {
+      __syncthreads();  // every wave is done reading the loaded tile
+      for (int idx = threadIdx.x; idx < TM * k4; idx += 256) {
+        const int r = idx / k4, c4 = (idx - r * k4) * 4;
+        const int row = row_base + r;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row < A.N) {
+          load_vec<4>(v, blocked_at(A.xr, A.xr_bc, A.xr_bs, A.ldr, row, c4));
+          if (A.pre_scale) {
+            float ps[4], pt[4];
+            load_vec<4>(ps, A.pre_scale + c4);
+            load_vec<4>(pt, A.pre_shift + c4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaf(v[i], ps[i], pt[i]);
+          }
+        }
+        store_vec<4>(&zt[r * ldz + c4], v);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        if (wave * 32 + tt * 128 < A.Nout) {
+#pragma unroll
+          for (int i = 0; i < S; ++i)
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zt[cc * ldz + 2 * i + kr], rreg[tt][i], acc[tt], 0, 0, 0);
+        }
+      }
+    }
+    if constexpr (CE) {
+      ce_epilogue(A, acc[0], zt, row_base, wave, lane, tile);
+    } else {
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const int n0 = wave * 32 + tt * 128;
+        if (n0 < A.Nout)
+          store_tile<true>(acc[tt], A.bias, A.out, A.ldo, row_base, A.N, n0, kr, cc, A.stats_part, A.Nout, A.out_blk,
+                           A.ob_c, A.ob_s, tile);
+      }
+    }
+    __syncthreads();  // the tile buffer is loaded again
+  }
+}
+
+// true when the streaming form took the launch
+template <int KC>
+bool launch_dense_stream(const FusedArgs& A, hipStream_t s) {
+  const int tiles = (int)cdiv(A.N, TM);
+  const size_t lds = (size_t)TM * ((A.ce_part && A.Nout > A.K ? A.Nout : A.K) + 4) * sizeof(float);
+  const bool root = A.xr != nullptr;
+  const int nt = A.Nout <= 128 ? 1 : 2;
+  if (A.Nout > 256 || (root && nt == 2)) return false;  // register budget: the one-tile-per-workgroup form
+  const int per_cu = (root || nt > 1) ? 2 : (A.ce_part ? 3 : 4);
+  const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+  if (A.ce_part) {
+    if (root) dense_stream_kernel<KC, 1, true, true><<<grid, 256, lds, s>>>(A, tiles);
+    else dense_stream_kernel<KC, 1, true, false><<<grid, 256, lds, s>>>(A, tiles);
+  } else if (nt == 1) {
+    if (root) dense_stream_kernel<KC, 1, false, true><<<grid, 256, lds, s>>>(A, tiles);
+    else dense_stream_kernel<KC, 1, false, false><<<grid, 256, lds, s>>>(A, tiles);
+  } else {
+    dense_stream_kernel<KC, 2, false, false><<<grid, 256, lds, s>>>(A, tiles);
+  }
+  return true;
+}
+
 template <int G, int KC, bool DENSE = false>
 int launch(const FusedArgs& A, hipStream_t s) {
   const int64_t blocks = cdiv(A.N, TM);
@@ -687,7 +811,9 @@ extern "C" int rgbx_fused_layer_f32(const rgbx_fused_layer_t* Lp, rgbx_stream_t 
   const int lanes = (int)(K / 4);
   int rc;
   if (dense) {  // the lane grouping of the gather is irrelevant: one instantiation per unrolled width
-    if (K == 128) rc = launch<32, 128, true>(A, s);
+    if (K == 128 && launch_dense_stream<128>(A, s)) { RGBX_CHECK_LAUNCH("dense_stream_kernel"); rc = RGBX_OK; }
+    else if (K == 64 && launch_dense_stream<64>(A, s)) { RGBX_CHECK_LAUNCH("dense_stream_kernel"); rc = RGBX_OK; }
+    else if (K == 128) rc = launch<32, 128, true>(A, s);
     else if (K == 64) rc = launch<16, 64, true>(A, s);
     else if (K == 256) rc = launch<64, 256, true>(A, s);
     else rc = launch<32, 0, true>(A, s);

@@ -184,26 +184,64 @@ class GridStack:
                            device=self.x.device)
 
     # ---- the exchange ----------------------------------------------------------------------------------------
-    def _inbound(self, i, blk, lo=0, hi=None, cols=None):
-        """Column slice c of every node's rows [cut(n_q, lo piece), ...) -> `cols` [N, dc]; returns (cols, work)."""
+    def _inbound(self, i, blk, piece=None, cols=None):
+        """Column slice c of every node's row -> `cols` [N, dc] (c = this rank's slice): every peer q = (r', c') is sent
+        slice c' of my rows — the same view for the R ranks that share it. `piece` = (k, n): only the k-th of n row
+        pieces of every rank's rows (rows [n_q k / n, n_q (k + 1) / n) of rank q), so that the exchange of a piece can
+        start as soon as its producer has written it. Returns (cols, work)."""
         R, C = self.shapes[i]
         P, b = self.P, self.bounds
         dc = blk.size(2)
         if cols is None:
             cols = torch.empty((self.N, dc), dtype=torch.float32, device=blk.device)
-        send = [blk[q % C] for q in range(P)]
-        recv = [cols[b[q]:b[q + 1]] for q in range(P)]
-        return cols, self.comm.all_to_all_views(send, recv, tag="in")
+        k, n = piece or (0, 1)
+        cut = lambda rows, j: rows * j // n
+        a0, a1 = cut(self.n_loc, k), cut(self.n_loc, k + 1)
+        send = [blk[q % C, a0:a1] for q in range(P)]
+        recv = [cols[b[q] + cut(b[q + 1] - b[q], k):b[q] + cut(b[q + 1] - b[q], k + 1)] for q in range(P)]
+        tag = "in" if n == 1 else f"in {k + 1}/{n}"
+        return cols, self.comm.all_to_all_views(send, recv, tag=tag)
 
-    def _propagate(self, i, direction, blk):
+    def _first_layer(self, wt, bias, wtr, train):
+        """Layer 0 on the resident features, launched in `pieces_in` row pieces; each piece's slices leave for their
+        consumers as soon as its launch is enqueued (the all-to-all runs on RCCL's stream while the next piece is
+        computed), so only the last piece's share of the inbound exchange is exposed. Training also keeps the raw
+        rows (BatchNorm's backward), the aggregate (dW_0) and the column sums (BatchNorm's statistics).
+        Returns (blk, (cols, works), h, z, colsums)."""
+        sp = self.specs[0]
+        handle, x_ext = self._first()
+        n, dev = self.n_loc, self.x.device
+        blk = self._blocked_buffer(1)
+        h = torch.empty((n, sp.d_out), dtype=torch.float32, device=dev) if train else None
+        z = torch.empty((n, sp.d_in), dtype=torch.float32, device=dev) if train else None
+        pieces = self.pieces_in if getattr(handle[0], "split", None) is None else 1
+        cols, works, cs = None, [], None
+        for k in range(pieces):
+            a, b = n * k // pieces, n * (k + 1) // pieces
+            rows = None if pieces == 1 else (a, b)
+            _, _, c = self.be.layer(x_ext, wt, handle=handle, rows=rows, bias=bias,
+                                    x_root=self.x[a:b] if wtr is not None else None, wt_root=wtr, want_out=False,
+                                    out=None if h is None else h[a:b], z=None if z is None else z[a:b],
+                                    want_colsums=train, out_blocked=blk[:, a:b], kind=f"{sp.kind}_linear_fwd")
+            cs = c if cs is None or c is None else cs + c
+            cols, work = self._inbound(1, blk, piece=(k, pieces), cols=cols)
+            works.append(work)
+        return blk, (cols, works), h, z, cs
+
+    def _propagate(self, i, direction, blk, inbound=None):
         """The exchanged aggregation of layer i: blocked rows of this rank in, blocked aggregated rows of this rank
-        out (u[c', r, :] = column slice c' of own row r of P x, or of P^T x for direction "bwd")."""
+        out (u[c', r, :] = column slice c' of own row r of P x, or of P^T x for direction "bwd"). `inbound` = (cols,
+        [work, ...]) when the caller has already issued the inbound exchange (piece by piece behind the producer)."""
         R, C = self.shapes[i]
         d = self.specs[i].d_in
         dg, P = self.dg, self.P
         half, handle = dg._grid_half(self.specs[i].kind, C, dg.pieces_for(d), direction)
-        cols, work = self._inbound(i, blk)
-        work.wait()
+        if inbound is None:
+            cols, work = self._inbound(i, blk)
+            inbound = (cols, [work])
+        cols, works = inbound
+        for work in works:
+            work.wait()
         dc = blk.size(2)
         u = self._blocked_buffer(i)
         empty = u[0, 0:0]
@@ -241,19 +279,16 @@ class GridStack:
         S, be = self.specs, self.be
         L = len(S)
         wt = lambda w: w.detach().t().contiguous()
-        handle, x_ext = self._first()
         s0 = S[0]
-        blk = self._blocked_buffer(1)
-        h, z, cs = be.layer(x_ext, wt(s0.W), handle=handle, bias=s0.bias(), x_root=self.x if s0.Wr is not None else None,
-                            wt_root=None if s0.Wr is None else wt(s0.Wr), want_z=True, want_colsums=True,
-                            out_blocked=blk, kind=f"{s0.kind}_linear_fwd")
+        blk, inbound, h, z, cs = self._first_layer(wt(s0.W), s0.bias(), None if s0.Wr is None else wt(s0.Wr), True)
         saved = [(z, None, None)]
         dl = None
         for i in range(1, L):
             sp, bn = S[i], self.bns[i - 1]
             stats = B.train_statistics(h, bn.weight, bn.bias, bn.eps, bn._reducer(h), bn.begin_training_step(), cs)
             mean, rstd, scale, shift, n = stats
-            u = self._propagate(i, "fwd", blk)
+            u = self._propagate(i, "fwd", blk, inbound)
+            inbound = None
             pre = (scale, shift, self.rowsum())
             root = dict(x_root=h, wt_root=wt(sp.Wr)) if sp.Wr is not None else {}
             if i == L - 1:
@@ -272,15 +307,17 @@ class GridStack:
         for i in range(L - 1, 0, -1):
             sp, bn = S[i], self.bns[i - 1]
             z, h_prev, (mean, rstd, scale, shift, n) = saved[i]
+            # q = dy W goes out first; the weight-gradient GEMMs run while its slices travel
+            q = self._blocked_buffer(i)
+            be.layer(dy, sp.W.detach().contiguous(), want_out=False, out_blocked=q, kind="return_linear_bwd")
+            cols, work = self._inbound(i, q)
             gw, gcol = be.gemm_tn(dy, z, colsum=True)
             sp.W.grad = gw
             for b in sp.biases:
                 b.grad = gcol if b is sp.biases[0] else gcol.clone()
             if sp.Wr is not None:  # dWr = dy^T BN(h) = (dy^T h) diag(s) + colsum(dy) t^T
                 sp.Wr.grad = be.gemm_tn(dy, h_prev) * scale + gcol[:, None] * shift
-            q = self._blocked_buffer(i)
-            be.layer(dy, sp.W.detach().contiguous(), want_out=False, out_blocked=q, kind="return_linear_bwd")
-            v = self._propagate(i, "bwd", q)
+            v = self._propagate(i, "bwd", q, (cols, [work]))
             g_a = be.blocked_to_rows(v)
             if sp.Wr is not None:
                 g_a.addmm_(dy, sp.Wr.detach())
@@ -302,8 +339,7 @@ class GridStack:
         every BatchNorm folded into the preceding layer's weights, no row-major activation written, no logits."""
         S, be = self.specs, self.be
         L = len(S)
-        handle, x_ext = self._first()
-        prev_blk = None
+        prev_blk = inbound = None
         for i in range(L):
             sp = S[i]
             W, b, Wr = sp.W.detach(), sp.bias(), None if sp.Wr is None else sp.Wr.detach()
@@ -313,12 +349,10 @@ class GridStack:
                 Wr = None if Wr is None else Wr * scale[:, None]
             wt, wtr = W.t().contiguous(), None if Wr is None else Wr.t().contiguous()
             if i == 0:
-                blk = self._blocked_buffer(1)
-                be.layer(x_ext, wt, handle=handle, bias=b, x_root=self.x if Wr is not None else None, wt_root=wtr,
-                         want_out=False, out_blocked=blk, kind=f"{sp.kind}_linear_fwd")
-                prev_blk = blk
+                prev_blk, inbound, _, _, _ = self._first_layer(wt, b, wtr, False)
                 continue
-            u = self._propagate(i, "fwd", prev_blk)
+            u = self._propagate(i, "fwd", prev_blk, inbound)
+            inbound = None
             root = dict(x_root=prev_blk, wt_root=wtr) if Wr is not None else {}
             if i == L - 1:
                 _, _, st = be.layer(u, wt, bias=b, ce=(self.y, self.masks[which], None), kind="return_linear_fwd", **root)

@@ -196,7 +196,7 @@ def _blocked(t, what):
 
 
 def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_root=None, pre=None, want_out=True,
-                out_blocked=None, want_z=False, want_colsums=False, ce=None, kind="linear"):
+                out_blocked=None, want_z=False, want_colsums=False, ce=None, kind="linear", out=None, z=None):
     """One conv layer's arithmetic on rgbx_fused_layer_f32 (no autograd):
         z   = rs * sum_p w_p x[col_p]   over `csr`            (csr given: aggregate)
             = x                                                 (csr None: DENSE mode, the rows are loaded)
@@ -206,7 +206,9 @@ def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_roo
     a partitioned run delivers them); `x_root` likewise. `out_blocked` ([B', N, Nout / B'], optional): the output is
     (also) written there, in the layout the exchange sends from. `want_out=False`: no row-major output.
     `want_z`: the (mapped) aggregate is stored. `want_colsums`: [2, Nout] float64 column sums of out and out^2.
-    `ce` = (y, mask, grad_scale): loss epilogue (see spmm_linear_raw). Returns (out, z, colsums or stats)."""
+    `ce` = (y, mask, grad_scale): loss epilogue (see spmm_linear_raw). `out` / `z`: caller's row-major [N, Nout] /
+    [N, K] tensors to write into (row ranges of bigger ones when a layer is launched piece by piece).
+    Returns (out, z, colsums or stats)."""
     _lib.require_device(x, wt, bias, x_root, wt_root, out_blocked)
     lib = _lib.load()
     L = _lib.FusedLayer()
@@ -269,19 +271,27 @@ def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_roo
         keep += [y, mask, ce_scratch, ce_arg]
         L.ce = ctypes.addressof(ce_arg)
         want_out = grad_scale is not None  # statistics only: the logits are never written
-    out = torch.empty((N, n_out), dtype=torch.float32, device=x.device) if want_out else None
     if out is not None:
-        L.out, L.ldo = out.data_ptr(), out.stride(0)
+        if tuple(out.shape) != (N, n_out) or out.stride(1) != 1 or out.dtype != torch.float32:
+            raise RuntimeError(f"fused_layer: out is {tuple(out.shape)}, expected a float32 [{N}, {n_out}] with contiguous rows")
+    elif want_out:
+        out = torch.empty((N, n_out), dtype=torch.float32, device=x.device)
+    if out is not None:
+        L.out, L.ldo = out.data_ptr(), out.stride(0) if N > 1 else n_out
     else:
         L.ldo = n_out
     if out_blocked is not None:
         L.out_blk, L.ob_cols, L.ob_stride = _blocked(out_blocked, "out_blocked")
         if out_blocked.size(1) != N or out_blocked.size(0) * out_blocked.size(2) != n_out:
             raise RuntimeError(f"fused_layer: out_blocked is {tuple(out_blocked.shape)} for a [{N}, {n_out}] output")
-    z = torch.empty((N, K), dtype=torch.float32, device=x.device) if want_z else None
     if z is not None:
-        L.z_out = z.data_ptr()
+        if tuple(z.shape) != (N, K) or z.stride(1) != 1 or z.dtype != torch.float32:
+            raise RuntimeError(f"fused_layer: z is {tuple(z.shape)}, expected a float32 [{N}, {K}] with contiguous rows")
+    elif want_z:
+        z = torch.empty((N, K), dtype=torch.float32, device=x.device)
     L.ldz = K
+    if z is not None:
+        L.z_out, L.ldz = z.data_ptr(), z.stride(0) if N > 1 else K
     colsums = None
     if want_colsums:
         nbytes = ctypes.c_size_t(0)

@@ -75,7 +75,8 @@ class TorchStackBackend:
         self.agg = agg
 
     def layer(self, x, wt, handle=None, rows=None, bias=None, x_root=None, wt_root=None, pre=None, want_out=True,
-              out_blocked=None, want_z=False, want_colsums=False, ce=None, kind=None):
+              out_blocked=None, want_z=False, want_colsums=False, ce=None, kind=None, out=None, z=None):
+        out_arg, z_arg = out, z
         if x.dim() == 3:
             assert handle is None
             x = _rows_of(x)
@@ -114,7 +115,11 @@ class TorchStackBackend:
                 g = torch.zeros_like(out)
                 g[sel] = (torch.softmax(out[sel], dim=1) - torch.nn.functional.one_hot(y[sel], out.size(1))) * grad_scale
                 out = g
-        return (out if want_out or ce is not None else None), (z.contiguous() if want_z else None), extra
+        if out_arg is not None:
+            out_arg.copy_(out)
+        if z_arg is not None:
+            z_arg.copy_(z)
+        return (out if want_out or ce is not None else out_arg), (z.contiguous() if want_z else z_arg), extra
 
     def run_rows(self, handle, x, lo, hi, out, kind):
         return self.agg.run_rows(handle, x, lo, hi, out, kind)
@@ -218,7 +223,7 @@ def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", inter
     model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
     r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
                    backend=OracleAggregator(), exchange=exchange, interleave_evals=interleave, fused=fused,
-                   pieces=pieces)
+                   pieces=pieces, pieces_in=pieces or 1)
     hist = [r.epoch()]
     if release:  # every structure exists after one epoch: the global edge list may go
         r.release_edge_list()
