@@ -793,13 +793,26 @@ def main():
         tick(f"warm-up step {i + 1}/{args.warmup}")
     sv.test_fault("timed_region", rank)
     events = []
+    # Per-launch HIP events (two event records around every aggregation launch and every exchange wait) separate
+    # consecutive kernels by a few microseconds each. One GPU: 7 fused launches per epoch, every step is instrumented.
+    # A partitioned rank makes ~40 such launches of 0.15 ms per epoch: there every third step carries events, and the
+    # per-launch averages come from those steps (same launches in every step).
+    every = 3 if parts > 1 else 1
+    timed_steps_with_events = len(range(0, args.steps, every))
+    timed_step = step
     if on_gpu:
-        ops.set_event_sink(events)
+        calls = [0]
+
+        def timed_step():
+            ops.set_event_sink(events if calls[0] % every == 0 else None)
+            calls[0] += 1
+            return step()
     if comm_obj is not None:
         comm_obj.bytes_sent, comm_obj.exchanges = 0, 0
+        runner.host_enqueue_s = 0.0
         if emu:
             comm_obj.log.clear()
-    elapsed, last, step_ms = time_steps(step, args.steps, 0, fence, tick=tick)
+    elapsed, last, step_ms = time_steps(timed_step, args.steps, 0, fence, tick=tick)
     ops.set_event_sink(None)
     sv.beat("timed region done")
     if world > 1:
@@ -812,13 +825,14 @@ def main():
     for k, s, e in events:
         by_kind.setdefault(k, []).append(s.elapsed_time(e))
     agg_total_ms = sum(sum(v) for k, v in by_kind.items() if k in AGG_KINDS)
+    agg_total_ms *= args.steps / timed_steps_with_events  # scaled from the instrumented steps to all of them
     agg_avg_s = agg_total_ms * 1e-3 / (n_prop * args.steps)  # aggregation kernel time per propagate (this rank)
     dominant = max((k for k in by_kind if k in AGG_KINDS), key=lambda k: sum(by_kind[k]), default=None)
     kernel = KERNEL_OF_KIND.get(dominant, "none recorded")
     achieved = None
     if alg_by_kind and agg_total_ms:  # partitioned run: launches of different shapes, sum bytes over those made
         done = sum(alg_by_kind[k] * len(v) for k, v in by_kind.items() if k in alg_by_kind)
-        achieved = done / (agg_total_ms * 1e-3) / 1e9
+        achieved = done / (agg_total_ms * timed_steps_with_events / args.steps * 1e-3) / 1e9
     elif dominant is not None:
         # the DOMINANT kernel's own launches: its algorithmic bytes per launch / its mean launch duration
         launches_per_event = kwargs.get("K", 1) if dominant.startswith("appnp") else 1
@@ -885,8 +899,10 @@ def main():
                 # exposed part of the exchanges, measured; RCCL runs only
                 "exposed_exchange_ms_per_step": (by_kind.get("exchange_wait", {"n": 0, "avg_ms": 0.0})["n"]
                                                  * by_kind.get("exchange_wait", {"n": 0, "avg_ms": 0.0})["avg_ms"]
-                                                 / args.steps),
+                                                 / timed_steps_with_events),
                 "rows": n_loc, "device": str(dev),
+                # host time to enqueue one epoch's launches and exchanges (before the read-back that waits for the GPU)
+                "host_enqueue_ms_per_step": runner.host_enqueue_s / args.steps * 1e3,
                 # where this rank's time went BEFORE the timed region (seconds): the partition plans are index arithmetic
                 # over the global edge list on every rank, the CSRs come from rgbx_csr_build
                 "setup_s": {k: round(v, 3) for k, v in setup.items()}}

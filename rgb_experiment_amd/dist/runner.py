@@ -33,6 +33,7 @@ class DistRunner:
         self.interleave_evals = interleave_evals and world > 1
         self._streams = None
         self._epochs_done = 0
+        self.host_enqueue_s = 0.0
         if device.type == "cuda":  # one timed all-to-all: the exchange cost model then uses this fabric's link rate
             self.link_gbs = self.comm.measure_link_gbs(device)
         # "replicate": every rank computes the first conv layer for all N nodes from the whole (static) feature
@@ -53,7 +54,10 @@ class DistRunner:
             for m in self.model.modules():
                 if isinstance(m, DistBatchNorm1d):
                     m.replicated_rows = N
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
+        # one fused multi-tensor launch per step on the GPU (the reference's torch.optim.Adam, itexperiments.py:391, same
+        # update rule)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay,
+                                    **({"fused": True} if device.type == "cuda" else {}))
         for part, m in zip(("train", "val", "test"), self.masks):
             sel = self.y[m]
             if sel.numel() and int(sel.min()) < 0:  # NLLLoss on out[mask] raises on such rows in the reference
@@ -102,6 +106,9 @@ class DistRunner:
             g.release_edges()
 
     def _sync_grads(self):
+        if self.engine is not None:  # the fused schedule wrote every gradient into one flat buffer (views as .grad)
+            self.comm.all_reduce_sum_(self.engine.flat_grads)
+            return
         grads = [p.grad for p in self.model.parameters() if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])
         self.comm.all_reduce_sum_(flat)
@@ -121,10 +128,10 @@ class DistRunner:
         """One training step. `sync=False`: returns this rank's share of the loss as a device tensor [1]
         (float64) instead of the all-reduced Python float — epoch() reduces everything once."""
         self.model.train()
-        self.opt.zero_grad()
         if self.engine is not None:
-            part = self.engine.train_step()  # forward + backward, every parameter's .grad set
+            part = self.engine.train_step()  # forward + backward, every parameter's .grad (over)written in place
         else:
+            self.opt.zero_grad()
             res = self.model(self.x_in, self.token)
             m = self.masks[0]
             loss = self._nll_sum(res, m) / self.mask_counts[0]
@@ -147,7 +154,7 @@ class DistRunner:
         m = self.masks[which]
         if res["emb"].is_cuda:
             from .. import ops
-            stats = ops.masked_ce_accuracy(res["emb"], self.y, m)[[0, 2]]
+            stats = ops.masked_ce_accuracy(res["emb"], self.y, m)[::2]  # a view: a list index would go through the host
         else:  # gloo/CPU tests
             out = res["out"]
             stats = torch.stack([F.nll_loss(out[m], self.y[m], reduction="sum"),
@@ -214,6 +221,8 @@ class DistRunner:
         numbers the reference reads with .item() along the way are only used after the epoch: they are reduced
         over the ranks in ONE all-reduce and read back in ONE copy, so the queues drain once per epoch, not three
         times."""
+        import time
+        t0 = time.perf_counter()
         tl = self.train_step(sync=False)
         # the first epoch builds what the eval forwards use lazily (cost tables, plans / CSRs of widths only the
         # no_grad path aggregates at) — on the MAIN stream, one forward after the other, so that no structure is
@@ -223,7 +232,11 @@ class DistRunner:
         else:
             v, _ = self.evaluate(1, sync=False)
             s, _ = self.evaluate(2, sync=False)
-        p = self.comm.all_reduce_sum_(torch.cat([tl, v, s])).tolist()
+        packed = self.comm.all_reduce_sum_(torch.cat([tl, v, s]))
+        # host time to ENQUEUE the epoch (before the one read-back that waits for the GPU): when this approaches the
+        # epoch's wall time the rank is host-bound, not kernel-bound (bench.py reports it per rank)
+        self.host_enqueue_s += time.perf_counter() - t0
+        p = packed.tolist()
         self._epochs_done += 1
         cv, cs = self.mask_counts[1], self.mask_counts[2]
         return p[0], p[1] / cv, p[2] / cv, p[3] / cs, p[4] / cs

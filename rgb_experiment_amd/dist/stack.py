@@ -63,9 +63,9 @@ class HipStackBackend:
     def run(self, handle, x, kind):
         return self.agg.run(handle, x, kind=kind)
 
-    def gemm_tn(self, a, b, colsum=False):
+    def gemm_tn(self, a, b, colsum=False, out=None, sums_out=None):
         from .. import ops
-        return ops.gemm_tn(a, b, colsum=colsum)
+        return ops.gemm_tn(a, b, colsum=colsum, out=out, sums_out=sums_out)
 
     def blocked_to_rows(self, blk):
         from .. import ops
@@ -160,6 +160,24 @@ class GridStack:
         self.mask_counts = mask_counts
         self.pieces_in = max(1, int(pieces_in))
         self._rowsum = None
+        self._folded = (None, None)
+        # every parameter gradient is a view of ONE flat buffer, written in place by the kernels that produce it: the
+        # gradient all-reduce then takes the buffer as it is (no flatten / copy-back launches), and nothing is zeroed
+        # between steps because every entry is overwritten
+        params = [p for p in model.parameters()]
+        self.flat_grads = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        off = 0
+        self._grad_views = {}
+        for p in params:
+            self._grad_views[id(p)] = self.flat_grads[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def _g(self, p):
+        """The gradient view of parameter `p` (installed as p.grad)."""
+        v = self._grad_views[id(p)]
+        if p.grad is not v:
+            p.grad = v
+        return v
 
     # ---- structures ------------------------------------------------------------------------------------------
     def _first(self):
@@ -273,6 +291,7 @@ class GridStack:
         return u
 
     # ---- training step -----------------------------------------------------------------------------------------
+    @torch.no_grad()  # forward AND backward are written out here: nothing is recorded for autograd
     def train_step(self):
         """Forward + backward of one training step; leaves every parameter's .grad set (this rank's share) and
         returns this rank's share of the loss as a float64 device tensor [1]."""
@@ -311,28 +330,44 @@ class GridStack:
             q = self._blocked_buffer(i)
             be.layer(dy, sp.W.detach().contiguous(), want_out=False, out_blocked=q, kind="return_linear_bwd")
             cols, work = self._inbound(i, q)
-            gw, gcol = be.gemm_tn(dy, z, colsum=True)
-            sp.W.grad = gw
-            for b in sp.biases:
-                b.grad = gcol if b is sp.biases[0] else gcol.clone()
+            _, gcol = be.gemm_tn(dy, z, colsum=True, out=self._g(sp.W), sums_out=self._g(sp.biases[0]))
+            for b in sp.biases[1:]:
+                self._g(b).copy_(gcol)
             if sp.Wr is not None:  # dWr = dy^T BN(h) = (dy^T h) diag(s) + colsum(dy) t^T
-                sp.Wr.grad = be.gemm_tn(dy, h_prev) * scale + gcol[:, None] * shift
+                torch.addcmul(gcol[:, None] * shift, be.gemm_tn(dy, h_prev), scale, out=self._g(sp.Wr))
             v = self._propagate(i, "bwd", q, (cols, [work]))
             g_a = be.blocked_to_rows(v)
             if sp.Wr is not None:
                 g_a.addmm_(dy, sp.Wr.detach())
-            dy, g_bnw, g_bnb = B.train_backward(g_a, h_prev, bn.weight, mean, rstd, n, bn._reducer(h_prev))
-            bn.weight.grad, bn.bias.grad = g_bnw, g_bnb
+            dy, _, _ = B.train_backward(g_a, h_prev, bn.weight, mean, rstd, n, bn._reducer(h_prev),
+                                        grads_out=(self._g(bn.weight), self._g(bn.bias)))
         z0 = saved[0][0]
-        gw, gcol = be.gemm_tn(dy, z0, colsum=True)
-        s0.W.grad = gw
-        for b in s0.biases:
-            b.grad = gcol if b is s0.biases[0] else gcol.clone()
+        _, gcol = be.gemm_tn(dy, z0, colsum=True, out=self._g(s0.W), sums_out=self._g(s0.biases[0]))
+        for b in s0.biases[1:]:
+            self._g(b).copy_(gcol)
         if s0.Wr is not None:
-            s0.Wr.grad = be.gemm_tn(dy, self.x)
+            be.gemm_tn(dy, self.x, out=self._g(s0.Wr))
         return loss_part
 
     # ---- eval forward ------------------------------------------------------------------------------------------
+    def _eval_weights(self):
+        """Per layer (W'^T, b', Wr'^T) with the eval-mode BatchNorm behind the layer folded in (W' = diag(scale) W,
+        b' = b scale + shift): made once per parameter state — the val and the test forward of an epoch share them."""
+        tensors = [p for p in self.model.parameters()] + [t for bn in self.bns for t in (bn.running_mean, bn.running_var)]
+        key = tuple(t._version for t in tensors)
+        if self._folded[0] != key:
+            out = []
+            L = len(self.specs)
+            for i, sp in enumerate(self.specs):
+                W, b, Wr = sp.W.detach(), sp.bias(), None if sp.Wr is None else sp.Wr.detach()
+                if i < L - 1:
+                    scale, shift = self.bns[i].eval_affine()
+                    W, b = W * scale[:, None], b * scale + shift
+                    Wr = None if Wr is None else Wr * scale[:, None]
+                out.append((W.t().contiguous(), b.contiguous(), None if Wr is None else Wr.t().contiguous()))
+            self._folded = (key, out)
+        return self._folded[1]
+
     @torch.no_grad()
     def eval_stats(self, which):
         """[masked NLL sum, correct count] (float64 device tensor) of this rank's rows under masks[which], eval mode:
@@ -340,23 +375,19 @@ class GridStack:
         S, be = self.specs, self.be
         L = len(S)
         prev_blk = inbound = None
+        folded = self._eval_weights()
         for i in range(L):
             sp = S[i]
-            W, b, Wr = sp.W.detach(), sp.bias(), None if sp.Wr is None else sp.Wr.detach()
-            if i < L - 1:
-                scale, shift = self.bns[i].eval_affine()
-                W, b = W * scale[:, None], b * scale + shift
-                Wr = None if Wr is None else Wr * scale[:, None]
-            wt, wtr = W.t().contiguous(), None if Wr is None else Wr.t().contiguous()
+            wt, b, wtr = folded[i]
             if i == 0:
                 prev_blk, inbound, _, _, _ = self._first_layer(wt, b, wtr, False)
                 continue
             u = self._propagate(i, "fwd", prev_blk, inbound)
             inbound = None
-            root = dict(x_root=prev_blk, wt_root=wtr) if Wr is not None else {}
+            root = dict(x_root=prev_blk, wt_root=wtr) if wtr is not None else {}
             if i == L - 1:
                 _, _, st = be.layer(u, wt, bias=b, ce=(self.y, self.masks[which], None), kind="return_linear_fwd", **root)
-                return st[[0, 2]]
+                return st[::2]  # (nll sum, hits): a view — indexing with a list would stage an index tensor through the host and drain the queue
             blk = self._blocked_buffer(i + 1)
             be.layer(u, wt, bias=b, want_out=False, out_blocked=blk, kind="return_linear_fwd", **root)
             prev_blk = blk

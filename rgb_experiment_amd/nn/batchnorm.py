@@ -125,15 +125,18 @@ def train_statistics(x, weight, bias, eps, reduce, running, colsums=None):
     return mean, rstd, scale, shift, n
 
 
-def train_backward(gy, x, weight, mean, rstd, n, reduce):
-    """(gx, g_weight, g_bias) of training-mode BatchNorm given the gradient gy of its output."""
+def train_backward(gy, x, weight, mean, rstd, n, reduce, grads_out=None):
+    """(gx, g_weight, g_bias) of training-mode BatchNorm given the gradient gy of its output. `grads_out` =
+    (g_weight, g_bias) tensors to write the parameter gradients into (device path)."""
     gy = gy if gy.stride(-1) == 1 else gy.contiguous()
     d = x.size(1)
     local = bwd_sums(gy, x, mean, rstd)            # [2, d]: sum gy, sum gy * xhat over the local rows
     glob = reduce(local.reshape(-1).clone())
     # parameter gradients are the LOCAL sums: a partitioned run all-reduces parameter gradients once
     if gy.is_cuda:
-        ca, cb, ck, gw, gb = (torch.empty(d, dtype=torch.float32, device=gy.device) for _ in range(5))
+        ca, cb, ck = (torch.empty(d, dtype=torch.float32, device=gy.device) for _ in range(3))
+        gw, gb = grads_out if grads_out is not None else (torch.empty(d, dtype=torch.float32, device=gy.device)
+                                                          for _ in range(2))
         _lib.check(_lib.load().rgbx_bn_bwd_finalize_f32(
             _lib.ptr(glob), _lib.ptr(local), _lib.ptr(n), _lib.ptr(weight.detach().contiguous()), _lib.ptr(rstd),
             _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(ck), _lib.ptr(gw), _lib.ptr(gb), d, _lib.stream_ptr()),
@@ -144,6 +147,10 @@ def train_backward(gy, x, weight, mean, rstd, n, reduce):
         cb = (glob[1] / n).float().contiguous()
         ck = (weight * rstd).contiguous()
         gw, gb = local[1].float(), local[0].float()
+        if grads_out is not None:
+            grads_out[0].copy_(gw)
+            grads_out[1].copy_(gb)
+            gw, gb = grads_out
     return bwd_apply(gy, x, mean, rstd, ca, cb, ck), gw, gb
 
 

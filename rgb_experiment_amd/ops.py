@@ -1026,9 +1026,10 @@ def scatter_add_rows(src, idx, dst):
 
 # ---- dense layers: forward through hipBLASLt, weight gradient through the split-K MFMA kernel --------
 
-def gemm_tn(a, b, alpha=1.0, colsum=False):
+def gemm_tn(a, b, alpha=1.0, colsum=False, out=None, sums_out=None):
     """a^T b for a [K,M], b [K,N] (fp32, device): rgbx_gemm_tn_f32. With `colsum` also the column sums of `a`
-    ([M], from the same pass): returns (a^T b, a.sum(0))."""
+    ([M], from the same pass): returns (a^T b, a.sum(0)). `out` ([M, N] contiguous) / `sums_out` ([M]): write there
+    (e.g. views of one flat gradient buffer)."""
     _lib.require_device(a, b)
     a = a if a.stride(-1) == 1 else a.contiguous()
     b = b if b.stride(-1) == 1 else b.contiguous()
@@ -1039,8 +1040,15 @@ def gemm_tn(a, b, alpha=1.0, colsum=False):
     nbytes = ctypes.c_size_t(0)
     _lib.check(lib.rgbx_gemm_tn_workspace_bytes(K, M, N, ctypes.byref(nbytes)), "rgbx_gemm_tn_workspace_bytes")
     ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=a.device)
-    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    sums = torch.empty(M, dtype=torch.float32, device=a.device) if colsum else None
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    elif tuple(out.shape) != (M, N) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise RuntimeError(f"gemm_tn: out must be a contiguous float32 [{M}, {N}] tensor")
+    sums = None
+    if colsum:
+        sums = sums_out if sums_out is not None else torch.empty(M, dtype=torch.float32, device=a.device)
+        if tuple(sums.shape) != (M,) or not sums.is_contiguous() or sums.dtype != torch.float32:
+            raise RuntimeError(f"gemm_tn: sums_out must be a contiguous float32 [{M}] tensor")
     with _Timed("gemm_tn"):
         _lib.check(lib.rgbx_gemm_tn_f32(pa, lda, pb, ldb, _lib.ptr(out), N, _lib.ptr(sums), K, M, N, float(alpha),
                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "rgbx_gemm_tn_f32")

@@ -127,9 +127,14 @@ class TorchStackBackend:
     def run(self, handle, x, kind):
         return self.agg.run(handle, x)
 
-    def gemm_tn(self, a, b, colsum=False):
-        out = a.t() @ b
-        return (out, a.sum(0)) if colsum else out
+    def gemm_tn(self, a, b, colsum=False, out=None, sums_out=None):
+        res = a.t() @ b
+        if out is not None:
+            res = out.copy_(res)
+        if not colsum:
+            return res
+        sums = a.sum(0)
+        return res, (sums if sums_out is None else sums_out.copy_(sums))
 
     def blocked_to_rows(self, blk):
         return _rows_of(blk).contiguous()
