@@ -56,8 +56,10 @@ class DistRunner:
                     m.replicated_rows = N
         # one fused multi-tensor launch per step on the GPU (the reference's torch.optim.Adam, itexperiments.py:391, same
         # update rule)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay,
-                                    **({"fused": True} if device.type == "cuda" else {}))
+        self._fused_adam = device.type == "cuda"
+        self._params = list(self.model.parameters())
+        self.opt = torch.optim.Adam(self._params, lr=lr, weight_decay=weight_decay,
+                                    **({"fused": True} if self._fused_adam else {}))
         for part, m in zip(("train", "val", "test"), self.masks):
             sel = self.y[m]
             if sel.numel() and int(sel.min()) < 0:  # NLLLoss on out[mask] raises on such rows in the reference
@@ -139,6 +141,9 @@ class DistRunner:
             part = loss.detach().double().reshape(1)
         self._sync_grads()
         self.opt.step()
+        if self._fused_adam:  # the fused step writes the parameters without moving their version counters: whatever
+            for p in self._params:  # is cached per parameter version (ops.weight_t) must not survive it
+                p.__dict__.pop("_rgbx_wt", None)
         if not sync:
             return part
         return self.comm.all_reduce_sum_(part.clone()).item()

@@ -161,6 +161,7 @@ class GridStack:
         self.pieces_in = max(1, int(pieces_in))
         self._rowsum = None
         self._folded = (None, None)
+        self._steps = 0
         # every parameter gradient is a view of ONE flat buffer, written in place by the kernels that produce it: the
         # gradient all-reduce then takes the buffer as it is (no flatten / copy-back launches), and nothing is zeroed
         # between steps because every entry is overwritten
@@ -297,6 +298,7 @@ class GridStack:
         returns this rank's share of the loss as a float64 device tensor [1]."""
         S, be = self.specs, self.be
         L = len(S)
+        self._steps += 1  # the parameters are about to change: folded eval weights of the previous state are stale
         wt = lambda w: w.detach().t().contiguous()
         s0 = S[0]
         blk, inbound, h, z, cs = self._first_layer(wt(s0.W), s0.bias(), None if s0.Wr is None else wt(s0.Wr), True)
@@ -353,8 +355,10 @@ class GridStack:
     def _eval_weights(self):
         """Per layer (W'^T, b', Wr'^T) with the eval-mode BatchNorm behind the layer folded in (W' = diag(scale) W,
         b' = b scale + shift): made once per parameter state — the val and the test forward of an epoch share them."""
+        # keyed by the training steps taken (a fused Adam step and the BatchNorm kernels write through raw pointers:
+        # version counters do not see them) and, for changes from outside (load_state_dict), by the version counters
         tensors = [p for p in self.model.parameters()] + [t for bn in self.bns for t in (bn.running_mean, bn.running_var)]
-        key = tuple(t._version for t in tensors)
+        key = (self._steps,) + tuple(t._version for t in tensors)
         if self._folded[0] != key:
             out = []
             L = len(self.specs)
