@@ -393,6 +393,20 @@ int rgbx_bn_finalize_f32(const double* packed, const float* weight, const float*
                          float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
                          float* shift, int64_t d, rgbx_stream_t stream);
 
+/* Eval forwards: the BatchNorm1d BEHIND a linear layer in eval mode (running statistics; models/gcn.py:27-28 under
+ * model.eval(), itexperiments.py:619-622) is a per-column affine map of that layer's output, i.e. the same layer with
+ * rescaled weights. One launch makes the operands the fused kernels read:
+ *   scale[n] = gamma[n] / sqrt(running_var[n] + eps),  shift[n] = beta[n] - running_mean[n] * scale[n]
+ *   wt[k, n]  = W[n, k]  * scale[n]      (W [Nout, K] row-major -> W'^T [K, Nout], the [K, Nout] operand layout)
+ *   wrt[k, n] = Wr[n, k] * scale[n]      (optional second weight: the root term of SAGEConv / my_SAGEConv)
+ *   b_out[n]  = (bias[n] + bias2[n]) * scale[n] + shift[n]      (bias, bias2, b_out optional)
+ * gamma == beta == running_mean == running_var == NULL: no BatchNorm (scale 1, shift 0), i.e. the plain transpose
+ * of the model's last layer. Replaces ~8 [out]-sized vector launches and two transposes per layer and eval forward. */
+int rgbx_fold_bn_linear_f32(const float* W, int64_t ldw, const float* Wr, int64_t ldwr, const float* bias,
+                            const float* bias2, const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, float* wt, float* wrt, float* b_out, int64_t Nout,
+                            int64_t K, rgbx_stream_t stream);
+
 /* Backward counterpart: ca = glob[0]/n, cb = glob[1]/n, ck = weight * rstd for rgbx_bn_bwd_apply_f32 (`glob` = the
  * [2, d] sums of rgbx_bn_bwd_reduce_f32 after any cross-rank reduction, `count` = device pointer to n), and the
  * parameter gradients of this rank, g_bias = local[0], g_weight = local[1]. */

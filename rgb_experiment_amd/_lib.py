@@ -75,6 +75,7 @@ SIGNATURES = {
     "rgbx_bn_scratch_doubles": [_I64, _I64, ctypes.POINTER(ctypes.c_int64)],
     "rgbx_bn_stats_f32": [_P, _I64, _I64, _I64, _P, _P, _I64, _P],
     "rgbx_bn_finalize_f32": [_P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I64, _P],
+    "rgbx_fold_bn_linear_f32": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I64, _I64, _P],
     "rgbx_bn_bwd_finalize_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
     "rgbx_affine_cols_f32": [_P, _I64, _P, _P, _P, _I64, _I64, _I64, _P],
     "rgbx_bn_bwd_reduce_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _P, _P, _I64, _P],

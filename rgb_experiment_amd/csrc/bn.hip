@@ -257,6 +257,49 @@ bn_bwd_finalize_kernel(const double* __restrict__ glob, const double* __restrict
   g_weight[c] = (float)local[d + c];
 }
 
+// Eval-mode BatchNorm folded into the linear layer in front of it, and the operand layout of the fused kernels made
+// in the same pass: wt[k, n] = W[n, k] * scale[n] (W [Nout, K] row-major -> W'^T [K, Nout]), 32 x 32 tiles through LDS
+// so that both sides move contiguous rows; the workgroups of the first K-tile also write b'[n].
+__global__ void __launch_bounds__(256)
+fold_bn_linear_kernel(const float* __restrict__ W, int64_t ldw, const float* __restrict__ Wr, int64_t ldwr,
+                      const float* __restrict__ bias, const float* __restrict__ bias2,
+                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                      float* __restrict__ wt, float* __restrict__ wrt, float* __restrict__ b_out, int Nout, int K) {
+  __shared__ float tile[2][32][33];
+  __shared__ float sc[32];
+  const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  if (threadIdx.x < 32) {
+    const int n = n0 + threadIdx.x;
+    float s = 1.f, t = 0.f;
+    if (n < Nout && gamma) {
+      s = gamma[n] * (1.0f / sqrtf(rvar[n] + eps));
+      t = beta[n] - rmean[n] * s;
+    }
+    sc[threadIdx.x] = s;
+    if (n < Nout && b_out && blockIdx.y == 0) {
+      float b = bias ? bias[n] : 0.f;
+      if (bias2) b += bias2[n];
+      b_out[n] = b * s + t;
+    }
+  }
+  for (int r = ty; r < 32; r += 8) {  // rows n of W, columns k
+    const int n = n0 + r, k = k0 + tx;
+    const bool ok = n < Nout && k < K;
+    tile[0][r][tx] = ok ? W[(int64_t)n * ldw + k] : 0.f;
+    if (Wr) tile[1][r][tx] = ok ? Wr[(int64_t)n * ldwr + k] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {  // rows k of the output, columns n
+    const int k = k0 + r, n = n0 + tx;
+    if (k < K && n < Nout) {
+      wt[(int64_t)k * Nout + n] = tile[0][tx][r] * sc[tx];
+      if (Wr) wrt[(int64_t)k * Nout + n] = tile[1][tx][r] * sc[tx];
+    }
+  }
+}
+
 int elt_grid(int64_t total) {
   int64_t b = cdiv(total, 256);
   return (int)(b < kMaxGrid ? (b < 1 ? 1 : b) : kMaxGrid);
@@ -266,6 +309,24 @@ int elt_grid(int64_t total) {
 }  // namespace rgbx
 
 using namespace rgbx;
+
+extern "C" int rgbx_fold_bn_linear_f32(const float* W, int64_t ldw, const float* Wr, int64_t ldwr, const float* bias,
+                                       const float* bias2, const float* gamma, const float* beta,
+                                       const float* running_mean, const float* running_var, float eps, float* wt,
+                                       float* wrt, float* b_out, int64_t Nout, int64_t K, rgbx_stream_t stream) {
+  if (Nout <= 0 || K <= 0) return fail(RGBX_E_ARG, "fold_bn_linear: bad size");
+  if (!W || !wt || (Wr && !wrt)) return fail(RGBX_E_ARG, "fold_bn_linear: null pointer");
+  const bool bn = gamma || beta || running_mean || running_var;
+  if (bn && !(gamma && beta && running_mean && running_var))
+    return fail(RGBX_E_ARG, "fold_bn_linear: gamma, beta, running_mean and running_var go together");
+  if (ldw < K || (Wr && ldwr < K)) return fail(RGBX_E_ARG, "fold_bn_linear: leading dimension too small");
+  if (Nout >= INT32_MAX || K >= INT32_MAX) return fail(RGBX_E_RANGE, "fold_bn_linear: size exceeds int32");
+  dim3 grid((unsigned)cdiv(Nout, 32), (unsigned)cdiv(K, 32));
+  fold_bn_linear_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(W, ldw, Wr, ldwr, bias, bias2, gamma, beta, running_mean,
+                                                            running_var, eps, wt, wrt, b_out, (int)Nout, (int)K);
+  RGBX_CHECK_LAUNCH("fold_bn_linear_kernel");
+  return RGBX_OK;
+}
 
 extern "C" int rgbx_bn_scratch_doubles(int64_t N, int64_t d, int64_t* count) {
   if (!count || N < 0 || d <= 0) return fail(RGBX_E_ARG, "bn_scratch_doubles: bad argument");

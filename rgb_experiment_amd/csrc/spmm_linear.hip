@@ -562,7 +562,7 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
 template <int KC, int NT, bool CE, bool ROOT>
 __global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE ? 3 : 4)) dense_stream_kernel(const FusedArgs A, int tiles) {
   extern __shared__ float zt[];  // [TM][KC + 4] (the loss epilogue re-uses it as [TM][Nout + 4])
-  constexpr int K = KC, ldz = KC + 4, k4 = KC / 4, S = KC / 2;
+  constexpr int ldz = KC + 4, k4 = KC / 4, S = KC / 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kr = lane >> 5, cc = lane & 31;
   float breg[NT][S];

@@ -95,7 +95,8 @@ class ConvStack(nn.Module):
         """(loss, stats) = NLLLoss(log_softmax(logits)[mask], y[mask]) and [nll sum, selected rows, correct] of this
         model's logits — what the training loop and the metrics need of a forward (itexperiments.py:429,434,624-626) —
         with the last conv taking the loss into its kernel where it can: the logits are then never written
-        (ops.propagate_linear_ce). Otherwise the same numbers from the materialised logits."""
+        (ops.propagate_linear_ce). Otherwise the same numbers from the materialised logits. Under no_grad in eval mode
+        the loss itself may be None (nobody reads it there): it is stats[0] / stats[1]."""
         return self._run(x, edge_index, ce=(y, mask))
 
     def _run(self, x, edge_index, ce=None):
@@ -106,8 +107,17 @@ class ConvStack(nn.Module):
         from .. import ops
         last = self.num_layers - 1
         pending = None  # a BatchNorm whose output has not been formed yet
+        if self.training and torch.is_grad_enabled():
+            self._train_forwards = getattr(self, "_train_forwards", 0) + 1  # statistics and weights are about to move
+        folded = self._eval_operands() if (not torch.is_grad_enabled() and not self.training and x.is_cuda) else None
         for i, conv in enumerate(self.convs):
             bn = self.bns[i] if i < last else None
+            if folded is not None and pending is None and folded[i] is not None:
+                # eval forward from prepared operands: one fused launch per layer, no weight arithmetic
+                res = conv.forward_folded(x, edge_index, folded[i], ce=ce if i == last else None)
+                if res is not None:
+                    x = res
+                    continue
             # a training-mode BatchNorm follows a conv that can hand it its column sums (taken from the fused kernel's
             # MFMA tiles): no statistics pass over the conv's output
             extra = {}
@@ -134,6 +144,31 @@ class ConvStack(nn.Module):
         if ce is not None and not isinstance(x, tuple):  # a last conv without the loss epilogue (GATConv)
             x = ops.ce_from_logits(x, ce[0], ce[1])
         return x
+
+
+def _eval_operands(self):
+    """Per conv layer the operands of its eval forward — W'^T, b', Wr'^T with the eval-mode BatchNorm behind the layer
+    folded in (rgbx_fold_bn_linear_f32, one launch per layer) — or None for layers without that form. Made once per
+    model state and shared by the val and the test forward of an epoch: keyed by the training forwards taken (BatchNorm's
+    kernels update the running statistics through raw pointers, and a fused optimizer step does not move version
+    counters either) plus every parameter's / buffer's version counter (load_state_dict and the like)."""
+    tensors = list(self.parameters()) + list(self.buffers())
+    key = (getattr(self, "_train_forwards", 0),) + tuple((t._version, t.data_ptr()) for t in tensors)
+    cached = getattr(self, "_folded_eval", None)
+    if cached is None or cached[0] != key:
+        last = self.num_layers - 1
+        out = []
+        for i, conv in enumerate(self.convs):
+            bn = self.bns[i] if i < last else None
+            make = getattr(conv, "eval_operands", None)
+            ok = make is not None and (bn is None or (hasattr(bn, "eval_affine") and bn.affine and bn.track_running_stats))
+            out.append(make(bn) if ok else None)
+        cached = (key, out)
+        self._folded_eval = cached
+    return cached[1]
+
+
+ConvStack._eval_operands = _eval_operands
 
 
 def masked_ce(model, fwd, y, mask):

@@ -27,6 +27,30 @@ def glorot_(t):
     return t
 
 
+def _forward_folded(conv, x, edge_index, operands, ce, loops_mode, kind, root):
+    """Eval forward of a GCN / SAGE layer from prepared operands (W'^T, b', Wr'^T): ONE rgbx_fused_layer_f32 launch, no
+    autograd node, no weight arithmetic on the way. Returns None when the fused kernel does not apply."""
+    if operands is None or torch.is_grad_enabled() or not x.is_cuda:
+        return None
+    graph = get_graph(edge_index, x.size(0), loops_mode)
+    if getattr(graph, "is_distributed", False) or not ops.fused_linear_ok(graph, conv.in_channels, conv.out_channels,
+                                                                          root=root, x=x):
+        return None
+    wt, b, wtr = operands
+    w = graph.w if kind == "gcn" else None
+    rs = graph.inv_deg if kind == "mean" else None
+    if ce is not None:
+        y, mask = ce
+        if not ops.fused_ce_ok(graph, conv.in_channels, conv.out_channels, root, x, y):
+            return None
+        _, _, stats = ops.fused_layer(x, wt, csr=graph.fwd, w=w, rs=rs, bias=b, x_root=x if root else None,
+                                      wt_root=wtr if root else None, ce=(y, mask, None), kind=f"{kind}_linear_fwd")
+        return None, stats  # an eval forward is read through its statistics; the mean loss is stats[0] / stats[1]
+    out, _, _ = ops.fused_layer(x, wt, csr=graph.fwd, w=w, rs=rs, bias=b, x_root=x if root else None,
+                                wt_root=wtr if root else None, kind=f"{kind}_linear_fwd")
+    return out
+
+
 class GCNConv(nn.Module):
     """out = A_hat (x W^T) + b, A_hat = D^-1/2 (A ∪ I) D^-1/2 with in-degree over the target index
     (gcn_norm restated at reference models/dagnn.py:12-31; message norm*x_j at dagnn.py:57-59).
@@ -64,6 +88,16 @@ class GCNConv(nn.Module):
             scale, shift = post_affine
             weight, bias = weight * scale[:, None], bias * scale + shift
         return self._conv(x, edge_index, weight, bias, want_colsums)
+
+    def eval_operands(self, bn=None):
+        """(W'^T, b', None) of this layer for an eval forward, the eval-mode BatchNorm `bn` behind it folded in."""
+        return ops.fold_bn_linear(self.lin.weight, self.bias, bn=bn)
+
+    def forward_folded(self, x, edge_index, operands, ce=None):
+        """Eval forward (no_grad) from prepared operands (eval_operands; models/_stack.ConvStack keeps them per
+        parameter state): one fused launch. `ce` = (y, mask): returns (None, stats). None when this layer / graph does
+        not take the fused kernel (the caller then runs the ordinary forward)."""
+        return _forward_folded(self, x, edge_index, operands, ce, LOOPS_ADD_REMAINING, "gcn", False)
 
     def _ce(self, x, edge_index, ce, bn, colsums):
         y, mask = ce
@@ -120,6 +154,13 @@ class SAGEConv(nn.Module):
 
     accepts_ce = True         # see GCNConv
 
+    def eval_operands(self, bn=None):
+        return ops.fold_bn_linear(self.lin_l.weight, self.lin_l.bias, root_weight=self.lin_r.weight, bn=bn)
+
+    def forward_folded(self, x, edge_index, operands, ce=None):
+        """See GCNConv.forward_folded."""
+        return _forward_folded(self, x, edge_index, operands, ce, LOOPS_KEEP, "mean", True)
+
     def _ce(self, x, edge_index, ce, bn, colsums):
         y, mask = ce
         graph = get_graph(edge_index, x.size(0), LOOPS_KEEP)
@@ -175,6 +216,17 @@ class MySAGEConv(nn.Module):
         self.lin_r = nn.Linear(in_channels, out_channels)
 
     accepts_ce = True         # see GCNConv
+
+    def eval_operands(self, bn=None):
+        if not self.add_self_loops:
+            return None
+        return ops.fold_bn_linear(self.lin_l.weight, self.lin_l.bias, self.lin_r.bias, root_weight=self.lin_r.weight,
+                                  bn=bn)
+
+    def forward_folded(self, x, edge_index, operands, ce=None):
+        """See GCNConv.forward_folded (mean over N(i) + {i}: the weights of a row sum to 1, so both biases and the
+        BatchNorm shift ride in the kernel's bias)."""
+        return _forward_folded(self, x, edge_index, operands, ce, LOOPS_REMOVE_ADD, "mean", True)
 
     def _ce(self, x, edge_index, ce, bn, colsums):
         y, mask = ce

@@ -337,6 +337,35 @@ def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_
     return out, z
 
 
+def fold_bn_linear(weight, bias=None, bias2=None, root_weight=None, bn=None):
+    """(W'^T [K, Nout], b' [Nout] or None, Wr'^T or None): the operands rgbx_fused_layer_f32 reads for a linear layer
+    with the eval-mode BatchNorm1d `bn` behind it folded in (bn None: the plain transposes), in ONE launch
+    (rgbx_fold_bn_linear_f32). No autograd: eval forwards only."""
+    _lib.require_device(weight, bias, bias2, root_weight)
+    W = weight.detach()
+    W = W if W.stride(-1) == 1 else W.contiguous()
+    n_out, K = W.shape
+    Wr = None
+    if root_weight is not None:
+        Wr = root_weight.detach()
+        Wr = Wr if Wr.stride(-1) == 1 else Wr.contiguous()
+    wt = torch.empty((K, n_out), dtype=torch.float32, device=W.device)
+    wrt = torch.empty_like(wt) if Wr is not None else None
+    has_b = bias is not None or bias2 is not None or bn is not None
+    b_out = torch.empty(n_out, dtype=torch.float32, device=W.device) if has_b else None
+    c = lambda t: None if t is None else t.detach().contiguous()
+    b1, b2 = c(bias), c(bias2)
+    g = be = rm = rv = None
+    eps = 0.0
+    if bn is not None:
+        g, be, rm, rv, eps = c(bn.weight), c(bn.bias), c(bn.running_mean), c(bn.running_var), bn.eps
+    _lib.check(_lib.load().rgbx_fold_bn_linear_f32(
+        _lib.ptr(W), W.stride(0), _lib.ptr(Wr), 0 if Wr is None else Wr.stride(0), _lib.ptr(b1), _lib.ptr(b2),
+        _lib.ptr(g), _lib.ptr(be), _lib.ptr(rm), _lib.ptr(rv), float(eps), _lib.ptr(wt), _lib.ptr(wrt), _lib.ptr(b_out),
+        n_out, K, _lib.stream_ptr()), "rgbx_fold_bn_linear_f32")
+    return wt, b_out, wrt
+
+
 class _PropagateLinear(torch.autograd.Function):
     """y = (P x) W^T + b (+ x Wr^T) with P = A_hat ('gcn'), the mean operator ('mean') or the plain edge sum ('sum'), in one launch
     (rgbx_spmm_linear_f32). Backward: dW = dy^T (P x) on the split-K MFMA kernel (P x was stored by the

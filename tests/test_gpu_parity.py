@@ -536,6 +536,32 @@ def test_loss_epilogue_with_frozen_weights(dev, name):
             assert (p.grad.cpu() - want).abs().max().item() < 2e-4 * max(1.0, want.abs().max().item()), k
 
 
+@pytest.mark.parametrize("n_out,K", [(128, 128), (47, 70), (32, 1433), (7, 64)])
+def test_fold_bn_linear_operands(dev, n_out, K):
+    """rgbx_fold_bn_linear_f32: W'^T = (diag(scale) W)^T, b' = (b + b2) scale + shift, Wr'^T, against the torch
+    formulation of the same fold (BatchNorm1d.eval_affine); without a BatchNorm, the plain transposes."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.nn import BatchNorm1d
+    g = torch.Generator().manual_seed(n_out * 3 + K)
+    W, Wr = torch.randn(n_out, K, generator=g).to(dev), torch.randn(n_out, K, generator=g).to(dev)
+    b, b2 = torch.randn(n_out, generator=g).to(dev), torch.randn(n_out, generator=g).to(dev)
+    bn = BatchNorm1d(n_out).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-1, 1)
+        bn.running_mean.uniform_(-1, 1)
+        bn.running_var.uniform_(0.2, 3)
+    scale, shift = bn.eval_affine()
+    wt, bo, wrt = ops.fold_bn_linear(W, b, b2, root_weight=Wr, bn=bn)
+    assert torch.allclose(wt, (W * scale[:, None]).t(), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(wrt, (Wr * scale[:, None]).t(), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(bo, (b + b2) * scale + shift, rtol=1e-5, atol=1e-6)
+    wt, bo, wrt = ops.fold_bn_linear(W, b)
+    assert torch.equal(wt, W.t().contiguous()) and torch.equal(bo, b) and wrt is None
+    wt, bo, wrt = ops.fold_bn_linear(W)
+    assert torch.equal(wt, W.t().contiguous()) and bo is None
+
+
 def _to_blocked(m, B):
     """[n, d] -> [B, n, d / B]: column slices stored one after the other (the exchange layout of a partitioned run)."""
     n, d = m.shape
