@@ -569,18 +569,25 @@ class _PropagateLinearCE(torch.autograd.Function):
         gcol = None
         if ctx.needs_input_grad[3]:  # z was stored by the forward exactly when the weight wants a gradient
             gw, gcol = gemm_tn(gy, z, colsum=True)
-            gw = gw * g
         if ctx.has_bias and ctx.needs_input_grad[4]:
-            gb = (gcol if gcol is not None else gy.sum(0)) * g
+            gb = gcol if gcol is not None else gy.sum(0)
         if root_weight is not None and ctx.needs_input_grad[5]:
             if ctx.has_bn:  # dWr = dy^T BN(x) = (dy^T x) diag(s) + colsum(dy) t^T
                 gcol = gcol if gcol is not None else gy.sum(0)
-                gwr = (gemm_tn(gy, x) * scale + gcol[:, None] * shift) * g
+                gwr = gemm_tn(gy, x) * scale + gcol[:, None] * shift
             else:
-                gwr = gemm_tn(gy, x) * g
-        if ctx.needs_input_grad[0] or (ctx.has_bn and (ctx.needs_input_grad[9] or ctx.needs_input_grad[10])):
-            g_h = _propagate_linear_input_grad(graph, kind, gy, weight.detach() * g,
-                                               None if root_weight is None else root_weight.detach() * g)
+                gwr = gemm_tn(gy, x)
+        need_h = ctx.needs_input_grad[0] or (ctx.has_bn and (ctx.needs_input_grad[9] or ctx.needs_input_grad[10]))
+        # the incoming scalar multiplies everything linear in dy: the small operands take it, in ONE multi-tensor launch
+        items = [(k, t) for k, t in (("gw", gw), ("gb", gb), ("gwr", gwr)) if t is not None]
+        if need_h:
+            items.append(("w", weight.detach()))
+            if root_weight is not None:
+                items.append(("wr", root_weight.detach()))
+        sc = dict(zip((k for k, _ in items), torch._foreach_mul([t for _, t in items], g))) if items else {}
+        gw, gb, gwr = sc.get("gw"), sc.get("gb"), sc.get("gwr")
+        if need_h:
+            g_h = _propagate_linear_input_grad(graph, kind, gy, sc["w"], sc.get("wr"))
             if ctx.has_bn:
                 gx, g_bnw, g_bnb = B.train_backward(g_h, x, bn_weight, mean, rstd, n, ctx.reduce)
             else:
