@@ -661,6 +661,10 @@ bool launch_dense_stream(const FusedArgs& A, hipStream_t s) {
   const bool root = A.xr != nullptr;
   const int nt = A.Nout <= 128 ? 1 : 2;
   if (A.Nout > 256 || (root && nt == 2)) return false;  // register budget: the one-tile-per-workgroup form
+  // the loss epilogue (barriers, LDS-pipe reductions per row) wants the 8 workgroups per CU of the one-tile form to hide
+  // behind: measured at 250 k rows, K = Nout = 128: 0.144 / 0.202 ms (eval / training) there against 0.180 / 0.269 here;
+  // the plain forms gain: 0.120 -> 0.100 ms
+  if (A.ce_part) return false;
   const int per_cu = (root || nt > 1) ? 2 : (A.ce_part ? 3 : 4);
   const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
   if (A.ce_part) {
