@@ -208,7 +208,8 @@ def experiment(model_init_param: dict, *,
                begin_early_stopping: int = 20,
                return_model: bool = False,
                use_hip_graph: bool = True,
-               share_eval_forward: bool = False):
+               share_eval_forward: bool = False,
+               cache_input_aggregate: bool = False):
     """Train + evaluate one model on one graph; returns {'ACC', 'precision_score', 'recall_score',
     'f1_macro', 'f1_micro'} (reference :603-605). ``return_model=True`` (an addition) also returns
     the trained module and the per-epoch curves under 'model' / 'history'. ``use_hip_graph=True`` (an
@@ -219,7 +220,11 @@ def experiment(model_init_param: dict, *,
     ``share_eval_forward=True``
     (an addition, off by default) takes the per-epoch test metrics from the val pass's eval-mode outputs
     instead of running the reference's second, identical eval forward (itexperiments.py:464-473): same
-    numbers, two forwards per epoch instead of three."""
+    numbers, two forwards per epoch instead of three. ``cache_input_aggregate=True`` (an addition, off by default)
+    keeps the first conv layer's aggregate of the input features — the same matrix in every forward of every epoch,
+    because features and graph are static (itexperiments.py:417-473 recomputes it three times per epoch) — so that a
+    2-layer GCN / GraphSAGE epoch runs 4 aggregations instead of 7; models whose first layer has no aggregate-first
+    form (in > out) ignore it."""
     say = print if print_print else (lambda *a, **k: None)
     say(f"running node classification: {'custom' if specify_data else dataset_name} data, model {model_name}")
 
@@ -292,6 +297,8 @@ def experiment(model_init_param: dict, *,
         net = REGISTRY[name](input_dim=input_dim, output_dim=output_dim, **model_init_param)
         fwd = {"x": features} if name == "mlp" else {"x": features, "edge_index": data.edge_index}
     net.to(device)
+    if cache_input_aggregate:
+        net.cache_input_aggregate = True  # read by models/_stack.ConvStack; other models have no such form
     graphed = None
     # capturable Adam keeps its step count on the device: required for graph capture, and used for the
     # eager GPU loop too so that both loops run the very same update kernels

@@ -51,6 +51,23 @@ def _forward_folded(conv, x, edge_index, operands, ce, loops_mode, kind, root):
     return out
 
 
+def _aggregate_input(x, edge_index, loops_mode, kind):
+    """P x of the static input features (no autograd), or None where the cached-aggregate route does not apply."""
+    graph = get_graph(edge_index, x.size(0), loops_mode)
+    if getattr(graph, "is_distributed", False) or not x.is_cuda or x.requires_grad:
+        return None
+    with torch.no_grad():
+        return ops.propagate_gcn(x, graph) if kind == "gcn" else ops.propagate_mean(x, graph)
+
+
+def _folded_from_aggregate(z, x, operands, root):
+    """Eval forward from the kept aggregate and prepared operands (W'^T, b', Wr'^T): one DENSE launch."""
+    wt, b, wtr = operands
+    out, _, _ = ops.fused_layer(z, wt, bias=b, x_root=x if root else None, wt_root=wtr if root else None,
+                                kind="cached_aggregate_linear_fwd")
+    return out
+
+
 class GCNConv(nn.Module):
     """out = A_hat (x W^T) + b, A_hat = D^-1/2 (A ∪ I) D^-1/2 with in-degree over the target index
     (gcn_norm restated at reference models/dagnn.py:12-31; message norm*x_j at dagnn.py:57-59).
@@ -92,6 +109,17 @@ class GCNConv(nn.Module):
     def eval_operands(self, bn=None):
         """(W'^T, b', None) of this layer for an eval forward, the eval-mode BatchNorm `bn` behind it folded in."""
         return ops.fold_bn_linear(self.lin.weight, self.bias, bn=bn)
+
+    # opt-in cache of the static input features' aggregate (models/_stack.ConvStack.cache_input_aggregate)
+    def aggregate_input(self, x, edge_index):
+        if self.in_channels > self.out_channels or not ops.aggregate_linear_ok(self.in_channels, self.out_channels):
+            return None
+        return _aggregate_input(x, edge_index, LOOPS_ADD_REMAINING, "gcn")
+
+    def forward_from_aggregate(self, z, x, want_colsums=False, folded=None):
+        if folded is not None:
+            return _folded_from_aggregate(z, x, folded, False)
+        return ops.aggregate_linear(z, self.lin.weight, self.bias, want_colsums=want_colsums)
 
     def forward_folded(self, x, edge_index, operands, ce=None):
         """Eval forward (no_grad) from prepared operands (eval_operands; models/_stack.ConvStack keeps them per
@@ -156,6 +184,16 @@ class SAGEConv(nn.Module):
 
     def eval_operands(self, bn=None):
         return ops.fold_bn_linear(self.lin_l.weight, self.lin_l.bias, root_weight=self.lin_r.weight, bn=bn)
+
+    def aggregate_input(self, x, edge_index):
+        if self.in_channels > self.out_channels or not ops.aggregate_linear_ok(self.in_channels, self.out_channels, True):
+            return None
+        return _aggregate_input(x, edge_index, LOOPS_KEEP, "mean")
+
+    def forward_from_aggregate(self, z, x, want_colsums=False, folded=None):
+        if folded is not None:
+            return _folded_from_aggregate(z, x, folded, True)
+        return ops.aggregate_linear(z, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, x, want_colsums)
 
     def forward_folded(self, x, edge_index, operands, ce=None):
         """See GCNConv.forward_folded."""
@@ -222,6 +260,18 @@ class MySAGEConv(nn.Module):
             return None
         return ops.fold_bn_linear(self.lin_l.weight, self.lin_l.bias, self.lin_r.bias, root_weight=self.lin_r.weight,
                                   bn=bn)
+
+    def aggregate_input(self, x, edge_index):
+        if (not self.add_self_loops or self.in_channels > self.out_channels
+                or not ops.aggregate_linear_ok(self.in_channels, self.out_channels, True)):
+            return None
+        return _aggregate_input(x, edge_index, LOOPS_REMOVE_ADD, "mean")
+
+    def forward_from_aggregate(self, z, x, want_colsums=False, folded=None):
+        if folded is not None:
+            return _folded_from_aggregate(z, x, folded, True)
+        return ops.aggregate_linear(z, self.lin_l.weight, self.lin_l.bias + self.lin_r.bias, self.lin_r.weight, x,
+                                    want_colsums)
 
     def forward_folded(self, x, edge_index, operands, ce=None):
         """See GCNConv.forward_folded (mean over N(i) + {i}: the weights of a row sum to 1, so both biases and the

@@ -337,6 +337,52 @@ def spmm_linear_raw(csr, w, rs, x, wt, bias=None, want_z=False, x_root=None, wt_
     return out, z
 
 
+class _AggregateLinear(torch.autograd.Function):
+    """y = z W^T + b (+ x_root Wr^T) for an aggregate z = P x that was formed earlier and is kept (the opt-in
+    cache of the static input features' aggregate, models/_stack.ConvStack.cache_input_aggregate): the DENSE form of
+    rgbx_fused_layer_f32. z and x_root take no gradient (they are functions of the input features only);
+    dW = dy^T z, db = column sums of dy, dWr = dy^T x_root."""
+
+    @staticmethod
+    def forward(ctx, z, weight, bias, root_weight, x_root, want_colsums):
+        out, _, cs = fused_layer(z, weight_t(weight), bias=None if bias is None else bias.detach(),
+                                 x_root=x_root if root_weight is not None else None,
+                                 wt_root=None if root_weight is None else weight_t(root_weight),
+                                 want_colsums=want_colsums, kind="cached_aggregate_linear_fwd")
+        ctx.save_for_backward(z, x_root if root_weight is not None else None)
+        ctx.has_bias = bias is not None
+        if want_colsums:
+            ctx.mark_non_differentiable(cs)
+            return out, cs
+        return out
+
+    @staticmethod
+    def backward(ctx, gy, _g_cs=None):
+        z, x_root = ctx.saved_tensors
+        gy = gy.contiguous()
+        gw = gb = gwr = None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            if want_b:
+                gw, gb = gemm_tn(gy, z, colsum=True)
+            else:
+                gw = gemm_tn(gy, z)
+        elif want_b:
+            gb = gy.sum(0)
+        if x_root is not None and ctx.needs_input_grad[3]:
+            gwr = gemm_tn(gy, x_root)
+        return None, gw, gb, gwr, None, None
+
+
+def aggregate_linear_ok(in_channels, out_channels, root=False):
+    return bool(_lib.load().rgbx_spmm_linear_supported(in_channels, out_channels, int(root)))
+
+
+def aggregate_linear(z, weight, bias=None, root_weight=None, x_root=None, want_colsums=False):
+    """Transform of a kept aggregate (see _AggregateLinear); the caller checked aggregate_linear_ok."""
+    return _tag_colsums(_AggregateLinear.apply(z, weight, bias, root_weight, x_root, want_colsums), want_colsums)
+
+
 def fold_bn_linear(weight, bias=None, bias2=None, root_weight=None, bn=None):
     """(W'^T [K, Nout], b' [Nout] or None, Wr'^T or None): the operands rgbx_fused_layer_f32 reads for a linear layer
     with the eval-mode BatchNorm1d `bn` behind it folded in (bn None: the plain transposes), in ONE launch

@@ -1503,6 +1503,39 @@ def test_shared_eval_forward_changes_nothing_but_the_forward_count(dev, graphed)
     assert a["ACC"] == b["ACC"]
 
 
+@pytest.mark.parametrize("name,graphed", [("gcn", False), ("graphsage", True), ("graphsage2", False)])
+def test_cached_input_aggregate_changes_nothing_but_the_aggregation_count(dev, name, graphed):
+    """cache_input_aggregate=True (opt-in): the first layer's aggregate of the static input features is formed once and
+    every forward transforms the kept matrix (DENSE launch) — 4 aggregations per epoch of a 2-layer stack instead of 7.
+    Same curves and weights as the recomputing run to rounding of the MFMA order (identical tiles: expected equal)."""
+    import rgb_experiment_amd as R
+    from rgb_experiment_amd import ops
+    n, f, c = 1500, 32, 5
+    gen = torch.Generator().manual_seed(13)
+    ei = rand_graph(n, 9000, 15, loops=4, dups=4)
+    data = R.Data(x=torch.randn(n, f, generator=gen), y=torch.randint(0, c, (n,), generator=gen), edge_index=ei)
+    params = R.InitialParameters.defaults_for(name)
+    params["hidden_unit"] = 64  # in <= out: the first layer aggregates first
+    counts = []
+    runs = []
+    for cache in (False, True):
+        events = []
+        ops.set_event_sink(events)
+        runs.append(R.experiment(params, specify_data=True, data=data, model_name=name, learning_rate=0.01, epoch=5,
+                                 need_to_reappear=True, print_print=False, return_model=True, use_hip_graph=graphed,
+                                 need_all_metrics=False, cache_input_aggregate=cache))
+        ops.set_event_sink(None)
+        counts.append(sum(1 for k, _, _ in events if k.endswith(("_linear_fwd", "_fwd")) and "cached" not in k))
+    a, b = runs
+    for key in ("train_loss", "val_loss", "test_loss"):
+        assert np.allclose(a["history"][key], b["history"][key], rtol=0, atol=1e-5), key
+    for (ka, va), (kb, vb) in zip(a["model"].state_dict().items(), b["model"].state_dict().items()):
+        assert ka == kb and (va.float() - vb.float()).abs().max().item() < 1e-4, ka
+    assert abs(a["ACC"] - b["ACC"]) < 0.02
+    if not graphed:  # eager loops record every launch: the cached run aggregates far less often
+        assert counts[1] < counts[0]
+
+
 def test_experiment_pta_and_sgc_run(dev):
     import rgb_experiment_amd as R
     n, f, c = 800, 16, 4
