@@ -678,6 +678,9 @@ def main():
                     help="N > 1: conv stacks through the modules (separate pack / GEMM / BatchNorm / loss launches) instead "
                          "of the fused per-rank schedule of rgb_experiment_amd/dist/stack.py — the conservative setting")
     ap.add_argument("--pieces-in", type=int, default=1, help="pieces of the inbound exchange (fused schedule)")
+    ap.add_argument("--cache-input-aggregate", action="store_true",
+                    help="SECONDARY runs only: keep the first layer's aggregate of the static input features across "
+                         "forwards and epochs (experiment(cache_input_aggregate=True)); the line says so in its metric")
     ap.add_argument("--emulate-rank", type=int, default=0, metavar="P",
                     help="one GPU: rank 0's launches of a P-rank job, exchanges replaced by stand-in rows")
     ap.add_argument("--degree", choices=("uniform", "powerlaw"), default="uniform",
@@ -753,6 +756,10 @@ def main():
 
     if args.degree != "uniform":
         wl_name += " [SECONDARY: power-law in- and out-degree, same |V| and |E|]"
+    if args.cache_input_aggregate:
+        model.cache_input_aggregate = True
+        n_prop -= 3 if args.model in ("gcn", "graphsage", "graphsage2") else 0  # aggregations actually run per epoch
+        wl_name += " [SECONDARY: cache_input_aggregate=True, the first layer's aggregate of the static features kept]"
     emu = args.emulate_rank if world == 1 else 0
     parts = max(world, emu)  # ranks the graph is partitioned over
     comm_obj = None
@@ -764,7 +771,8 @@ def main():
         t_mark = time.perf_counter()
         runner = DistRunner(model, ei, x, y, (train_mask, val_mask, test_mask), 0 if emu else rank, parts, dev,
                             lr=0.01, comm=comm_obj, backend=test_backend, exchange=args.exchange, pieces=args.pieces,
-                            interleave_evals=not args.no_interleave, fused=not args.no_fused, pieces_in=args.pieces_in)
+                            interleave_evals=not args.no_interleave, fused=not args.no_fused, pieces_in=args.pieces_in,
+                            cache_input_aggregate=args.cache_input_aggregate)
         dgraph = runner.graphs[loops_mode]
         step = runner.epoch
         n_loc = runner.hi - runner.lo

@@ -108,7 +108,8 @@ class GridStack:
     caller then runs the generic module path, which is what every other model uses)."""
 
     @classmethod
-    def build(cls, model, graphs, comm, backend, x_local, y, masks, mask_counts, pieces_in=1):
+    def build(cls, model, graphs, comm, backend, x_local, y, masks, mask_counts, pieces_in=1,
+              cache_input_aggregate=False):
         convs, bns = getattr(model, "convs", None), getattr(model, "bns", None)
         if comm.world < 2 or convs is None or bns is None or len(convs) < 2 or len(bns) != len(convs) - 1:
             return None
@@ -147,9 +148,11 @@ class GridStack:
             shapes.append(shape)
         if specs[-1].d_out > 128:  # the loss epilogue's limit
             return None
-        return cls(model, specs, bns, dg, shapes, comm, stack_be, x_local, y, masks, mask_counts, pieces_in)
+        return cls(model, specs, bns, dg, shapes, comm, stack_be, x_local, y, masks, mask_counts, pieces_in,
+                   cache_input_aggregate)
 
-    def __init__(self, model, specs, bns, dg, shapes, comm, be, x_local, y, masks, mask_counts, pieces_in):
+    def __init__(self, model, specs, bns, dg, shapes, comm, be, x_local, y, masks, mask_counts, pieces_in,
+                 cache_input_aggregate=False):
         self.model, self.specs, self.bns, self.dg, self.comm, self.be = model, specs, list(bns), dg, comm, be
         self.shapes = [None] + shapes  # per layer: (R, C) of its exchange
         self.x, self.y, self.masks = x_local, y, masks
@@ -160,6 +163,10 @@ class GridStack:
         self.mask_counts = mask_counts
         self.pieces_in = max(1, int(pieces_in))
         self._rowsum = None
+        # OPT-IN (never the headline): keep this rank's rows of P x, the first layer's aggregate of the static input
+        # features — the same matrix in every forward of every epoch; layer 0 is then a DENSE launch over it
+        self.cache_input_aggregate = bool(cache_input_aggregate)
+        self._z0 = None
         self._folded = (None, None)
         self._steps = 0
         # every parameter gradient is a view of ONE flat buffer, written in place by the kernels that produce it: the
@@ -232,16 +239,25 @@ class GridStack:
         n, dev = self.n_loc, self.x.device
         blk = self._blocked_buffer(1)
         h = torch.empty((n, sp.d_out), dtype=torch.float32, device=dev) if train else None
-        z = torch.empty((n, sp.d_in), dtype=torch.float32, device=dev) if train else None
+        cached = self.cache_input_aggregate
+        if cached and self._z0 is None:
+            self._z0 = self.be.run(handle, x_ext, kind=f"{sp.kind}_fwd")
+        z = self._z0 if cached else (torch.empty((n, sp.d_in), dtype=torch.float32, device=dev) if train else None)
         pieces = self.pieces_in if getattr(handle[0], "split", None) is None else 1
         cols, works, cs = None, [], None
         for k in range(pieces):
             a, b = n * k // pieces, n * (k + 1) // pieces
             rows = None if pieces == 1 else (a, b)
-            _, _, c = self.be.layer(x_ext, wt, handle=handle, rows=rows, bias=bias,
-                                    x_root=self.x[a:b] if wtr is not None else None, wt_root=wtr, want_out=False,
-                                    out=None if h is None else h[a:b], z=None if z is None else z[a:b],
-                                    want_colsums=train, out_blocked=blk[:, a:b], kind=f"{sp.kind}_linear_fwd")
+            if cached:  # transform of the kept aggregate: no gather at all
+                _, _, c = self.be.layer(z[a:b], wt, bias=bias, x_root=self.x[a:b] if wtr is not None else None,
+                                        wt_root=wtr, want_out=False, out=None if h is None else h[a:b],
+                                        want_colsums=train, out_blocked=blk[:, a:b],
+                                        kind="cached_aggregate_linear_fwd")
+            else:
+                _, _, c = self.be.layer(x_ext, wt, handle=handle, rows=rows, bias=bias,
+                                        x_root=self.x[a:b] if wtr is not None else None, wt_root=wtr, want_out=False,
+                                        out=None if h is None else h[a:b], z=None if z is None else z[a:b],
+                                        want_colsums=train, out_blocked=blk[:, a:b], kind=f"{sp.kind}_linear_fwd")
             cs = c if cs is None or c is None else cs + c
             cols, work = self._inbound(1, blk, piece=(k, pieces), cols=cols)
             works.append(work)

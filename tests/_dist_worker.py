@@ -218,7 +218,7 @@ def reshard_chunk_worker(rank, world, port, out_dir, exchange="reshard"):
 
 
 def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", interleave=True, release=False, fused=True,
-                  pieces=None):
+                  pieces=None, cache=False):
     """Three epochs of DistRunner (train + evals) — compared by the test with single-process training."""
     _init(rank, world, port)
     from rgb_experiment_amd import models as M
@@ -228,7 +228,7 @@ def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", inter
     model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
     r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
                    backend=OracleAggregator(), exchange=exchange, interleave_evals=interleave, fused=fused,
-                   pieces=pieces, pieces_in=pieces or 1)
+                   pieces=pieces, pieces_in=pieces or 1, cache_input_aggregate=cache)
     hist = [r.epoch()]
     if release:  # every structure exists after one epoch: the global edge list may go
         r.release_edge_list()

@@ -241,6 +241,23 @@ def test_fused_grid_schedule_matches_single_process(model_name, world, exchange,
             assert eng[1].item() == mod_stats[1].item()
 
 
+@pytest.mark.parametrize("model_name,world,exchange", [("gcn_grid", 2, "reshard"), ("graphsage_grid", 4, "2x2")])
+def test_fused_grid_schedule_with_the_kept_input_aggregate(model_name, world, exchange, tmp_path):
+    """cache_input_aggregate=True on the partitioned run (opt-in): layer 0 transforms the kept aggregate of the static
+    features instead of gathering it again; same losses and weights as the recomputing run."""
+    runs = []
+    for cache in (False, True):
+        mp.spawn(W.runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, True, True, True, 2,
+                                        cache), nprocs=world, join=True)
+        runs.append(torch.load(os.path.join(tmp_path, f"run_{model_name}_0.pt")))
+    a, b = runs
+    assert a["engine"] and b["engine"]
+    for x, y in zip(a["hist"], b["hist"]):
+        assert abs(x[0] - y[0]) < 1e-6 and abs(x[1] - y[1]) < 1e-5 and abs(x[3] - y[3]) < 1e-5, (x, y)
+    for k, v in a["state"].items():
+        assert torch.allclose(v, b["state"][k], atol=1e-6), k
+
+
 @pytest.mark.parametrize("model_name,with_resident,without", [("gcn", 8, 11), ("graphsage2", 4, 7), ("gat", 4, 8)])
 def test_resident_input_features_remove_the_first_layer_exchange(model_name, with_resident, without, tmp_path):
     """The boundary rows of the static feature matrix are fetched once (DistGraph.pin_resident): a steady-state
