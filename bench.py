@@ -677,7 +677,9 @@ def main():
     ap.add_argument("--no-fused", action="store_true",
                     help="N > 1: conv stacks through the modules (separate pack / GEMM / BatchNorm / loss launches) instead "
                          "of the fused per-rank schedule of rgb_experiment_amd/dist/stack.py — the conservative setting")
-    ap.add_argument("--pieces-in", type=int, default=1, help="pieces of the inbound exchange (fused schedule)")
+    ap.add_argument("--pieces-in", type=int, default=2,
+                    help="fused schedule: row pieces the first layer is launched in; each piece's slices leave for their "
+                         "consumers while the next piece is computed (1 = one launch, the whole inbound exchange exposed)")
     ap.add_argument("--cache-input-aggregate", action="store_true",
                     help="SECONDARY runs only: keep the first layer's aggregate of the static input features across "
                          "forwards and epochs (experiment(cache_input_aggregate=True)); the line says so in its metric")

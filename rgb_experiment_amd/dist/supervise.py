@@ -30,7 +30,7 @@ import time
 ATTEMPTS = [
     ("as asked", []),
     ("the scheme as asked, through the modules: no fused schedule, sequential evals, one-piece exchanges",
-     ["--no-fused", "--no-interleave", "--pieces", "1"]),
+     ["--no-fused", "--no-interleave", "--pieces", "1", "--pieces-in", "1"]),
     ("conservative: val and test forward one after the other, one-piece transpose exchange",
      ["--no-fused", "--no-interleave", "--pieces", "1", "--exchange", "reshard"]),
     ("halo exchange, sequential evals", ["--no-fused", "--no-interleave", "--pieces", "1", "--exchange", "halo"]),

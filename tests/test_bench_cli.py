@@ -69,7 +69,7 @@ def test_a_failing_or_stalled_rank_ends_in_a_line_from_fresh_conservative_ranks(
     assert len(lines) == 1, proc.stdout
     res = json.loads(lines[0])
     la = res["launcher"]
-    assert la["attempt"] == 1 and la["extra_flags"] == ["--no-fused", "--no-interleave", "--pieces", "1"]
+    assert la["attempt"] == 1 and la["extra_flags"] == ["--no-fused", "--no-interleave", "--pieces", "1", "--pieces-in", "1"]
     assert res["scheme"] == "reshard" and res["ranks_seen"] == 2 and res["value"] > 0 and not res["fused_schedule"]
     failed = la["fallback"]["failed"]
     assert len(failed) == 1 and failed[0]["attempt"] == 0
