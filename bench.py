@@ -622,7 +622,9 @@ def dist_alg_bytes(dgraph, kind, d, N, n_loc, world, K=10, replica=None):
                     "dist_fwd_remote": spmm_alg_bytes(n_loc, nr, d) + n_loc * 4 * d,
                     "dist_bwd_local": spmm_alg_bytes(n_loc, cnt(b.loc_agg), d),
                     "dist_bwd_remote": spmm_alg_bytes(n_loc, cnt(b.rem_agg), d) + n_loc * 4 * d})
-    for (k, C, pieces), gst in dgraph._grid.items():
+    for key, gst in dgraph._grid.items():
+        k, C, pieces = key[:3]
+        src_pieces = key[4] if len(key) > 3 else 1  # fused schedule: one launch per (target piece, source piece)
         if k != kind:
             continue
         plan = gst["plan"]
@@ -632,14 +634,23 @@ def dist_alg_bytes(dgraph, kind, d, N, n_loc, world, K=10, replica=None):
             out.update({"dist_fwd_appnp_colshard": per, "dist_bwd_appnp_colshard": per})
         else:
             for direction, half in (("fwd", plan.fwd), ("bwd", plan.bwd)):
-                out[f"dist_{direction}_colshard"] = spmm_alg_bytes(half.n_group / pieces, half.nnz / pieces, dc)
+                out[f"dist_{direction}_colshard"] = spmm_alg_bytes(half.n_group / pieces, half.nnz / pieces / src_pieces,
+                                                                   dc)
     return out
 
 
 def link_model(log, steps_logged, gbs=(50.0, 60.0, 76.8)):
     """Link arithmetic on the emulated rank's exchange log: per epoch, the bytes the busiest link carries per
     direction, summed over all exchanges (`serial`) and over those whose transfer nothing of the SAME propagate can
-    hide (`exposed`: the inbound exchange, the last outbound piece, halo / resident fetches)."""
+    hide (`exposed`). What counts as exposed, by tag:
+      "out k/n"            the last outbound piece (piece k < n travels while piece k + 1 is aggregated);
+      "in k/n producer"    inbound pieces issued behind the producing kernel's pieces (fused schedule, layer 0): piece
+                           k < n travels while the producer computes piece k + 1, piece n while the consumer aggregates
+                           the sources of piece n - 1 -> nothing exposed for n > 1, everything for n = 1;
+      "in k/n"             inbound pieces issued at once (backward, deeper layers): piece 1 exposed, piece k > 1 travels
+                           while the sources of piece k - 1 are aggregated;
+      anything else        (module path: "in", "halo", "resident") exposed in full.
+    The overlap of the two interleaved eval forwards with each other is NOT credited here."""
     tot = exp = 0
     by_tag = {}
     for tag, b_out, b_in in log:
@@ -649,8 +660,17 @@ def link_model(log, steps_logged, gbs=(50.0, 60.0, 76.8)):
         by_tag.setdefault(t, [0, 0])
         by_tag[t][0] += 1
         by_tag[t][1] += b
-        last_piece = t.startswith("out") and t.split()[1].split("/")[0] == t.split()[1].split("/")[1]
-        if not t.startswith("out") or last_piece:
+        parts = t.split()
+        k, n = (int(v) for v in parts[1].split("/")) if len(parts) > 1 and "/" in parts[1] else (1, 1)
+        if parts[0] == "out":
+            exposed = k == n
+        elif parts[0] == "in" and len(parts) > 2 and parts[2] == "producer":
+            exposed = n == 1
+        elif parts[0] == "in" and len(parts) > 1:
+            exposed = k == 1
+        else:
+            exposed = True
+        if exposed:
             exp += b
     per = lambda v: v / max(steps_logged, 1)
     return {"link_bytes_per_epoch_serial": per(tot), "link_bytes_per_epoch_exposed": per(exp),

@@ -24,16 +24,20 @@ class HipAggregator:
             return ops.spmm_raw(csr, w, None, x, kind=kind)
         return ops.spmm_raw(csr, w, None, x, y=y, a=1.0, b=1.0, out=y, kind=kind)
 
-    def run_rows(self, handle, x, lo, hi, out, kind="dist_spmm"):
-        """Rows [lo, hi) of the same product, written into `out` ([hi - lo, d]); False when the CSR carries a
-        hub-row plan (row ids in the plan are absolute: the caller then takes the unchunked route)."""
+    def run_rows(self, handle, x, lo, hi, out, kind="dist_spmm", accumulate=False):
+        """Rows [lo, hi) of the same product, written into `out` ([hi - lo, d]) — or ADDED to it (`accumulate`: the
+        second and later source pieces of a propagate whose sources arrive piece by piece); False when the CSR carries
+        a hub-row plan (row ids in the plan are absolute: the caller then takes the unchunked route)."""
         from .. import ops
         csr, w = handle
         if csr.split is not None:
             return False
         if hi > lo:
             view = _graph.CSR(csr.rowptr[lo:hi + 1], csr.col, csr.perm, hi - lo, csr.nnz, None)
-            ops.spmm_raw(view, w, None, x, out=out, kind=kind)
+            if accumulate:
+                ops.spmm_raw(view, w, None, x, y=out, a=1.0, b=1.0, out=out, kind=kind)
+            else:
+                ops.spmm_raw(view, w, None, x, out=out, kind=kind)
         return True
 
     def gather(self, x, idx):
@@ -286,12 +290,38 @@ class DistGraph:
             self._grid[key] = st
         return st
 
-    def _grid_half(self, kind, C, pieces, direction):
-        st = self._get_grid(kind, C, pieces)
+    def _grid_half(self, kind, C, pieces, direction, src_pieces=1):
+        """(GridHalf, CSR handle) of one direction — or, with `src_pieces` > 1, (GridHalf, [handle per source piece]):
+        the edges are split by which row piece of its owner the SOURCE lies in (piece k of rank q = its rows
+        [n_q k / n, n_q (k + 1) / n), the cut the inbound exchange of the fused schedule uses), so that the aggregation
+        over the sources of piece k can run while piece k + 1 is still on the links."""
+        if src_pieces <= 1:
+            st = self._get_grid(kind, C, pieces)
+            if direction not in st:
+                half = getattr(st["plan"], direction)
+                st[direction] = (half, self.backend.prepare(half.agg, half.gather, half.n_group, half.w))
+                half.agg = half.gather = half.w = None  # the CSR holds them now
+            return st[direction]
+        key = (kind, C, pieces, "split", src_pieces)
+        st = self._grid.get(key)
+        if st is None:
+            st = {"plan": GridPlan(self._edges(), self.N_global, self.comm.world, self.comm.rank, self.loops_mode, kind,
+                                   C, pieces)}
+            self._grid[key] = st
         if direction not in st:
             half = getattr(st["plan"], direction)
-            st[direction] = (half, self.backend.prepare(half.agg, half.gather, half.n_group, half.w))
-            half.agg = half.gather = half.w = None  # the CSR holds them now
+            b = torch.tensor(self.bounds, dtype=half.gather.dtype, device=half.gather.device)
+            owner = torch.bucketize(half.gather, b[1:], right=True)
+            r = half.gather - b[owner]
+            n_q = (b[1:] - b[:-1])[owner].clamp(min=1)
+            piece = ((r + 1) * src_pieces - 1) // n_q
+            handles = []
+            for k in range(src_pieces):
+                m = piece == k
+                handles.append(self.backend.prepare(half.agg[m], half.gather[m], half.n_group,
+                                                    None if half.w is None else half.w[m]))
+            st[direction] = (half, handles)
+            half.agg = half.gather = half.w = None
         return st[direction]
 
     def grid_plan(self, kind, d):

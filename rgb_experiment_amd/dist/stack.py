@@ -57,8 +57,8 @@ class HipStackBackend:
                 csr = G.CSR(csr.rowptr[lo:hi + 1], csr.col, csr.perm, hi - lo, csr.nnz, None)
         return ops.fused_layer(x, wt, csr=csr, w=w, **kw)
 
-    def run_rows(self, handle, x, lo, hi, out, kind):
-        return self.agg.run_rows(handle, x, lo, hi, out, kind=kind)
+    def run_rows(self, handle, x, lo, hi, out, kind, accumulate=False):
+        return self.agg.run_rows(handle, x, lo, hi, out, kind=kind, accumulate=accumulate)
 
     def run(self, handle, x, kind):
         return self.agg.run(handle, x, kind=kind)
@@ -266,6 +266,100 @@ class GridStack:
     def _propagate(self, i, direction, blk, inbound=None):
         """The exchanged aggregation of layer i: blocked rows of this rank in, blocked aggregated rows of this rank
         out (u[c', r, :] = column slice c' of own row r of P x, or of P^T x for direction "bwd"). `inbound` = (cols,
+        [work per source piece]) when the caller has already issued the inbound exchange (piece by piece behind the
+        producer); the aggregation over the sources of piece k starts as soon as piece k has landed, i.e. while piece
+        k + 1 is still on the links (one CSR per source piece, later pieces add to the rows of the earlier ones in a
+        fixed order: reproducible). Outbound: one send per target piece, in flight while the next one is aggregated."""
+        R, C = self.shapes[i]
+        d = self.specs[i].d_in
+        dg, P = self.dg, self.P
+        if inbound is None:
+            cols, works = None, []
+            for k in range(self.pieces_in):
+                cols, work = self._inbound(i, blk, piece=(k, self.pieces_in), cols=cols)
+                works.append(work)
+            inbound = (cols, works)
+        cols, works = inbound
+        src_pieces = len(works)
+        half, handles = dg._grid_half(self.specs[i].kind, C, dg.pieces_for(d), direction, src_pieces)
+        if src_pieces == 1:
+            handles = [handles]
+        dc = blk.size(2)
+        u = self._blocked_buffer(i)
+        empty = u[0, 0:0]
+        tag = f"dist_{direction}_colshard"
+        ranges = [(half.piece_ptr[k], half.piece_ptr[k + 1]) for k in range(half.pieces)]
+        sends = [cols.new_empty((hi - lo, dc)) for lo, hi in ranges]
+        full = None
+        pending = []
+        for ks in range(src_pieces):
+            works[ks].wait()
+            last_src = ks == src_pieces - 1
+            for k, (lo, hi) in enumerate(ranges):
+                if full is None and self.be.run_rows(handles[ks], cols, lo, hi, sends[k], tag, accumulate=ks > 0) is False:
+                    if ks or k:
+                        raise RuntimeError("grid exchange: backend refused a row range after accepting one")
+                    # hub-row plan (row ids in it are absolute): the whole group's rows in one launch per source piece
+                    full = [self.be.run(h, cols, tag) for h in handles]
+                    for extra in full[1:]:
+                        full[0].add_(extra)
+                    for works_left in works[1:]:
+                        works_left.wait()
+                    sends = [full[0][a:b] for a, b in ranges]
+                    last_src = True
+                if last_src:  # this target piece is complete: it leaves while the next one is aggregated
+                    a, b = half.my_piece[k]
+                    sv, rv, off = [], [], 0
+                    for q in range(P):
+                        cnt = half.piece_counts[k][q]
+                        sv.append(sends[k][off:off + cnt])
+                        off += cnt
+                        rv.append(u[q % C, a:b] if q in half.members else empty)
+                    pending.append(self.comm.all_to_all_views(sv, rv, tag=f"out {k + 1}/{half.pieces}"))
+            if full is not None:
+                break
+        for w in pending:  # `sends` stay referenced until their exchanges were waited on
+            w.wait()
+        return u
+
+    def _first_layer(self, wt, bias, wtr, train):
+        """Layer 0 on the resident features, launched in `pieces_in` row pieces; each piece's slices leave for their
+        consumers as soon as its launch is enqueued (the all-to-all runs on RCCL's stream while the next piece is
+        computed), so only the last piece's share of the inbound exchange is exposed. Training also keeps the raw
+        rows (BatchNorm's backward), the aggregate (dW_0) and the column sums (BatchNorm's statistics).
+        Returns (blk, (cols, works), h, z, colsums)."""
+        sp = self.specs[0]
+        handle, x_ext = self._first()
+        n, dev = self.n_loc, self.x.device
+        blk = self._blocked_buffer(1)
+        h = torch.empty((n, sp.d_out), dtype=torch.float32, device=dev) if train else None
+        cached = self.cache_input_aggregate
+        if cached and self._z0 is None:
+            self._z0 = self.be.run(handle, x_ext, kind=f"{sp.kind}_fwd")
+        z = self._z0 if cached else (torch.empty((n, sp.d_in), dtype=torch.float32, device=dev) if train else None)
+        pieces = self.pieces_in if getattr(handle[0], "split", None) is None else 1
+        cols, works, cs = None, [], None
+        for k in range(pieces):
+            a, b = n * k // pieces, n * (k + 1) // pieces
+            rows = None if pieces == 1 else (a, b)
+            if cached:  # transform of the kept aggregate: no gather at all
+                _, _, c = self.be.layer(z[a:b], wt, bias=bias, x_root=self.x[a:b] if wtr is not None else None,
+                                        wt_root=wtr, want_out=False, out=None if h is None else h[a:b],
+                                        want_colsums=train, out_blocked=blk[:, a:b],
+                                        kind="cached_aggregate_linear_fwd")
+            else:
+                _, _, c = self.be.layer(x_ext, wt, handle=handle, rows=rows, bias=bias,
+                                        x_root=self.x[a:b] if wtr is not None else None, wt_root=wtr, want_out=False,
+                                        out=None if h is None else h[a:b], z=None if z is None else z[a:b],
+                                        want_colsums=train, out_blocked=blk[:, a:b], kind=f"{sp.kind}_linear_fwd")
+            cs = c if cs is None or c is None else cs + c
+            cols, work = self._inbound(1, blk, piece=(k, pieces), cols=cols)
+            works.append(work)
+        return blk, (cols, works), h, z, cs
+
+    def _propagate(self, i, direction, blk, inbound=None):
+        """The exchanged aggregation of layer i: blocked rows of this rank in, blocked aggregated rows of this rank
+        out (u[c', r, :] = column slice c' of own row r of P x, or of P^T x for direction "bwd"). `inbound` = (cols,
         [work, ...]) when the caller has already issued the inbound exchange (piece by piece behind the producer)."""
         R, C = self.shapes[i]
         d = self.specs[i].d_in
@@ -347,13 +441,16 @@ class GridStack:
             # q = dy W goes out first; the weight-gradient GEMMs run while its slices travel
             q = self._blocked_buffer(i)
             be.layer(dy, sp.W.detach().contiguous(), want_out=False, out_blocked=q, kind="return_linear_bwd")
-            cols, work = self._inbound(i, q)
+            cols, works = None, []
+            for k in range(self.pieces_in):
+                cols, work = self._inbound(i, q, piece=(k, self.pieces_in), cols=cols)
+                works.append(work)
             _, gcol = be.gemm_tn(dy, z, colsum=True, out=self._g(sp.W), sums_out=self._g(sp.biases[0]))
             for b in sp.biases[1:]:
                 self._g(b).copy_(gcol)
             if sp.Wr is not None:  # dWr = dy^T BN(h) = (dy^T h) diag(s) + colsum(dy) t^T
                 torch.addcmul(gcol[:, None] * shift, be.gemm_tn(dy, h_prev), scale, out=self._g(sp.Wr))
-            v = self._propagate(i, "bwd", q, (cols, [work]))
+            v = self._propagate(i, "bwd", q, (cols, works))
             g_a = be.blocked_to_rows(v)
             if sp.Wr is not None:
                 g_a.addmm_(dy, sp.Wr.detach())

@@ -25,8 +25,9 @@ class OracleAggregator:
         out = O.propagate(ei, x, n_rows, w, "add")
         return out if y is None else y.add_(out)
 
-    def run_rows(self, handle, x, lo, hi, out, kind=None):
-        out.copy_(self.run(handle, x)[lo:hi])
+    def run_rows(self, handle, x, lo, hi, out, kind=None, accumulate=False):
+        rows = self.run(handle, x)[lo:hi]
+        out.add_(rows) if accumulate else out.copy_(rows)
         return True
 
     def gather(self, x, idx):
@@ -121,8 +122,8 @@ class TorchStackBackend:
             z_arg.copy_(z)
         return (out if want_out or ce is not None else out_arg), (z.contiguous() if want_z else z_arg), extra
 
-    def run_rows(self, handle, x, lo, hi, out, kind):
-        return self.agg.run_rows(handle, x, lo, hi, out, kind)
+    def run_rows(self, handle, x, lo, hi, out, kind, accumulate=False):
+        return self.agg.run_rows(handle, x, lo, hi, out, kind, accumulate)
 
     def run(self, handle, x, kind):
         return self.agg.run(handle, x)
