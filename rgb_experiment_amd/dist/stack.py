@@ -63,6 +63,10 @@ class HipStackBackend:
     def run(self, handle, x, kind):
         return self.agg.run(handle, x, kind=kind)
 
+    def rows_ok(self, handle):
+        """Row ranges of this CSR can be launched on their own (no hub-row plan: its row ids are absolute)."""
+        return handle[0].split is None
+
     def gemm_tn(self, a, b, colsum=False, out=None, sums_out=None):
         from .. import ops
         return ops.gemm_tn(a, b, colsum=colsum, out=out, sums_out=sums_out)
@@ -210,7 +214,7 @@ class GridStack:
                            device=self.x.device)
 
     # ---- the exchange ----------------------------------------------------------------------------------------
-    def _inbound(self, i, blk, piece=None, cols=None):
+    def _inbound(self, i, blk, piece=None, cols=None, behind_producer=False):
         """Column slice c of every node's row -> `cols` [N, dc] (c = this rank's slice): every peer q = (r', c') is sent
         slice c' of my rows — the same view for the R ranks that share it. `piece` = (k, n): only the k-th of n row
         pieces of every rank's rows (rows [n_q k / n, n_q (k + 1) / n) of rank q), so that the exchange of a piece can
@@ -225,7 +229,7 @@ class GridStack:
         a0, a1 = cut(self.n_loc, k), cut(self.n_loc, k + 1)
         send = [blk[q % C, a0:a1] for q in range(P)]
         recv = [cols[b[q] + cut(b[q + 1] - b[q], k):b[q] + cut(b[q + 1] - b[q], k + 1)] for q in range(P)]
-        tag = "in" if n == 1 else f"in {k + 1}/{n}"
+        tag = f"in {k + 1}/{n}" + (" producer" if behind_producer else "")
         return cols, self.comm.all_to_all_views(send, recv, tag=tag)
 
     def _first_layer(self, wt, bias, wtr, train):
@@ -243,7 +247,7 @@ class GridStack:
         if cached and self._z0 is None:
             self._z0 = self.be.run(handle, x_ext, kind=f"{sp.kind}_fwd")
         z = self._z0 if cached else (torch.empty((n, sp.d_in), dtype=torch.float32, device=dev) if train else None)
-        pieces = self.pieces_in if getattr(handle[0], "split", None) is None else 1
+        pieces = self.pieces_in if self.be.rows_ok(handle) else 1
         cols, works, cs = None, [], None
         for k in range(pieces):
             a, b = n * k // pieces, n * (k + 1) // pieces
@@ -259,7 +263,7 @@ class GridStack:
                                         out=None if h is None else h[a:b], z=None if z is None else z[a:b],
                                         want_colsums=train, out_blocked=blk[:, a:b], kind=f"{sp.kind}_linear_fwd")
             cs = c if cs is None or c is None else cs + c
-            cols, work = self._inbound(1, blk, piece=(k, pieces), cols=cols)
+            cols, work = self._inbound(1, blk, piece=(k, pieces), cols=cols, behind_producer=True)
             works.append(work)
         return blk, (cols, works), h, z, cs
 
@@ -290,114 +294,36 @@ class GridStack:
         tag = f"dist_{direction}_colshard"
         ranges = [(half.piece_ptr[k], half.piece_ptr[k + 1]) for k in range(half.pieces)]
         sends = [cols.new_empty((hi - lo, dc)) for lo, hi in ranges]
-        full = None
         pending = []
-        for ks in range(src_pieces):
-            works[ks].wait()
-            last_src = ks == src_pieces - 1
-            for k, (lo, hi) in enumerate(ranges):
-                if full is None and self.be.run_rows(handles[ks], cols, lo, hi, sends[k], tag, accumulate=ks > 0) is False:
-                    if ks or k:
-                        raise RuntimeError("grid exchange: backend refused a row range after accepting one")
-                    # hub-row plan (row ids in it are absolute): the whole group's rows in one launch per source piece
-                    full = [self.be.run(h, cols, tag) for h in handles]
-                    for extra in full[1:]:
-                        full[0].add_(extra)
-                    for works_left in works[1:]:
-                        works_left.wait()
-                    sends = [full[0][a:b] for a, b in ranges]
-                    last_src = True
-                if last_src:  # this target piece is complete: it leaves while the next one is aggregated
-                    a, b = half.my_piece[k]
-                    sv, rv, off = [], [], 0
-                    for q in range(P):
-                        cnt = half.piece_counts[k][q]
-                        sv.append(sends[k][off:off + cnt])
-                        off += cnt
-                        rv.append(u[q % C, a:b] if q in half.members else empty)
-                    pending.append(self.comm.all_to_all_views(sv, rv, tag=f"out {k + 1}/{half.pieces}"))
-            if full is not None:
-                break
-        for w in pending:  # `sends` stay referenced until their exchanges were waited on
-            w.wait()
-        return u
 
-    def _first_layer(self, wt, bias, wtr, train):
-        """Layer 0 on the resident features, launched in `pieces_in` row pieces; each piece's slices leave for their
-        consumers as soon as its launch is enqueued (the all-to-all runs on RCCL's stream while the next piece is
-        computed), so only the last piece's share of the inbound exchange is exposed. Training also keeps the raw
-        rows (BatchNorm's backward), the aggregate (dW_0) and the column sums (BatchNorm's statistics).
-        Returns (blk, (cols, works), h, z, colsums)."""
-        sp = self.specs[0]
-        handle, x_ext = self._first()
-        n, dev = self.n_loc, self.x.device
-        blk = self._blocked_buffer(1)
-        h = torch.empty((n, sp.d_out), dtype=torch.float32, device=dev) if train else None
-        cached = self.cache_input_aggregate
-        if cached and self._z0 is None:
-            self._z0 = self.be.run(handle, x_ext, kind=f"{sp.kind}_fwd")
-        z = self._z0 if cached else (torch.empty((n, sp.d_in), dtype=torch.float32, device=dev) if train else None)
-        pieces = self.pieces_in if getattr(handle[0], "split", None) is None else 1
-        cols, works, cs = None, [], None
-        for k in range(pieces):
-            a, b = n * k // pieces, n * (k + 1) // pieces
-            rows = None if pieces == 1 else (a, b)
-            if cached:  # transform of the kept aggregate: no gather at all
-                _, _, c = self.be.layer(z[a:b], wt, bias=bias, x_root=self.x[a:b] if wtr is not None else None,
-                                        wt_root=wtr, want_out=False, out=None if h is None else h[a:b],
-                                        want_colsums=train, out_blocked=blk[:, a:b],
-                                        kind="cached_aggregate_linear_fwd")
-            else:
-                _, _, c = self.be.layer(x_ext, wt, handle=handle, rows=rows, bias=bias,
-                                        x_root=self.x[a:b] if wtr is not None else None, wt_root=wtr, want_out=False,
-                                        out=None if h is None else h[a:b], z=None if z is None else z[a:b],
-                                        want_colsums=train, out_blocked=blk[:, a:b], kind=f"{sp.kind}_linear_fwd")
-            cs = c if cs is None or c is None else cs + c
-            cols, work = self._inbound(1, blk, piece=(k, pieces), cols=cols)
-            works.append(work)
-        return blk, (cols, works), h, z, cs
-
-    def _propagate(self, i, direction, blk, inbound=None):
-        """The exchanged aggregation of layer i: blocked rows of this rank in, blocked aggregated rows of this rank
-        out (u[c', r, :] = column slice c' of own row r of P x, or of P^T x for direction "bwd"). `inbound` = (cols,
-        [work, ...]) when the caller has already issued the inbound exchange (piece by piece behind the producer)."""
-        R, C = self.shapes[i]
-        d = self.specs[i].d_in
-        dg, P = self.dg, self.P
-        half, handle = dg._grid_half(self.specs[i].kind, C, dg.pieces_for(d), direction)
-        if inbound is None:
-            cols, work = self._inbound(i, blk)
-            inbound = (cols, [work])
-        cols, works = inbound
-        for work in works:
-            work.wait()
-        dc = blk.size(2)
-        u = self._blocked_buffer(i)
-        empty = u[0, 0:0]
-        tag = f"dist_{direction}_colshard"
-        pending, full = [], None
-        for k in range(half.pieces):
-            lo, hi = half.piece_ptr[k], half.piece_ptr[k + 1]
-            send = None
-            if full is None:
-                send = cols.new_empty((hi - lo, dc))
-                if self.be.run_rows(handle, cols, lo, hi, send, tag) is False:
-                    if pending:
-                        raise RuntimeError("grid exchange: backend refused a row range after accepting one")
-                    send = None
-            if send is None:  # hub-row plan (row ids in it are absolute)
-                if full is None:
-                    full = self.be.run(handle, cols, tag)
-                send = full[lo:hi]
+        def send_piece(k):  # target piece k is complete: it leaves while the next one is aggregated
             a, b = half.my_piece[k]
             sv, rv, off = [], [], 0
             for q in range(P):
                 cnt = half.piece_counts[k][q]
-                sv.append(send[off:off + cnt])
+                sv.append(sends[k][off:off + cnt])
                 off += cnt
                 rv.append(u[q % C, a:b] if q in half.members else empty)
-            pending.append((self.comm.all_to_all_views(sv, rv, tag=f"out {k + 1}/{half.pieces}"), send))
-        for w, _send in pending:  # `_send` stays referenced until its exchange was waited on
+            pending.append(self.comm.all_to_all_views(sv, rv, tag=f"out {k + 1}/{half.pieces}"))
+
+        if not all(self.be.rows_ok(h) for h in handles):
+            # hub-row plan (row ids in it are absolute): whole-group launches once everything has landed
+            for work in works:
+                work.wait()
+            full = self.be.run(handles[0], cols, tag)
+            for h in handles[1:]:
+                full.add_(self.be.run(h, cols, tag))
+            sends = [full[a:b] for a, b in ranges]
+            for k in range(half.pieces):
+                send_piece(k)
+        else:
+            for ks in range(src_pieces):
+                works[ks].wait()
+                for k, (lo, hi) in enumerate(ranges):
+                    self.be.run_rows(handles[ks], cols, lo, hi, sends[k], tag, accumulate=ks > 0)
+                    if ks == src_pieces - 1:
+                        send_piece(k)
+        for w in pending:  # `sends` stay referenced until their exchanges were waited on
             w.wait()
         return u
 
