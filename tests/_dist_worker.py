@@ -234,6 +234,10 @@ def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", inter
                    backend=OracleAggregator(), exchange=exchange, interleave_evals=interleave, fused=fused,
                    pieces=pieces, pieces_in=pieces or 1, cache_input_aggregate=cache)
     hist = [r.epoch()]
+    if r.engine is not None:  # the module path's own structures (compared below) must exist before the release
+        engine, r.engine = r.engine, None
+        r.evaluate(1, sync=False)
+        r.engine = engine
     if release:  # every structure exists after one epoch: the global edge list may go
         r.release_edge_list()
     hist += [r.epoch() for _ in range(2)]
