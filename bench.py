@@ -639,16 +639,17 @@ def dist_alg_bytes(dgraph, kind, d, N, n_loc, world, K=10, replica=None):
     return out
 
 
-def link_model(log, steps_logged, gbs=(50.0, 60.0, 76.8)):
+def link_model(log, steps_logged, gbs=(50.0, 60.0, 76.8), src_split=False):
     """Link arithmetic on the emulated rank's exchange log: per epoch, the bytes the busiest link carries per
     direction, summed over all exchanges (`serial`) and over those whose transfer nothing of the SAME propagate can
     hide (`exposed`). What counts as exposed, by tag:
       "out k/n"            the last outbound piece (piece k < n travels while piece k + 1 is aggregated);
       "in k/n producer"    inbound pieces issued behind the producing kernel's pieces (fused schedule, layer 0): piece
-                           k < n travels while the producer computes piece k + 1, piece n while the consumer aggregates
-                           the sources of piece n - 1 -> nothing exposed for n > 1, everything for n = 1;
-      "in k/n"             inbound pieces issued at once (backward, deeper layers): piece 1 exposed, piece k > 1 travels
-                           while the sources of piece k - 1 are aggregated;
+                           k < n travels while the producer computes piece k + 1; the last piece is exposed, unless
+                           --src-split lets the consumer aggregate the sources of piece n - 1 meanwhile (then nothing
+                           is exposed for n > 1);
+      "in k/n"             inbound pieces issued at once (backward, deeper layers): all exposed; with --src-split
+                           only piece 1 (piece k > 1 travels while the sources of piece k - 1 are aggregated);
       anything else        (module path: "in", "halo", "resident") exposed in full.
     The overlap of the two interleaved eval forwards with each other is NOT credited here."""
     tot = exp = 0
@@ -665,9 +666,9 @@ def link_model(log, steps_logged, gbs=(50.0, 60.0, 76.8)):
         if parts[0] == "out":
             exposed = k == n
         elif parts[0] == "in" and len(parts) > 2 and parts[2] == "producer":
-            exposed = n == 1
+            exposed = (n == 1) if src_split else (k == n)  # without the source split the last piece is waited for
         elif parts[0] == "in" and len(parts) > 1:
-            exposed = k == 1
+            exposed = (k == 1) if src_split else True
         else:
             exposed = True
         if exposed:
@@ -700,6 +701,9 @@ def main():
     ap.add_argument("--pieces-in", type=int, default=2,
                     help="fused schedule: row pieces the first layer is launched in; each piece's slices leave for their "
                          "consumers while the next piece is computed (1 = one launch, the whole inbound exchange exposed)")
+    ap.add_argument("--src-split", action="store_true",
+                    help="fused schedule: aggregate the sources of inbound piece k while piece k + 1 is on the links (one "
+                         "CSR per source piece): less exposed exchange for more aggregation time — for slow links")
     ap.add_argument("--cache-input-aggregate", action="store_true",
                     help="SECONDARY runs only: keep the first layer's aggregate of the static input features across "
                          "forwards and epochs (experiment(cache_input_aggregate=True)); the line says so in its metric")
@@ -794,7 +798,7 @@ def main():
         runner = DistRunner(model, ei, x, y, (train_mask, val_mask, test_mask), 0 if emu else rank, parts, dev,
                             lr=0.01, comm=comm_obj, backend=test_backend, exchange=args.exchange, pieces=args.pieces,
                             interleave_evals=not args.no_interleave, fused=not args.no_fused, pieces_in=args.pieces_in,
-                            cache_input_aggregate=args.cache_input_aggregate)
+                            cache_input_aggregate=args.cache_input_aggregate, src_split=args.src_split)
         dgraph = runner.graphs[loops_mode]
         step = runner.epoch
         n_loc = runner.hi - runner.lo
@@ -972,7 +976,7 @@ def main():
                               "what": "rank 0's structures and kernel launches of the partitioned job on one GPU; every "
                                       "exchange delivers stand-in rows, so ms_per_step is the rank's COMPUTE per epoch and "
                                       "`value` is what the job would reach if the exchanges were free",
-                              **link_model(comm_obj.log, args.steps)}
+                              **link_model(comm_obj.log, args.steps, src_split=args.src_split)}
         result["metric"] = "EMULATED rank compute, not a benchmark value: " + result["metric"]
 
     def secondary(key, fn):

@@ -17,7 +17,7 @@ class DistRunner:
 
     def __init__(self, model, edge_index, x, y, masks, rank, world, device, lr=0.01, weight_decay=0.0,
                  comm=None, backend=None, exchange="auto", resident_features=True, pieces=None,
-                 interleave_evals=True, fused=True, pieces_in=1, cache_input_aggregate=False):
+                 interleave_evals=True, fused=True, pieces_in=1, cache_input_aggregate=False, src_split=False):
         self.comm = comm or Comm()
         self.rank, self.world, self.device = rank, world, device
         N = x.size(0)
@@ -74,7 +74,7 @@ class DistRunner:
             from .stack import GridStack
             self.engine = GridStack.build(self.model, self.graphs, self.comm, backend or self.graphs[0].backend, self.x,
                                           self.y, self.masks, self.mask_counts, pieces_in=pieces_in,
-                                          cache_input_aggregate=cache_input_aggregate)
+                                          cache_input_aggregate=cache_input_aggregate, src_split=src_split)
 
     _REPLICABLE = {"GCNConv": 1, "SAGEConv": 0, "MySAGEConv": 2}  # conv class -> the loops mode its graph is keyed by
 

@@ -232,7 +232,7 @@ def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", inter
     model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
     r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
                    backend=OracleAggregator(), exchange=exchange, interleave_evals=interleave, fused=fused,
-                   pieces=pieces, pieces_in=pieces or 1, cache_input_aggregate=cache)
+                   pieces=pieces, pieces_in=pieces or 1, cache_input_aggregate=cache, src_split=(pieces or 1) % 2 == 0)
     hist = [r.epoch()]
     if r.engine is not None:  # the module path's own structures (compared below) must exist before the release
         engine, r.engine = r.engine, None
