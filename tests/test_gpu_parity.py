@@ -882,6 +882,33 @@ def test_gat_hub_rows_are_split(dev, H, C, monkeypatch):
     G.clear_cache()
 
 
+@pytest.mark.parametrize("H,C", [(8, 16), (1, 128)])
+def test_gat_each_form_is_bitwise_reproducible(dev, H, C):
+    """The training-form GAT forward (3 neighbour rows in flight, stores the positive-score parts) and the inference
+    form (4 rows in flight) sum a row's terms in different orders, so train and eval logits of the same weights agree
+    to rounding only. WITHIN a form every run gives the same bits: outputs of both
+    forms and all gradients of the training form, run twice."""
+    from rgb_experiment_amd.nn import GATConv
+    n = 3000
+    ei = rand_graph(n, 30000, 77, loops=6, dups=6).to(dev)
+    torch.manual_seed(3)
+    conv = GATConv(64, C, heads=H, concat=H > 1).to(dev)
+    x = torch.randn(n, 64, generator=torch.Generator().manual_seed(4)).to(dev)
+    go = torch.randn(n, H * C if H > 1 else C, generator=torch.Generator().manual_seed(5)).to(dev)
+    runs = []
+    for _ in range(2):
+        conv.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        out = conv(xg, ei)
+        out.backward(go)
+        with torch.no_grad():
+            ev = conv(x, ei)
+        runs.append([out.detach().clone(), ev.clone(), xg.grad.clone()] + [p.grad.clone() for p in conv.parameters()])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    assert (runs[0][0] - runs[0][1]).abs().max().item() < 1e-5  # train form vs inference form: rounding only
+
+
 def test_gat_backward_two_implementations_agree(dev):
     """g_a_dst from the per-node path (ops: positive-score parts stored by the forward, combined in the streaming
     prep pass) equals the direct target-side gather kernel rgbx_gat_bwd_dst_f32 (the first implementation, still
