@@ -183,6 +183,15 @@ class DistRunner:
         turns = TakeTurns(2)
         out, err = [None, None], [None, None]
         main = torch.cuda.current_stream(self.device) if cuda else None
+        self.model.eval()
+        # what both forwards share is made HERE, on the main stream, before either eval stream starts (each waits for
+        # the main stream): the eval operands with the BatchNorms folded in are cached per model state, and the thread
+        # that found them cached would otherwise read tensors another stream is still writing
+        if self.engine is not None:
+            self.engine._eval_weights()
+        elif cuda and hasattr(self.model, "_eval_operands"):
+            with torch.no_grad():
+                self.model._eval_operands()
 
         def run(i):
             turns.enter(i)
