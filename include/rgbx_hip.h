@@ -234,10 +234,11 @@ typedef struct rgbx_fused_layer {
 
 int rgbx_fused_layer_f32(const rgbx_fused_layer_t* layer, rgbx_stream_t stream);
 
-/* dst[i, c] (row-major, ldd) = src (blocked as above: blk_cols, blk_stride)[i, c] for i < n, c < d: the unpack of
- * received column slices where a consumer wants plain rows (e.g. BatchNorm's backward kernels). */
+/* dst[i, c] (row-major, ldd) = src (blocked as above: blk_cols, blk_stride)[i, c] (+ bias[c], bias optional) for
+ * i < n, c < d: the unpack of received column slices where a consumer wants plain rows (BatchNorm's backward kernels; the
+ * logits of an eval forward whose last transform ran before the exchange, + the layer's bias). */
 int rgbx_blocked_to_rows_f32(const float* src, int64_t blk_cols, int64_t blk_stride, float* dst, int64_t ldd,
-                             int64_t n, int64_t d, rgbx_stream_t stream);
+                             int64_t n, int64_t d, const float* bias, rgbx_stream_t stream);
 
 /* z_0 = h;  z_{k+1} = (1-alpha) * A_hat z_k + alpha * h, k = 0..K-1; result in `out`.
  * `tmp` is an [N, d] scratch (ld = ldo); h, out, tmp must not alias. K >= 0. */

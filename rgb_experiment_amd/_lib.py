@@ -55,7 +55,7 @@ SIGNATURES = {
     "rgbx_spmm_linear_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P,
                              ctypes.c_size_t, _P, _I64, _I64, _I64, _P, _P],
     "rgbx_fused_layer_f32": [_P, _P],
-    "rgbx_blocked_to_rows_f32": [_P, _I64, _I64, _P, _I64, _I64, _I64, _P],
+    "rgbx_blocked_to_rows_f32": [_P, _I64, _I64, _P, _I64, _I64, _I64, _P, _P],
     "rgbx_appnp_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _F, _P, _P],
     "rgbx_dagnn_gate_fwd_f32": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _P],
     "rgbx_dagnn_gate_bwd_workspace_bytes": [_I64, ctypes.POINTER(ctypes.c_size_t)],

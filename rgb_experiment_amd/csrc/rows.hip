@@ -57,12 +57,16 @@ int run(const float* src, int64_t lds, const int32_t* idx, int64_t n, int64_t d,
 // contiguous runs of blk_cols floats
 __global__ void __launch_bounds__(256)
 blocked_to_rows_kernel(const float* __restrict__ src, int64_t bc, int64_t bs, float* __restrict__ dst, int64_t ldd,
-                       int64_t n, int d4) {
+                       int64_t n, int d4, const float* __restrict__ bias) {
   const int64_t total = n * d4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t row = i / d4;
     const int c = (int)(i - row * d4) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)(c / (int)bc) * bs + row * bc + (c % (int)bc));
+    float4 v = *reinterpret_cast<const float4*>(src + (int64_t)(c / (int)bc) * bs + row * bc + (c % (int)bc));
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + c);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
     *reinterpret_cast<float4*>(dst + row * ldd + c) = v;
   }
 }
@@ -71,18 +75,19 @@ blocked_to_rows_kernel(const float* __restrict__ src, int64_t bc, int64_t bs, fl
 }  // namespace rgbx
 
 extern "C" int rgbx_blocked_to_rows_f32(const float* src, int64_t blk_cols, int64_t blk_stride, float* dst, int64_t ldd,
-                                        int64_t n, int64_t d, rgbx_stream_t stream) {
+                                        int64_t n, int64_t d, const float* bias, rgbx_stream_t stream) {
   using namespace rgbx;
   if (n < 0 || d < 0) return fail(RGBX_E_ARG, "blocked_to_rows: negative size");
   if (n == 0 || d == 0) return RGBX_OK;
   if (!src || !dst) return fail(RGBX_E_ARG, "blocked_to_rows: null pointer");
   if (blk_cols <= 0 || blk_cols % 4 || d % blk_cols || blk_stride % 4 || ldd < d || ldd % 4 || !aligned16(src) ||
-      !aligned16(dst))
+      !aligned16(dst) || (bias && !aligned16(bias)))
     return fail(RGBX_E_ARG, "blocked_to_rows: block width must be a multiple of 4 that divides d; 16-byte alignment");
   if (n >= INT32_MAX || d >= INT32_MAX) return fail(RGBX_E_RANGE, "blocked_to_rows: size exceeds int32");
   int64_t blocks = cdiv(n * (d / 4), 256);
   if (blocks > kMaxGrid) blocks = kMaxGrid;
-  blocked_to_rows_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(src, blk_cols, blk_stride, dst, ldd, n, (int)(d / 4));
+  blocked_to_rows_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(src, blk_cols, blk_stride, dst, ldd, n, (int)(d / 4),
+                                                                      bias);
   RGBX_CHECK_LAUNCH("blocked_to_rows");
   return RGBX_OK;
 }

@@ -71,9 +71,14 @@ class HipStackBackend:
         from .. import ops
         return ops.gemm_tn(a, b, colsum=colsum, out=out, sums_out=sums_out)
 
-    def blocked_to_rows(self, blk):
+    def blocked_to_rows(self, blk, bias=None):
         from .. import ops
-        return ops.blocked_to_rows(blk)
+        return ops.blocked_to_rows(blk, bias=bias)
+
+    def ce_stats(self, logits, y, mask):
+        """[nll sum, selected rows, hits] (float64, device) of materialised logits."""
+        from .. import ops
+        return ops.masked_ce_accuracy(logits, y, mask)
 
 
 class LayerSpec:
@@ -167,6 +172,15 @@ class GridStack:
         self.mask_counts = mask_counts
         self.pieces_in = max(1, int(pieces_in))
         self.src_split = bool(src_split)
+        # Eval forwards of a stack WITHOUT root terms (GCN): the last layer's transform is applied by the layer before it
+        # (the eval-mode model is linear between the aggregations: P((z W'^T + b') W_last^T) = P(z (W_last W')^T + W_last b')),
+        # so the return stage of the last exchange is bias + loss statistics with no product left — on a rank whose gathers
+        # run elsewhere that product is exposed fp32 MFMA time. Same numbers to rounding
+        # (reassociation, as the BatchNorm fold). Needs the slices of the logits to be exchangeable: width % C, % 4.
+        last, prev = specs[-1], specs[-2]
+        C_last = shapes[-1][1]
+        self.last_transform_first = (all(sp.Wr is None for sp in specs) and last.d_out % C_last == 0
+                                     and (last.d_out // C_last) % 4 == 0 and _supported(prev.d_in, last.d_out, False))
         self._rowsum = None
         # OPT-IN (never the headline): keep this rank's rows of P x, the first layer's aggregate of the static input
         # features — the same matrix in every forward of every epoch; layer 0 is then a DENSE launch over it
@@ -208,10 +222,12 @@ class GridStack:
             self._rowsum = self.be.run(handle, ones, kind="rowsum").reshape(-1).contiguous()
         return self._rowsum
 
-    def _blocked_buffer(self, i, rows=None):
-        """Send / receive buffer of layer i's exchange: [C, rows, d_in / C]."""
+    def _blocked_buffer(self, i, rows=None, width=None):
+        """Send / receive buffer of layer i's exchange: [C, rows, width / C] (width: the layer's input width unless the
+        exchanged matrix is something else, see _eval_weights)."""
         C = self.shapes[i][1]
-        return torch.empty((C, self.n_loc if rows is None else rows, self.specs[i].d_in // C), dtype=torch.float32,
+        width = self.specs[i].d_in if width is None else width
+        return torch.empty((C, self.n_loc if rows is None else rows, width // C), dtype=torch.float32,
                            device=self.x.device)
 
     # ---- the exchange ----------------------------------------------------------------------------------------
@@ -242,7 +258,7 @@ class GridStack:
         sp = self.specs[0]
         handle, x_ext = self._first()
         n, dev = self.n_loc, self.x.device
-        blk = self._blocked_buffer(1)
+        blk = self._blocked_buffer(1, width=wt.size(1))
         h = torch.empty((n, sp.d_out), dtype=torch.float32, device=dev) if train else None
         cached = self.cache_input_aggregate
         if cached and self._z0 is None:
@@ -302,7 +318,7 @@ class GridStack:
         if src_pieces == 1:
             handles = [handles]
         dc = blk.size(2)
-        u = self._blocked_buffer(i)
+        u = self._blocked_buffer(i, width=C * dc)
         empty = u[0, 0:0]
         tag = f"dist_{direction}_colshard"
         ranges = [(half.piece_ptr[k], half.piece_ptr[k + 1]) for k in range(half.pieces)]
@@ -420,7 +436,17 @@ class GridStack:
                     scale, shift = self.bns[i].eval_affine()
                     W, b = W * scale[:, None], b * scale + shift
                     Wr = None if Wr is None else Wr * scale[:, None]
-                out.append((W.t().contiguous(), b.contiguous(), None if Wr is None else Wr.t().contiguous()))
+                out.append([W, b, Wr])
+            if self.last_transform_first:
+                # eval mode, no root term: logits = P (a W_last^T) + b_last = P (a') + b_last with a' = a W_last^T, and
+                # a = z W'^T + b' is itself linear in the previous aggregate, so the previous layer applies the product
+                # W_last W' (and carries W_last b'); the last layer's return stage has no GEMM left
+                W_last = out[L - 1][0]
+                out[L - 2][1] = W_last @ out[L - 2][1]
+                out[L - 2][0] = W_last @ out[L - 2][0]
+                out[L - 1][0] = None
+            out = [(None if W is None else W.t().contiguous(), b.contiguous(), None if Wr is None else Wr.t().contiguous())
+                   for W, b, Wr in out]
             self._folded = (key, out)
         return self._folded[1]
 
@@ -441,9 +467,12 @@ class GridStack:
             u = self._propagate(i, "fwd", prev_blk, inbound)
             inbound = None
             root = dict(x_root=prev_blk, wt_root=wtr) if wtr is not None else {}
+            if i == L - 1 and wt is None:  # the transform ran before the exchange: logits = aggregate + bias
+                st = be.ce_stats(be.blocked_to_rows(u, bias=b), self.y, self.masks[which])
+                return st[::2]
             if i == L - 1:
                 _, _, st = be.layer(u, wt, bias=b, ce=(self.y, self.masks[which], None), kind="return_linear_fwd", **root)
                 return st[::2]  # (nll sum, hits): a view — indexing with a list would stage an index tensor through the host and drain the queue
-            blk = self._blocked_buffer(i + 1)
+            blk = self._blocked_buffer(i + 1, width=wt.size(1))
             be.layer(u, wt, bias=b, want_out=False, out_blocked=blk, kind="return_linear_fwd", **root)
             prev_blk = blk

@@ -308,15 +308,16 @@ def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_roo
     return out, z, (ce_stats if ce is not None else colsums)
 
 
-def blocked_to_rows(src, out=None):
-    """[B, n, cols] blocked -> [n, B * cols] row-major (rgbx_blocked_to_rows_f32)."""
-    _lib.require_device(src)
+def blocked_to_rows(src, out=None, bias=None):
+    """[B, n, cols] blocked -> [n, B * cols] row-major (+ bias per column) (rgbx_blocked_to_rows_f32)."""
+    _lib.require_device(src, bias)
     ptr, bc, bs = _blocked(src, "src")
     n, d = src.size(1), src.size(0) * src.size(2)
     if out is None:
         out = torch.empty((n, d), dtype=torch.float32, device=src.device)
-    _lib.check(_lib.load().rgbx_blocked_to_rows_f32(ptr, bc, bs, out.data_ptr(), out.stride(0), n, d, _lib.stream_ptr()),
-               "rgbx_blocked_to_rows_f32")
+    b = None if bias is None else bias.detach().contiguous()
+    _lib.check(_lib.load().rgbx_blocked_to_rows_f32(ptr, bc, bs, out.data_ptr(), out.stride(0), n, d, _lib.ptr(b),
+                                                    _lib.stream_ptr()), "rgbx_blocked_to_rows_f32")
     return out
 
 

@@ -140,8 +140,17 @@ class TorchStackBackend:
         sums = a.sum(0)
         return res, (sums if sums_out is None else sums_out.copy_(sums))
 
-    def blocked_to_rows(self, blk):
-        return _rows_of(blk).contiguous()
+    def blocked_to_rows(self, blk, bias=None):
+        rows = _rows_of(blk).contiguous()
+        return rows if bias is None else rows + bias
+
+    def ce_stats(self, logits, y, mask):
+        sel = (y >= 0) & (y < logits.size(1))
+        if mask is not None:
+            sel = sel & mask.bool()
+        logp = torch.log_softmax(logits, dim=1)
+        return torch.stack([-logp[sel, y[sel]].double().sum(), sel.sum().double(),
+                            (logits[sel].argmax(1) == y[sel]).sum().double()])
 
 
 def _stack_backend(self):

@@ -96,10 +96,11 @@ def test_shape_and_alignment_errors_of_the_fused_and_dense_entry_points():
     assert layer(out=None, out_blk=p, ob_cols=48, ob_stride=480) == -1            # 48 does not divide Nout
     assert layer(out_blk=p, ob_cols=32, ob_stride=320, ce=ctypes.addressof(ce)) == -1   # loss epilogue: no blocked output
     assert layer(K=130) == -5
-    assert lib.rgbx_blocked_to_rows_f32(p, 32, 320, p, 128, 10, 100, None) == -1  # 32 does not divide d = 100
-    assert lib.rgbx_blocked_to_rows_f32(p, 32, 320, p, 64, 10, 128, None) == -1   # ldd < d
-    assert lib.rgbx_blocked_to_rows_f32(None, 32, 320, p, 128, 10, 128, None) == -1
-    assert lib.rgbx_blocked_to_rows_f32(p, 32, 320, p, 128, 0, 128, None) == 0    # nothing to do
+    assert lib.rgbx_blocked_to_rows_f32(p, 32, 320, p, 128, 10, 100, None, None) == -1  # 32 does not divide d = 100
+    assert lib.rgbx_blocked_to_rows_f32(p, 32, 320, p, 64, 10, 128, None, None) == -1   # ldd < d
+    assert lib.rgbx_blocked_to_rows_f32(None, 32, 320, p, 128, 10, 128, None, None) == -1
+    assert lib.rgbx_blocked_to_rows_f32(p, 32, 320, p, 128, 10, 128, p + 4, None) == -1  # bias not 16-byte aligned
+    assert lib.rgbx_blocked_to_rows_f32(p, 32, 320, p, 128, 0, 128, None, None) == 0    # nothing to do
     # weight-gradient GEMM: workspace too small / leading dimension
     n = ctypes.c_size_t(0)
     assert lib.rgbx_gemm_tn_workspace_bytes(1000, 128, 128, ctypes.byref(n)) == 0 and n.value >= 128 * 128 * 4

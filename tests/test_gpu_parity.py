@@ -599,6 +599,7 @@ def test_dense_mode_and_blocked_layouts_of_the_fused_layer(dev, K, n_out, B, Bo)
     want_cs = torch.stack([out.double().sum(0), (out.double() ** 2).sum(0)]).cpu()
     assert (cs.cpu() - want_cs).abs().max().item() < 1e-3 * max(1.0, want_cs.abs().max().item()) * 1e-2
     assert torch.equal(ops.blocked_to_rows(ob), out)
+    assert torch.equal(ops.blocked_to_rows(ob, bias=d(b)), out + d(b))
     # blocked output only, plain input, no pre-affine: the plain product (dy W of the backward pass)
     ob2 = torch.empty_like(ob)
     out2, z2, _ = ops.fused_layer(d(x), d(W).t().contiguous(), want_out=False, out_blocked=ob2)
