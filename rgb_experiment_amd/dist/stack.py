@@ -35,6 +35,17 @@ from ..nn import batchnorm as B
 from .plan import partition_bounds
 
 
+class _AllOf:
+    """Several exchange works waited for as one."""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class HipStackBackend:
     """Product compute backend of GridStack: rgbx_fused_layer_f32, rgbx_spmm_csr_f32, rgbx_gemm_tn_f32,
     rgbx_blocked_to_rows_f32 (through rgb_experiment_amd.ops). `agg` = the HipAggregator the DistGraph was built with."""
@@ -305,14 +316,7 @@ class GridStack:
             inbound = (cols, works)
         cols, works = inbound
         if not self.src_split and len(works) > 1:  # every inbound piece must have landed before the one aggregation
-            class _All:
-                def __init__(self, ws):
-                    self.ws = ws
-
-                def wait(self):
-                    for w in self.ws:
-                        w.wait()
-            works = [_All(works)]
+            works = [_AllOf(works)]
         src_pieces = len(works)
         half, handles = dg._grid_half(self.specs[i].kind, C, dg.pieces_for(d), direction, src_pieces)
         if src_pieces == 1:
