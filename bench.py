@@ -963,6 +963,7 @@ def main():
         result["ranks_seen"] = len(per_rank)
         result["scheme"] = scheme
         result["fused_schedule"] = runner.engine is not None
+        result["interleaved_evals"] = {"on": runner.interleave_evals, "decision": runner.interleave_decision}
         result["per_rank"] = per_rank
         result["exchange_mb_per_rank_per_step"] = max(r["exchange_mb_per_step"] for r in per_rank)
         result["modelled_seconds_per_propagate"] = dgraph._choice.get(("costs", d)) or next(

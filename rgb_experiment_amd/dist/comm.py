@@ -205,6 +205,17 @@ class Comm:
         t.copy_(h)
         return t
 
+    def all_reduce_max_(self, t):
+        if self.world == 1:
+            return t
+        if self.backend == "nccl" or not t.is_cuda:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            return t
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+        t.copy_(h)
+        return t
+
     def barrier(self):
         if self.world > 1:
             dist.barrier(group=self.group)
@@ -288,6 +299,9 @@ class EmulatedComm(Comm):
 
     def all_reduce_sum_(self, t):
         return t.mul_(self.world)  # as if every rank had contributed this rank's share
+
+    def all_reduce_max_(self, t):
+        return t
 
     def barrier(self):
         pass

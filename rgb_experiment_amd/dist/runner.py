@@ -34,6 +34,8 @@ class DistRunner:
         self._streams = None
         self._epochs_done = 0
         self.host_enqueue_s = 0.0
+        self._interleave_settled = False
+        self.interleave_decision = None
         if device.type == "cuda":  # one timed all-to-all: the exchange cost model then uses this fabric's link rate
             self.link_gbs = self.comm.measure_link_gbs(device)
         # "replicate": every rank computes the first conv layer for all N nodes from the whole (static) feature
@@ -238,6 +240,7 @@ class DistRunner:
         times."""
         import time
         t0 = time.perf_counter()
+        enq0 = self.host_enqueue_s
         tl = self.train_step(sync=False)
         # the first epoch builds what the eval forwards use lazily (cost tables, plans / CSRs of widths only the
         # no_grad path aggregates at) — on the MAIN stream, one forward after the other, so that no structure is
@@ -253,8 +256,29 @@ class DistRunner:
         self.host_enqueue_s += time.perf_counter() - t0
         p = packed.tolist()
         self._epochs_done += 1
+        self._settle_interleave(self.host_enqueue_s - enq0, time.perf_counter() - t0)
         cv, cs = self.mask_counts[1], self.mask_counts[2]
         return p[0], p[1] / cv, p[2] / cv, p[3] / cs, p[4] / cs
+
+    def _settle_interleave(self, enqueue_s, wall_s):
+        """Two host threads issuing the eval forwards hide one forward's exchange behind the other's aggregation, but
+        cost host time (3.7 instead of 1.5 ms per epoch for rank 0 of 8 on the benchmark). On a slow or
+        crowded host that makes the rank HOST-bound: when, in the second interleaved epoch, enqueueing took more than
+        80 % of the epoch's wall time on ANY rank (one small all-reduce: every rank must take the same decision), the
+        evals run one after the other from then on. RGBX_INTERLEAVE=always | never overrides."""
+        if not self.interleave_evals or self._interleave_settled or self._epochs_done != 3:
+            return
+        self._interleave_settled = True
+        import os
+        mode = os.environ.get("RGBX_INTERLEAVE", "auto")
+        if mode == "always":
+            return
+        ratio = torch.tensor([1.0 if mode == "never" else enqueue_s / max(wall_s, 1e-9)], dtype=torch.float64,
+                             device=self.device)
+        worst = self.comm.all_reduce_max_(ratio).item()
+        self.interleave_decision = {"host_enqueue_over_wall": worst, "kept": worst <= 0.8}
+        if worst > 0.8:
+            self.interleave_evals = False
 
     def logits(self, training=False):
         self.model.train(training)
