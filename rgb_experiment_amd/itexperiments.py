@@ -15,6 +15,7 @@ Deliberate deviations from reference quirks:
     ``(not valid_list) or (not valid_tensor)`` (:210) is always true, so it remade masks always.
     Pass ``remake_data_mask=True`` for the reference behaviour.
 """
+import os
 import random
 from copy import deepcopy
 
@@ -209,7 +210,8 @@ def experiment(model_init_param: dict, *,
                return_model: bool = False,
                use_hip_graph: bool = True,
                share_eval_forward: bool = False,
-               cache_input_aggregate: bool = False):
+               cache_input_aggregate: bool = False,
+               distributed=None):
     """Train + evaluate one model on one graph; returns {'ACC', 'precision_score', 'recall_score',
     'f1_macro', 'f1_micro'} (reference :603-605). ``return_model=True`` (an addition) also returns
     the trained module and the per-epoch curves under 'model' / 'history'. ``use_hip_graph=True`` (an
@@ -224,7 +226,11 @@ def experiment(model_init_param: dict, *,
     keeps the first conv layer's aggregate of the input features — the same matrix in every forward of every epoch,
     because features and graph are static (itexperiments.py:417-473 recomputes it three times per epoch) — so that a
     2-layer GCN / GraphSAGE epoch runs 4 aggregations instead of 7; models whose first layer has no aggregate-first
-    form (in > out) ignore it."""
+    form (in > out) ignore it. ``distributed`` (an addition; the reference is single-device, :246): None = take the
+    node-partitioned route when the script runs as one of several ranks (``torchrun --nproc-per-node N script.py``:
+    WORLD_SIZE > 1 in the environment, one process per GPU, device = LOCAL_RANK); every rank calls experiment() with
+    the same arguments and the same data and gets the same result dict. Models: gcn / graphsage / graphsage2 / gat /
+    appnpstack (rgb_experiment_amd.dist.DistRunner); no hipGraph, no post_cs there."""
     say = print if print_print else (lambda *a, **k: None)
     say(f"running node classification: {'custom' if specify_data else dataset_name} data, model {model_name}")
 
@@ -256,10 +262,20 @@ def experiment(model_init_param: dict, *,
         data.edge_index = to_undirected(data.edge_index, num_nodes=data.num_nodes)
 
     # ---- device (reference :246-258): the message-passing path is HIP-only -------------------
-    if name != "mlp" and (use_cpu or not torch.cuda.is_available()):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if distributed is None:  # one of several ranks a launcher started, and a model with a node-partitioned form
+        from .dist.experiment import SUPPORTED
+        distributed = world > 1 and name in SUPPORTED and not post_cs
+    dist_ctx = None
+    if distributed:
+        from .dist.experiment import DistContext
+        dist_ctx = DistContext.open(name, post_cs, use_cpu)  # process group, rank's device; raises for unsupported set-ups
+        cuda_index = dist_ctx.cuda_index
+    elif name != "mlp" and (use_cpu or not torch.cuda.is_available()):
         raise RuntimeError("rgb_experiment_amd runs message passing in HIP kernels on an MI355X device; "
                            "use_cpu=True / no visible GPU is not supported (no CPU fallback)")
-    device = torch.device(f"cuda:{cuda_index}" if (torch.cuda.is_available() and not use_cpu) else "cpu")
+    device = dist_ctx.device if dist_ctx is not None else torch.device(
+        f"cuda:{cuda_index}" if (torch.cuda.is_available() and not use_cpu) else "cpu")
     data = data.to(device)
     features = data.x
     if normalize_feature in ("row", "col", "all"):
@@ -299,6 +315,13 @@ def experiment(model_init_param: dict, *,
     net.to(device)
     if cache_input_aggregate:
         net.cache_input_aggregate = True  # read by models/_stack.ConvStack; other models have no such form
+    runner = None
+    if dist_ctx is not None:
+        # 1-D node partition: this rank keeps its node range of features / labels / masks and the structures of its
+        # share of the graph; parameters are replicated (the seeds above made them equal on every rank)
+        runner = dist_ctx.runner(net, data.edge_index, features, y, (train_mask, val_mask, test_mask), learning_rate,
+                                 weight_decay, cache_input_aggregate)
+        use_hip_graph = False
     graphed = None
     # capturable Adam keeps its step count on the device: required for graph capture, and used for the
     # eager GPU loop too so that both loops run the very same update kernels
@@ -334,6 +357,11 @@ def experiment(model_init_param: dict, *,
 
     def generic_epoch(i):
         """reference :427-440, :464-473: 1 train forward+backward, 2 eval forwards."""
+        if runner is not None:  # the same epoch on the node partition; the five numbers are all-reduced over the ranks
+            tl, vl, va, sl, sa = runner.epoch()
+            for key, v in (("train_loss", tl), ("train_acc", float("nan")), ("test_loss", sl), ("test_acc", sa)):
+                hist[key].append(v)
+            return va, vl, None
         if graphed is not None:
             tl, ta, vl, va, sl, sa = graphed.run()
             hist["train_loss"].append(tl)
@@ -424,6 +452,8 @@ def experiment(model_init_param: dict, *,
         final = dict(best_pta_metrics)
         final.setdefault("label", y[idx[2]])
         final.setdefault("pred", final["emb"][idx[2]].max(dim=1)[1])
+    elif runner is not None:  # every rank's test rows gathered: the same metrics dict on every rank
+        final = dist_ctx.final_test(runner, y, test_mask, need_all_metrics, compare_pred_label)
     else:
         final = test(net, fwd, y, test_mask, need_all_metrics)
 
@@ -457,4 +487,7 @@ def experiment(model_init_param: dict, *,
         result["history"] = hist
         result["used_hip_graph"] = graphed is not None
         result["emb"] = final["emb"]
+        if runner is not None:
+            result["distributed"] = {"world": dist_ctx.world, "rank": dist_ctx.rank, "rows": (runner.lo, runner.hi),
+                                     "fused_schedule": runner.engine is not None}
     return result

@@ -318,6 +318,31 @@ def exchange_count_worker(rank, world, port, out_dir, model_name, resident):
     dist.destroy_process_group()
 
 
+def experiment_worker(rank, world, port, out_dir, model_name, on_gpu=False):
+    """experiment() called as one of `world` ranks (environment as torch.distributed.run sets it): the distributed
+    route of rgb_experiment_amd.itexperiments.experiment."""
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port), "RGBX_DIST_BACKEND": "gloo"})
+    if not on_gpu:
+        os.environ["RGBX_TEST_AGGREGATOR"] = "_dist_worker:OracleAggregator"
+    torch.set_num_threads(1)
+    import rgb_experiment_amd as R
+    n, e, f, c = (5000, 60000, 32, 8) if on_gpu else (97, 900, 12, 5)
+    ei, x, y, masks = make_problem(n=n, e=e, f=f, c=c)
+    data = R.Data(x=x, y=y, edge_index=ei)
+    data.train_mask, data.val_mask, data.test_mask = masks
+    params = R.InitialParameters.defaults_for(model_name)
+    params["hidden_unit"] = 32
+    res = R.experiment(params, specify_data=True, data=data, model_name=model_name, learning_rate=0.01, epoch=6,
+                       need_to_reappear=True, print_print=False, return_model=True, need_all_metrics=True,
+                       remake_data_mask=False)
+    torch.save({"metrics": {k: res[k] for k in ("ACC", "precision_score", "recall_score", "f1_macro", "f1_micro")},
+                "history": res["history"], "distributed": res["distributed"],
+                "state": {k: v.cpu().clone() for k, v in res["model"].state_dict().items()}},
+               os.path.join(out_dir, f"exp_{model_name}_{world}_{rank}.pt"))
+    dist.destroy_process_group()
+
+
 def build_model(M, name, f, c):
     if name.endswith("_wide"):  # in <= hidden, hidden % 32 == 0: the first conv takes the fused / resident route
         cls = {"gcn_wide": M.GCN, "graphsage_wide": M.GraphSAGE, "graphsage2_wide": M.GraphSAGE2}[name]

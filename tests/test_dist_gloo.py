@@ -4,6 +4,7 @@ import copy
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
@@ -259,6 +260,25 @@ def test_fused_grid_schedule_with_the_kept_input_aggregate(model_name, world, ex
         assert abs(x[0] - y[0]) < 1e-6 and abs(x[1] - y[1]) < 1e-5 and abs(x[3] - y[3]) < 1e-5, (x, y)
     for k, v in a["state"].items():
         assert torch.allclose(v, b["state"][k], atol=1e-6), k
+
+
+@pytest.mark.parametrize("model_name", ["gcn", "appnpstack"])
+def test_experiment_runs_as_one_of_several_ranks(model_name, tmp_path):
+    """experiment() under WORLD_SIZE > 1 takes the node-partitioned route (dist/experiment.py): every rank returns the
+    same metrics and trained weights, and 2 ranks train like 3 ranks (the partition changes summation orders only)."""
+    runs = {}
+    for world in (2, 3):
+        mp.spawn(W.experiment_worker, args=(world, _free_port(), str(tmp_path), model_name), nprocs=world, join=True)
+        runs[world] = [torch.load(os.path.join(tmp_path, f"exp_{model_name}_{world}_{r}.pt")) for r in range(world)]
+        first = runs[world][0]
+        assert first["distributed"]["world"] == world and len(first["history"]["val_loss"]) == 6
+        for other in runs[world][1:]:
+            assert other["metrics"] == first["metrics"] and other["history"]["val_loss"] == first["history"]["val_loss"]
+            for k, v in first["state"].items():
+                assert torch.equal(v, other["state"][k]), k
+    a, b = runs[2][0], runs[3][0]
+    assert np.allclose(a["history"]["train_loss"], b["history"]["train_loss"], rtol=0, atol=2e-5)
+    assert abs(a["metrics"]["ACC"] - b["metrics"]["ACC"]) <= 0.11  # 19 test nodes: two of them may flip
 
 
 @pytest.mark.parametrize("model_name,with_resident,without", [("gcn", 8, 11), ("graphsage2", 4, 7), ("gat", 4, 8)])

@@ -78,3 +78,28 @@ def test_partitioned_hip_run_matches_single_gpu(model_name, world, exchange, tmp
         assert abs(vl - hist[step][1]) < 5e-3 and abs(sl - hist[step][2]) < 5e-3
     got = torch.cat([p["logits_train"] for p in parts])
     assert (got - emb).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("model_name", ["gcn", "graphsage"])
+def test_experiment_as_several_ranks_matches_one_gpu(model_name, tmp_path):
+    """experiment() under WORLD_SIZE = 2 (the ranks share the one GPU, gloo staging) against experiment() on one GPU:
+    same loss curves (train tightly; eval within the +-lr noise of pre-BatchNorm biases, see above), same accuracy to a
+    handful of rows."""
+    import rgb_experiment_amd as R
+    mp.spawn(W.experiment_worker, args=(2, _free_port(), str(tmp_path), model_name, True), nprocs=2, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"exp_{model_name}_2_{r}.pt")) for r in range(2)]
+    assert parts[0]["metrics"] == parts[1]["metrics"] and parts[0]["distributed"]["world"] == 2
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RGBX_DIST_BACKEND"):
+        os.environ.pop(key, None)
+    ei, x, y, masks = W.make_problem(n=5000, e=60000, f=32, c=8)
+    data = R.Data(x=x, y=y, edge_index=ei)
+    data.train_mask, data.val_mask, data.test_mask = masks
+    params = R.InitialParameters.defaults_for(model_name)
+    params["hidden_unit"] = 32
+    one = R.experiment(params, specify_data=True, data=data, model_name=model_name, learning_rate=0.01, epoch=6,
+                       need_to_reappear=True, print_print=False, return_model=True, need_all_metrics=True,
+                       remake_data_mask=False, use_hip_graph=False)
+    a, b = parts[0]["history"], one["history"]
+    assert max(abs(p - q) for p, q in zip(a["train_loss"], b["train_loss"])) < 1e-4
+    assert max(abs(p - q) for p, q in zip(a["val_loss"], b["val_loss"])) < 5e-3
+    assert abs(parts[0]["metrics"]["ACC"] - one["ACC"]) < 0.02
