@@ -364,14 +364,25 @@ def build_model(M, name, f, c):
     raise KeyError(name)
 
 
-def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo"):
+def hub_problem():
+    """make_problem(n=5000, ...) plus two hub nodes: node 7 with 3000 extra in-edges, node 11 with 3000 extra
+    out-edges — rows beyond LONG_ROW_SLOTS in the forward and in the transposed CSR (hub-row plans)."""
+    ei, x, y, masks = make_problem(n=5000, e=60000, f=32, c=8)
+    g = torch.Generator().manual_seed(99)
+    others = torch.randint(0, 5000, (3000,), generator=g)
+    extra = torch.cat([torch.stack([others, torch.full_like(others, 7)]),
+                       torch.stack([torch.full_like(others, 11), others])], dim=1)
+    return torch.cat([ei, extra], dim=1), x, y, masks
+
+
+def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", hub=False):
     """Rehearsal of the real per-rank HIP path: `world` ranks share cuda:0, collectives go through gloo
     with host staging (RCCL cannot put two ranks on one device)."""
     _init(rank, world, port)
     from rgb_experiment_amd import models as M
     from rgb_experiment_amd.dist import Comm, DistRunner
     dev = torch.device("cuda:0")
-    ei, x, y, masks = make_problem(n=5000, e=60000, f=32, c=8)
+    ei, x, y, masks = hub_problem() if hub else make_problem(n=5000, e=60000, f=32, c=8)
     torch.manual_seed(14530529)
     model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
     r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm(), exchange=exchange)

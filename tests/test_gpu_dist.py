@@ -18,10 +18,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _single_gpu(model_name):
+def _single_gpu(model_name, hub=False):
     from rgb_experiment_amd import models as M
     dev = torch.device("cuda:0")
-    ei, x, y, masks = W.make_problem(n=5000, e=60000, f=32, c=8)
+    ei, x, y, masks = W.hub_problem() if hub else W.make_problem(n=5000, e=60000, f=32, c=8)
     torch.manual_seed(14530529)
     model = W.build_model(M, model_name, x.size(1), int(y.max()) + 1).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=0.01)
@@ -103,3 +103,18 @@ def test_experiment_as_several_ranks_matches_one_gpu(model_name, tmp_path):
     assert max(abs(p - q) for p, q in zip(a["train_loss"], b["train_loss"])) < 1e-4
     assert max(abs(p - q) for p, q in zip(a["val_loss"], b["val_loss"])) < 5e-3
     assert abs(parts[0]["metrics"]["ACC"] - one["ACC"]) < 0.02
+
+
+@pytest.mark.parametrize("model_name,world,exchange", [("gcn_grid", 2, "reshard"), ("graphsage_grid", 4, "2x2")])
+def test_fused_schedule_with_hub_rows(model_name, world, exchange, tmp_path):
+    """Two hub nodes (3000 extra in-edges / out-edges: rows beyond LONG_ROW_SLOTS in the forward and the transposed
+    CSRs of the ranks that own them): the fused schedule takes its whole-group launches for CSRs with a hub-row plan
+    (row ranges of such a CSR cannot be launched on their own) and one-piece layer-0 launches; same numbers as one GPU."""
+    mp.spawn(W.gpu_runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, True), nprocs=world,
+             join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"gpu_{model_name}_{r}.pt")) for r in range(world)]
+    assert all(p["engine"] for p in parts)
+    hist, emb = _single_gpu(model_name, hub=True)
+    for step in range(2):
+        assert abs(parts[0]["hist"][step][0] - hist[step][0]) < 1e-4
+    assert (torch.cat([p["logits_train"] for p in parts]) - emb).abs().max().item() < 1e-3

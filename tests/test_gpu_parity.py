@@ -628,6 +628,30 @@ def test_dense_mode_and_blocked_layouts_of_the_fused_layer(dev, K, n_out, B, Bo)
         assert torch.equal(stats_e, stats)
 
 
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 97])
+def test_dense_mode_on_tiny_and_ragged_row_counts(dev, n):
+    """DENSE launches (one-tile and streaming forms) with fewer rows than a tile, exactly one tile, one row more."""
+    from rgb_experiment_amd import ops
+    g = torch.Generator().manual_seed(n)
+    for K, n_out in ((128, 128), (64, 32), (8, 32)):
+        x = torch.randn(n, K, generator=g).to(dev)
+        W = (torch.randn(n_out, K, generator=g) / K ** 0.5).to(dev)
+        b = torch.randn(n_out, generator=g).to(dev)
+        want = (x.double() @ W.double().t() + b.double()).float()
+        out, _, _ = ops.fused_layer(x, W.t().contiguous(), bias=b)
+        assert (out - want).abs().max().item() < 1e-4
+        B = 4 if K % 16 == 0 else 2
+        blk = torch.empty((2, n, n_out // 2), device=dev)
+        out2, z, cs = ops.fused_layer(_to_blocked(x, B), W.t().contiguous(), bias=b, want_z=True, want_colsums=True,
+                                      out_blocked=blk)
+        assert torch.equal(out2, out) and torch.equal(z, x) and torch.equal(ops.blocked_to_rows(blk), out)
+        assert (cs[0].float() - out.sum(0)).abs().max().item() < 1e-3
+        y = torch.randint(0, n_out, (n,), generator=g).to(dev)
+        _, _, st = ops.fused_layer(x, W.t().contiguous(), bias=b, ce=(y, None, None))
+        want_st = ops.masked_ce_accuracy(out, y, None)
+        assert torch.equal(st[1:], want_st[1:]) and abs(st[0].item() - want_st[0].item()) < 1e-5 * max(1.0, want_st[0].item())
+
+
 @pytest.mark.parametrize("K,n_out,Bo,kind", [(128, 128, 4, "gcn"), (64, 64, 2, "mean"), (32, 96, 3, "sum")])
 def test_fused_aggregate_transform_writes_the_blocked_exchange_layout(dev, K, n_out, Bo, kind):
     """The aggregating form with a blocked output (a partitioned run's producer writes straight into its send
