@@ -189,7 +189,8 @@ def weight_t(weight):
 def _blocked(t, what):
     """(pointer, block columns, block stride) of a blocked matrix: a [B, n, cols] tensor whose blocks are contiguous
     [n, cols] matrices (views over the row range of a bigger one keep the block stride of their base)."""
-    if t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != t.size(2):
+    if (t.dtype != torch.float32 or t.dim() != 3 or (t.size(2) > 1 and t.stride(2) != 1)
+            or (t.size(1) > 1 and t.stride(1) != t.size(2))):  # strides of size-1 dimensions mean nothing
         raise RuntimeError(f"{what}: expected a float32 [blocks, rows, cols] tensor with contiguous blocks, got "
                            f"{t.dtype} {tuple(t.shape)} strides {t.stride()}")
     return t.data_ptr(), t.size(2), t.stride(0)
