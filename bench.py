@@ -585,7 +585,17 @@ def launch_ranks(n):
     deadline_s = sv.limits()[0]
     attempts = int(os.environ.get("RGBX_LAUNCH_ATTEMPTS", len(sv.ATTEMPTS)))
     total = attempts * (deadline_s + 90) + 120  # backstop only: the supervisors keep their own, tighter limits
-    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    import signal
+    # the ranks live in their own process group: whoever ends THIS process (the driver's own timeout, Ctrl-C) must take
+    # them along — by the handlers below, or, if this process is killed outright, by the parent-death signal
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True, preexec_fn=sv.die_with_parent(signal.SIGTERM))
+
+    def on_signal(signum, _frame):
+        sv.kill_group(proc, grace=8.0)
+        sys.exit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, on_signal)
     try:
         return proc.wait(timeout=total)
     except subprocess.TimeoutExpired:

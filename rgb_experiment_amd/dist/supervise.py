@@ -98,6 +98,18 @@ def _wait_for(paths, timeout):
         time.sleep(0.05)
 
 
+def die_with_parent(sig=signal.SIGKILL):
+    """preexec_fn for a child that must not outlive this process (PR_SET_PDEATHSIG): a launcher or supervisor that is
+    killed outright (SIGKILL: no handler runs) would otherwise leave ranks behind that hold their GPUs."""
+    def set_pdeathsig():
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(sig))  # PR_SET_PDEATHSIG = 1
+        except OSError:
+            pass
+    return set_pdeathsig
+
+
 def kill_group(proc, grace=5.0):
     """SIGTERM to the child's process group, SIGKILL after `grace` seconds."""
     if proc.poll() is not None:
@@ -182,6 +194,7 @@ def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
     for s in (signal.SIGTERM, signal.SIGINT):
         signal.signal(s, on_signal)
 
+    agent = os.getppid()
     history = []
     for k, (name, flags) in enumerate(attempts):
         port_file = os.path.join(d, f"attempt{k}.port")
@@ -204,7 +217,7 @@ def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
         t0 = time.monotonic()
         with open(out_path, "w") as fout:
             proc = subprocess.Popen([sys.executable, script] + list(argv) + flags, env=env, stdout=fout,
-                                    start_new_session=True)
+                                    start_new_session=True, preexec_fn=die_with_parent())
         child[0] = proc
         failed_glob = os.path.join(d, f"attempt{k}.failed.*")
         ok_file = os.path.join(d, f"attempt{k}.ok")
@@ -213,6 +226,10 @@ def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
             rc = proc.poll()
             if rc is not None:
                 break
+            if os.getppid() != agent:  # the launcher above is gone (killed outright): nobody is waiting for a line
+                kill_group(proc, grace=2.0)
+                print(f"[bench supervisor rank {rank}] the launcher is gone: worker ended, leaving", file=sys.stderr)
+                return 1
             now = time.monotonic()
             peer = glob.glob(failed_glob)
             if peer:

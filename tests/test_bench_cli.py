@@ -101,3 +101,51 @@ def test_bench_refuses_a_cpu_run_of_the_product_path():
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "T", "--steps", "1"], env=env,
                           capture_output=True, text=True, timeout=300)
     assert proc.returncode != 0 and "no MI355X visible" in proc.stderr
+
+
+def test_ending_the_launcher_ends_every_rank():
+    """SIGTERM (handler) and SIGKILL (parent-death signal) to `python bench.py --gpus N` must not leave supervisors or
+    workers behind: on a GPU box a leftover rank would keep its GPU."""
+    import signal
+    import time
+    env = dict(os.environ)
+    env.update({"RGBX_DIST_BACKEND": "gloo", "RGBX_TEST_AGGREGATOR": "_dist_worker:OracleAggregator",
+                "PYTHONPATH": os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", ""),
+                "OMP_NUM_THREADS": "1", "CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": "",
+                "RGBX_TEST_FAULT": "stall:1:0:first_epoch", "RGBX_LAUNCH_STALL_S": "300"})
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+
+    def descendants(pid):
+        out = subprocess.run(["ps", "-eo", "pid,ppid"], capture_output=True, text=True).stdout.split("\n")[1:]
+        kids = {}
+        for line in out:
+            if line.strip():
+                c, p = (int(v) for v in line.split())
+                kids.setdefault(p, []).append(c)
+        todo, seen = [pid], []
+        while todo:
+            for c in kids.get(todo.pop(), []):
+                seen.append(c)
+                todo.append(c)
+        return seen
+
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        marker = f"--steps=2{int(sig)}"  # makes this run's processes recognisable in the process list
+        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "T", marker,
+                                 "--warmup", "1"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        deadline = time.time() + 90
+        while time.time() < deadline and len(descendants(proc.pid)) < 5:  # agent, 2 supervisors, 2 workers
+            time.sleep(0.5)
+        assert len(descendants(proc.pid)) >= 5
+        proc.send_signal(sig)
+        proc.wait(timeout=60)
+        deadline = time.time() + 60
+        alive = None
+        while time.time() < deadline:
+            ps = subprocess.run(["ps", "-eo", "pid,cmd"], capture_output=True, text=True).stdout
+            alive = [ln for ln in ps.splitlines() if marker in ln]
+            if not alive:
+                break
+            time.sleep(0.5)
+        assert not alive, alive
