@@ -424,6 +424,7 @@ class GridStack:
         return loss_part
 
     # ---- eval forward ------------------------------------------------------------------------------------------
+    @torch.no_grad()  # also called with autograd on (the pre-warm of the interleaved evals): nothing to record
     def _eval_weights(self):
         """Per layer (W'^T, b', Wr'^T) with the eval-mode BatchNorm behind the layer folded in (W' = diag(scale) W,
         b' = b scale + shift): made once per parameter state — the val and the test forward of an epoch share them."""
@@ -476,7 +477,9 @@ class GridStack:
                 return st[::2]
             if i == L - 1:
                 _, _, st = be.layer(u, wt, bias=b, ce=(self.y, self.masks[which], None), kind="return_linear_fwd", **root)
-                return st[::2]  # (nll sum, hits): a view — indexing with a list would stage an index tensor through the host and drain the queue
+                # (nll sum, hits) as a VIEW: indexing with a list would stage an index tensor through the host and
+                # drain the queue (it did, twice per epoch, until round 3)
+                return st[::2]
             blk = self._blocked_buffer(i + 1, width=wt.size(1))
             be.layer(u, wt, bias=b, want_out=False, out_blocked=blk, kind="return_linear_fwd", **root)
             prev_blk = blk
