@@ -1067,7 +1067,11 @@ def main():
         secondary("configs_1_same_run", configs_1_leg)
         secondary("configs_0_same_run", lambda: cora_shaped(dev))
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+    # from here on only the teardown is left: a supervisor that has to end this worker later (a process group that does
+    # not come down) still counts the run — the line is out
+    sv.beat("done")
+    sv.test_fault("teardown", rank)
     if world > 1:
         dist.destroy_process_group()
 

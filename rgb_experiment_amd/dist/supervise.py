@@ -250,7 +250,10 @@ def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
             time.sleep(0.1)
         child[0] = None
         line = _last_json_line(out_path) if rank == 0 else None
-        good = reason is None and rc == 0 and (rank != 0 or line is not None)
+        # a worker that reported "done" (its line is out, only the teardown was left) counts even if it had to be ended
+        # afterwards or left with a non-zero status: a process group that does not come down must not cost the result
+        done = (_read(hb) or "").startswith("done")
+        good = ((reason is None and rc == 0) or done) and (rank != 0 or line is not None)
         if good and rank != 0:
             # my worker is through; the attempt counts if rank 0 got its line (a peer may still have failed)
             hit = _wait_for([ok_file, os.path.join(d, f"attempt{k}.failed.0"), os.path.join(d, f"attempt{k + 1}.port")], 120)

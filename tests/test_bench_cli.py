@@ -81,6 +81,20 @@ def test_a_failing_or_stalled_rank_ends_in_a_line_from_fresh_conservative_ranks(
         assert "peer failed" in failed[0]["reason"] or "no milestone" in failed[0]["reason"]
 
 
+@pytest.mark.parametrize("rank", [0, 1])
+def test_a_hang_after_the_line_does_not_cost_the_result(rank):
+    """A rank that hangs in its TEARDOWN (a process group that does not come down) is ended by its supervisor, but the
+    attempt counts: its line was out, the workers had reported "done"."""
+    proc = _run(["--gpus", "2", "--workload", "T", "--steps", "2", "--warmup", "1", "--exchange", "reshard"],
+                extra_env={"RGBX_TEST_FAULT": f"stall:{rank}:0:teardown", "RGBX_LAUNCH_STALL_S": "6",
+                           "RGBX_LAUNCH_DEADLINE_S": "120"})
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    res = json.loads(lines[0])
+    assert res["launcher"]["attempt"] == 0 and res["launcher"]["fallback"] is None and res["value"] > 0
+
+
 def test_every_attempt_failing_ends_in_a_diagnostic_line_and_a_nonzero_status():
     proc = _run(["--gpus", "2", "--workload", "T", "--steps", "1", "--warmup", "0"],
                 extra_env={"RGBX_TEST_FAULT": "raise:1:*:first_epoch", "RGBX_LAUNCH_ATTEMPTS": "2",
