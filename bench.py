@@ -875,6 +875,10 @@ def main():
     elapsed, last, step_ms = time_steps(timed_step, args.steps, 0, fence, tick=tick)
     ops.set_event_sink(None)
     sv.beat("timed region done")
+    if world > 1 and not all(v == v and abs(v) != float("inf") for v in last):
+        # numbers that are not finite after real exchanges mean the run is wrong, not slow: fail, so that the
+        # supervisors start the next, more conservative attempt instead of relaying this line
+        raise RuntimeError(f"bench.py: non-finite results after the timed region: {last}")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

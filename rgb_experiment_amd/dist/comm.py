@@ -155,6 +155,37 @@ class Comm:
         done = _TimedWait(_Done()) if cuda else _Done()
         return done if self.turns is None else _TurnWork(done, self.turns)
 
+    def self_test_views(self, device):
+        """One small view exchange with a known answer, before the fused schedule relies on `all_to_all_views`: blocks
+        of one buffer handed to several peers (the same view in more than one slot), row ranges of one buffer as
+        receive targets, and EMPTY entries for some pairs — what the schedule does, at 8 rows. Every rank checks what it
+        received, the verdict is all-reduced (MIN) so that all ranks agree; False means this backend / build does not
+        deliver the views as assumed and the caller must stay on the single-buffer exchanges."""
+        P, r = self.world, self.rank
+        if P == 1:
+            return True
+        C, rows, w = (2 if P % 2 == 0 else 1), 8, 4
+        base = torch.arange(C * rows * w, dtype=torch.float32, device=device).view(C, rows, w)
+        src = base + 1000.0 * r
+        dst = torch.full((P, rows, w), -1.0, dtype=torch.float32, device=device)
+        silent = lambda a, b: a != b and (a + b) % 3 == 0  # these pairs exchange nothing (both ways)
+        send = [src[0, 0:0] if silent(r, q) else src[q % C] for q in range(P)]
+        recv = [dst[0, 0:0] if silent(r, q) else dst[q] for q in range(P)]
+        self.all_to_all_views(send, recv, tag="self-test").wait()
+        ok = True
+        for q in range(P):
+            want = torch.full((rows, w), -1.0, device=device) if silent(r, q) else base[r % C] + 1000.0 * q
+            ok = ok and bool(torch.equal(dst[q], want))
+        verdict = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
+        if self.backend == "nccl" or not verdict.is_cuda:
+            dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=self.group)
+        else:
+            h = verdict.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MIN, group=self.group)
+            verdict.copy_(h)
+        self.bytes_sent, self.exchanges = 0, 0
+        return bool(verdict.item() == 1.0)
+
     def measure_link_gbs(self, device, mb_per_peer=16, reps=3):
         """GB/s one xGMI link carries per direction under an all-to-all (every pair busy at once), measured: `reps`
         timed all-to-alls of `mb_per_peer` MB per peer after two warm-ups; the slowest rank's time counts and all ranks
@@ -302,6 +333,9 @@ class EmulatedComm(Comm):
 
     def all_reduce_max_(self, t):
         return t
+
+    def self_test_views(self, device):
+        return True
 
     def barrier(self):
         pass

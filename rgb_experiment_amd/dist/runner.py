@@ -77,6 +77,11 @@ class DistRunner:
             self.engine = GridStack.build(self.model, self.graphs, self.comm, backend or self.graphs[0].backend, self.x,
                                           self.y, self.masks, self.mask_counts, pieces_in=pieces_in,
                                           cache_input_aggregate=cache_input_aggregate, src_split=src_split)
+            # the schedule moves views (the list form of all-to-all): one small exchange with a known answer first — a
+            # backend / build that does not deliver them as assumed must fail HERE, loudly, not train on wrong rows
+            if self.engine is not None and not self.comm.self_test_views(device):
+                raise RuntimeError("dist: the view all-to-all self-test failed on this backend (rows did not arrive "
+                                   "where the fused schedule expects them); run with fused=False (bench.py --no-fused)")
 
     _REPLICABLE = {"GCNConv": 1, "SAGEConv": 0, "MySAGEConv": 2}  # conv class -> the loops mode its graph is keyed by
 
