@@ -660,8 +660,10 @@ def link_model(log, steps_logged, gbs=(50.0, 60.0, 76.8), src_split=False):
                            is exposed for n > 1);
       "in k/n"             inbound pieces issued at once (backward, deeper layers): all exposed; with --src-split
                            only piece 1 (piece k > 1 travels while the sources of piece k - 1 are aggregated);
+      "... paired1|2"      exchanges of the two eval forwards of the fused schedule, interleaved on one thread: hidden
+                           behind the partner forward's kernels except the last outbound piece of the second forward;
       anything else        (module path: "in", "halo", "resident") exposed in full.
-    The overlap of the two interleaved eval forwards with each other is NOT credited here."""
+    The overlap of the MODULE path's two eval threads with each other is not credited."""
     tot = exp = 0
     by_tag = {}
     for tag, b_out, b_in in log:
@@ -673,7 +675,12 @@ def link_model(log, steps_logged, gbs=(50.0, 60.0, 76.8), src_split=False):
         by_tag[t][1] += b
         parts = t.split()
         k, n = (int(v) for v in parts[1].split("/")) if len(parts) > 1 and "/" in parts[1] else (1, 1)
-        if parts[0] == "out":
+        if parts[-1].startswith("paired"):
+            # the two eval forwards of the fused schedule, interleaved on one thread (GridStack.eval_pair): an exchange
+            # of one forward travels while the other forward's layer 0 / slice SpMM runs; what nothing covers is the
+            # last outbound piece of the SECOND forward
+            exposed = parts[-1] == "paired2" and parts[0] == "out" and k == n
+        elif parts[0] == "out":
             exposed = k == n
         elif parts[0] == "in" and len(parts) > 2 and parts[2] == "producer":
             exposed = (n == 1) if src_split else (k == n)  # without the source split the last piece is waited for

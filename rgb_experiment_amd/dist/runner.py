@@ -250,7 +250,11 @@ class DistRunner:
         # the first epoch builds what the eval forwards use lazily (cost tables, plans / CSRs of widths only the
         # no_grad path aggregates at) — on the MAIN stream, one forward after the other, so that no structure is
         # produced on one of the two eval streams and consumed on the other; interleaving starts with the second epoch
-        if self.interleave_evals and self._epochs_done > 0:
+        if self.interleave_evals and self.engine is not None:
+            # fused schedule: the two forwards interleaved on ONE thread and stream (GridStack.eval_pair)
+            self.model.eval()
+            v, s = self.engine.eval_pair(1, 2)
+        elif self.interleave_evals and self._epochs_done > 0:
             v, s = self._interleaved_evals()
         else:
             v, _ = self.evaluate(1, sync=False)
@@ -271,7 +275,8 @@ class DistRunner:
         crowded host that makes the rank HOST-bound: when, in the second interleaved epoch, enqueueing took more than
         80 % of the epoch's wall time on ANY rank (one small all-reduce: every rank must take the same decision), the
         evals run one after the other from then on. RGBX_INTERLEAVE=always | never overrides."""
-        if not self.interleave_evals or self._interleave_settled or self._epochs_done != 3:
+        if (not self.interleave_evals or self._interleave_settled or self._epochs_done != 3
+                or self.engine is not None):  # the fused schedule interleaves without a second thread
             return
         self._interleave_settled = True
         import os

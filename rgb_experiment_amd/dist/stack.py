@@ -46,6 +46,19 @@ class _AllOf:
             w.wait()
 
 
+def _drive(gen):
+    """Run a schedule generator to its end: it yields every exchange it is about to depend on, the driver waits for it.
+    (GridStack.eval_pair drives TWO such generators alternately instead, so that one forward's exchange is in flight
+    while the other forward's kernels are enqueued.)"""
+    try:
+        work = next(gen)
+        while True:
+            work.wait()
+            work = gen.send(None)
+    except StopIteration as done:
+        return done.value
+
+
 class HipStackBackend:
     """Product compute backend of GridStack: rgbx_fused_layer_f32, rgbx_spmm_csr_f32, rgbx_gemm_tn_f32,
     rgbx_blocked_to_rows_f32 (through rgb_experiment_amd.ops). `agg` = the HipAggregator the DistGraph was built with."""
@@ -199,6 +212,7 @@ class GridStack:
         self._z0 = None
         self._folded = (None, None)
         self._steps = 0
+        self._pair_tag = ""
         # every parameter gradient is a view of ONE flat buffer, written in place by the kernels that produce it: the
         # gradient all-reduce then takes the buffer as it is (no flatten / copy-back launches), and nothing is zeroed
         # between steps because every entry is overwritten
@@ -257,7 +271,7 @@ class GridStack:
         a0, a1 = cut(self.n_loc, k), cut(self.n_loc, k + 1)
         send = [blk[q % C, a0:a1] for q in range(P)]
         recv = [cols[b[q] + cut(b[q + 1] - b[q], k):b[q] + cut(b[q + 1] - b[q], k + 1)] for q in range(P)]
-        tag = f"in {k + 1}/{n}" + (" producer" if behind_producer else "")
+        tag = f"in {k + 1}/{n}" + (" producer" if behind_producer else "") + self._pair_tag
         return cols, self.comm.all_to_all_views(send, recv, tag=tag)
 
     def _first_layer(self, wt, bias, wtr, train):
@@ -296,6 +310,9 @@ class GridStack:
         return blk, (cols, works), h, z, cs
 
     def _propagate(self, i, direction, blk, inbound=None):
+        return _drive(self._propagate_g(i, direction, blk, inbound))
+
+    def _propagate_g(self, i, direction, blk, inbound=None):
         """The exchanged aggregation of layer i: blocked rows of this rank in, blocked aggregated rows of this rank
         out (u[c', r, :] = column slice c' of own row r of P x, or of P^T x for direction "bwd"). `inbound` = (cols,
         [work per source piece]) when the caller has already issued the inbound exchange (piece by piece behind the
@@ -304,7 +321,9 @@ class GridStack:
         earlier ones in a fixed order: reproducible) — measured on the emulated rank 0 of 8 this costs 0.7 ms of
         aggregation time per epoch at 2 pieces (half-length rows per launch, the output read again) for 1.9 ms less
         exposed exchange at 60 GB/s per link: the setting for slow links, off by default. Outbound: one send per target
-        piece, in flight while the next one is aggregated."""
+        piece, in flight while the next one is aggregated.
+        A generator: it YIELDS every exchange it is about to depend on (the caller waits — or first lets another forward
+        enqueue its share, eval_pair) and returns `u`."""
         R, C = self.shapes[i]
         d = self.specs[i].d_in
         dg, P = self.dg, self.P
@@ -337,12 +356,12 @@ class GridStack:
                 sv.append(sends[k][off:off + cnt])
                 off += cnt
                 rv.append(u[q % C, a:b] if q in half.members else empty)
-            pending.append(self.comm.all_to_all_views(sv, rv, tag=f"out {k + 1}/{half.pieces}"))
+            pending.append(self.comm.all_to_all_views(sv, rv, tag=f"out {k + 1}/{half.pieces}" + self._pair_tag))
 
         if not all(self.be.rows_ok(h) for h in handles):
             # hub-row plan (row ids in it are absolute): whole-group launches once everything has landed
             for work in works:
-                work.wait()
+                yield work
             full = self.be.run(handles[0], cols, tag)
             for h in handles[1:]:
                 full.add_(self.be.run(h, cols, tag))
@@ -351,13 +370,13 @@ class GridStack:
                 send_piece(k)
         else:
             for ks in range(src_pieces):
-                works[ks].wait()
+                yield works[ks]
                 for k, (lo, hi) in enumerate(ranges):
                     self.be.run_rows(handles[ks], cols, lo, hi, sends[k], tag, accumulate=ks > 0)
                     if ks == src_pieces - 1:
                         send_piece(k)
         for w in pending:  # `sends` stay referenced until their exchanges were waited on
-            w.wait()
+            yield w
         return u
 
     # ---- training step -----------------------------------------------------------------------------------------
@@ -459,6 +478,37 @@ class GridStack:
     def eval_stats(self, which):
         """[masked NLL sum, correct count] (float64 device tensor) of this rank's rows under masks[which], eval mode:
         every BatchNorm folded into the preceding layer's weights, no row-major activation written, no logits."""
+        return _drive(self._eval_g(which))
+
+    @torch.no_grad()
+    def eval_pair(self, first, second):
+        """The val and the test forward of an epoch (itexperiments.py:464-473: two full eval forwards, both run),
+        INTERLEAVED on one host thread and one stream: each forward is a generator that yields the exchange it is about
+        to depend on; the other forward then enqueues its kernels and exchanges up to ITS next dependency before the
+        first one's exchange is waited for. One forward's exchange is therefore in flight while the other's layer 0 /
+        slice SpMM runs, in an order that depends only on the model and the scheme (identical on every rank), without a
+        second thread (the module path's interleave costs 3.7 instead of 1.5 ms of host time per epoch, section 4.3).
+        Same kernels and numbers as two forwards in a row."""
+        gens = [self._eval_g(first), self._eval_g(second)]
+        works, out, live = [None, None], [None, None], [True, True]
+        started = [False, False]
+        i = 0
+        while live[0] or live[1]:
+            if live[i]:
+                self._pair_tag = f" paired{i + 1}"  # names the forward in the exchange log (bench.py's link model)
+                try:
+                    if works[i] is not None:
+                        works[i].wait()
+                    works[i] = gens[i].send(None) if started[i] else next(gens[i])
+                    started[i] = True
+                except StopIteration as done:
+                    out[i], live[i] = done.value, False
+                finally:
+                    self._pair_tag = ""
+            i = 1 - i
+        return out
+
+    def _eval_g(self, which):
         S, be = self.specs, self.be
         L = len(S)
         prev_blk = inbound = None
@@ -469,7 +519,7 @@ class GridStack:
             if i == 0:
                 prev_blk, inbound, _, _, _ = self._first_layer(wt, b, wtr, False)
                 continue
-            u = self._propagate(i, "fwd", prev_blk, inbound)
+            u = yield from self._propagate_g(i, "fwd", prev_blk, inbound)
             inbound = None
             root = dict(x_root=prev_blk, wt_root=wtr) if wtr is not None else {}
             if i == L - 1 and wt is None:  # the transform ran before the exchange: logits = aggregate + bias

@@ -253,6 +253,8 @@ def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", inter
     both = None
     if r.engine is not None:  # the same weights through the fused schedule and through the modules
         eng = [r.engine.eval_stats(w) for w in (1, 2)]
+        pair = r.engine.eval_pair(1, 2)  # the two forwards interleaved on one thread: the same bits
+        assert all(torch.equal(a, b) for a, b in zip(eng, pair)), (eng, pair)
         engine, r.engine = r.engine, None
         both = (eng, [r.evaluate(w, sync=False)[0] for w in (1, 2)])
         r.engine = engine
