@@ -30,7 +30,8 @@ class DistRunner:
         # on the device only until this rank's structures exist (release_edge_list)
         self.token = torch.zeros((2, 1), dtype=torch.int64, device=device)
         self.graphs = install(self.token, hi - lo, edge_index.to(device), N, self.comm, backend, exchange, pieces)
-        self.interleave_evals = interleave_evals and world > 1
+        import os
+        self.interleave_evals = interleave_evals and world > 1 and os.environ.get("RGBX_INTERLEAVE", "auto") != "never"
         self._streams = None
         self._epochs_done = 0
         self.host_enqueue_s = 0.0
