@@ -66,6 +66,8 @@ KERNEL_OF_KIND = {
     "mean_bwd": "spmm_csr_kernel", "appnp_fwd": "spmm_csr_kernel (K launches)",
     "appnp_bwd": "spmm_csr_kernel (K launches)", "gat_fwd": "gat_fwd_kernel", "gat_bwd_src": "gat_bwd_src_kernel",
     "gat_bwd_prep": "gat_bwd_prep_kernel",
+    # single-head GATConv run aggregate-first (ops.gat_attend_linear): coefficients per edge, then the fused kernel
+    "gat_linear_fwd": "spmm_linear_kernel", "gat_edge_softmax": "gat_edge_softmax_kernel",
     "dist_fwd_local": "spmm_csr_kernel", "dist_fwd_remote": "spmm_csr_kernel", "dist_bwd_local": "spmm_csr_kernel",
     "dist_bwd_remote": "spmm_csr_kernel", "dist_fwd_resident": "spmm_csr_kernel",
     "dist_fwd_colshard": "spmm_csr_kernel", "dist_bwd_colshard": "spmm_csr_kernel",
@@ -172,19 +174,43 @@ def gat_launch_bytes(n_rows, nnz, H, C):
             "bwd_prep": n_rows * (12 * d + 36 * H)}
 
 
+def gat_single_head_linear(d):
+    """The bench model's last layer (one head, d -> d classes) runs aggregate-first (ops.gat_linear_ok)."""
+    return d in (64, 128, 256) and d <= 128
+
+
+def gat_linear_launch_bytes(n_rows, nnz, d):
+    """The single-head layer run aggregate-first (ops._GATAttendLinear), per launch:
+      edge_softmax : per edge col + the a_src gather + the alpha store (training: + alpha_pos); per target rowptr, a_dst,
+                     max, 1/sum (training: + a_pos)
+      fwd          : rgbx_fused_layer_f32 with w = alpha and the loss epilogue: per edge col + alpha + the source row;
+                     per target rowptr, label and mask; inference stores nothing (statistics only); training reads
+                     alpha_pos per edge and stores the aggregate, its positive-score part and the loss gradient"""
+    soft = nnz * 12 + n_rows * 12 + 4 * (n_rows + 1)
+    fwd = nnz * (8 + 4 * d) + n_rows * 9 + 4 * (n_rows + 1)
+    return {"edge_softmax_infer": soft, "edge_softmax_train": soft + nnz * 4 + n_rows * 4,
+            "fwd_infer": fwd, "fwd_train": fwd + nnz * 4 + n_rows * 12 * d}
+
+
 def gat_alg_bytes(n_rows, nnz, d, H=8):
     """Mean algorithmic bytes per propagate of a 2-layer GAT epoch (layer 1: H heads of d/H channels, layer 2: one head
     of d): 4 inference-form forwards (two eval forwards), 2 training-form forwards, 2 backward source passes with
-    their streaming prep pass — 8 propagates."""
+    their streaming prep pass — 8 propagates. Layer 2's forwards are the aggregate-first launches where they apply."""
     l1, l2 = gat_launch_bytes(n_rows, nnz, H, d // H), gat_launch_bytes(n_rows, nnz, 1, d)
     tot = sum(2 * l["fwd_infer"] + l["fwd_train"] + l["bwd_src"] + l["bwd_prep"] for l in (l1, l2))
+    if gat_single_head_linear(d):
+        lin = gat_linear_launch_bytes(n_rows, nnz, d)
+        tot += (2 * (lin["fwd_infer"] + lin["edge_softmax_infer"]) + lin["fwd_train"] + lin["edge_softmax_train"]
+                - 2 * l2["fwd_infer"] - l2["fwd_train"])
     return tot / 8
 
 
 def gat_fwd_launch_bytes(n_rows, nnz, d, H=8):
-    """Mean over the 6 forward launches of an epoch (per layer: 2 inference-form, 1 training-form)."""
+    """Mean over the `gat_fwd` launches of an epoch (per layer: 2 inference-form, 1 training-form): both layers, or
+    layer 1 alone when the single-head layer 2 runs aggregate-first (kinds gat_edge_softmax + gat_linear_fwd)."""
     l1, l2 = gat_launch_bytes(n_rows, nnz, H, d // H), gat_launch_bytes(n_rows, nnz, 1, d)
-    return sum(2 * l["fwd_infer"] + l["fwd_train"] for l in (l1, l2)) / 6
+    layers = (l1,) if gat_single_head_linear(d) else (l1, l2)
+    return sum(2 * l["fwd_infer"] + l["fwd_train"] for l in layers) / (3 * len(layers))
 
 
 def spmm_alg_bytes(n_rows, nnz, d):
@@ -907,9 +933,16 @@ def main():
     elif dominant is not None:
         # the DOMINANT kernel's own launches: its algorithmic bytes per launch / its mean launch duration
         launches_per_event = kwargs.get("K", 1) if dominant.startswith("appnp") else 1
-        if dominant == "gat_fwd":  # the forward launches alone, both layers, inference and training form
+        if dominant == "gat_fwd":  # the forward launches alone (gat_fwd_launch_bytes), inference and training form
             rows_here, nnz_here = (N, nnz_total) if parts == 1 else (n_loc, plan.nnz_local)
             alg = gat_fwd_launch_bytes(rows_here, nnz_here, d, kwargs.get("heads", 8))
+            if parts > 1:  # partitioned GAT runs every layer on the halo scheme's own kernels
+                l1, l2 = gat_launch_bytes(rows_here, nnz_here, kwargs.get("heads", 8), d // kwargs.get("heads", 8)), \
+                    gat_launch_bytes(rows_here, nnz_here, 1, d)
+                alg = sum(2 * l["fwd_infer"] + l["fwd_train"] for l in (l1, l2)) / 6
+        elif dominant == "gat_linear_fwd":
+            lin = gat_linear_launch_bytes(N, nnz_total, d)
+            alg = (2 * lin["fwd_infer"] + lin["fwd_train"]) / 3
         dom_s = sum(by_kind[dominant]) / len(by_kind[dominant]) / launches_per_event * 1e-3
         achieved = alg / dom_s / 1e9
     by_kind = {k: {"n": len(v), "avg_ms": sum(v) / len(v)} for k, v in sorted(by_kind.items())}

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define RGBX_VERSION 300 /* major*10000 + minor*100 + patch */
+#define RGBX_VERSION 310 /* major*10000 + minor*100 + patch */
 
 #define RGBX_OK 0
 #define RGBX_E_ARG (-1)    /* null pointer / negative size / bad enum */
@@ -230,6 +230,13 @@ typedef struct rgbx_fused_layer {
   const rgbx_ce_epilogue_t* ce;
   int64_t N, K, Nout;
   const rgbx_row_split_t* split;
+  /* Second aggregate (both NULL, or both set): z_pos_out[i,:] (ld = ldz) = sum_p w_pos[p] x[col[p],:] over the same
+   * slots, from the rows the launch gathers anyway; never transformed. Single-head GAT's training forward: w = the
+   * attention coefficients, w_pos = those of edges with a positive score (rgbx_gat_edge_softmax_f32), the pair
+   * (z_out, z_pos_out) = (out, out_pos) of rgbx_gat_bwd_prep_f32. Needs w and z_out, K in {64, 128, 256}, Nout <= 128,
+   * no rs / pre_* / out_blk; with `split`, split->partial must hold n_chunks * K + 2 * n_long * K floats. */
+  const float* w_pos;
+  float* z_pos_out;
 } rgbx_fused_layer_t;
 
 int rgbx_fused_layer_f32(const rgbx_fused_layer_t* layer, rgbx_stream_t stream);
@@ -320,6 +327,20 @@ int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* col, const 
                                float* out, int64_t ldo, float* m, float* rden, float* out_pos, float* a_pos,
                                int64_t N, int H, int C, float slope, const rgbx_row_split_t* split,
                                rgbx_stream_t stream);
+
+/* Single head: the attention coefficients of every in-edge as a per-edge vector in CSR slot order,
+ *   alpha[p] = exp(e_p - max) / (sum + 1e-16),  e_p = leaky_relu(a_src[col[p]] + a_dst[i], slope)   (p in row i),
+ * plus m[i] / rden[i] as rgbx_gat_aggregate_fwd_f32 saves them. With ONE head the transform of a GATConv can run
+ * behind the aggregation, out_i = (sum_j alpha_ij x_j) W^T + b with scores a = x (W^T att) (GATConv.forward with
+ * heads = 1 [PyG], the last layer of reference models/gat.py:21,30), which is rgbx_fused_layer_f32 with w = alpha:
+ * no h = x W^T product and no logits pass (the loss epilogue applies). `alpha_pos` ([E']) and `a_pos` ([N]): both NULL
+ * (inference) or both set — alpha_pos[p] = alpha[p] where the pre-activation score is positive, else 0, a_pos[i] their
+ * sum: rgbx_fused_layer_f32's w_pos / z_pos_out then yield the out_pos of rgbx_gat_bwd_prep_f32.
+ * `split` (optional): rows with more than split->threshold slots (split->long_row, n_long) get a workgroup each
+ * instead of 8 lanes; no scratch needed (split->partial is not used). */
+int rgbx_gat_edge_softmax_f32(const int32_t* rowptr, const int32_t* col, const float* a_src, const float* a_dst,
+                              float slope, float* alpha, float* alpha_pos, float* m, float* rden, float* a_pos,
+                              int64_t N, const rgbx_row_split_t* split, rgbx_stream_t stream);
 
 /* Backward, target side (same CSR as forward). Per target i, head h:
  *   dsum[i,h]    = <gout[i,h,:], out[i,h,:]>

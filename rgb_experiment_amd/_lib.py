@@ -39,7 +39,7 @@ class FusedLayer(ctypes.Structure):
                 ("ldo", _I64), ("out_blk", _P), ("ob_cols", _I64), ("ob_stride", _I64), ("z_out", _P), ("ldz", _I64),
                 ("pre_scale", _P), ("pre_shift", _P), ("pre_rowsum", _P), ("out_colsums", _P), ("stats_ws", _P),
                 ("stats_ws_bytes", ctypes.c_size_t), ("ce", _P), ("N", _I64), ("K", _I64), ("Nout", _I64),
-                ("split", _P)]
+                ("split", _P), ("w_pos", _P), ("z_pos_out", _P)]
 
 
 # name -> argtypes, exactly the declarations of include/rgbx_hip.h
@@ -66,6 +66,7 @@ SIGNATURES = {
     "rgbx_gat_scores_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I, _I, _P],
     "rgbx_gat_aggregate_fwd_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _I64, _I, _I, _F, _P,
                                    _P],
+    "rgbx_gat_edge_softmax_f32": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I64, _P, _P],
     "rgbx_gat_bwd_dst_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I,
                              _F, _P],
     "rgbx_gat_bwd_prep_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _F, _P, _I64, _I, _I, _P],

@@ -821,6 +821,96 @@ int check_common(int64_t N, int H, int C, const char* name) {
   return RGBX_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Single-head attention coefficients as a per-edge array (rgbx_gat_edge_softmax_f32): with ONE head the coefficients
+// are 4 bytes per edge next to the 4 * C bytes of the row the edge gathers, so a layer whose transform can run BEHIND
+// the aggregation (out_i = (sum_j alpha_ij x_j) W^T, single head: GAT's last layer, models/gat.py:21,30) is a plain
+// weighted aggregation + MFMA epilogue on rgbx_fused_layer_f32 once alpha exists. The pass is a chain of dependent
+// loads (rowptr -> col -> a_src) over short rows, i.e. latency-bound: 8 lanes per target row (8 rows per wave) with up
+// to 8 slots per lane in registers keep 8 independent gathers per lane in flight (32 lanes per row and 2 slots per
+// lane: 0.66 ms at |E'| = 62 M; this form: see DESIGN 3.4b); rows beyond 64 slots recompute their scores from the
+// cache-resident score vectors. Sums: per lane in slot order, then a butterfly over the row's lanes — a fixed order.
+template <bool TRAIN>
+__global__ void __launch_bounds__(256)
+gat_edge_softmax_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ a_src,
+                        const float* __restrict__ a_dst, float slope, float* __restrict__ alpha,
+                        float* __restrict__ alpha_pos, float* __restrict__ m_out, float* __restrict__ rden_out,
+                        float* __restrict__ apos_out, int N, int threshold) {
+  constexpr int LPR = 8;  // lanes per row
+  constexpr int R = 8;    // slots per lane kept in registers (LPR * R = 64 slots of a row)
+  const int sub = threadIdx.x & (LPR - 1);
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+  if (row >= N) return;  // the LPR lanes of a row leave together: the butterflies below stay inside a row's lanes
+  const int start = rowptr[row], end = rowptr[row + 1];
+  if (threshold > 0 && end - start > threshold) return;  // hub row: gat_edge_softmax_long_kernel owns it
+  const float ad = a_dst[row];
+  int src[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int p = start + k * LPR + sub;
+    src[k] = p < end ? col[p] : -1;
+  }
+  float er[R];
+  float mx = kNegBig;
+  unsigned posbits = 0;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    er[k] = kNegBig;
+    if (src[k] >= 0) {
+      const float s = a_src[src[k]] + ad;
+      if (s > 0.f) posbits |= 1u << k;
+      er[k] = s > 0.f ? s : slope * s;
+    }
+    mx = fmaxf(mx, er[k]);
+  }
+  for (int p = start + R * LPR + sub; p < end; p += LPR) {
+    const float s = a_src[col[p]] + ad;
+    mx = fmaxf(mx, s > 0.f ? s : slope * s);
+  }
+#pragma unroll
+  for (int off = LPR >> 1; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float l = 0.f, lp = 0.f;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    er[k] = src[k] >= 0 ? expf(er[k] - mx) : 0.f;
+    l += er[k];
+    if (TRAIN && (posbits >> k & 1u)) lp += er[k];
+  }
+  for (int p = start + R * LPR + sub; p < end; p += LPR) {
+    const float s = a_src[col[p]] + ad;
+    const float ex = expf((s > 0.f ? s : slope * s) - mx);
+    l += ex;
+    if (TRAIN && s > 0.f) lp += ex;
+  }
+#pragma unroll
+  for (int off = LPR >> 1; off > 0; off >>= 1) {
+    l += __shfl_xor(l, off);
+    if (TRAIN) lp += __shfl_xor(lp, off);
+  }
+  const float rd = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int p = start + k * LPR + sub;
+    if (src[k] >= 0) {
+      const float a = er[k] * rd;
+      alpha[p] = a;
+      if (TRAIN) alpha_pos[p] = (posbits >> k & 1u) ? a : 0.f;
+    }
+  }
+  for (int p = start + R * LPR + sub; p < end; p += LPR) {
+    const float s = a_src[col[p]] + ad;
+    const float a = expf((s > 0.f ? s : slope * s) - mx) * rd;
+    alpha[p] = a;
+    if (TRAIN) alpha_pos[p] = s > 0.f ? a : 0.f;
+  }
+  if (sub == 0) {
+    m_out[row] = l > 0.f ? mx : 0.f;
+    rden_out[row] = rd;
+    if (TRAIN) apos_out[row] = lp * rd;
+  }
+}
+
 }  // namespace
 }  // namespace rgbx
 
@@ -1053,5 +1143,103 @@ extern "C" int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_
   else RGBX_GAT_BS(1);
 #undef RGBX_GAT_BS
   RGBX_CHECK_LAUNCH("gat_bwd_src_kernel");
+  return RGBX_OK;
+}
+
+namespace {
+// Hub rows (more than split->threshold slots): one 256-thread workgroup per row instead of 8 lanes; three sweeps over
+// the row (max, sum, store) with the scores recomputed from the cache-resident vectors; block reductions over a fixed
+// tree, so the result does not depend on scheduling.
+template <bool TRAIN>
+__global__ void __launch_bounds__(256)
+gat_edge_softmax_long_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                             const float* __restrict__ a_src, const float* __restrict__ a_dst, float slope,
+                             float* __restrict__ alpha, float* __restrict__ alpha_pos, float* __restrict__ m_out,
+                             float* __restrict__ rden_out, float* __restrict__ apos_out,
+                             const int* __restrict__ long_row) {
+  __shared__ float sh[2][256];
+  const int row = long_row[blockIdx.x];
+  const int start = rowptr[row], end = rowptr[row + 1];
+  const float ad = a_dst[row];
+  const int t = threadIdx.x;
+  float mx = rgbx::kNegBig;
+  for (int p = start + t; p < end; p += 256) {
+    const float s = a_src[col[p]] + ad;
+    mx = fmaxf(mx, s > 0.f ? s : slope * s);
+  }
+  sh[0][t] = mx;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) sh[0][t] = fmaxf(sh[0][t], sh[0][t + w]);
+    __syncthreads();
+  }
+  mx = sh[0][0];
+  __syncthreads();
+  float l = 0.f, lp = 0.f;
+  for (int p = start + t; p < end; p += 256) {
+    const float s = a_src[col[p]] + ad;
+    const float ex = expf((s > 0.f ? s : slope * s) - mx);
+    l += ex;
+    if (TRAIN && s > 0.f) lp += ex;
+  }
+  sh[0][t] = l;
+  sh[1][t] = lp;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) {
+      sh[0][t] += sh[0][t + w];
+      sh[1][t] += sh[1][t + w];
+    }
+    __syncthreads();
+  }
+  l = sh[0][0];
+  lp = sh[1][0];
+  const float rd = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
+  for (int p = start + t; p < end; p += 256) {
+    const float s = a_src[col[p]] + ad;
+    const float a = expf((s > 0.f ? s : slope * s) - mx) * rd;
+    alpha[p] = a;
+    if (TRAIN) alpha_pos[p] = s > 0.f ? a : 0.f;
+  }
+  if (t == 0) {
+    m_out[row] = l > 0.f ? mx : 0.f;
+    rden_out[row] = rd;
+    if (TRAIN) apos_out[row] = lp * rd;
+  }
+}
+}  // namespace
+
+extern "C" int rgbx_gat_edge_softmax_f32(const int32_t* rowptr, const int32_t* col, const float* a_src,
+                                         const float* a_dst, float slope, float* alpha, float* alpha_pos, float* m,
+                                         float* rden, float* a_pos, int64_t N, const rgbx_row_split_t* split,
+                                         rgbx_stream_t stream) {
+  if (N < 0) return fail(RGBX_E_ARG, "gat_edge_softmax: bad size");
+  if (N == 0) return RGBX_OK;
+  if (!rowptr || !col || !a_src || !a_dst || !alpha || !m || !rden)
+    return fail(RGBX_E_ARG, "gat_edge_softmax: null pointer");
+  if ((alpha_pos != nullptr) != (a_pos != nullptr))
+    return fail(RGBX_E_ARG, "gat_edge_softmax: alpha_pos and a_pos go together");
+  if (N >= INT32_MAX) return fail(RGBX_E_RANGE, "gat_edge_softmax: N exceeds int32");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t blocks = cdiv(N, 32);  // 8 lanes per row: 32 rows per 256-thread workgroup
+  const bool hubs = split && split->threshold > 0 && split->n_long > 0;
+  const int threshold = hubs ? split->threshold : 0;
+  if (hubs && !split->long_row) return fail(RGBX_E_ARG, "gat_edge_softmax: split without long_row");
+  if (alpha_pos)
+    gat_edge_softmax_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(rowptr, col, a_src, a_dst, slope, alpha, alpha_pos, m,
+                                                                   rden, a_pos, (int)N, threshold);
+  else
+    gat_edge_softmax_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(rowptr, col, a_src, a_dst, slope, alpha, nullptr, m,
+                                                                    rden, nullptr, (int)N, threshold);
+  RGBX_CHECK_LAUNCH("gat_edge_softmax_kernel");
+  if (hubs) {
+    if (alpha_pos)
+      gat_edge_softmax_long_kernel<true><<<split->n_long, 256, 0, s>>>(rowptr, col, a_src, a_dst, slope, alpha, alpha_pos,
+                                                                       m, rden, a_pos, split->long_row);
+    else
+      gat_edge_softmax_long_kernel<false><<<split->n_long, 256, 0, s>>>(rowptr, col, a_src, a_dst, slope, alpha, nullptr,
+                                                                        m, rden, nullptr, split->long_row);
+    RGBX_CHECK_LAUNCH("gat_edge_softmax_long_kernel");
+  }
   return RGBX_OK;
 }

@@ -66,6 +66,11 @@ struct FusedArgs {
   int64_t x_bc, x_bs, xr_bc, xr_bs;
   float* out_blk;
   int64_t ob_c, ob_s;
+  // POS instantiations (rgbx_fused_layer_t.w_pos): a second aggregate of the same gathered rows under a second weight
+  // vector, stored next to z_out (same ldz) — never transformed
+  const float* w2;
+  float* zpos_out;
+  const float* zlong_pos;
 };
 
 __device__ __forceinline__ const float* blocked_at(const float* base, int64_t bc, int64_t bs, int64_t ld, int row,
@@ -317,8 +322,11 @@ ce_tiles_finish_kernel(const double* __restrict__ part2, int n, double* __restri
 // return stage of the partitioned run's exchange, or a plain x * wt product, with the same phase 2 and epilogues.
 // BLK: the blocked layouts of FusedArgs are honoured (partitioned runs); the single-GPU instantiations are compiled
 // without them, so their register budget (64 VGPRs, no SGPR spills in the gather loop) is what it was.
-template <int G, bool HAS_W, int KC, int NT, bool CE = false, bool DENSE = false, bool BLK = false>
-__global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const FusedArgs A) {
+// POS: every gathered row is also accumulated under the second weight vector A.w2 into A.zpos_out (single-head GAT's
+// training forward: the part of the aggregate carried by edges with a positive score, see gat.hip). One more
+// accumulator per lane: 7 waves per SIMD instead of 8.
+template <int G, bool HAS_W, int KC, int NT, bool CE = false, bool DENSE = false, bool BLK = false, bool POS = false>
+__global__ void __launch_bounds__(256, POS ? 7 : (NT == 2 ? 5 : 8)) spmm_linear_kernel(const FusedArgs A) {
   constexpr int NG = kWave / G;
   constexpr int U = 4;
   extern __shared__ float zt[];  // [TM][K + 4]
@@ -363,6 +371,7 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
     if (lr >= TM) break;
     const int row = row_base + lr;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float accp[4] = {0.f, 0.f, 0.f, 0.f};  // POS only
     if (row < A.N) {
       const int start = __builtin_amdgcn_readfirstlane(A.rowptr[row]);
       const int end = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
@@ -375,30 +384,37 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
           if (A.long_row[mid] < row) lo = mid + 1;
           else hi = mid;
         }
-        if (g == 0 && active) load_vec<4>(acc, A.zlong + (int64_t)lo * K + c);
+        if (g == 0 && active) {
+          load_vec<4>(acc, A.zlong + (int64_t)lo * K + c);
+          if constexpr (POS) load_vec<4>(accp, A.zlong_pos + (int64_t)lo * K + c);
+        }
       } else {
         const float* xc = A.x + c;
         for (int base = start; base < end; base += kWave) {
           const int n = min(kWave, end - base);
           int mycol = 0;
-          float myw = 0.f;
+          float myw = 0.f, mywp = 0.f;
           if (lane < n) {
             mycol = A.col[base + lane];
             if constexpr (HAS_W) myw = A.w[base + lane];
+            if constexpr (POS) mywp = A.w2[base + lane];
           }
           for (int k = 0; k < n; k += NG * U) {
             float v[U][4];
             float ww[U];
+            float wp[POS ? U : 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
               const int idx = k + u * NG + g;
               const int src = __shfl(mycol, idx & 63);
               if constexpr (HAS_W) ww[u] = __shfl(myw, idx & 63);
+              if constexpr (POS) wp[u] = __shfl(mywp, idx & 63);
               const bool ok = active && idx < n;
 #pragma unroll
               for (int i = 0; i < 4; ++i) v[u][i] = 0.f;
               if (ok) load_vec<4>(v[u], xc + (int64_t)src * A.ldx);
               if constexpr (HAS_W) { if (!ok) ww[u] = 0.f; }
+              if constexpr (POS) { if (!ok) wp[u] = 0.f; }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -406,6 +422,7 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
               for (int i = 0; i < 4; ++i) {
                 if constexpr (HAS_W) acc[i] = fmaf(ww[u], v[u][i], acc[i]);
                 else acc[i] += v[u][i];
+                if constexpr (POS) accp[i] = fmaf(wp[u], v[u][i], accp[i]);
               }
             }
           }
@@ -414,6 +431,10 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
         for (int off = 32; off >= G; off >>= 1) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], off);
+          if constexpr (POS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accp[i] += __shfl_xor(accp[i], off);
+          }
         }
         if (A.rs) {
           const float s = A.rs[row];
@@ -433,6 +454,9 @@ __global__ void __launch_bounds__(256, NT == 2 ? 5 : 8) spmm_linear_kernel(const
       }
       store_vec<4>(&zt[lr * ldz + c], acc);
       if (A.z_out && row < A.N) store_vec<4>(A.z_out + (int64_t)row * A.ldz + c, acc);
+      if constexpr (POS) {
+        if (row < A.N) store_vec<4>(A.zpos_out + (int64_t)row * A.ldz + c, accp);
+      }
     }
   }
   // the first batch of W^T values of this wave's first column tile does not depend on the tile: fetch it now, so its
@@ -693,6 +717,14 @@ int launch(const FusedArgs& A, hipStream_t s) {
     if (blk) spmm_linear_kernel<G, HW, KC, NTV, false, DENSE, true><<<(int)blocks, 256, lds, s>>>(A); \
     else spmm_linear_kernel<G, HW, KC, NTV, false, DENSE, DENSE><<<(int)blocks, 256, lds, s>>>(A);   \
   } while (0)
+  if constexpr (!DENSE && KC > 0) {
+    if (A.w2) {  // the entry point checked: w set, Nout <= 128, no blocked layouts
+      if (A.ce_part) spmm_linear_kernel<G, true, KC, 1, true, false, false, true><<<(int)blocks, 256, lds, s>>>(A);
+      else spmm_linear_kernel<G, true, KC, 1, false, false, false, true><<<(int)blocks, 256, lds, s>>>(A);
+      RGBX_CHECK_LAUNCH("spmm_linear_kernel (second aggregate)");
+      return RGBX_OK;
+    }
+  }
   if (A.ce_part) {  // nt == 1: the entry point checked Nout <= 128; the loss epilogue has no blocked output
     if (A.w && !DENSE) spmm_linear_kernel<G, !DENSE, KC, 1, true, DENSE, DENSE><<<(int)blocks, 256, lds, s>>>(A);
     else if (blk) spmm_linear_kernel<G, false, KC, 1, true, DENSE, true><<<(int)blocks, 256, lds, s>>>(A);
@@ -758,6 +790,16 @@ extern "C" int rgbx_fused_layer_f32(const rgbx_fused_layer_t* Lp, rgbx_stream_t 
     if (L.out_blk) return fail(RGBX_E_ARG, "spmm_linear: a blocked output and the cross-entropy epilogue exclude each other");
     if (ce->grad_scale && !L.out) return fail(RGBX_E_ARG, "spmm_linear: the loss gradient needs `out`");
   }
+  if ((L.w_pos != nullptr) != (L.z_pos_out != nullptr))
+    return fail(RGBX_E_ARG, "fused_layer: w_pos and z_pos_out go together");
+  if (L.w_pos) {
+    if (dense || !L.w || L.rs || L.pre_scale || L.out_blk || L.z_out == nullptr)
+      return fail(RGBX_E_ARG, "fused_layer: w_pos needs an aggregating launch with w and z_out, without rs / pre_* / out_blk");
+    if ((K != 64 && K != 128 && K != 256) || Nout > 128)
+      return fail(RGBX_E_SHAPE, "fused_layer: w_pos needs K in {64, 128, 256} and Nout <= 128 (got K=%lld, Nout=%lld)",
+                  (long long)K, (long long)Nout);
+    if (!aligned16(L.z_pos_out)) return fail(RGBX_E_ALIGN, "fused_layer: z_pos_out must be 16-byte aligned");
+  }
   if (N >= INT32_MAX) return fail(RGBX_E_RANGE, "spmm_linear: N exceeds int32");
   if ((L.x_root != nullptr) != (L.wt_root != nullptr))
     return fail(RGBX_E_ARG, "spmm_linear: x_root and wt_root go together");
@@ -794,6 +836,7 @@ extern "C" int rgbx_fused_layer_f32(const rgbx_fused_layer_t* Lp, rgbx_stream_t 
   hipStream_t s = (hipStream_t)stream;
   const int* long_row = nullptr;
   const float* zlong = nullptr;
+  const float* zlong_pos = nullptr;
   int threshold = 0, n_long = 0;
   const rgbx_row_split_t* split = dense ? nullptr : L.split;
   if (split && split->threshold > 0 && split->n_chunks > 0) {
@@ -801,6 +844,11 @@ extern "C" int rgbx_fused_layer_f32(const rgbx_fused_layer_t* Lp, rgbx_stream_t 
     // [n_chunks, K] partials
     float* zl = split->partial ? split->partial + (size_t)split->n_chunks * K : nullptr;
     if (int rc = spmm_long_rows_compact(L.rowptr, L.col, L.w, L.rs, L.x, L.ldx, (int)K, split, zl, s)) return rc;
+    if (L.w_pos) {  // the same rows under the second weight vector: [n_long, K] more behind the first
+      float* zlp = zl ? zl + (size_t)split->n_long * K : nullptr;
+      if (int rc = spmm_long_rows_compact(L.rowptr, L.col, L.w_pos, L.rs, L.x, L.ldx, (int)K, split, zlp, s)) return rc;
+      zlong_pos = zlp;
+    }
     long_row = split->long_row;
     zlong = zl;
     threshold = split->threshold;
@@ -811,7 +859,7 @@ extern "C" int rgbx_fused_layer_f32(const rgbx_fused_layer_t* Lp, rgbx_stream_t 
               L.pre_scale, L.pre_shift, L.pre_rowsum, stats_part,
               ce ? ce->y : nullptr, ce ? ce->mask : nullptr, ce ? ce->grad_scale : nullptr, ce ? ce->scratch : nullptr,
               x_blk ? L.x_blk_cols : 0, L.x_blk_stride, xr_blk ? L.xr_blk_cols : 0, L.xr_blk_stride,
-              L.out_blk, L.ob_cols, L.ob_stride};
+              L.out_blk, L.ob_cols, L.ob_stride, L.w_pos, L.z_pos_out, zlong_pos};
   const int lanes = (int)(K / 4);
   int rc;
   if (dense) {  // the lane grouping of the gather is irrelevant: one instantiation per unrolled width

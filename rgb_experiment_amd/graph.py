@@ -40,12 +40,11 @@ class CSR:
     def split_arg(self, d, device, hub_rows=False):
         """ctypes rgbx_row_split_t for one launch at width d (allocates the partial scratch), or None.
         `hub_rows`: room for the n_long finished hub-row aggregates after the chunk partials
-        (rgbx_spmm_linear_f32)."""
+        (rgbx_spmm_linear_f32); 2 = for two sets of them (rgbx_fused_layer_t.w_pos)."""
         if self.split is None:
             return None, None
         sp = self.split
-        partial = torch.empty((sp["n_chunks"] + (sp["n_long"] if hub_rows else 0), d), dtype=torch.float32,
-                              device=device)
+        partial = torch.empty((sp["n_chunks"] + sp["n_long"] * int(hub_rows), d), dtype=torch.float32, device=device)
         st = _lib.RowSplit(sp["threshold"], sp["n_chunks"], sp["n_long"], sp["chunk_begin"].data_ptr(),
                            sp["chunk_end"].data_ptr(), sp["chunk_row"].data_ptr(), sp["long_row"].data_ptr(),
                            sp["long_chunk_ptr"].data_ptr(), partial.data_ptr())

@@ -358,13 +358,23 @@ class GATConv(nn.Module):
         nn.init.zeros_(self.bias)
 
     folds_post_affine = True  # forward(..., post_affine=(scale, shift)): see models/_stack.py
+    accepts_ce = True  # forward(..., ce=(y, mask)) returns (loss, stats): see models/_stack.py
 
-    def forward(self, x, edge_index, post_affine=None):
+    def forward(self, x, edge_index, post_affine=None, ce=None):
         """`post_affine` = (scale, shift) of an eval-mode BatchNorm that follows this layer (no_grad only): applied in
         the aggregation kernel's store, out = aggregate * scale + (bias * scale + shift), when the bias rides there
-        too; otherwise after the layer."""
+        too; otherwise after the layer. `ce` = (y, mask): the layer is the model's last; returns (loss, stats) of the
+        masked cross-entropy of its output instead of the output."""
         H, C = self.heads, self.out_channels
         graph = get_graph(edge_index, x.size(0), LOOPS_REMOVE_ADD)
+        if (H == 1 and post_affine is None
+                and ops.gat_linear_ok(graph, self.in_channels, C, x, None if ce is None else ce[0])):
+            # one head: sum_j alpha_ij (W x_j) = W sum_j alpha_ij x_j — scores from x, the coefficients as a per-edge
+            # vector, then aggregation + transform (+ loss) in ONE launch of the fused kernel; no h = x W^T product
+            return ops.gat_attend_linear(x, self.lin_src.weight, self.att_src, self.att_dst, graph,
+                                         self.negative_slope, bias=self.bias, ce=ce)
+        if ce is not None:
+            return ops.ce_from_logits(self.forward(x, edge_index, post_affine), ce[0], ce[1])
         # the bias rides in the aggregation kernel's store when it applies to the stored row as is
         # (concatenated heads, or a single head, whose "mean over heads" is the identity)
         in_kernel = self.concat or H == 1

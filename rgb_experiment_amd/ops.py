@@ -197,7 +197,7 @@ def _blocked(t, what):
 
 
 def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_root=None, pre=None, want_out=True,
-                out_blocked=None, want_z=False, want_colsums=False, ce=None, kind="linear", out=None, z=None):
+                out_blocked=None, want_z=False, want_colsums=False, ce=None, kind="linear", out=None, z=None, w_pos=None):
     """One conv layer's arithmetic on rgbx_fused_layer_f32 (no autograd):
         z   = rs * sum_p w_p x[col_p]   over `csr`            (csr given: aggregate)
             = x                                                 (csr None: DENSE mode, the rows are loaded)
@@ -209,6 +209,8 @@ def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_roo
     `want_z`: the (mapped) aggregate is stored. `want_colsums`: [2, Nout] float64 column sums of out and out^2.
     `ce` = (y, mask, grad_scale): loss epilogue (see spmm_linear_raw). `out` / `z`: caller's row-major [N, Nout] /
     [N, K] tensors to write into (row ranges of bigger ones when a layer is launched piece by piece).
+    `w_pos` (second weight vector over the same slots; implies want_z): z_pos = sum_p w_pos_p x[col_p] is stored as well
+    and the return value is (out, (z, z_pos), colsums or stats).
     Returns (out, z, colsums or stats)."""
     _lib.require_device(x, wt, bias, x_root, wt_root, out_blocked)
     lib = _lib.load()
@@ -232,7 +234,7 @@ def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_roo
     L.wt = wt.data_ptr()
     if not dense:
         L.rowptr, L.col, L.w, L.rs = _lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), _lib.ptr(rs)
-        split, _scratch = csr.split_arg(K, x.device, hub_rows=True)
+        split, _scratch = csr.split_arg(K, x.device, hub_rows=2 if w_pos is not None else 1)
         keep.append(_scratch)
         if split is not None:
             keep.append(split)
@@ -288,11 +290,17 @@ def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_roo
     if z is not None:
         if tuple(z.shape) != (N, K) or z.stride(1) != 1 or z.dtype != torch.float32:
             raise RuntimeError(f"fused_layer: z is {tuple(z.shape)}, expected a float32 [{N}, {K}] with contiguous rows")
-    elif want_z:
+    elif want_z or w_pos is not None:
         z = torch.empty((N, K), dtype=torch.float32, device=x.device)
     L.ldz = K
     if z is not None:
         L.z_out, L.ldz = z.data_ptr(), z.stride(0) if N > 1 else K
+    z_pos = None
+    if w_pos is not None:
+        _lib.require_device(w_pos)
+        z_pos = torch.empty_strided((N, K), (L.ldz, 1), dtype=torch.float32, device=x.device)
+        keep.append(w_pos)
+        L.w_pos, L.z_pos_out = w_pos.data_ptr(), z_pos.data_ptr()
     colsums = None
     if want_colsums:
         nbytes = ctypes.c_size_t(0)
@@ -306,7 +314,7 @@ def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_roo
     with _Timed(kind):
         _lib.check(lib.rgbx_fused_layer_f32(ctypes.byref(L), _lib.stream_ptr()), "rgbx_fused_layer_f32")
     del keep
-    return out, z, (ce_stats if ce is not None else colsums)
+    return out, (z if w_pos is None else (z, z_pos)), (ce_stats if ce is not None else colsums)
 
 
 def blocked_to_rows(src, out=None, bias=None):
@@ -1071,6 +1079,127 @@ def gat_attend(h, att_src, att_dst, graph, H, C, slope=0.2, bias=None, out_scale
     want_grad = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (h, att_src, att_dst, bias))
     return _GATAttend.apply(h, att_src, att_dst, graph, H, C, slope, bias, out_scale, want_grad)
+
+
+def gat_linear_ok(graph, in_channels, out_channels, x=None, y=None):
+    """A single-head GATConv can run aggregate-first (gat_attend_linear): widths the fused kernel's second-aggregate
+    form takes, aggregating at the input width not the more expensive order, single-GPU graph."""
+    return (not _is_dist(graph) and in_channels in (64, 128, 256) and in_channels <= out_channels <= 128
+            and out_channels % 32 == 0 and (x is None or x.is_cuda)
+            and (y is None or (y.is_cuda and y.dtype == torch.int64)))
+
+
+def gat_edge_softmax(csr, a_src, a_dst, slope, train, N):
+    """(alpha [E'], alpha_pos or None, m [N], rden [N], a_pos or None) of a single head (rgbx_gat_edge_softmax_f32)."""
+    dev = a_src.device
+    alpha = torch.empty(max(csr.nnz, 1), dtype=torch.float32, device=dev)
+    alpha_pos = torch.empty_like(alpha) if train else None
+    m = torch.empty(N, dtype=torch.float32, device=dev)
+    rden = torch.empty_like(m)
+    a_pos = torch.empty_like(m) if train else None
+    split, _scratch = csr.split_arg(1, dev)  # hub rows: a workgroup each (no scratch used)
+    with _Timed("gat_edge_softmax"):
+        _lib.check(_lib.load().rgbx_gat_edge_softmax_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(a_src),
+                                                         _lib.ptr(a_dst), float(slope), _lib.ptr(alpha),
+                                                         _lib.ptr(alpha_pos), _lib.ptr(m), _lib.ptr(rden),
+                                                         _lib.ptr(a_pos), N,
+                                                         None if split is None else ctypes.byref(split),
+                                                         _lib.stream_ptr()),
+                   "rgbx_gat_edge_softmax_f32")
+    return alpha, alpha_pos, m, rden, a_pos
+
+
+class _GATAttendLinear(torch.autograd.Function):
+    """A single-head GATConv with its transform BEHIND the aggregation:
+        out_i = (sum_j alpha_ij x_j) W^T + b,   alpha = edge softmax of leaky_relu(a_src[j] + a_dst[i]),
+        a_src = x (W^T att_src),  a_dst = x (W^T att_dst)
+    — the same function as lin -> scores -> edge softmax -> aggregate -> + bias of GATConv.forward with heads = 1 [PyG]
+    (the last layer of reference models/gat.py:21,30), re-associated: sum_j alpha_ij (W x_j) = W sum_j alpha_ij x_j.
+    Launches: scores over x (no h = x W^T product), the coefficients as a per-edge vector (rgbx_gat_edge_softmax_f32;
+    one head: 4 bytes per edge), then rgbx_fused_layer_f32 with w = alpha — the transform on the MFMA units under the
+    gather and, with labels given, the loss inside the kernel (no logits). A forward that prepares a backward also
+    stores the aggregate z (dW = dy^T z) and its positive-score part (w_pos): exactly the (out, out_pos) pair the
+    per-node GAT backward needs with hfeat := x and gout := dy W, so the backward is that of _GATAttend on those
+    operands plus the chain through v = att W. `y` / `mask`: returns (loss, stats) as _PropagateLinearCE does."""
+
+    @staticmethod
+    def forward(ctx, x, weight, att_src, att_dst, bias, graph, slope, y, mask, want_grad):
+        _lib.require_device(x, weight, att_src, att_dst, bias)
+        x = x.contiguous()
+        W = weight.detach()
+        C, K = W.shape
+        att = torch.stack([att_src.detach().reshape(C), att_dst.detach().reshape(C)])  # [2, C]
+        v = (att @ W).contiguous()  # [2, K]: the scores are products of x with these vectors
+        n_src, N, dev = x.size(0), graph.fwd.N, x.device
+        a_src = torch.empty(n_src, dtype=torch.float32, device=dev)
+        a_dst = torch.empty_like(a_src)
+        px, ldx = _lib.mat(x, "x")
+        _lib.check(_lib.load().rgbx_gat_scores_f32(px, ldx, _lib.ptr(v[0]), _lib.ptr(v[1]), _lib.ptr(a_src),
+                                                   _lib.ptr(a_dst), n_src, 1, K, _lib.stream_ptr()), "rgbx_gat_scores_f32")
+        alpha, alpha_pos, m, rden, a_pos = gat_edge_softmax(graph.fwd, a_src, a_dst, slope, want_grad, N)
+        ce = None
+        if y is not None:
+            ce = (y, mask, mask_scale(y, mask, C) if want_grad else None)
+        out, zz, stats = fused_layer(x, weight_t(weight), csr=graph.fwd, w=alpha,
+                                     bias=None if bias is None else bias.detach(), ce=ce, kind="gat_linear_fwd",
+                                     w_pos=alpha_pos)
+        ctx.graph, ctx.slope, ctx.has_bias, ctx.ce = graph, slope, bias is not None, y is not None
+        ctx.shapes = (att_src.shape, att_dst.shape)
+        if want_grad:
+            z, z_pos = zz
+            ctx.save_for_backward(x, a_src, a_dst, m, rden, z, z_pos, a_pos, v, weight, att, out if ctx.ce else None)
+        if y is None:
+            return out
+        ctx.mark_non_differentiable(stats)
+        return (stats[0] / stats[1]).float(), stats
+
+    @staticmethod
+    def backward(ctx, g, _g_stats=None):
+        if not ctx.saved_tensors:
+            raise RuntimeError("gat_attend_linear: backward asked of a forward that was run without want_grad")
+        x, a_src, a_dst, m, rden, z, z_pos, a_pos, v, weight, att, dlogits = ctx.saved_tensors
+        W = weight.detach()
+        C, K = W.shape
+        if ctx.ce:  # the kernel stored the loss gradient w.r.t. the logits; the incoming scalar rides on W and dW
+            dy, scalar = dlogits, g.reshape(()).float()
+            Wg = W * scalar
+        else:
+            dy, scalar, Wg = g.contiguous(), None, W
+        g_z = dy @ Wg  # [N, K]: gradient w.r.t. the aggregate
+        gw, gcol = gemm_tn(dy, z, colsum=True)
+        g_x, g_as, g_ad = _gat_backward_core(ctx.graph, x, a_src, a_dst, m, rden, z, g_z, 1, K, ctx.slope, opos=z_pos,
+                                             apos=a_pos, att=(v[0:1], v[1:2]))
+        lib = _lib.load()
+        n = x.size(0)
+        n_scr = ctypes.c_int64(0)
+        _lib.check(lib.rgbx_gat_scores_bwd_scratch_floats(n, 1, K, ctypes.byref(n_scr)), "rgbx_gat_scores_bwd_scratch_floats")
+        scratch = torch.empty(n_scr.value, dtype=torch.float32, device=x.device)
+        g_v = torch.empty((2, K), dtype=torch.float32, device=x.device)
+        px, ldx = _lib.mat(x, "x")
+        with _Timed("gat_scores_bwd"):  # the source pass folded the score terms into g_x: the vectors' sums only
+            _lib.check(
+                lib.rgbx_gat_scores_bwd_f32(px, ldx, _lib.ptr(g_as), _lib.ptr(g_ad), g_ad.size(0), _lib.ptr(v[0]),
+                                            _lib.ptr(v[1]), None, 0, _lib.ptr(g_v[0]), _lib.ptr(g_v[1]),
+                                            _lib.ptr(scratch), n_scr.value, n, 1, K, _lib.stream_ptr()),
+                "rgbx_gat_scores_bwd_f32")
+        # v = att W: g_att = g_v W^T, and W collects att^T g_v next to dy^T z
+        g_att = g_v @ W.t()
+        if scalar is not None:
+            gw, gcol = gw * scalar, gcol * scalar
+        gw = torch.addmm(gw, att.t(), g_v)
+        need = ctx.needs_input_grad
+        return (g_x if need[0] else None, gw if need[1] else None,
+                g_att[0].reshape(ctx.shapes[0]) if need[2] else None, g_att[1].reshape(ctx.shapes[1]) if need[3] else None,
+                gcol if ctx.has_bias and need[4] else None, None, None, None, None, None)
+
+
+def gat_attend_linear(x, weight, att_src, att_dst, graph, slope=0.2, bias=None, ce=None):
+    """Single-head GATConv, aggregate-first (the caller checked gat_linear_ok). `ce` = (y, mask): returns
+    (loss, stats) with the loss taken inside the kernel; else the logits."""
+    want_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (x, weight, att_src, att_dst, bias))
+    y, mask = ce if ce is not None else (None, None)
+    return _GATAttendLinear.apply(x, weight, att_src, att_dst, bias, graph, slope, y, mask, want_grad)
 
 
 def _scores_in_kernel(C):

@@ -860,6 +860,151 @@ def test_fused_kernel_takes_hub_rows_from_the_split_row_kernels(dev, K, n_out, k
     assert (xg.grad - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
 
 
+def _hub_graph(n, seed, hub_in=40000, hub_mid=3000, hub_out=15000, e=200000):
+    gen = torch.Generator().manual_seed(seed)
+    rnd = torch.randint(0, n, (2, e), generator=gen)
+    a = torch.stack([torch.randint(0, n, (hub_in,), generator=gen), torch.full((hub_in,), 5)])
+    b = torch.stack([torch.randint(0, n, (hub_mid,), generator=gen), torch.full((hub_mid,), 77)])
+    c = torch.stack([torch.full((hub_out,), 9), torch.randint(0, n, (hub_out,), generator=gen)])
+    return torch.cat([rnd, a, b, c], dim=1)
+
+
+def test_gat_edge_softmax_kernel(dev):
+    """rgbx_gat_edge_softmax_f32 against the segment softmax of the oracle (PyG's softmax: max-shifted, + 1e-16), on
+    rows of 1 ... 40 k slots (registers for the first 64 scores of a row, recomputation beyond) and rows without
+    slots (rectangular CSR); the positive-score parts add up; reproducible."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n = 50000
+    ei = _hub_graph(n, 3)
+    g = Graph(ei.to(dev), n, 2)
+    gen = torch.Generator().manual_seed(4)
+    a_src, a_dst = torch.randn(n, generator=gen) * 2, torch.randn(n, generator=gen) * 2
+    slope = 0.2
+    alpha, alpha_pos, m, rden, a_pos = ops.gat_edge_softmax(g.fwd, a_src.to(dev), a_dst.to(dev), slope, True, n)
+    again = ops.gat_edge_softmax(g.fwd, a_src.to(dev), a_dst.to(dev), slope, False, n)
+    assert torch.equal(alpha, again[0]) and again[1] is None and torch.equal(m, again[2]) and torch.equal(rden, again[3])
+    rowptr, col = g.fwd.rowptr.cpu().long(), g.fwd.col.cpu().long()
+    tgt = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+    s = a_src.double()[col] + a_dst.double()[tgt]
+    e = torch.where(s > 0, s, slope * s)
+    want = O.segment_softmax(e.view(-1, 1), tgt, n).view(-1)
+    assert (alpha.cpu().double() - want).abs().max().item() < 1e-6
+    pos = torch.where(s > 0, want, torch.zeros_like(want))
+    # a score within rounding of 0 may take the other branch in fp32: compare where the sign is beyond doubt
+    sure = s.abs() > 1e-5
+    assert (alpha_pos.cpu().double() - pos)[sure].abs().max().item() < 1e-6
+    ap = torch.zeros(n, dtype=torch.float64).index_add_(0, tgt, alpha_pos.cpu().double())
+    assert (a_pos.cpu().double() - ap).abs().max().item() < 1e-5
+    mx = torch.full((n,), -1e30, dtype=torch.float64).scatter_reduce_(0, tgt, e, "amax")
+    assert (m.cpu().double() - mx).abs().max().item() < 1e-5
+    # rows without slots: a rectangular CSR (targets = the first rows only)
+    csr = g.fwd
+    from rgb_experiment_amd.graph import CSR
+    rp = torch.cat([csr.rowptr[:101], csr.rowptr[100:101].expand(50)]).contiguous()  # 100 real rows + 50 empty ones
+    cut = CSR(rp, csr.col, csr.perm, 150, int(rp[-1].item()), None)
+    al, _, m2, rd2, _ = ops.gat_edge_softmax(cut, a_src.to(dev), a_dst.to(dev), slope, False, 150)
+    # (no split plan here: the hub rows 5 and 77 go through the 8-lane kernel — another summation order)
+    assert (al[:cut.nnz] - alpha[:cut.nnz]).abs().max().item() < 1e-6
+    assert m2[100:].abs().max().item() == 0 and rd2[100:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("K,n_out", [(128, 128), (64, 64), (64, 128), (256, 32)])
+def test_fused_layer_second_aggregate(dev, K, n_out):
+    """rgbx_fused_layer_t.w_pos / z_pos_out: a second aggregate of the gathered rows under a second weight vector, hub
+    rows (split plan) included; z and the transformed output are what the launch without it gives, bit for bit."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n = 60000
+    ei = _hub_graph(n, K + n_out)
+    g = Graph(ei.to(dev), n, 2)
+    assert g.fwd.split is not None
+    gen = torch.Generator().manual_seed(K)
+    x = torch.randn(n, K, generator=gen).to(dev)
+    wt = (torch.randn(K, n_out, generator=gen) / K ** 0.5).to(dev)
+    b = torch.randn(n_out, generator=gen).to(dev)
+    w = torch.rand(g.fwd.nnz, generator=gen).to(dev)
+    w_pos = torch.where(torch.rand(g.fwd.nnz, generator=gen).to(dev) > 0.5, w, torch.zeros_like(w))
+    out, (z, z_pos), _ = ops.fused_layer(x, wt, csr=g.fwd, w=w, bias=b, w_pos=w_pos)
+    out1, z1, _ = ops.fused_layer(x, wt, csr=g.fwd, w=w, bias=b, want_z=True)
+    assert torch.equal(out, out1) and torch.equal(z, z1)
+    _, zp1, _ = ops.fused_layer(x, wt, csr=g.fwd, w=w_pos, bias=b, want_z=True)
+    assert (z_pos - zp1).abs().max().item() < 1e-4 * max(1.0, zp1.abs().max().item())
+    want = ops.spmm_raw(g.fwd, w_pos, None, x)
+    assert (z_pos - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    out2, (z2, zp2), _ = ops.fused_layer(x, wt, csr=g.fwd, w=w, bias=b, w_pos=w_pos)
+    assert torch.equal(out, out2) and torch.equal(z_pos, zp2)
+
+
+@pytest.mark.parametrize("f,C", [(128, 128), (64, 64), (64, 96), (64, 128)])
+def test_gat_single_head_runs_aggregate_first(dev, f, C):
+    """heads = 1 with widths the fused kernel takes: GATConv re-associates sum_j alpha_ij (W x_j) = W sum_j alpha_ij x_j
+    (scores from x, coefficients per edge, one fused aggregate + transform launch). Same function as the oracle's
+    GATConv: output, every gradient, and the loss form (cross-entropy inside the kernel) incl. its gradients; hub
+    rows included."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.nn import GATConv
+    from rgb_experiment_amd.graph import get_graph, LOOPS_REMOVE_ADD
+    n = 3000
+    gen = torch.Generator().manual_seed(f + C)
+    ei = torch.cat([rand_graph(n, 40000, f + C, loops=10, dups=10),
+                    torch.stack([torch.randint(0, n, (2500,), generator=gen), torch.full((2500,), 11)])], dim=1)
+    x = torch.randn(n, f, generator=gen) * 0.5
+    y = torch.randint(0, C, (n,), generator=gen)
+    mask = torch.rand(n, generator=gen) < 0.3
+    torch.manual_seed(5)
+    conv = GATConv(f, C, 1, concat=False)
+    with torch.no_grad():
+        conv.bias.uniform_(-1, 1)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in conv.state_dict().items() if "lin_dst" not in k}
+    conv.to(dev)
+    eid = ei.to(dev)
+    assert ops.gat_linear_ok(get_graph(eid, n, LOOPS_REMOVE_ADD), f, C, x.to(dev))
+    sink = []
+    ops.set_event_sink(sink)
+    try:
+        xg = x.to(dev).requires_grad_(True)
+        og = conv(xg, eid)
+    finally:
+        ops.set_event_sink(None)
+    seen = [kind for kind, _, _ in sink]
+    assert "gat_linear_fwd" in seen and "gat_fwd" not in seen, seen
+    xc = x.clone().requires_grad_(True)
+    oc = O.gat_conv(xc, ei, sd["lin_src.weight"], sd["att_src"], sd["att_dst"], sd["bias"], 1, False)
+    assert (og.detach().cpu() - oc.detach()).abs().max().item() < TOL
+    go = torch.randn(oc.shape, generator=gen)
+    og.backward(go.to(dev))
+    oc.backward(go)
+    names = (("lin_src.weight", conv.lin_src.weight), ("att_src", conv.att_src), ("att_dst", conv.att_dst),
+             ("bias", conv.bias))
+    assert (xg.grad.cpu() - xc.grad).abs().max().item() < 2e-4 * max(1.0, xc.grad.abs().max().item())
+    for name, p in names:
+        ref = sd[name].grad
+        assert (p.grad.cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), name
+    with torch.no_grad():
+        assert (conv(x.to(dev), eid).cpu() - oc.detach()).abs().max().item() < TOL  # inference form: no second aggregate
+    # the loss form
+    for t in [xc] + list(sd.values()):
+        t.grad = None
+    conv.zero_grad()
+    xg.grad = None
+    loss, stats = conv(xg, eid, ce=(y.to(dev), mask.to(dev)))
+    (loss * 3.0).backward()
+    oc = O.gat_conv(xc, ei, sd["lin_src.weight"], sd["att_src"], sd["att_dst"], sd["bias"], 1, False)
+    lc = torch.nn.functional.cross_entropy(oc[mask], y[mask])
+    (lc * 3.0).backward()
+    assert abs(loss.item() - lc.item()) < 1e-5 * max(1.0, abs(lc.item()))
+    hits = (oc.detach().argmax(1) == y)[mask].sum().item()
+    assert stats[1].item() == mask.sum().item() and abs(stats[2].item() - hits) <= 2
+    assert (xg.grad.cpu() - xc.grad).abs().max().item() < 2e-4 * max(1e-3, xc.grad.abs().max().item())
+    for name, p in names:
+        ref = sd[name].grad
+        assert (p.grad.cpu() - ref).abs().max().item() < 2e-4 * max(1e-3, ref.abs().max().item()), name
+    with torch.no_grad():
+        l2, st2 = conv(x.to(dev), eid, ce=(y.to(dev), mask.to(dev)))
+    assert abs((st2[0] / st2[1]).item() - lc.item()) < 1e-5 * max(1.0, abs(lc.item()))
+
+
 @pytest.mark.parametrize("H,C", [(4, 8), (1, 7), (8, 16)])
 def test_gat_hub_rows_are_split(dev, H, C, monkeypatch):
     """Hub target (40k in-edges) and hub source (15k out-edges). Forward: the chunked online-softmax states
