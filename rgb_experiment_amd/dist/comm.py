@@ -236,6 +236,16 @@ class Comm:
         t.copy_(h)
         return t
 
+    def all_reduce_sum_async(self, t):
+        """all_reduce_sum_ in place, returned as a work object: RCCL enqueues it on its own stream and .wait() makes
+        the caller's stream depend on it — a schedule that has other kernels to enqueue does that first (dist/stack.py)."""
+        if self.world == 1:
+            return _Done()
+        if self.backend == "nccl":
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.all_reduce_sum_(t)
+        return _Done()
+
     def all_reduce_max_(self, t):
         if self.world == 1:
             return t
@@ -268,6 +278,21 @@ class Comm:
         os._exit(70)
 
 
+class _TracedDone:
+    """Work of an emulated exchange: .wait() leaves a marker in the event trace bench.py listens to, so that the
+    schedule (which kernels were enqueued between an exchange's issue and the wait for it) can be replayed against a
+    link model."""
+
+    def __init__(self, xid):
+        self.xid = xid
+
+    def wait(self):
+        from .. import ops
+        if ops._EVENT_SINK is not None:
+            ops._EVENT_SINK.append(("@wait", self.xid))
+        return None
+
+
 class EmulatedComm(Comm):
     """ONE process standing in for rank `rank` of a `world`-rank job (bench.py --emulate-rank): every structure
     and every kernel launch is exactly that rank's; an exchange delivers stand-in rows (copies of the rows being
@@ -293,8 +318,9 @@ class EmulatedComm(Comm):
         peers_out = [c for q, c in enumerate(send_counts) if q != self.rank]
         peers_in = [c for q, c in enumerate(recv_counts) if q != self.rank]
         self.log.append((tag, max(peers_out, default=0) * width * 4, max(peers_in, default=0) * width * 4))
+        work = self._traced(tag, max(max(peers_out, default=0), max(peers_in, default=0)) * width * 4)
         if send.size(0) == 0 or n_recv == 0:
-            return send.new_zeros((n_recv, width)), _Done()
+            return send.new_zeros((n_recv, width)), work
         # a real exchange lands the rows by DMA, at no cost in kernel time: the stand-in buffer of every exchange
         # shape is filled once (with rows being sent, so the values are ordinary activations) and handed out again
         key = (tag, n_recv, width, getattr(self.turns, "local", None) and getattr(self.turns.local, "me", None))
@@ -303,7 +329,7 @@ class EmulatedComm(Comm):
             reps = -(-n_recv // send.size(0))
             recv = (send if reps == 1 else send.repeat(reps, 1))[:n_recv].clone()
             self._pool[key] = recv
-        return recv, (_Done() if self.turns is None else _TurnWork(_Done(), self.turns))
+        return recv, (work if self.turns is None else _TurnWork(work, self.turns))
 
     def all_to_all_views(self, send, recv, tag=None):
         """Stand-in for the view exchange: the receive views are filled ONCE per (tag, shapes) with rows being sent
@@ -314,6 +340,7 @@ class EmulatedComm(Comm):
         self.bytes_sent += sum(out_b)
         self.exchanges += 1
         self.log.append((tag, max(out_b, default=0), max(in_b, default=0)))
+        work = self._traced(tag, max(max(out_b, default=0), max(in_b, default=0)))
         key = ("views", tag, tuple(t.data_ptr() for t in recv if t.numel()),
                getattr(self.turns, "local", None) and getattr(self.turns.local, "me", None))
         if key not in self._pool:
@@ -326,10 +353,23 @@ class EmulatedComm(Comm):
             self._pool[key] = True
             if len(self._pool) > 4096:
                 self._pool.clear()
-        return _Done() if self.turns is None else _TurnWork(_Done(), self.turns)
+        return work if self.turns is None else _TurnWork(work, self.turns)
+
+    def _traced(self, tag, link_bytes):
+        """Marker of an exchange's ISSUE in bench.py's event trace (kernels recorded before it are its producers) and a
+        work object whose wait() marks where the schedule starts to depend on it."""
+        from .. import ops
+        self._xid = getattr(self, "_xid", 0) + 1
+        if ops._EVENT_SINK is not None:
+            ops._EVENT_SINK.append(("@issue", self._xid, tag, link_bytes))
+        return _TracedDone(self._xid)
 
     def all_reduce_sum_(self, t):
         return t.mul_(self.world)  # as if every rank had contributed this rank's share
+
+    def all_reduce_sum_async(self, t):
+        t.mul_(self.world)
+        return self._traced("all-reduce", t.numel() * t.element_size())
 
     def all_reduce_max_(self, t):
         return t

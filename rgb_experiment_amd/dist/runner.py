@@ -17,7 +17,8 @@ class DistRunner:
 
     def __init__(self, model, edge_index, x, y, masks, rank, world, device, lr=0.01, weight_decay=0.0,
                  comm=None, backend=None, exchange="auto", resident_features=True, pieces=None,
-                 interleave_evals=True, fused=True, pieces_in=1, cache_input_aggregate=False, src_split=False):
+                 interleave_evals=True, fused=True, pieces_in=1, cache_input_aggregate=False, src_split=False,
+                 pipeline=True):
         self.comm = comm or Comm()
         self.rank, self.world, self.device = rank, world, device
         N = x.size(0)
@@ -32,6 +33,8 @@ class DistRunner:
         self.graphs = install(self.token, hi - lo, edge_index.to(device), N, self.comm, backend, exchange, pieces)
         import os
         self.interleave_evals = interleave_evals and world > 1 and os.environ.get("RGBX_INTERLEAVE", "auto") != "never"
+        self.pipeline = bool(pipeline)  # epoch(more=True) may compute the next training step ahead (fused schedule)
+        self._spec = None
         self._streams = None
         self._epochs_done = 0
         self.host_enqueue_s = 0.0
@@ -138,6 +141,7 @@ class DistRunner:
     def train_step(self, sync=True):
         """One training step. `sync=False`: returns this rank's share of the loss as a device tensor [1]
         (float64) instead of the all-reduced Python float — epoch() reduces everything once."""
+        self.discard_speculation()
         self.model.train()
         if self.engine is not None:
             part = self.engine.train_step()  # forward + backward, every parameter's .grad (over)written in place
@@ -148,14 +152,26 @@ class DistRunner:
             loss = self._nll_sum(res, m) / self.mask_counts[0]
             loss.backward()
             part = loss.detach().double().reshape(1)
-        self._sync_grads()
-        self.opt.step()
-        if self._fused_adam:  # the fused step writes the parameters without moving their version counters: whatever
-            for p in self._params:  # is cached per parameter version (ops.weight_t) must not survive it
-                p.__dict__.pop("_rgbx_wt", None)
+        self._optimizer_step()
         if not sync:
             return part
         return self.comm.all_reduce_sum_(part.clone()).item()
+
+    def _optimizer_step(self):
+        self._sync_grads()
+        self.opt.step()
+        if self.engine is not None:
+            self.engine.note_optimizer_step()
+        if self._fused_adam:  # the fused step writes the parameters without moving their version counters: whatever
+            for p in self._params:  # is cached per parameter version (ops.weight_t) must not survive it
+                p.__dict__.pop("_rgbx_wt", None)
+
+    def discard_speculation(self):
+        """Drop the next epoch's training step if epoch(more=True) has computed one ahead (a loop that stops early,
+        a caller that steps by hand): it has written nothing but the gradient buffer."""
+        if self._spec is not None:
+            self._spec = None
+            self.engine.discard_speculation()
 
     def evaluate(self, which, sync=True):
         """Eval forward + (masked NLL sum, correct count) of this rank's rows. `sync=True`: all-reduced and
@@ -239,19 +255,33 @@ class DistRunner:
                 main.wait_stream(s)
         return out
 
-    def epoch(self):
+    def epoch(self, more=False):
         """1 train forward+backward+Adam, then val and test forwards, as the reference loop body. The five
         numbers the reference reads with .item() along the way are only used after the epoch: they are reduced
         over the ranks in ONE all-reduce and read back in ONE copy, so the queues drain once per epoch, not three
-        times."""
+        times.
+        `more` (fused schedule with interleaved evals): the caller will ask for another epoch unless this one's numbers
+        stop the loop. The eval forwards of THIS epoch are then interleaved with the forward + backward of the NEXT
+        epoch's training step (GridStack.eval_pair_and_next_step: all three read the parameters this epoch's optimizer
+        step left), whose optimizer step is taken at the top of the next call — or never (discard_speculation). Same
+        arithmetic per step, same five numbers; the exchanges of the training step travel while the eval forwards
+        aggregate and the other way round."""
         import time
         t0 = time.perf_counter()
         enq0 = self.host_enqueue_s
-        tl = self.train_step(sync=False)
+        if self._spec is not None:  # the step computed ahead during the previous epoch's eval forwards
+            tl, self._spec = self._spec, None
+            self.engine.accept_speculation()
+            self._optimizer_step()
+        else:
+            tl = self.train_step(sync=False)
         # the first epoch builds what the eval forwards use lazily (cost tables, plans / CSRs of widths only the
         # no_grad path aggregates at) — on the MAIN stream, one forward after the other, so that no structure is
         # produced on one of the two eval streams and consumed on the other; interleaving starts with the second epoch
-        if self.interleave_evals and self.engine is not None:
+        if self.interleave_evals and self.engine is not None and more and self.pipeline:
+            self.model.eval()
+            v, s, self._spec = self.engine.eval_pair_and_next_step(1, 2)
+        elif self.interleave_evals and self.engine is not None:
             # fused schedule: the two forwards interleaved on ONE thread and stream (GridStack.eval_pair)
             self.model.eval()
             v, s = self.engine.eval_pair(1, 2)

@@ -213,6 +213,7 @@ class GridStack:
         self._folded = (None, None)
         self._steps = 0
         self._pair_tag = ""
+        self._pending_bn, self._commit_list, self._opt_steps = [], [], 0
         # every parameter gradient is a view of ONE flat buffer, written in place by the kernels that produce it: the
         # gradient all-reduce then takes the buffer as it is (no flatten / copy-back launches), and nothing is zeroed
         # between steps because every entry is overwritten
@@ -312,7 +313,7 @@ class GridStack:
     def _propagate(self, i, direction, blk, inbound=None):
         return _drive(self._propagate_g(i, direction, blk, inbound))
 
-    def _propagate_g(self, i, direction, blk, inbound=None):
+    def _propagate_g(self, i, direction, blk, inbound=None, landed=False):
         """The exchanged aggregation of layer i: blocked rows of this rank in, blocked aggregated rows of this rank
         out (u[c', r, :] = column slice c' of own row r of P x, or of P^T x for direction "bwd"). `inbound` = (cols,
         [work per source piece]) when the caller has already issued the inbound exchange (piece by piece behind the
@@ -323,7 +324,9 @@ class GridStack:
         exposed exchange at 60 GB/s per link: the setting for slow links, off by default. Outbound: one send per target
         piece, in flight while the next one is aggregated.
         A generator: it YIELDS every exchange it is about to depend on (the caller waits — or first lets another forward
-        enqueue its share, eval_pair) and returns `u`."""
+        enqueue its share, eval_pair) and returns `u`. `landed`: the caller has just come back from another yield, i.e.
+        the inbound pieces have had a whole segment of someone else's work to travel: they are waited for directly
+        instead of handing over once more after next to nothing."""
         R, C = self.shapes[i]
         d = self.specs[i].d_in
         dg, P = self.dg, self.P
@@ -370,7 +373,10 @@ class GridStack:
                 send_piece(k)
         else:
             for ks in range(src_pieces):
-                yield works[ks]
+                if landed:
+                    works[ks].wait()
+                else:
+                    yield works[ks]
                 for k, (lo, hi) in enumerate(ranges):
                     self.be.run_rows(handles[ks], cols, lo, hi, sends[k], tag, accumulate=ks > 0)
                     if ks == src_pieces - 1:
@@ -384,9 +390,53 @@ class GridStack:
     def train_step(self):
         """Forward + backward of one training step; leaves every parameter's .grad set (this rank's share) and
         returns this rank's share of the loss as a float64 device tensor [1]."""
+        return _drive(self._train_g())
+
+    def _bn_statistics_g(self, bn, h, cs, speculative):
+        """B.train_statistics with the [2 d + 1] all-reduce issued asynchronously and YIELDED: another schedule's
+        kernels can be enqueued before this one's stream starts to wait for it. A SPECULATIVE step (see
+        eval_pair_and_next_step) moves copies of the running statistics; commit_speculation installs them."""
+        packed = B.pack_statistics(h, cs)
+        yield self.comm.all_reduce_sum_async(packed)
+        if speculative:
+            self._commit_if_due()
+            rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+            mom = bn.momentum if bn.momentum is not None else 1.0 / (float(bn.num_batches_tracked) + 1.0)
+            self._pending_bn.append((bn, rm, rv))
+            running = (rm, rv, mom)
+        else:
+            running = bn.begin_training_step()
+        return B.train_statistics(h, bn.weight, bn.bias, bn.eps, None, running, packed=packed)
+
+    def accept_speculation(self):
+        """The speculative step is THE next step after all (the caller takes its optimizer step): its running statistics
+        become the model's — by three small copies that are enqueued where they cost nothing, i.e. behind the first
+        large launch of the epoch's schedule and before anything reads the statistics (_commit_if_due)."""
+        self._commit_list, self._pending_bn = self._pending_bn, []
+
+    def note_optimizer_step(self):
+        """The parameters changed (a fused Adam step moves no version counter): folded eval operands are stale."""
+        self._opt_steps += 1
+
+    def _commit_if_due(self):
+        for bn, rm, rv in self._commit_list:
+            bn.running_mean.copy_(rm)
+            bn.running_var.copy_(rv)
+            bn.num_batches_tracked += 1
+        self._commit_list = []
+
+    def discard_speculation(self):
+        """The loop ended (or took another turn): nothing of the speculative step has touched the model."""
+        self._pending_bn = []
+
+    def _train_g(self, speculative=False):
+        """train_step as a schedule generator (yields every exchange / all-reduce it is about to depend on)."""
         S, be = self.specs, self.be
         L = len(S)
         self._steps += 1  # the parameters are about to change: folded eval weights of the previous state are stale
+        # (the module path keeps its own cache of eval operands, keyed by the model's count of training forwards)
+        self.model._train_forwards = getattr(self.model, "_train_forwards", 0) + 1
+        self._pending_bn = []
         wt = lambda w: w.detach().t().contiguous()
         s0 = S[0]
         blk, inbound, h, z, cs = self._first_layer(wt(s0.W), s0.bias(), None if s0.Wr is None else wt(s0.Wr), True)
@@ -394,9 +444,9 @@ class GridStack:
         dl = None
         for i in range(1, L):
             sp, bn = S[i], self.bns[i - 1]
-            stats = B.train_statistics(h, bn.weight, bn.bias, bn.eps, bn._reducer(h), bn.begin_training_step(), cs)
+            stats = yield from self._bn_statistics_g(bn, h, cs, speculative)
             mean, rstd, scale, shift, n = stats
-            u = self._propagate(i, "fwd", blk, inbound)
+            u = yield from self._propagate_g(i, "fwd", blk, inbound, landed=True)  # (the statistics' all-reduce yielded)
             inbound = None
             pre = (scale, shift, self.rowsum())
             root = dict(x_root=h, wt_root=wt(sp.Wr)) if sp.Wr is not None else {}
@@ -428,12 +478,15 @@ class GridStack:
                 self._g(b).copy_(gcol)
             if sp.Wr is not None:  # dWr = dy^T BN(h) = (dy^T h) diag(s) + colsum(dy) t^T
                 torch.addcmul(gcol[:, None] * shift, be.gemm_tn(dy, h_prev), scale, out=self._g(sp.Wr))
-            v = self._propagate(i, "bwd", q, (cols, works))
+            v = yield from self._propagate_g(i, "bwd", q, (cols, works))
             g_a = be.blocked_to_rows(v)
             if sp.Wr is not None:
                 g_a.addmm_(dy, sp.Wr.detach())
-            dy, _, _ = B.train_backward(g_a, h_prev, bn.weight, mean, rstd, n, bn._reducer(h_prev),
-                                        grads_out=(self._g(bn.weight), self._g(bn.bias)))
+            local = B.bwd_sums(g_a, h_prev, mean, rstd)
+            glob = local.reshape(-1).clone()
+            yield self.comm.all_reduce_sum_async(glob)
+            dy, _, _ = B.train_backward(g_a, h_prev, bn.weight, mean, rstd, n, None,
+                                        grads_out=(self._g(bn.weight), self._g(bn.bias)), sums=(local, glob))
         z0 = saved[0][0]
         _, gcol = be.gemm_tn(dy, z0, colsum=True, out=self._g(s0.W), sums_out=self._g(s0.biases[0]))
         for b in s0.biases[1:]:
@@ -449,8 +502,9 @@ class GridStack:
         b' = b scale + shift): made once per parameter state — the val and the test forward of an epoch share them."""
         # keyed by the training steps taken (a fused Adam step and the BatchNorm kernels write through raw pointers:
         # version counters do not see them) and, for changes from outside (load_state_dict), by the version counters
+        self._commit_if_due()
         tensors = [p for p in self.model.parameters()] + [t for bn in self.bns for t in (bn.running_mean, bn.running_var)]
-        key = (self._steps,) + tuple(t._version for t in tensors)
+        key = (self._steps, self._opt_steps) + tuple(t._version for t in tensors)
         if self._folded[0] != key:
             out = []
             L = len(self.specs)
@@ -480,6 +534,60 @@ class GridStack:
         every BatchNorm folded into the preceding layer's weights, no row-major activation written, no logits."""
         return _drive(self._eval_g(which))
 
+    def _interleave(self, gens, tags, width=None):
+        """Drive several schedule generators in turn on this one thread and stream: a generator runs until it yields the
+        exchange (or all-reduce) it is about to depend on; the others then enqueue their kernels and exchanges up to THEIR
+        next dependency before the first one's is waited for. The order depends only on the model and the scheme —
+        identical on every rank, as the collectives of one communicator must be. `tags[i]` marks generator i's
+        exchanges in the exchange log (bench.py). `width`: at most that many generators are in play at a time, the next
+        one starts when one ends (a long schedule next to short ones: the short ones are then spread along it instead
+        of all running beside its first part). Returns the generators' return values."""
+        n = len(gens)
+        width = n if width is None else width
+        works, out, started = [None] * n, [None] * n, [False] * n
+        active, waiting = list(range(min(width, n))), list(range(min(width, n), n))
+        pos = 0
+        while active:
+            i = active[pos]
+            self._pair_tag = tags[i]
+            try:
+                if works[i] is not None:
+                    works[i].wait()
+                works[i] = gens[i].send(None) if started[i] else next(gens[i])
+                started[i] = True
+                pos = (pos + 1) % len(active)
+            except StopIteration as done:
+                out[i] = done.value
+                if waiting:
+                    active[pos] = waiting.pop(0)  # the newcomer runs NEXT: it has a whole first segment to offer the
+                else:                             # exchange the other generator has just issued
+                    active.pop(pos)
+                    pos = pos % len(active) if active else 0
+            finally:
+                self._pair_tag = ""
+        return out
+
+    @torch.no_grad()
+    def eval_pair_and_next_step(self, first, second):
+        """The val and the test forward of THIS epoch interleaved with the forward + backward of the NEXT epoch's
+        training step (all three read the parameters the optimizer step of this epoch left; the next optimizer step is
+        the caller's, once it knows the loop goes on — DistRunner.epoch). The training step's exchanges — above all the
+        backward's inbound one, behind which a step on its own has nothing to run — travel while the eval forwards
+        aggregate, and the other way round. Same kernels and numbers as eval_pair followed by train_step.
+        The step is SPECULATIVE: it writes the gradient buffer and COPIES of the BatchNorm running statistics only, so
+        the model is exactly the one the finished epoch left (state_dict, best-model snapshots, a loop that stops
+        here: discard_speculation) until commit_speculation + the optimizer step make it the next step.
+        Returns (stats of `first`, stats of `second`, loss share of the next step)."""
+        # The training generator goes first: its layer-0 launches are in the queue before the small launches that fold
+        # the eval operands (first thing the eval generators do) — an epoch that opens with twenty 5-microsecond launches
+        # right after the host read-back runs them at the host's pace (measured: + 0.2 ms per epoch).
+        # Two generators in play at a time: the first eval forward runs beside the training forward, the second one
+        # beside the backward (all three at once would put both eval forwards beside the forward and leave the
+        # backward's exchanges without company).
+        t, a, b = self._interleave([self._train_g(speculative=True), self._eval_g(first), self._eval_g(second)],
+                                   [" tri1", " tri2", " tri3"], width=2)
+        return a, b, t
+
     @torch.no_grad()
     def eval_pair(self, first, second):
         """The val and the test forward of an epoch (itexperiments.py:464-473: two full eval forwards, both run),
@@ -489,30 +597,13 @@ class GridStack:
         slice SpMM runs, in an order that depends only on the model and the scheme (identical on every rank), without a
         second thread (the module path's interleave costs 3.7 instead of 1.5 ms of host time per epoch, section 4.3).
         Same kernels and numbers as two forwards in a row."""
-        gens = [self._eval_g(first), self._eval_g(second)]
-        works, out, live = [None, None], [None, None], [True, True]
-        started = [False, False]
-        i = 0
-        while live[0] or live[1]:
-            if live[i]:
-                self._pair_tag = f" paired{i + 1}"  # names the forward in the exchange log (bench.py's link model)
-                try:
-                    if works[i] is not None:
-                        works[i].wait()
-                    works[i] = gens[i].send(None) if started[i] else next(gens[i])
-                    started[i] = True
-                except StopIteration as done:
-                    out[i], live[i] = done.value, False
-                finally:
-                    self._pair_tag = ""
-            i = 1 - i
-        return out
+        return self._interleave([self._eval_g(first), self._eval_g(second)], [" paired1", " paired2"])
 
-    def _eval_g(self, which):
+    def _eval_g(self, which, folded=None):
         S, be = self.specs, self.be
         L = len(S)
         prev_blk = inbound = None
-        folded = self._eval_weights()
+        folded = self._eval_weights() if folded is None else folded
         for i in range(L):
             sp = S[i]
             wt, b, wtr = folded[i]

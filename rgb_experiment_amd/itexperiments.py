@@ -358,7 +358,9 @@ def experiment(model_init_param: dict, *,
     def generic_epoch(i):
         """reference :427-440, :464-473: 1 train forward+backward, 2 eval forwards."""
         if runner is not None:  # the same epoch on the node partition; the five numbers are all-reduced over the ranks
-            tl, vl, va, sl, sa = runner.epoch()
+            # more=True: the next epoch's training forward + backward may be computed during this epoch's eval forwards
+            # (its optimizer step waits for the next call; the model is untouched until then, see DistRunner.epoch)
+            tl, vl, va, sl, sa = runner.epoch(more=i < epoch - 1)
             for key, v in (("train_loss", tl), ("train_acc", float("nan")), ("test_loss", sl), ("test_acc", sa)):
                 hist[key].append(v)
             return va, vl, None
@@ -446,6 +448,8 @@ def experiment(model_init_param: dict, *,
             if patience > early_stopping:
                 break
 
+    if runner is not None:
+        runner.discard_speculation()  # the loop stopped early: a step computed ahead is dropped
     if best_state:
         net.load_state_dict(best_state)
     if is_pta:  # reference :509-510

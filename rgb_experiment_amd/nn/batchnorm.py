@@ -89,19 +89,26 @@ class _BNTrain(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None
 
 
-def train_statistics(x, weight, bias, eps, reduce, running, colsums=None):
-    """Training-mode statistics of x [N, d] (row-contiguous): (mean, rstd, scale, shift, n) with
-    BN(x) = x * scale + shift, running statistics updated in place (`running` = (running_mean, running_var,
-    momentum) or None). Column sums -> [reduce over ranks] -> one finalize launch. `colsums` ([2, d] float64): the
-    column sums of x and x^2 when the kernel that produced x already took them (rgbx_spmm_linear_f32 out_colsums):
-    the pass over x is then skipped."""
+def pack_statistics(x, colsums=None):
+    """[sum x, sum x^2, rows] of this rank's rows as ONE float64 vector [2 d + 1]: what the ranks all-reduce."""
     d = x.size(1)
     # the row count rides along as a device scalar made by a fill kernel (a host->device copy would break
     # hipGraph capture)
     count = torch.full((1,), float(x.size(0)), dtype=torch.float64, device=x.device)
     sums = colsums if colsums is not None and tuple(colsums.shape) == (2, d) else column_sums(x)
-    packed = torch.cat([sums.reshape(-1), count])
-    packed = reduce(packed)  # identity on one GPU; all-reduce over the node partition otherwise
+    return torch.cat([sums.reshape(-1), count])
+
+
+def train_statistics(x, weight, bias, eps, reduce, running, colsums=None, packed=None):
+    """Training-mode statistics of x [N, d] (row-contiguous): (mean, rstd, scale, shift, n) with
+    BN(x) = x * scale + shift, running statistics updated in place (`running` = (running_mean, running_var,
+    momentum) or None). Column sums -> [reduce over ranks] -> one finalize launch. `colsums` ([2, d] float64): the
+    column sums of x and x^2 when the kernel that produced x already took them (rgbx_spmm_linear_f32 out_colsums):
+    the pass over x is then skipped. `packed`: pack_statistics' vector ALREADY reduced over the ranks (a caller that
+    issues the all-reduce itself, asynchronously: dist/stack.py); `reduce` is then not called."""
+    d = x.size(1)
+    if packed is None:
+        packed = reduce(pack_statistics(x, colsums))  # identity on one GPU; all-reduce over the node partition otherwise
     n = packed[2 * d:2 * d + 1]
     if x.is_cuda:
         mean, rstd, scale, shift = (torch.empty(d, dtype=torch.float32, device=x.device) for _ in range(4))
@@ -125,13 +132,18 @@ def train_statistics(x, weight, bias, eps, reduce, running, colsums=None):
     return mean, rstd, scale, shift, n
 
 
-def train_backward(gy, x, weight, mean, rstd, n, reduce, grads_out=None):
+def train_backward(gy, x, weight, mean, rstd, n, reduce, grads_out=None, sums=None):
     """(gx, g_weight, g_bias) of training-mode BatchNorm given the gradient gy of its output. `grads_out` =
-    (g_weight, g_bias) tensors to write the parameter gradients into (device path)."""
+    (g_weight, g_bias) tensors to write the parameter gradients into (device path). `sums` = (local, global):
+    bwd_sums of this rank's rows and their all-reduced copy when the caller made both (asynchronous all-reduce:
+    dist/stack.py); `reduce` is then not called."""
     gy = gy if gy.stride(-1) == 1 else gy.contiguous()
     d = x.size(1)
-    local = bwd_sums(gy, x, mean, rstd)            # [2, d]: sum gy, sum gy * xhat over the local rows
-    glob = reduce(local.reshape(-1).clone())
+    if sums is None:
+        local = bwd_sums(gy, x, mean, rstd)            # [2, d]: sum gy, sum gy * xhat over the local rows
+        glob = reduce(local.reshape(-1).clone())
+    else:
+        local, glob = sums
     # parameter gradients are the LOCAL sums: a partitioned run all-reduces parameter gradients once
     if gy.is_cuda:
         ca, cb, ck = (torch.empty(d, dtype=torch.float32, device=gy.device) for _ in range(3))

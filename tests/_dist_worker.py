@@ -231,8 +231,12 @@ def reshard_chunk_worker(rank, world, port, out_dir, exchange="reshard"):
 
 
 def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", interleave=True, release=False, fused=True,
-                  pieces=None, cache=False):
-    """Three epochs of DistRunner (train + evals) — compared by the test with single-process training."""
+                  pieces=None, cache=False, ahead=None):
+    """Three epochs of DistRunner (train + evals) — compared by the test with single-process training.
+    `ahead`: "all" = every epoch but the last announces a successor (epoch(more=True): the next training step is
+    computed during this epoch's eval forwards); "stop" = so does the last one, and the loop then stops
+    (discard_speculation)."""
+    more = lambda last: bool(ahead) and (not last or ahead == "stop")
     _init(rank, world, port)
     from rgb_experiment_amd import models as M
     from rgb_experiment_amd.dist import Comm, DistRunner
@@ -242,14 +246,17 @@ def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", inter
     r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
                    backend=OracleAggregator(), exchange=exchange, interleave_evals=interleave, fused=fused,
                    pieces=pieces, pieces_in=pieces or 1, cache_input_aggregate=cache, src_split=(pieces or 1) % 2 == 0)
-    hist = [r.epoch()]
+    hist = [r.epoch(more=more(False))]
     if r.engine is not None:  # the module path's own structures (compared below) must exist before the release
         engine, r.engine = r.engine, None
         r.evaluate(1, sync=False)
         r.engine = engine
     if release:  # every structure exists after one epoch: the global edge list may go
         r.release_edge_list()
-    hist += [r.epoch() for _ in range(2)]
+    hist += [r.epoch(more=more(False)), r.epoch(more=more(True))]
+    if ahead:
+        assert (r._spec is not None) == (ahead == "stop" and r.engine is not None)
+    r.discard_speculation()
     both = None
     if r.engine is not None:  # the same weights through the fused schedule and through the modules
         eng = [r.engine.eval_stats(w) for w in (1, 2)]
@@ -377,9 +384,10 @@ def hub_problem():
     return torch.cat([ei, extra], dim=1), x, y, masks
 
 
-def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", hub=False):
+def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", hub=False, ahead=True):
     """Rehearsal of the real per-rank HIP path: `world` ranks share cuda:0, collectives go through gloo
-    with host staging (RCCL cannot put two ranks on one device)."""
+    with host staging (RCCL cannot put two ranks on one device). `ahead`: the first epoch announces the second
+    (epoch(more=True): the fused schedule computes the second training step beside the first epoch's eval forwards)."""
     _init(rank, world, port)
     from rgb_experiment_amd import models as M
     from rgb_experiment_amd.dist import Comm, DistRunner
@@ -388,9 +396,9 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", h
     torch.manual_seed(14530529)
     model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
     r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm(), exchange=exchange)
-    hist = [r.epoch() for _ in range(2)]
+    hist = [r.epoch(more=ahead), r.epoch()]
     torch.cuda.synchronize()
     torch.save({"hist": hist, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi,
-                "engine": r.engine is not None},
+                "engine": r.engine is not None, "state": {k: v.cpu() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"gpu_{model_name}_{rank}.pt"))
     dist.destroy_process_group()

@@ -54,6 +54,7 @@ def test_bench_gpus_n_launches_its_own_ranks(gpus, exchange, scheme):
     assert "link_gbs_measured" in res and "small_all_to_all_us_measured" in res  # None on gloo, measured on RCCL
     # conv stacks under a column-slice scheme run the fused per-rank schedule (dist/stack.py)
     assert res["fused_schedule"] == (scheme in ("reshard", "grid2x2"))
+    assert res["next_step_ahead"] == res["fused_schedule"]  # the next training step rides beside the eval forwards
     assert res["median_ms_per_step"] > 0
 
 

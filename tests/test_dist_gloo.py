@@ -245,6 +245,30 @@ def test_fused_grid_schedule_matches_single_process(model_name, world, exchange,
         assert abs(a[0] - b[0]) < 2e-5 and abs(a[1] - b[1]) < 3e-2 and abs(a[3] - b[3]) < 3e-2, (a, b)
 
 
+@pytest.mark.parametrize("model_name,world,exchange,pieces", [("gcn_grid", 2, "reshard", 2), ("graphsage_grid", 4, "2x2", 1),
+                                                              ("gcn3_grid", 3, "reshard", 3)])
+def test_next_training_step_computed_during_the_eval_forwards(model_name, world, exchange, pieces, tmp_path):
+    """DistRunner.epoch(more=True): the eval forwards of an epoch are interleaved with the forward + backward of the
+    NEXT epoch's training step (one thread; its optimizer step waits for the next call). Same kernels on the same
+    operands: losses, accuracies and the whole state_dict (running statistics and their counter included) equal the
+    sequential schedule's bit for bit — also when the loop stops with a step computed ahead (nothing of it may show)."""
+    runs = {}
+    for ahead in (None, "all", "stop"):
+        mp.spawn(W.runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, True, True, True, pieces,
+                                        False, ahead), nprocs=world, join=True)
+        runs[ahead] = [torch.load(os.path.join(tmp_path, f"run_{model_name}_{r}.pt")) for r in range(world)]
+    base = runs[None]
+    assert all(p["engine"] for p in base)
+    for ahead in ("all", "stop"):
+        for p, q in zip(base, runs[ahead]):
+            assert p["hist"] == q["hist"], (ahead, p["hist"], q["hist"])
+            for k, v in p["state"].items():
+                assert torch.equal(v, q["state"][k]), (ahead, k)
+            assert torch.equal(p["logits_eval"], q["logits_eval"])
+            for a, b in zip(p["eval_both"][0], q["eval_both"][0]):
+                assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("model_name,world,exchange", [("gcn_grid", 2, "reshard"), ("graphsage_grid", 4, "2x2")])
 def test_fused_grid_schedule_with_the_kept_input_aggregate(model_name, world, exchange, tmp_path):
     """cache_input_aggregate=True on the partitioned run (opt-in): layer 0 transforms the kept aggregate of the static

@@ -118,3 +118,21 @@ def test_fused_schedule_with_hub_rows(model_name, world, exchange, tmp_path):
     for step in range(2):
         assert abs(parts[0]["hist"][step][0] - hist[step][0]) < 1e-4
     assert (torch.cat([p["logits_train"] for p in parts]) - emb).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("model_name,world,exchange", [("gcn_grid", 4, "2x2"), ("graphsage2_grid", 2, "reshard")])
+def test_step_computed_ahead_gives_the_same_bits(model_name, world, exchange, tmp_path):
+    """Real kernels: the second training step computed beside the first epoch's eval forwards (epoch(more=True), the
+    default of every other case in this file) against the plain sequence of the same run — same launches on the same
+    operands, so every number and every tensor of the state_dict is bit-identical."""
+    runs = []
+    for ahead in (True, False):
+        mp.spawn(W.gpu_runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, False, ahead),
+                 nprocs=world, join=True)
+        runs.append([torch.load(os.path.join(tmp_path, f"gpu_{model_name}_{r}.pt")) for r in range(world)])
+    for p, q in zip(*runs):
+        assert p["engine"] and q["engine"]
+        assert p["hist"] == q["hist"], (p["hist"], q["hist"])
+        assert torch.equal(p["logits_train"], q["logits_train"])
+        for k, v in p["state"].items():
+            assert torch.equal(v, q["state"][k]), k
