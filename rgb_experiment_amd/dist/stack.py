@@ -214,6 +214,7 @@ class GridStack:
         self._steps = 0
         self._pair_tag = ""
         self._pending_bn, self._commit_list, self._opt_steps = [], [], 0
+        self._pieces_first = None
         # every parameter gradient is a view of ONE flat buffer, written in place by the kernels that produce it: the
         # gradient all-reduce then takes the buffer as it is (no flatten / copy-back launches), and nothing is zeroed
         # between steps because every entry is overwritten
@@ -275,6 +276,16 @@ class GridStack:
         tag = f"in {k + 1}/{n}" + (" producer" if behind_producer else "") + self._pair_tag
         return cols, self.comm.all_to_all_views(send, recv, tag=tag)
 
+    def _first_layer_pieces(self, handle):
+        """Row pieces layer 0 is launched in — the SAME number on every rank (each piece is followed by an exchange): a
+        rank whose [local; halo] CSR has a hub-row plan cannot launch row ranges of it, and then nobody does. Agreed
+        once, by one small all-reduce at the first layer-0 launch (every rank makes it at the same point)."""
+        if self._pieces_first is None:
+            mine = torch.tensor([0.0 if self.be.rows_ok(handle) else 1.0], dtype=torch.float64, device=self.x.device)
+            anyone = self.comm.all_reduce_max_(mine).item() > 0
+            self._pieces_first = 1 if anyone else self.pieces_in
+        return self._pieces_first
+
     def _first_layer(self, wt, bias, wtr, train):
         """Layer 0 on the resident features, launched in `pieces_in` row pieces; each piece's slices leave for their
         consumers as soon as its launch is enqueued (the all-to-all runs on RCCL's stream while the next piece is
@@ -290,7 +301,7 @@ class GridStack:
         if cached and self._z0 is None:
             self._z0 = self.be.run(handle, x_ext, kind=f"{sp.kind}_fwd")
         z = self._z0 if cached else (torch.empty((n, sp.d_in), dtype=torch.float32, device=dev) if train else None)
-        pieces = self.pieces_in if self.be.rows_ok(handle) else 1
+        pieces = self._first_layer_pieces(handle)
         cols, works, cs = None, [], None
         for k in range(pieces):
             a, b = n * k // pieces, n * (k + 1) // pieces
@@ -362,9 +373,14 @@ class GridStack:
             pending.append(self.comm.all_to_all_views(sv, rv, tag=f"out {k + 1}/{half.pieces}" + self._pair_tag))
 
         if not all(self.be.rows_ok(h) for h in handles):
-            # hub-row plan (row ids in it are absolute): whole-group launches once everything has landed
+            # hub-row plan (row ids in it are absolute): whole-group launches once everything has landed. WHICH ranks
+            # have such a plan depends on the graph: this branch must yield exactly where the other one does (the
+            # interleave order of the generators, i.e. the order of the collectives, follows the yields)
             for work in works:
-                yield work
+                if landed:
+                    work.wait()
+                else:
+                    yield work
             full = self.be.run(handles[0], cols, tag)
             for h in handles[1:]:
                 full.add_(self.be.run(h, cols, tag))

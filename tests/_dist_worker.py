@@ -129,7 +129,10 @@ class TorchStackBackend:
         return self.agg.run(handle, x)
 
     def rows_ok(self, handle):
-        return True
+        """RGBX_TEST_HUB_RANK = r: rank r behaves like one whose CSRs carry a hub-row plan (no row-range launches) —
+        which ranks do depends on the graph, and the schedule's collectives must not."""
+        hub = os.environ.get("RGBX_TEST_HUB_RANK")
+        return hub is None or int(hub) != dist.get_rank()
 
     def gemm_tn(self, a, b, colsum=False, out=None, sums_out=None):
         res = a.t() @ b

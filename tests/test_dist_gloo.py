@@ -269,6 +269,35 @@ def test_next_training_step_computed_during_the_eval_forwards(model_name, world,
                 assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("model_name,world,exchange,pieces", [("graphsage_grid", 4, "2x2", 2), ("gcn_grid", 3, "reshard", 1)])
+def test_one_rank_without_row_range_launches(model_name, world, exchange, pieces, tmp_path, monkeypatch):
+    """A rank whose CSRs carry a hub-row plan launches whole row groups and layer 0 in one piece; which ranks do depends
+    on the graph. The order and number of the collectives must not: every rank takes the same number of layer-0 pieces
+    and the generators yield at the same places (a first build let rank-dependent yields reorder the interleaved
+    collectives: wrong rows, no error). Same numbers as the run where every rank launches row ranges."""
+    runs = []
+    for hub in (None, "1"):
+        if hub is None:
+            monkeypatch.delenv("RGBX_TEST_HUB_RANK", raising=False)
+        else:
+            monkeypatch.setenv("RGBX_TEST_HUB_RANK", hub)
+        mp.spawn(W.runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, True, True, True, pieces,
+                                        False, "all"), nprocs=world, join=True)
+        runs.append([torch.load(os.path.join(tmp_path, f"run_{model_name}_{r}.pt")) for r in range(world)])
+    n_layers = 3 if model_name in ("gcn3_grid", "graphsage2_grid") else 2
+    for p, q in zip(*runs):
+        assert p["engine"] and q["engine"]
+        for a, b in zip(p["hist"], q["hist"]):
+            # (other piece counts = other summation orders: the pre-BatchNorm biases, whose true gradient is zero, take
+            # Adam's +-lr steps on rounding noise and move the eval-mode losses in the third decimal — see
+            # test_dist_runner_training_matches_single_process; wrong ROWS would move everything by O(1))
+            assert abs(a[0] - b[0]) < 1e-5 and abs(a[1] - b[1]) < 3e-2 and abs(a[3] - b[3]) < 3e-2, (a, b)
+        for k, v in p["state"].items():
+            pre_bn_bias = k.endswith("bias") and not k.startswith(("bns.", f"convs.{n_layers - 1}."))
+            if v.is_floating_point() and "running" not in k and not pre_bn_bias:
+                assert torch.allclose(v, q["state"][k], atol=2e-5), k
+
+
 @pytest.mark.parametrize("model_name,world,exchange", [("gcn_grid", 2, "reshard"), ("graphsage_grid", 4, "2x2")])
 def test_fused_grid_schedule_with_the_kept_input_aggregate(model_name, world, exchange, tmp_path):
     """cache_input_aggregate=True on the partitioned run (opt-in): layer 0 transforms the kept aggregate of the static
