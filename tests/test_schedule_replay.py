@@ -1,0 +1,59 @@
+"""bench.replay_schedule: the emulated rank's recorded schedule against a FIFO link model."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+
+
+class _Ev:
+    """Stand-in for a pair of HIP events `ms` apart."""
+
+    def __init__(self, ms=None):
+        self.ms = ms
+
+    def elapsed_time(self, end):
+        return end.ms
+
+
+def _launch(kind, ms):
+    return (kind, _Ev(), _Ev(ms))
+
+
+def _replay(trace, steps=1, **kw):
+    import bench
+    r = bench.replay_schedule(trace, steps, gbs=(1.0,), **kw)  # 1 GB/s: 1e6 bytes take 1 ms
+    return r, r["by_link_rate"]["1 GB/s per link and direction"]
+
+
+def test_an_exchange_hidden_behind_later_launches():
+    # 1 ms launch, exchange of 0.5 ms issued, 0.3 ms launch, wait: the stream stands still for the missing 0.2 ms
+    trace = [_launch("a", 1.0), ("@issue", 1, "x", 500_000), _launch("b", 0.3), ("@wait", 1), _launch("c", 1.0)]
+    r, at = _replay(trace)
+    assert abs(at["exposed_ms_per_epoch"] - 0.2) < 1e-9 and abs(at["replayed_ms_per_epoch"] - 2.5) < 1e-9
+    assert abs(r["timed_launch_ms_per_epoch"] - 2.3) < 1e-9 and r["exchanges_per_epoch"] == 1
+    assert at["stalls_by_exchange_ms"] == {"x": 0.2}
+    # enough work behind it: nothing shows
+    trace[2] = _launch("b", 0.7)
+    assert _replay(trace)[1]["exposed_ms_per_epoch"] == 0.0
+
+
+def test_exchanges_share_one_fifo_link_and_start_after_their_producer():
+    # two exchanges issued back to back after a 1 ms producer: the second one queues behind the first
+    trace = [_launch("p", 1.0), ("@issue", 1, "first", 400_000), ("@issue", 2, "second", 400_000),
+             _launch("q", 0.5), ("@wait", 2), ("@wait", 1)]
+    _, at = _replay(trace)
+    # link: 1.0 -> 1.4 -> 1.8; compute reaches the wait at 1.5: stands still until 1.8, the first one is long done
+    assert abs(at["exposed_ms_per_epoch"] - 0.3) < 1e-9 and at["stalls_by_exchange_ms"] == {"second": 0.3}
+    # an exchange cannot start before the launches enqueued ahead of its issue have finished
+    trace = [("@issue", 1, "early", 100_000), _launch("p", 1.0), ("@issue", 2, "late", 100_000), ("@wait", 2)]
+    _, at = _replay(trace)
+    assert abs(at["exposed_ms_per_epoch"] - 0.1) < 1e-9 and list(at["stalls_by_exchange_ms"]) == ["late"]
+
+
+def test_latency_per_exchange_and_per_epoch_averages():
+    step = [_launch("a", 1.0), ("@issue", 1, "x", 200_000), ("@wait", 1)]
+    trace = step + [_launch("a", 1.0), ("@issue", 2, "x", 200_000), ("@wait", 2)]
+    _, at = _replay(trace, steps=2)
+    assert abs(at["exposed_ms_per_epoch"] - 0.2) < 1e-9
+    _, at = _replay(trace, steps=2, latency_us=50.0)
+    assert abs(at["exposed_ms_per_epoch"] - 0.25) < 1e-9
