@@ -752,6 +752,12 @@ def main():
                          "rows by every rank, no activation exchange)")
     ap.add_argument("--pieces", type=int, default=None, help="pieces of the outbound exchange (default 4)")
     ap.add_argument("--no-interleave", action="store_true", help="val and test forward one after the other")
+    ap.add_argument("--task-split", choices=("auto", "on", "off"), default="auto",
+                    help="N > 1: training steps on half of the ranks, eval forwards on the other half, each half with the "
+                         "whole graph (dist/tasksplit.py); auto = where the slice width of N ranks falls below the 128-byte "
+                         "line (APPNP stacks at N >= 4)")
+    ap.add_argument("--emulate-role", choices=("train", "eval"), default="train",
+                    help="--emulate-rank with task split: which group's rank 0 this process stands for")
     ap.add_argument("--no-ahead", action="store_true",
                     help="fused schedule: do NOT compute the next epoch's training forward + backward during this epoch's "
                          "eval forwards (DistRunner.epoch(more=True))")
@@ -850,17 +856,30 @@ def main():
     parts = max(world, emu)  # ranks the graph is partitioned over
     comm_obj = None
     scheme, alg_by_kind, runner = "single GPU", None, None
+    group = parts  # ranks ONE copy of the graph is partitioned over (task split: half of them)
+    task_split = False
     if parts > 1:
-        from rgb_experiment_amd.dist import DistRunner
+        from rgb_experiment_amd.dist import DistRunner, TaskSplitRunner
+        from rgb_experiment_amd.dist import tasksplit
         from rgb_experiment_amd.dist.comm import Comm, EmulatedComm
         comm_obj = EmulatedComm(emu, 0) if emu else Comm()
         t_mark = time.perf_counter()
-        runner = DistRunner(model, ei, x, y, (train_mask, val_mask, test_mask), 0 if emu else rank, parts, dev,
-                            lr=0.01, comm=comm_obj, backend=test_backend, exchange=args.exchange, pieces=args.pieces,
-                            interleave_evals=not args.no_interleave, fused=not args.no_fused, pieces_in=args.pieces_in,
-                            cache_input_aggregate=args.cache_input_aggregate, src_split=args.src_split)
+        common = dict(lr=0.01, comm=comm_obj, backend=test_backend, exchange=args.exchange, pieces=args.pieces,
+                      interleave_evals=not args.no_interleave, fused=not args.no_fused, pieces_in=args.pieces_in,
+                      cache_input_aggregate=args.cache_input_aggregate, src_split=args.src_split)
+        task_split = args.task_split == "on" or (args.task_split == "auto" and tasksplit.pays(model, parts, d))
+        if task_split:
+            # training steps on ranks [0, P/2), eval forwards on ranks [P/2, P), each group with the whole graph
+            # (dist/tasksplit.py); an emulated run stands for rank 0 of the group --emulate-role names
+            group = parts // 2
+            runner = TaskSplitRunner(model, ei, x, y, (train_mask, val_mask, test_mask), 0 if emu else rank, parts, dev,
+                                     role=args.emulate_role if emu else None, **common)
+            comm_obj = runner.inner.comm  # the exchanges (and their log) are the group's
+        else:
+            runner = DistRunner(model, ei, x, y, (train_mask, val_mask, test_mask), 0 if emu else rank, parts, dev,
+                                **common)
         dgraph = runner.graphs[loops_mode]
-        ahead = not args.no_ahead and not args.no_interleave and runner.engine is not None
+        ahead = not args.no_ahead and (task_split or (not args.no_interleave and runner.engine is not None))
         step = (lambda: runner.epoch(more=True)) if ahead else runner.epoch
         n_loc = runner.hi - runner.lo
         sv.beat("runner built (link rate measured)")
@@ -877,8 +896,8 @@ def main():
         scheme = "replicate" if replica is not None else (dgraph.scheme(d) if kind != "gat" else "halo")
         if replica is not None:
             nnz_total = replica._st[kind]["nnz_total"]
-            alg_by_kind = dist_alg_bytes(dgraph, kind, d, N, n_loc, parts, K=kwargs.get("K", 10), replica=replica)
-            alg = spmm_alg_bytes(n_loc, nnz_total / parts, d)  # an ideal 1/P share of one propagate
+            alg_by_kind = dist_alg_bytes(dgraph, kind, d, N, n_loc, group, K=kwargs.get("K", 10), replica=replica)
+            alg = spmm_alg_bytes(n_loc, nnz_total / group, d)  # an ideal 1/P share of one propagate
         elif kind == "gat":
             plan = dgraph._kinds["gat"]["plan"]
             nnz_total = plan.nnz_total
@@ -886,8 +905,8 @@ def main():
         else:
             plans = [st["plan"] for st in list(dgraph._kinds.values()) + list(dgraph._grid.values())]
             nnz_total = plans[0].nnz_total
-            alg_by_kind = dist_alg_bytes(dgraph, kind, d, N, n_loc, parts, K=kwargs.get("K", 10))
-            alg = spmm_alg_bytes(n_loc, nnz_total / parts, d)  # an ideal 1/P share of one propagate
+            alg_by_kind = dist_alg_bytes(dgraph, kind, d, N, n_loc, group, K=kwargs.get("K", 10))
+            alg = spmm_alg_bytes(n_loc, nnz_total / group, d)  # an ideal 1/P share of one propagate
     else:
         step, nnz_total, alg = build_single_gpu(model, ei, x, y, (train_mask, val_mask, test_mask), dev, loops_mode,
                                                 kind, N, d)
@@ -1007,7 +1026,7 @@ def main():
                      "kernel": kernel, "kernel_source_hash": kernel_source_hash(kernel),
                      "algorithmic_bytes_per_launch": alg,
                      "compulsory_bytes_per_launch": spmm_compulsory_bytes(N if parts == 1 else n_loc,
-                                                                          nnz_total / parts, d),
+                                                                          nnz_total / group, d),
                      "note": ("an ideal 1/P share of one propagate" if parts > 1 else "whole graph, one propagate")
                      + "; `achieved` = ALGORITHMIC bytes (SURVEY 8d formula, every gathered row counted once per edge) / "
                      "mean launch duration, `frac` = that over the 8 TB/s spec peak. It is not an HBM-pin fraction: "
@@ -1037,6 +1056,10 @@ def main():
         result["scheme"] = scheme
         result["fused_schedule"] = runner.engine is not None
         result["next_step_ahead"] = ahead
+        result["task_split"] = ({"groups": 2, "ranks_per_group": group, "role_of_rank_0": runner.role,
+                                 "what": "ranks [0, P/2) run the training steps (the next one computed ahead while) ranks "
+                                         "[P/2, P) run the val and test forwards; each group holds the whole graph"}
+                                if task_split else None)
         result["interleaved_evals"] = {"on": runner.interleave_evals, "decision": runner.interleave_decision}
         result["per_rank"] = per_rank
         result["exchange_mb_per_rank_per_step"] = max(r["exchange_mb_per_step"] for r in per_rank)

@@ -5,6 +5,7 @@ from .graph import DistGraph, HipAggregator, ReplicaGraph, install, install_repl
 from .nn import DistBatchNorm1d
 from .plan import GridPlan, HalfPlan, PartitionPlan, partition_bounds
 from .runner import DistRunner
+from .tasksplit import TaskSplitRunner
 
 DistGCNRunner = DistRunner  # bench.py's name for the 2-layer GCN workload
 

@@ -142,20 +142,24 @@ class DistRunner:
         """One training step. `sync=False`: returns this rank's share of the loss as a device tensor [1]
         (float64) instead of the all-reduced Python float — epoch() reduces everything once."""
         self.discard_speculation()
-        self.model.train()
-        if self.engine is not None:
-            part = self.engine.train_step()  # forward + backward, every parameter's .grad (over)written in place
-        else:
-            self.opt.zero_grad()
-            res = self.model(self.x_in, self.token)
-            m = self.masks[0]
-            loss = self._nll_sum(res, m) / self.mask_counts[0]
-            loss.backward()
-            part = loss.detach().double().reshape(1)
+        part = self._forward_backward()
         self._optimizer_step()
         if not sync:
             return part
         return self.comm.all_reduce_sum_(part.clone()).item()
+
+    def _forward_backward(self):
+        """Training forward + backward: every parameter's .grad holds this rank's share afterwards; returns this rank's
+        share of the loss (float64 device tensor [1]). The optimizer step is the caller's (_optimizer_step)."""
+        self.model.train()
+        if self.engine is not None:
+            return self.engine.train_step()  # forward + backward, every parameter's .grad (over)written in place
+        self.opt.zero_grad()
+        res = self.model(self.x_in, self.token)
+        m = self.masks[0]
+        loss = self._nll_sum(res, m) / self.mask_counts[0]
+        loss.backward()
+        return loss.detach().double().reshape(1)
 
     def _optimizer_step(self):
         self._sync_grads()

@@ -29,12 +29,15 @@ import time
 # flags appended to the command line as typed (argparse: the last occurrence wins), most ambitious first
 ATTEMPTS = [
     ("as asked", []),
-    ("the scheme as asked, through the modules: no fused schedule, sequential evals, one-piece exchanges",
-     ["--no-fused", "--no-interleave", "--pieces", "1", "--pieces-in", "1"]),
+    ("the scheme as asked, through the modules: no fused schedule, no step computed ahead, no task split, sequential "
+     "evals, one-piece exchanges",
+     ["--no-fused", "--no-interleave", "--task-split", "off", "--pieces", "1", "--pieces-in", "1"]),
     ("conservative: val and test forward one after the other, one-piece transpose exchange",
-     ["--no-fused", "--no-interleave", "--pieces", "1", "--exchange", "reshard"]),
-    ("halo exchange, sequential evals", ["--no-fused", "--no-interleave", "--pieces", "1", "--exchange", "halo"]),
-    ("replicate: no activation exchange, all-reduces only", ["--no-fused", "--no-interleave", "--exchange", "replicate"]),
+     ["--no-fused", "--no-interleave", "--task-split", "off", "--pieces", "1", "--exchange", "reshard"]),
+    ("halo exchange, sequential evals",
+     ["--no-fused", "--no-interleave", "--task-split", "off", "--pieces", "1", "--exchange", "halo"]),
+    ("replicate: no activation exchange, all-reduces only",
+     ["--no-fused", "--no-interleave", "--task-split", "off", "--exchange", "replicate"]),
 ]
 
 

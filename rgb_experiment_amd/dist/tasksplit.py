@@ -1,0 +1,163 @@
+"""The epoch split by TASK over two groups of ranks (new capability: the reference is single-device,
+itexperiments.py:246): ranks [0, P/2) run the training step, ranks [P/2, P) the val and the test forward of the
+reference loop body (itexperiments.py:427-440 and :464-473), each group holding the WHOLE graph node-partitioned over its
+P/2 ranks (a DistRunner of its own on a sub-communicator).
+
+Why: a column-slice scheme cuts every feature row into P slices, and below 32 floats a slice costs the same 128-byte line
+per gathered row as a 32-float one — at P = 8 and d = 128 an APPNP rank (K = 10: all ten steps between one
+pair of transposes, on width-16 slices of ALL rows) does twice the work of an ideal share. The reference epoch is four
+independent K-step chains (training forward, its backward, val forward, test forward); with two groups of 4 ranks each
+chain runs at width 32, and a rank runs two chains instead of four.
+
+What makes the groups run at the same time: the eval forwards of epoch t and the forward + backward of epoch t + 1's
+training step read the same parameters (what the optimizer step of epoch t left). So after its optimizer step the
+training group hands the parameters and BatchNorm buffers to the eval group (one small broadcast) and, if the caller
+announces another epoch, computes the next step's gradients AHEAD while the eval group evaluates — speculatively: the
+model of the training ranks is exactly what the finished epoch left (the step's BatchNorm running statistics are set
+aside, its gradients sit in .grad) until the next call accepts it (optimizer step) or discard_speculation drops it.
+Same five numbers per epoch as DistRunner.epoch, same arithmetic per step."""
+import torch
+import torch.distributed as dist
+
+from .comm import Comm, EmulatedComm
+from .runner import DistRunner
+
+
+def pays(model, world, width):
+    """Task split is worth it where halving the group doubles the slice width below the 128-byte line: an APPNP stack
+    (its K steps dominate the epoch and run on width / P slices) on an even number of at least 4 ranks."""
+    return (type(model).__name__ == "APPNPStack" and world >= 4 and world % 2 == 0 and width // world < 32
+            and width // (world // 2) >= 16)
+
+
+class TaskSplitRunner:
+    """See the module docstring. `epoch(more=...)` / `discard_speculation()` / `logits()` as DistRunner."""
+
+    def __init__(self, model, edge_index, x, y, masks, rank, world, device, lr=0.01, weight_decay=0.0, comm=None,
+                 role=None, **runner_kw):
+        if world < 4 or world % 2:
+            raise RuntimeError(f"task split needs an even number of at least 4 ranks, got {world}")
+        half = world // 2
+        self.rank, self.world_size, self.device = rank, world, device
+        self.role = role or ("train" if rank < half else "eval")
+        if isinstance(comm, EmulatedComm):  # bench.py --emulate-rank: one process stands for one rank of one group
+            self.world = comm
+            inner = EmulatedComm(half)
+        else:
+            self.world = comm or Comm()
+            # every rank creates BOTH groups, in the same order (torch.distributed's rule)
+            groups = [dist.new_group(list(range(half))), dist.new_group(list(range(half, world)))]
+            inner = Comm(groups[0 if self.role == "train" else 1])
+        self.inner = DistRunner(model, edge_index, x, y, masks, rank % half, half, device, lr=lr,
+                                weight_decay=weight_decay, comm=inner, pipeline=False, **runner_kw)
+        self.model = self.inner.model
+        self.lo, self.hi, self.N = self.inner.lo, self.inner.hi, self.inner.N
+        self.masks, self.y, self.mask_counts = self.inner.masks, self.inner.y, self.inner.mask_counts
+        self.engine = None
+        self._state = [p.data for p in self.model.parameters()] + [b.data for b in self.model.buffers()]
+        self._bns = [m for m in self.model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+        self._spec = None          # loss share of a step computed ahead
+        self._spec_bn = None       # its BatchNorm buffers, set aside until the step is accepted
+        self.host_enqueue_s = 0.0
+
+    # ---- hand-over of the model state -----------------------------------------------------------------------------
+    def _hand_over(self):
+        """Parameters and buffers of the training group's model -> every rank (source: rank 0; the training ranks hold
+        identical copies, the eval ranks install what arrives). One flat float32 buffer + one for the integer
+        counters."""
+        if isinstance(self.world, EmulatedComm):
+            return
+        for floats in (True, False):
+            ts = [t for t in self._state if t.is_floating_point() == floats]
+            if not ts:
+                continue
+            flat = torch.cat([t.reshape(-1).to(torch.float32 if floats else torch.int64) for t in ts])
+            self._broadcast(flat)
+            if self.role == "eval":
+                off = 0
+                for t in ts:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))  # copy_ moves the version counters: caches follow
+                    off += t.numel()
+
+    def _broadcast(self, flat):
+        if self.world.backend == "nccl" or not flat.is_cuda:
+            dist.broadcast(flat, 0, group=self.world.group)
+            return
+        h = flat.cpu()
+        dist.broadcast(h, 0, group=self.world.group)
+        flat.copy_(h)
+
+    # ---- the speculative step of the training group ------------------------------------------------------------------
+    def _bn_buffers(self):
+        return [(bn.running_mean, bn.running_var, bn.num_batches_tracked) for bn in self._bns
+                if bn.running_mean is not None]
+
+    def _step_ahead(self):
+        """Forward + backward of the NEXT training step: gradients stay in .grad, the running statistics the forward
+        moved are set aside and the model's own are put back."""
+        r = self.inner
+        before = [tuple(t.clone() for t in trio) for trio in self._bn_buffers()]
+        part = r._forward_backward()
+        after = []
+        for trio, old in zip(self._bn_buffers(), before):
+            after.append(tuple(t.clone() for t in trio))
+            for t, o in zip(trio, old):
+                t.copy_(o)
+        self._spec, self._spec_bn = part, after
+
+    def discard_speculation(self):
+        self._spec = self._spec_bn = None
+
+    # ---- one epoch --------------------------------------------------------------------------------------------------
+    def epoch(self, more=False):
+        import time
+        t0 = time.perf_counter()
+        r = self.inner
+        dev = self.device
+        zeros = lambda n: torch.zeros(n, dtype=torch.float64, device=dev)
+        if self.role == "train":
+            if self._spec is not None:  # the step computed during the previous epoch's eval forwards
+                tl, self._spec = self._spec, None
+                for trio, new in zip(self._bn_buffers(), self._spec_bn):
+                    for t, n in zip(trio, new):
+                        t.copy_(n)
+                self._spec_bn = None
+            else:
+                tl = r._forward_backward()
+            r._optimizer_step()
+            self._hand_over()
+            if more:
+                self._step_ahead()
+            v, s = zeros(2), zeros(2)
+        else:
+            self._hand_over()
+            r.model.eval()
+            if r.interleave_evals and r._epochs_done > 0:
+                v, s = r._interleaved_evals()
+            else:
+                v, _ = r.evaluate(1, sync=False)
+                s, _ = r.evaluate(2, sync=False)
+            r._epochs_done += 1
+            tl = zeros(1)
+        # the five numbers of the epoch: the loss shares come from the training ranks, the eval statistics from the eval
+        # ranks (everybody else adds zeros): ONE all-reduce over all ranks, one read-back
+        packed = self.world.all_reduce_sum_(torch.cat([tl.reshape(1).double(), v.double(), s.double()]))
+        self.host_enqueue_s += time.perf_counter() - t0
+        p = packed.tolist()
+        cv, cs = self.mask_counts[1], self.mask_counts[2]
+        return p[0], p[1] / cv, p[2] / cv, p[3] / cs, p[4] / cs
+
+    # what bench.py reads of a runner
+    graphs = property(lambda self: self.inner.graphs)
+    replicated = property(lambda self: self.inner.replicated)
+    replicas = property(lambda self: getattr(self.inner, "replicas", None))
+    interleave_evals = property(lambda self: self.inner.interleave_evals)
+    interleave_decision = property(lambda self: self.inner.interleave_decision)
+    link_gbs = property(lambda self: getattr(self.inner, "link_gbs", None))
+
+    def logits(self, training=False):
+        """This rank's rows (of its GROUP's partition) of the model's logits."""
+        return self.inner.logits(training)
+
+    def release_edge_list(self):
+        self.inner.release_edge_list()

@@ -275,6 +275,26 @@ def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", inter
     dist.destroy_process_group()
 
 
+def tasksplit_worker(rank, world, port, out_dir, model_name, exchange="reshard", stop_early=False):
+    """Three epochs of dist.TaskSplitRunner: ranks [0, world / 2) train, the others evaluate; every epoch but the last
+    announces a successor (`stop_early`: the last one does too, and the loop then stops — the step computed ahead
+    must leave no trace)."""
+    _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import TaskSplitRunner
+    ei, x, y, masks = make_problem()
+    torch.manual_seed(14530529)
+    model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
+    r = TaskSplitRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, backend=OracleAggregator(),
+                        exchange=exchange)
+    hist = [r.epoch(more=True), r.epoch(more=True), r.epoch(more=stop_early)]
+    r.discard_speculation()
+    torch.save({"hist": hist, "role": r.role, "lo": r.lo, "hi": r.hi,
+                "state": {k: v.clone() for k, v in r.model.state_dict().items()}},
+               os.path.join(out_dir, f"split_{model_name}_{rank}.pt"))
+    dist.destroy_process_group()
+
+
 def failing_eval_worker(rank, world, port, out_dir):
     """Rank 1 raises inside an eval forward of the second epoch (the interleaved pair, on a helper thread): the
     process must END (Comm.abort), so that the job terminates instead of leaving rank 0 in an all-to-all."""

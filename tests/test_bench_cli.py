@@ -24,6 +24,21 @@ def _run(args, timeout=600, extra_env=None):
     return proc
 
 
+def test_bench_gpus_n_with_the_epoch_split_by_task():
+    """--task-split on: ranks 0-1 train (the next step computed ahead), ranks 2-3 evaluate; one line from rank 0 with the
+    split named on it and all four ranks seen."""
+    proc = _run(["--gpus", "4", "--workload", "T", "--model", "appnpstack", "--steps", "2", "--warmup", "1",
+                 "--task-split", "on", "--exchange", "reshard"])
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 4 and res["ranks_seen"] == 4 and res["value"] > 0
+    assert res["task_split"]["ranks_per_group"] == 2 and res["task_split"]["role_of_rank_0"] == "train"
+    assert res["next_step_ahead"] and not res["fused_schedule"] and res["launcher"]["attempt"] == 0
+    assert res["final_losses"]["val"] == res["final_losses"]["val"] and res["final_losses"]["val"] > 0  # from the eval group
+
+
 @pytest.mark.parametrize("gpus,exchange,scheme", [(2, "reshard", "reshard"), (4, "2x2", "grid2x2"), (2, "halo", "halo"),
                                                   (2, "auto", None), (3, "replicate", "replicate")])
 def test_bench_gpus_n_launches_its_own_ranks(gpus, exchange, scheme):
@@ -70,7 +85,7 @@ def test_a_failing_or_stalled_rank_ends_in_a_line_from_fresh_conservative_ranks(
     assert len(lines) == 1, proc.stdout
     res = json.loads(lines[0])
     la = res["launcher"]
-    assert la["attempt"] == 1 and la["extra_flags"] == ["--no-fused", "--no-interleave", "--pieces", "1", "--pieces-in", "1"]
+    assert la["attempt"] == 1 and la["extra_flags"] == ["--no-fused", "--no-interleave", "--task-split", "off", "--pieces", "1", "--pieces-in", "1"]
     assert res["scheme"] == "reshard" and res["ranks_seen"] == 2 and res["value"] > 0 and not res["fused_schedule"]
     failed = la["fallback"]["failed"]
     assert len(failed) == 1 and failed[0]["attempt"] == 0

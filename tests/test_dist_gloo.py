@@ -198,6 +198,41 @@ def test_dist_runner_training_matches_single_process(model_name, world, exchange
     assert parts[0]["lo"] == 0 and parts[-1]["hi"] == 97
 
 
+@pytest.mark.parametrize("model_name,world,exchange,stop_early", [("appnpstack", 4, "reshard", False),
+                                                                   ("appnpstack", 4, "reshard", True),
+                                                                   ("gcn", 4, "halo", False), ("appnpstack", 6, "halo", True)])
+def test_epoch_split_by_task_over_two_groups(model_name, world, exchange, stop_early, tmp_path):
+    """dist.TaskSplitRunner: ranks [0, P/2) run the training steps, ranks [P/2, P) the val and test forwards, each group
+    with the whole graph partitioned over its ranks; the training group computes step t + 1 ahead while the eval group
+    evaluates the model step t left. Every rank reports the same five numbers per epoch; train losses and trained
+    weights equal single-process oracle training; the eval group's model IS the training group's (state_dict bit for
+    bit, also after a step computed ahead was dropped); eval losses equal those of a plain DistRunner run."""
+    mp.spawn(W.tasksplit_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, stop_early),
+             nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"split_{model_name}_{r}.pt")) for r in range(world)]
+    assert [p["role"] for p in parts] == ["train"] * (world // 2) + ["eval"] * (world // 2)
+    assert [(p["lo"], p["hi"]) for p in parts[:world // 2]] == [(p["lo"], p["hi"]) for p in parts[world // 2:]]
+    for p in parts[1:]:
+        assert p["hist"] == parts[0]["hist"]
+        for k, v in parts[0]["state"].items():
+            assert torch.equal(v, p["state"][k]), (p["role"], k)
+    hist, params = _single_process_reference(model_name)
+    for step in range(3):
+        assert abs(parts[0]["hist"][step][0] - hist[step][0]) < 2e-5, (step, parts[0]["hist"][step], hist[step])
+    last = {"gcn": "convs.2.", "appnpstack": "lin2."}[model_name]
+    for k, v in params.items():
+        pre_bn_bias = k.endswith("bias") and not k.startswith(("bns.", "bn.", last))
+        if v.is_floating_point() and "running" not in k and not pre_bn_bias:
+            assert torch.allclose(parts[0]["state"][k], v.detach(), atol=2e-5), k
+    # the eval statistics against a plain DistRunner over world / 2 ranks (the same partition as a group's)
+    mp.spawn(W.runner_worker, args=(world // 2, _free_port(), str(tmp_path), model_name, exchange, False, False, False),
+             nprocs=world // 2, join=True)
+    ref = torch.load(os.path.join(tmp_path, f"run_{model_name}_0.pt"))
+    for a, b in zip(parts[0]["hist"], ref["hist"]):
+        assert abs(a[0] - b[0]) < 2e-5 and abs(a[1] - b[1]) < 3e-2 and abs(a[3] - b[3]) < 3e-2, (a, b)
+        assert abs(a[2] - b[2]) < 0.05 and abs(a[4] - b[4]) < 0.05
+
+
 @pytest.mark.parametrize("model_name,world,exchange,pieces,also_modules", [
     ("gcn_grid", 2, "reshard", 1, True), ("gcn_grid", 3, "reshard", 3, False), ("gcn_grid", 4, "2x2", 2, False),
     ("gcn3_grid", 4, "2x2", 3, False), ("graphsage_grid", 2, "reshard", 2, False),
