@@ -68,12 +68,18 @@ class DistContext:
         """DistRunner over this rank's node range. Parameters, buffers and masks are taken from rank 0, so that the
         ranks agree even when the caller seeded nothing (need_to_reappear=False, or a splitter that draws from the
         global generator: utils/mask.py get_random_mask's val / test shuffle, reference mask.py:133)."""
+        from . import tasksplit
         from .comm import Comm
         from .runner import DistRunner
         with torch.no_grad():
             for t in list(net.parameters()) + list(net.buffers()):
                 self._from_rank0(t.data)
         masks = tuple(self._from_rank0(m.to(torch.uint8)).bool() for m in masks)
+        if tasksplit.pays(net, self.world):
+            # training steps on one half of the ranks, eval forwards on the other (APPNP stacks whose column slices
+            # would fall below the 128-byte line: dist/tasksplit.py); same loop, same numbers
+            return tasksplit.TaskSplitRunner(net, edge_index, features, y, masks, self.rank, self.world, self.device,
+                                             lr=lr, weight_decay=weight_decay, comm=Comm(), backend=self.test_backend)
         return DistRunner(net, edge_index, features, y, masks, self.rank, self.world, self.device, lr=lr,
                           weight_decay=weight_decay, comm=Comm(), backend=self.test_backend,
                           cache_input_aggregate=cache_input_aggregate)
@@ -84,6 +90,8 @@ class DistContext:
         emb = runner.logits(training=False)
         out = torch.log_softmax(emb, dim=1)
         m = runner.masks[2]  # this rank's rows of the test mask every rank agreed on (runner())
+        if getattr(runner, "role", "train") != "train":  # task split: both groups hold every row; one of them reports
+            m = torch.zeros_like(m)
         pred = out.max(dim=1)[1][m].cpu()
         label = runner.y[m].cpu()
         parts = [None] * self.world

@@ -23,11 +23,14 @@ from .comm import Comm, EmulatedComm
 from .runner import DistRunner
 
 
-def pays(model, world, width):
+def pays(model, world, width=None):
     """Task split is worth it where halving the group doubles the slice width below the 128-byte line: an APPNP stack
-    (its K steps dominate the epoch and run on width / P slices) on an even number of at least 4 ranks."""
-    return (type(model).__name__ == "APPNPStack" and world >= 4 and world % 2 == 0 and width // world < 32
-            and width // (world // 2) >= 16)
+    (its K steps dominate the epoch and run on width / P slices of the propagated matrix, width = output_dim:
+    reference models/appnp_stack.py:29) on an even number of at least 4 ranks."""
+    if type(model).__name__ != "APPNPStack" or world < 4 or world % 2:
+        return False
+    width = model.lin2.out_features if width is None else width
+    return width // world < 32 and width // (world // 2) >= 16
 
 
 class TaskSplitRunner:

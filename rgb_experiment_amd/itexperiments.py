@@ -493,5 +493,7 @@ def experiment(model_init_param: dict, *,
         result["emb"] = final["emb"]
         if runner is not None:
             result["distributed"] = {"world": dist_ctx.world, "rank": dist_ctx.rank, "rows": (runner.lo, runner.hi),
-                                     "fused_schedule": runner.engine is not None}
+                                     "fused_schedule": runner.engine is not None,
+                                     "task_split_role": getattr(runner, "role", None),
+                                     "test_rows": int(final["label"].numel())}
     return result

@@ -350,7 +350,7 @@ def exchange_count_worker(rank, world, port, out_dir, model_name, resident):
     dist.destroy_process_group()
 
 
-def experiment_worker(rank, world, port, out_dir, model_name, on_gpu=False):
+def experiment_worker(rank, world, port, out_dir, model_name, on_gpu=False, classes=None):
     """experiment() called as one of `world` ranks (environment as torch.distributed.run sets it): the distributed
     route of rgb_experiment_amd.itexperiments.experiment."""
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
@@ -360,7 +360,7 @@ def experiment_worker(rank, world, port, out_dir, model_name, on_gpu=False):
     torch.set_num_threads(1)
     import rgb_experiment_amd as R
     n, e, f, c = (5000, 60000, 32, 8) if on_gpu else (97, 900, 12, 5)
-    ei, x, y, masks = make_problem(n=n, e=e, f=f, c=c)
+    ei, x, y, masks = make_problem(n=n, e=e, f=f, c=classes or c)
     data = R.Data(x=x, y=y, edge_index=ei)
     data.train_mask, data.val_mask, data.test_mask = masks
     params = R.InitialParameters.defaults_for(model_name)
@@ -424,4 +424,23 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", h
     torch.save({"hist": hist, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi,
                 "engine": r.engine is not None, "state": {k: v.cpu() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"gpu_{model_name}_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def gpu_tasksplit_worker(rank, world, port, out_dir, model_name, exchange="reshard"):
+    """dist.TaskSplitRunner on the real kernels: `world` ranks share cuda:0 (gloo staging), two epochs, the first one
+    announcing the second (the training group computes the second step ahead)."""
+    _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import TaskSplitRunner
+    dev = torch.device("cuda:0")
+    ei, x, y, masks = make_problem(n=5000, e=60000, f=32, c=8)
+    torch.manual_seed(14530529)
+    model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
+    r = TaskSplitRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, exchange=exchange)
+    hist = [r.epoch(more=True), r.epoch()]
+    torch.cuda.synchronize()
+    torch.save({"hist": hist, "role": r.role, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi,
+                "state": {k: v.cpu() for k, v in r.model.state_dict().items()}},
+               os.path.join(out_dir, f"gpusplit_{model_name}_{rank}.pt"))
     dist.destroy_process_group()

@@ -369,6 +369,31 @@ def test_experiment_runs_as_one_of_several_ranks(model_name, tmp_path):
     assert abs(a["metrics"]["ACC"] - b["metrics"]["ACC"]) <= 0.11  # 19 test nodes: two of them may flip
 
 
+def test_experiment_takes_the_task_split_where_it_pays(tmp_path):
+    """experiment() with an APPNP stack of 40 classes on 4 ranks: 4 column slices of 10 floats would fall below the
+    128-byte line, two groups of 2 ranks do not (dist.tasksplit.pays) — ranks 0-1 train, ranks 2-3 evaluate, every rank
+    returns the same history, metrics (each test row counted once) and weights; same training as 2 plain ranks."""
+    runs = {}
+    for world in (4, 2):
+        mp.spawn(W.experiment_worker, args=(world, _free_port(), str(tmp_path), "appnpstack", False, 40), nprocs=world,
+                 join=True)
+        runs[world] = [torch.load(os.path.join(tmp_path, f"exp_appnpstack_{world}_{r}.pt")) for r in range(world)]
+        first = runs[world][0]
+        for other in runs[world][1:]:
+            assert other["metrics"] == first["metrics"]
+            for key in ("train_loss", "val_loss", "val_acc", "test_loss", "test_acc"):  # (train_acc: nan on this route)
+                assert other["history"][key] == first["history"][key], key
+            for k, v in first["state"].items():
+                assert torch.equal(v, other["state"][k]), k
+    a, b = runs[4][0], runs[2][0]
+    assert a["distributed"]["test_rows"] == b["distributed"]["test_rows"]  # both groups hold every row: one reports
+    assert [p["distributed"]["task_split_role"] for p in runs[4]] == ["train", "train", "eval", "eval"]
+    assert runs[2][0]["distributed"]["task_split_role"] is None
+    assert np.allclose(a["history"]["train_loss"], b["history"]["train_loss"], rtol=0, atol=2e-5)
+    assert np.allclose(a["history"]["val_loss"], b["history"]["val_loss"], rtol=0, atol=3e-2)
+    assert abs(a["metrics"]["ACC"] - b["metrics"]["ACC"]) <= 0.11
+
+
 @pytest.mark.parametrize("model_name,with_resident,without", [("gcn", 8, 11), ("graphsage2", 4, 7), ("gat", 4, 8)])
 def test_resident_input_features_remove_the_first_layer_exchange(model_name, with_resident, without, tmp_path):
     """The boundary rows of the static feature matrix are fetched once (DistGraph.pin_resident): a steady-state

@@ -136,3 +136,23 @@ def test_step_computed_ahead_gives_the_same_bits(model_name, world, exchange, tm
         assert torch.equal(p["logits_train"], q["logits_train"])
         for k, v in p["state"].items():
             assert torch.equal(v, q["state"][k]), k
+
+
+@pytest.mark.parametrize("model_name,exchange", [("appnpstack", "reshard"), ("gcn", "auto")])
+def test_epoch_split_by_task_on_the_real_kernels(model_name, exchange, tmp_path):
+    """dist.TaskSplitRunner, 4 ranks on the one GPU: ranks 0-1 train (second step computed ahead), ranks 2-3 evaluate;
+    same numbers as one GPU, the eval group's model is the training group's bit for bit."""
+    mp.spawn(W.gpu_tasksplit_worker, args=(4, _free_port(), str(tmp_path), model_name, exchange), nprocs=4, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"gpusplit_{model_name}_{r}.pt")) for r in range(4)]
+    assert [p["role"] for p in parts] == ["train", "train", "eval", "eval"]
+    for p in parts[1:]:
+        assert p["hist"] == parts[0]["hist"]
+        for k, v in parts[0]["state"].items():
+            assert torch.equal(v, p["state"][k]), (p["role"], k)
+    hist, emb = _single_gpu(model_name)
+    for step in range(2):
+        tl, vl, _, sl, _ = parts[0]["hist"][step]
+        assert abs(tl - hist[step][0]) < 1e-4, (step, tl, hist[step][0])
+        assert abs(vl - hist[step][1]) < 5e-3 and abs(sl - hist[step][2]) < 5e-3
+    for grp in (parts[:2], parts[2:]):
+        assert (torch.cat([p["logits_train"] for p in grp]) - emb).abs().max().item() < 1e-3
