@@ -874,11 +874,11 @@ def main():
             group = parts // 2
             runner = TaskSplitRunner(model, ei, x, y, (train_mask, val_mask, test_mask), 0 if emu else rank, parts, dev,
                                      role=args.emulate_role if emu else None, **common)
-            comm_obj = runner.inner.comm  # the exchanges (and their log) are the group's
+            comm_obj = getattr(runner.inner, "comm", comm_obj)  # the exchanges (and their log) are the group's
         else:
             runner = DistRunner(model, ei, x, y, (train_mask, val_mask, test_mask), 0 if emu else rank, parts, dev,
                                 **common)
-        dgraph = runner.graphs[loops_mode]
+        dgraph = runner.graphs[loops_mode] if runner.graphs is not None else None  # None: a group of ONE rank
         ahead = not args.no_ahead and (task_split or (not args.no_interleave and runner.engine is not None))
         step = (lambda: runner.epoch(more=True)) if ahead else runner.epoch
         n_loc = runner.hi - runner.lo
@@ -893,8 +893,15 @@ def main():
         sv.beat("first epoch done: plans and CSRs built")
         runner.release_edge_list()  # ... after which the global edge list leaves HBM
         replica = runner.replicas[loops_mode] if runner.replicated else None
-        scheme = "replicate" if replica is not None else (dgraph.scheme(d) if kind != "gat" else "halo")
-        if replica is not None:
+        if dgraph is not None:
+            scheme = "replicate" if replica is not None else (dgraph.scheme(d) if kind != "gat" else "halo")
+        if dgraph is None:  # task split over 2 ranks: each rank holds the whole graph and runs the single-GPU kernels
+            from rgb_experiment_amd.graph import get_graph
+            scheme = "whole graph per rank (no partition, no exchange)"
+            nnz_total = get_graph(runner.inner.fwd["edge_index"], N, loops_mode).fwd.nnz
+            alg = gat_alg_bytes(N, nnz_total, d) if kind == "gat" else spmm_alg_bytes(N, nnz_total, d) - (
+                4 * nnz_total if kind == "sum" else 0)
+        elif replica is not None:
             nnz_total = replica._st[kind]["nnz_total"]
             alg_by_kind = dist_alg_bytes(dgraph, kind, d, N, n_loc, group, K=kwargs.get("K", 10), replica=replica)
             alg = spmm_alg_bytes(n_loc, nnz_total / group, d)  # an ideal 1/P share of one propagate
@@ -972,9 +979,10 @@ def main():
         # the DOMINANT kernel's own launches: its algorithmic bytes per launch / its mean launch duration
         launches_per_event = kwargs.get("K", 1) if dominant.startswith("appnp") else 1
         if dominant == "gat_fwd":  # the forward launches alone (gat_fwd_launch_bytes), inference and training form
-            rows_here, nnz_here = (N, nnz_total) if parts == 1 else (n_loc, plan.nnz_local)
+            whole = parts == 1 or dgraph is None
+            rows_here, nnz_here = (N, nnz_total) if whole else (n_loc, plan.nnz_local)
             alg = gat_fwd_launch_bytes(rows_here, nnz_here, d, kwargs.get("heads", 8))
-            if parts > 1:  # partitioned GAT runs every layer on the halo scheme's own kernels
+            if not whole:  # partitioned GAT runs every layer on the halo scheme's own kernels
                 l1, l2 = gat_launch_bytes(rows_here, nnz_here, kwargs.get("heads", 8), d // kwargs.get("heads", 8)), \
                     gat_launch_bytes(rows_here, nnz_here, 1, d)
                 alg = sum(2 * l["fwd_infer"] + l["fwd_train"] for l in (l1, l2)) / 6
@@ -1009,6 +1017,8 @@ def main():
         "config": {"workload": wl_name, "nodes": N, "edges_in": E, "edges_aggregated_per_propagate": nnz_total,
                    "width": d, "propagates_per_step": n_prop,
                    "parallelism": "single GPU" if parts == 1 else
+                   (f"epoch split by task over 2 groups of {group} rank(s): training steps (the next one computed ahead) "
+                    f"on one group, val and test forwards on the other; within a group: {scheme}") if task_split else
                    ("1-D node partition x%d, replicate scheme: first conv layer on all rows by every rank, second on "
                     "its own targets, no activation exchange (RCCL all-reduces of loss / gradients only)" % parts)
                    if scheme == "replicate" else
@@ -1027,7 +1037,8 @@ def main():
                      "algorithmic_bytes_per_launch": alg,
                      "compulsory_bytes_per_launch": spmm_compulsory_bytes(N if parts == 1 else n_loc,
                                                                           nnz_total / group, d),
-                     "note": ("an ideal 1/P share of one propagate" if parts > 1 else "whole graph, one propagate")
+                     "note": ("an ideal 1/P share of one propagate" if parts > 1 and dgraph is not None
+                              else "whole graph, one propagate")
                      + "; `achieved` = ALGORITHMIC bytes (SURVEY 8d formula, every gathered row counted once per edge) / "
                      "mean launch duration, `frac` = that over the 8 TB/s spec peak. It is not an HBM-pin fraction: "
                      "FETCH_SIZE counts at the L2's fabric side, and about a quarter of the gathered rows of a 1 GB "
@@ -1063,8 +1074,8 @@ def main():
         result["interleaved_evals"] = {"on": runner.interleave_evals, "decision": runner.interleave_decision}
         result["per_rank"] = per_rank
         result["exchange_mb_per_rank_per_step"] = max(r["exchange_mb_per_step"] for r in per_rank)
-        result["modelled_seconds_per_propagate"] = dgraph._choice.get(("costs", d)) or next(
-            (v for k, v in dgraph._choice.items() if isinstance(k, tuple) and k[0] == "costs"), None)
+        result["modelled_seconds_per_propagate"] = None if dgraph is None else (dgraph._choice.get(("costs", d)) or next(
+            (v for k, v in dgraph._choice.items() if isinstance(k, tuple) and k[0] == "costs"), None))
         result["modelled_seconds_per_epoch_first_two_layers"] = getattr(runner, "replicate_costs", None)
         result["link_gbs_measured"] = getattr(comm_obj, "link_gbs", None)  # 16 MB-per-peer all-to-all at start-up
         result["small_all_to_all_us_measured"] = getattr(comm_obj, "link_latency_us", None)  # one row per peer

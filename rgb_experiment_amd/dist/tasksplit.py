@@ -27,10 +27,69 @@ def pays(model, world, width=None):
     """Task split is worth it where halving the group doubles the slice width below the 128-byte line: an APPNP stack
     (its K steps dominate the epoch and run on width / P slices of the propagated matrix, width = output_dim:
     reference models/appnp_stack.py:29) on an even number of at least 4 ranks."""
+    if world == 2:
+        # two ranks share ONE xGMI link: any exchange scheme moves more than 250 MB per propagate over it (34 ms per epoch
+        # at the benchmark's size) and the exchange-free replicate scheme repeats the first layer on every rank
+        # (DESIGN.md 4.2: 0.79 of a single-GPU epoch). One rank training and one evaluating, each on the whole graph with
+        # the single-GPU kernels and no exchange at all, is max(training step, two eval forwards) = 0.5 of it.
+        return True
     if type(model).__name__ != "APPNPStack" or world < 4 or world % 2:
         return False
     width = model.lin2.out_features if width is None else width
     return width // world < 32 and width // (world // 2) >= 16
+
+
+class WholeGraphRunner:
+    """What TaskSplitRunner needs of a group of ONE rank: the reference's training step and eval forwards on the whole
+    graph, on this rank's GPU, with the single-GPU kernels (fused aggregate + transform, loss inside the last layer's
+    kernel: models/_stack.masked_ce) — no partition, no exchange."""
+
+    engine, replicated, interleave_evals, interleave_decision, graphs = None, False, False, None, None
+
+    def __init__(self, model, edge_index, x, y, masks, device, lr=0.01, weight_decay=0.0):
+        self.device = device
+        self.model = model.to(device)
+        self.fwd = {"x": x.to(device).contiguous(), "edge_index": edge_index.to(device)}
+        self.y = y.to(device)
+        self.masks = [m.to(device) for m in masks]
+        self.mask_counts = [float(m.sum()) for m in self.masks]
+        self.N = x.size(0)
+        self.lo, self.hi = 0, self.N
+        self._params = list(self.model.parameters())
+        self._fused_adam = device.type == "cuda"
+        self.opt = torch.optim.Adam(self._params, lr=lr, weight_decay=weight_decay,
+                                    **({"fused": True} if self._fused_adam else {}))
+        self._epochs_done = 0
+        self.host_enqueue_s = 0.0
+
+    def _forward_backward(self):
+        from ..models._stack import masked_ce
+        self.model.train()
+        self.opt.zero_grad()
+        loss = masked_ce(self.model, self.fwd, self.y, self.masks[0])[0]
+        loss.backward()
+        return loss.detach().double().reshape(1)
+
+    def _optimizer_step(self):
+        self.opt.step()
+        if self._fused_adam:  # see DistRunner._optimizer_step
+            for p in self._params:
+                p.__dict__.pop("_rgbx_wt", None)
+
+    def evaluate(self, which, sync=False):
+        from ..models._stack import masked_ce
+        self.model.eval()
+        with torch.no_grad():
+            stats = masked_ce(self.model, self.fwd, self.y, self.masks[which])[1]  # [nll sum, rows, correct]
+        return stats[::2], None
+
+    def logits(self, training=False):
+        self.model.train(training)
+        with torch.no_grad():
+            return self.model(**self.fwd)["emb"]
+
+    def release_edge_list(self):
+        pass
 
 
 class TaskSplitRunner:
@@ -38,8 +97,8 @@ class TaskSplitRunner:
 
     def __init__(self, model, edge_index, x, y, masks, rank, world, device, lr=0.01, weight_decay=0.0, comm=None,
                  role=None, **runner_kw):
-        if world < 4 or world % 2:
-            raise RuntimeError(f"task split needs an even number of at least 4 ranks, got {world}")
+        if world < 2 or world % 2:
+            raise RuntimeError(f"task split needs an even number of ranks, got {world}")
         half = world // 2
         self.rank, self.world_size, self.device = rank, world, device
         self.role = role or ("train" if rank < half else "eval")
@@ -51,8 +110,11 @@ class TaskSplitRunner:
             # every rank creates BOTH groups, in the same order (torch.distributed's rule)
             groups = [dist.new_group(list(range(half))), dist.new_group(list(range(half, world)))]
             inner = Comm(groups[0 if self.role == "train" else 1])
-        self.inner = DistRunner(model, edge_index, x, y, masks, rank % half, half, device, lr=lr,
-                                weight_decay=weight_decay, comm=inner, pipeline=False, **runner_kw)
+        if half == 1 and device.type == "cuda" and runner_kw.get("backend") is None:
+            self.inner = WholeGraphRunner(model, edge_index, x, y, masks, device, lr=lr, weight_decay=weight_decay)
+        else:  # (a group of one rank on the CPU: the gloo rehearsal, through the partitioned path with its injected aggregator)
+            self.inner = DistRunner(model, edge_index, x, y, masks, rank % half, half, device, lr=lr,
+                                    weight_decay=weight_decay, comm=inner, pipeline=False, **runner_kw)
         self.model = self.inner.model
         self.lo, self.hi, self.N = self.inner.lo, self.inner.hi, self.inner.N
         self.masks, self.y, self.mask_counts = self.inner.masks, self.inner.y, self.inner.mask_counts
@@ -134,6 +196,9 @@ class TaskSplitRunner:
             v, s = zeros(2), zeros(2)
         else:
             self._hand_over()
+            if getattr(r, "_fused_adam", False):  # parameters written from outside: what is cached per version follows,
+                for p in r._params:               # what is cached per training step (none here) would not
+                    p.__dict__.pop("_rgbx_wt", None)
             r.model.eval()
             if r.interleave_evals and r._epochs_done > 0:
                 v, s = r._interleaved_evals()

@@ -24,6 +24,17 @@ def _run(args, timeout=600, extra_env=None):
     return proc
 
 
+def test_two_ranks_split_the_epoch_by_task_by_default():
+    """--gpus 2: one rank trains, one evaluates (dist.tasksplit.pays: two GPUs share one link, every partition scheme
+    costs more than it saves)."""
+    proc = _run(["--gpus", "2", "--workload", "T", "--steps", "2", "--warmup", "1"])
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    res = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["task_split"]["ranks_per_group"] == 1
+    assert res["next_step_ahead"] and res["launcher"]["attempt"] == 0 and res["value"] > 0
+    assert all(v == v and v > 0 for v in res["final_losses"].values())
+
+
 def test_bench_gpus_n_with_the_epoch_split_by_task():
     """--task-split on: ranks 0-1 train (the next step computed ahead), ranks 2-3 evaluate; one line from rank 0 with the
     split named on it and all four ranks seen."""
@@ -42,7 +53,9 @@ def test_bench_gpus_n_with_the_epoch_split_by_task():
 @pytest.mark.parametrize("gpus,exchange,scheme", [(4, "2x2", "grid2x2"), (2, "halo", "halo"),
                                                   (2, "auto", None), (3, "replicate", "replicate")])
 def test_bench_gpus_n_launches_its_own_ranks(gpus, exchange, scheme):
-    proc = _run(["--gpus", str(gpus), "--workload", "T", "--steps", "2", "--warmup", "1", "--exchange", exchange])
+    # (--task-split off: two ranks would otherwise split the epoch by task, each on the whole graph — its own test below)
+    proc = _run(["--gpus", str(gpus), "--workload", "T", "--steps", "2", "--warmup", "1", "--exchange", exchange,
+                 "--task-split", "off"])
     assert proc.returncode == 0, proc.stderr[-3000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, proc.stdout  # rank 0's line, once

@@ -199,6 +199,7 @@ def test_dist_runner_training_matches_single_process(model_name, world, exchange
 
 
 @pytest.mark.parametrize("model_name,world,exchange,stop_early", [("appnpstack", 4, "reshard", True),
+                                                                   ("gcn", 2, "halo", True), ("graphsage2", 2, "halo", False),
                                                                    ("gcn", 4, "halo", False), ("appnpstack", 6, "halo", True)])
 def test_epoch_split_by_task_over_two_groups(model_name, world, exchange, stop_early, tmp_path):
     """dist.TaskSplitRunner: ranks [0, P/2) run the training steps, ranks [P/2, P) the val and test forwards, each group
@@ -218,12 +219,14 @@ def test_epoch_split_by_task_over_two_groups(model_name, world, exchange, stop_e
     hist, params = _single_process_reference(model_name)
     for step in range(3):
         assert abs(parts[0]["hist"][step][0] - hist[step][0]) < 2e-5, (step, parts[0]["hist"][step], hist[step])
-    last = {"gcn": "convs.2.", "appnpstack": "lin2."}[model_name]
+    last = {"gcn": "convs.2.", "appnpstack": "lin2.", "graphsage2": "convs.1."}[model_name]
     for k, v in params.items():
         pre_bn_bias = k.endswith("bias") and not k.startswith(("bns.", "bn.", last))
         if v.is_floating_point() and "running" not in k and not pre_bn_bias:
             assert torch.allclose(parts[0]["state"][k], v.detach(), atol=2e-5), k
     # the eval statistics against a plain DistRunner over world / 2 ranks (the same partition as a group's)
+    if world == 2:  # (groups of one rank: nothing to compare a partition with)
+        return
     mp.spawn(W.runner_worker, args=(world // 2, _free_port(), str(tmp_path), model_name, exchange, False, False, False),
              nprocs=world // 2, join=True)
     ref = torch.load(os.path.join(tmp_path, f"run_{model_name}_0.pt"))

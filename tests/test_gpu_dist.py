@@ -138,13 +138,17 @@ def test_step_computed_ahead_gives_the_same_bits(model_name, world, exchange, tm
             assert torch.equal(v, q["state"][k]), k
 
 
-@pytest.mark.parametrize("model_name,exchange", [("appnpstack", "reshard"), ("gcn", "auto")])
-def test_epoch_split_by_task_on_the_real_kernels(model_name, exchange, tmp_path):
-    """dist.TaskSplitRunner, 4 ranks on the one GPU: ranks 0-1 train (second step computed ahead), ranks 2-3 evaluate;
-    same numbers as one GPU, the eval group's model is the training group's bit for bit."""
-    mp.spawn(W.gpu_tasksplit_worker, args=(4, _free_port(), str(tmp_path), model_name, exchange), nprocs=4, join=True)
-    parts = [torch.load(os.path.join(tmp_path, f"gpusplit_{model_name}_{r}.pt")) for r in range(4)]
-    assert [p["role"] for p in parts] == ["train", "train", "eval", "eval"]
+@pytest.mark.parametrize("model_name,exchange,world", [("appnpstack", "reshard", 4), ("gcn", "auto", 4), ("gcn", "auto", 2),
+                                                       ("gat", "auto", 2), ("graphsage", "auto", 2)])
+def test_epoch_split_by_task_on_the_real_kernels(model_name, exchange, world, tmp_path):
+    """dist.TaskSplitRunner on the one GPU: the first half of the ranks trains (second step computed ahead), the other
+    half evaluates — 4 ranks: groups of 2 on the partitioned path; 2 ranks: each on the WHOLE graph with the single-GPU
+    kernels (WholeGraphRunner). Same numbers as one GPU, the eval group's model is the training group's bit for bit."""
+    mp.spawn(W.gpu_tasksplit_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange), nprocs=world,
+             join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"gpusplit_{model_name}_{r}.pt")) for r in range(world)]
+    half = world // 2
+    assert [p["role"] for p in parts] == ["train"] * half + ["eval"] * half
     for p in parts[1:]:
         assert p["hist"] == parts[0]["hist"]
         for k, v in parts[0]["state"].items():
@@ -154,5 +158,5 @@ def test_epoch_split_by_task_on_the_real_kernels(model_name, exchange, tmp_path)
         tl, vl, _, sl, _ = parts[0]["hist"][step]
         assert abs(tl - hist[step][0]) < 1e-4, (step, tl, hist[step][0])
         assert abs(vl - hist[step][1]) < 5e-3 and abs(sl - hist[step][2]) < 5e-3
-    for grp in (parts[:2], parts[2:]):
+    for grp in (parts[:half], parts[half:]):
         assert (torch.cat([p["logits_train"] for p in grp]) - emb).abs().max().item() < 1e-3
