@@ -56,9 +56,11 @@ class WholeGraphRunner:
         self.N = x.size(0)
         self.lo, self.hi = 0, self.N
         self._params = list(self.model.parameters())
-        self._fused_adam = device.type == "cuda"
-        self.opt = torch.optim.Adam(self._params, lr=lr, weight_decay=weight_decay,
-                                    **({"fused": True} if self._fused_adam else {}))
+        # torch.optim.Adam exactly as experiment() builds it on one GPU (itexperiments.py: capturable; reference :391) — not the
+        # fused flavour the partitioned runners take: the training rank then produces the SAME BITS as a one-GPU run
+        # (same kernels, same optimizer arithmetic), and two GPUs return the model one GPU returns
+        self._fused_adam = False
+        self.opt = torch.optim.Adam(self._params, lr=lr, weight_decay=weight_decay, capturable=device.type == "cuda")
         self._epochs_done = 0
         self.host_enqueue_s = 0.0
 
@@ -119,7 +121,9 @@ class TaskSplitRunner:
         self.lo, self.hi, self.N = self.inner.lo, self.inner.hi, self.inner.N
         self.masks, self.y, self.mask_counts = self.inner.masks, self.inner.y, self.inner.mask_counts
         self.engine = None
-        self._state = [p.data for p in self.model.parameters()] + [b.data for b in self.model.buffers()]
+        # the tensors themselves, not their .data aliases: an alias has a version counter of its own, and what is cached
+        # per parameter version (folded eval operands, transposed weights) must see the eval ranks' copies arrive
+        self._state = list(self.model.parameters()) + list(self.model.buffers())
         self._bns = [m for m in self.model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
         self._spec = None          # loss share of a step computed ahead
         self._spec_bn = None       # its BatchNorm buffers, set aside until the step is accepted
@@ -136,13 +140,14 @@ class TaskSplitRunner:
             ts = [t for t in self._state if t.is_floating_point() == floats]
             if not ts:
                 continue
-            flat = torch.cat([t.reshape(-1).to(torch.float32 if floats else torch.int64) for t in ts])
+            flat = torch.cat([t.detach().reshape(-1).to(torch.float32 if floats else torch.int64) for t in ts])
             self._broadcast(flat)
             if self.role == "eval":
                 off = 0
-                for t in ts:
-                    t.copy_(flat[off:off + t.numel()].view_as(t))  # copy_ moves the version counters: caches follow
-                    off += t.numel()
+                with torch.no_grad():
+                    for t in ts:
+                        t.copy_(flat[off:off + t.numel()].view_as(t))  # copy_ moves the version counters: caches follow
+                        off += t.numel()
 
     def _broadcast(self, flat):
         if self.world.backend == "nccl" or not flat.is_cuda:

@@ -373,9 +373,9 @@ def test_experiment_runs_as_one_of_several_ranks(model_name, tmp_path):
 def test_experiment_takes_the_task_split_where_it_pays(tmp_path):
     """experiment() with an APPNP stack of 40 classes on 4 ranks: 4 column slices of 10 floats would fall below the
     128-byte line, two groups of 2 ranks do not (dist.tasksplit.pays) — ranks 0-1 train, ranks 2-3 evaluate, every rank
-    returns the same history, metrics (each test row counted once) and weights; same training as 2 plain ranks."""
+    returns the same history, metrics (each test row counted once) and weights; same training as 3 plain ranks."""
     runs = {}
-    for world in (4, 2):
+    for world in (4, 3):
         mp.spawn(W.experiment_worker, args=(world, _free_port(), str(tmp_path), "appnpstack", False, 40), nprocs=world,
                  join=True)
         runs[world] = [torch.load(os.path.join(tmp_path, f"exp_appnpstack_{world}_{r}.pt")) for r in range(world)]
@@ -386,10 +386,10 @@ def test_experiment_takes_the_task_split_where_it_pays(tmp_path):
                 assert other["history"][key] == first["history"][key], key
             for k, v in first["state"].items():
                 assert torch.equal(v, other["state"][k]), k
-    a, b = runs[4][0], runs[2][0]
+    a, b = runs[4][0], runs[3][0]
     assert a["distributed"]["test_rows"] == b["distributed"]["test_rows"]  # both groups hold every row: one reports
     assert [p["distributed"]["task_split_role"] for p in runs[4]] == ["train", "train", "eval", "eval"]
-    assert runs[2][0]["distributed"]["task_split_role"] is None
+    assert runs[3][0]["distributed"]["task_split_role"] is None
     assert np.allclose(a["history"]["train_loss"], b["history"]["train_loss"], rtol=0, atol=2e-5)
     assert np.allclose(a["history"]["val_loss"], b["history"]["val_loss"], rtol=0, atol=3e-2)
     assert abs(a["metrics"]["ACC"] - b["metrics"]["ACC"]) <= 0.11

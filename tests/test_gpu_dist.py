@@ -100,9 +100,15 @@ def test_experiment_as_several_ranks_matches_one_gpu(model_name, tmp_path):
                        need_to_reappear=True, print_print=False, return_model=True, need_all_metrics=True,
                        remake_data_mask=False, use_hip_graph=False)
     a, b = parts[0]["history"], one["history"]
-    assert max(abs(p - q) for p, q in zip(a["train_loss"], b["train_loss"])) < 1e-4
-    assert max(abs(p - q) for p, q in zip(a["val_loss"], b["val_loss"])) < 5e-3
-    assert abs(parts[0]["metrics"]["ACC"] - one["ACC"]) < 0.02
+    # two ranks split the epoch by task, each on the whole graph with the single-GPU kernels and the same optimizer
+    # (dist.tasksplit.WholeGraphRunner): the training rank's weights are the one-GPU run's bit for bit; the eval rank
+    # reads its loss from the last layer's kernel where experiment() on one GPU reads materialised log-probabilities
+    assert a["train_loss"] == b["train_loss"]
+    assert max(abs(p - q) for p, q in zip(a["val_loss"], b["val_loss"])) < 1e-5, (a["val_loss"], b["val_loss"])
+    assert parts[0]["metrics"]["ACC"] == one["ACC"]
+    sd = one["model"].state_dict()
+    for k, v in parts[0]["state"].items():
+        assert torch.equal(v, sd[k].cpu()), k
 
 
 @pytest.mark.parametrize("model_name,world,exchange", [("gcn_grid", 2, "reshard"), ("graphsage_grid", 4, "2x2")])
