@@ -489,7 +489,12 @@ class DistGraph:
         if self._pieces_fixed or self.comm.world == 1 or self.exchange == "halo":
             return self.pieces
         self.costs(d)
-        return self._choice.get(("pieces", d, self.scheme(d)), self.pieces)
+        n = self._choice.get(("pieces", d, self.scheme(d)), self.pieces)
+        # The cost model prices the last outbound piece as exposed. A schedule that interleaves other work with the
+        # exchanges (dist/stack.py: the eval pair, the step computed ahead) hides it anyway and only pays for the extra
+        # launches and exchanges: `auto_pieces_cap` (set by DistRunner for that schedule; measured: DESIGN.md 4.4)
+        cap = getattr(self, "auto_pieces_cap", None)
+        return n if cap is None else min(n, cap)
 
     def shape(self, d):
         """(R, C) of the grid scheme a propagate of width d uses, or None for the halo scheme."""

@@ -83,6 +83,12 @@ class DistRunner:
                                           cache_input_aggregate=cache_input_aggregate, src_split=src_split)
             # the schedule moves views (the list form of all-to-all): one small exchange with a known answer first — a
             # backend / build that does not deliver them as assumed must fail HERE, loudly, not train on wrong rows
+            if self.engine is not None and self.interleave_evals:
+                # under the interleaved schedule 2 outbound pieces beat the cost model's 4 at every link rate and latency
+                # replayed: fewer, longer slice launches, and the pieces' exchanges are hidden by other
+                # generators' work rather than by the next piece
+                for g in self.graphs.values():
+                    g.auto_pieces_cap = 2
             if self.engine is not None and not self.comm.self_test_views(device):
                 raise RuntimeError("dist: the view all-to-all self-test failed on this backend (rows did not arrive "
                                    "where the fused schedule expects them); run with fused=False (bench.py --no-fused)")
