@@ -462,7 +462,9 @@ class GridStack:
             sp, bn = S[i], self.bns[i - 1]
             stats = yield from self._bn_statistics_g(bn, h, cs, speculative)
             mean, rstd, scale, shift, n = stats
-            u = yield from self._propagate_g(i, "fwd", blk, inbound, landed=True)  # (the statistics' all-reduce yielded)
+            # layer 1's inbound pieces were issued behind layer 0's launches and the statistics' all-reduce has just
+            # yielded: they have landed; a deeper layer issues its exchange inside _propagate_g and yields it as usual
+            u = yield from self._propagate_g(i, "fwd", blk, inbound, landed=inbound is not None)
             inbound = None
             pre = (scale, shift, self.rowsum())
             root = dict(x_root=h, wt_root=wt(sp.Wr)) if sp.Wr is not None else {}
