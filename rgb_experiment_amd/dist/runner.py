@@ -167,8 +167,9 @@ class DistRunner:
         loss.backward()
         return loss.detach().double().reshape(1)
 
-    def _optimizer_step(self):
-        self._sync_grads()
+    def _optimizer_step(self, grads_reduced=False):
+        if not grads_reduced:
+            self._sync_grads()
         self.opt.step()
         if self.engine is not None:
             self.engine.note_optimizer_step()
@@ -282,7 +283,7 @@ class DistRunner:
         if self._spec is not None:  # the step computed ahead during the previous epoch's eval forwards
             tl, self._spec = self._spec, None
             self.engine.accept_speculation()
-            self._optimizer_step()
+            self._optimizer_step(grads_reduced=True)  # (reduced at the end of the call that computed them, see below)
         else:
             tl = self.train_step(sync=False)
         # the first epoch builds what the eval forwards use lazily (cost tables, plans / CSRs of widths only the
@@ -291,6 +292,10 @@ class DistRunner:
         if self.interleave_evals and self.engine is not None and more and self.pipeline:
             self.model.eval()
             v, s, self._spec = self.engine.eval_pair_and_next_step(1, 2)
+            # the gradient all-reduce of the step computed ahead goes out NOW, behind this epoch's work, instead of at the
+            # top of the next call, where the queue is empty and every launch is paid at the host's pace (it touches the
+            # gradient buffer only: a dropped step drops it too)
+            self._sync_grads()
         elif self.interleave_evals and self.engine is not None:
             # fused schedule: the two forwards interleaved on ONE thread and stream (GridStack.eval_pair)
             self.model.eval()
