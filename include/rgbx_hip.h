@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define RGBX_VERSION 310 /* major*10000 + minor*100 + patch */
+#define RGBX_VERSION 311 /* major*10000 + minor*100 + patch */
 
 #define RGBX_OK 0
 #define RGBX_E_ARG (-1)    /* null pointer / negative size / bad enum */
@@ -478,6 +478,15 @@ int rgbx_masked_nll_bwd_f32(const int64_t* y, const uint8_t* mask, int64_t N, in
 int rgbx_masked_ce_fwd_f32(const float* logits, int64_t ld, const int64_t* y, const uint8_t* mask, int64_t N,
                            int64_t C, double* stats, double* scratch, int64_t scratch_doubles,
                            rgbx_stream_t stream);
+
+/* The same statistics from BLOCKED logits (+ bias[c], optional): element (i, c) at logits + (c / blk_cols) * blk_stride
+ * + i * blk_cols + c % blk_cols, the layout a node-partitioned run's exchange delivers (rgbx_fused_layer_t) — the eval
+ * forward's loss straight from the received column slices (new capability: the reference is single-device,
+ * itexperiments.py:246; the arithmetic is itexperiments.py:624-626 on models/gcn.py:29-31). Only the selected rows are
+ * read. C % 4 == 0, C <= 256, blk_cols % 4 == 0 dividing C. */
+int rgbx_masked_ce_fwd_blocked_f32(const float* logits, int64_t blk_cols, int64_t blk_stride, const float* bias,
+                                   const int64_t* y, const uint8_t* mask, int64_t N, int64_t C, double* stats,
+                                   double* scratch, int64_t scratch_doubles, rgbx_stream_t stream);
 
 /* grad[i,c] = scale[0] * (softmax(z_i)[c] - [c == y[i]]) for selected rows, 0 otherwise: the gradient of
  * scale * stats[0] w.r.t. the logits, one pass. `scale` is a device scalar. */

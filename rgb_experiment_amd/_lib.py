@@ -84,6 +84,7 @@ SIGNATURES = {
     "rgbx_masked_nll_scratch_doubles": [_I64, _I, ctypes.POINTER(ctypes.c_int64)],
     "rgbx_masked_nll_fwd_f32": [_P, _I64, _P, _P, _I64, _I64, _P, _P, _I64, _I, _P],
     "rgbx_masked_ce_fwd_f32": [_P, _I64, _P, _P, _I64, _I64, _P, _P, _I64, _P],
+    "rgbx_masked_ce_fwd_blocked_f32": [_P, _I64, _I64, _P, _P, _P, _I64, _I64, _P, _P, _I64, _P],
     "rgbx_masked_ce_bwd_f32": [_P, _I64, _P, _P, _I64, _I64, _P, _P, _I64, _P],
     "rgbx_masked_nll_bwd_f32": [_P, _P, _I64, _I64, _P, _P, _I64, _P],
     "rgbx_gather_rows_f32": [_P, _I64, _P, _I64, _I64, _P, _I64, _P],

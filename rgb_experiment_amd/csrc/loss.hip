@@ -224,9 +224,15 @@ __device__ __forceinline__ void group_lse_argmax(const float (&v)[4], int c, int
   lse = best + logf(s);
 }
 
+// BLK: the logits are BLOCKED (element (i, c) at z + (c / bc) * bs + i * bc + c % bc: column slices as a node-partitioned
+// run's exchange delivers them, rgbx_fused_layer_t) and `bias` [C] is added on the fly — the eval forwards of the fused
+// per-rank schedule whose last transform ran before the exchange read their loss statistics straight from the received
+// slices: only the SELECTED rows are touched, no pass turns all rows into row-major logits first.
+template <bool BLK>
 __global__ void __launch_bounds__(256)
 ce_fwd_vec_kernel(const float* __restrict__ z, int64_t ld, const int64_t* __restrict__ y,
-                  const uint8_t* __restrict__ mask, int64_t N, int C, int lpr, double* __restrict__ partials) {
+                  const uint8_t* __restrict__ mask, int64_t N, int C, int lpr, double* __restrict__ partials,
+                  int64_t bc, int64_t bs, const float* __restrict__ bias) {
   __shared__ double sh[4];
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -251,14 +257,28 @@ ce_fwd_vec_kernel(const float* __restrict__ z, int64_t ld, const int64_t* __rest
         if (k == grp) myrow = r;
       }
       float v[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* row = z + (base + (myrow >= 0 ? myrow : 0)) * ld;
-      if (myrow >= 0 && c < C) load_vec<4>(v, row + c);
+      const int64_t ri = base + (myrow >= 0 ? myrow : 0);
+      const float* row = z + ri * ld;
+      if (myrow >= 0 && c < C) {
+        if constexpr (BLK) {
+          load_vec<4>(v, z + (int64_t)(c / (int)bc) * bs + ri * bc + (c % (int)bc));
+          if (bias) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += bias[c + k];
+          }
+        } else {
+          load_vec<4>(v, row + c);
+        }
+      }
       float lse;
       int arg;
       group_lse_argmax(v, c, C, lpr, lse, arg);
       const int tr = __shfl(t, myrow >= 0 ? myrow : 0);
       if (myrow >= 0 && c == 0) {
-        loss += (double)(lse - row[tr]);
+        float zt;
+        if constexpr (BLK) zt = z[(int64_t)(tr / (int)bc) * bs + ri * bc + (tr % (int)bc)] + (bias ? bias[tr] : 0.f);
+        else zt = row[tr];
+        loss += (double)(lse - zt);
         cnt += 1.0;
         hit += arg == tr ? 1.0 : 0.0;
       }
@@ -418,11 +438,39 @@ extern "C" int rgbx_masked_ce_fwd_f32(const float* logits, int64_t ld, const int
   if (C % 4 == 0 && C <= 256 && ld % 4 == 0 && aligned16(logits)) {
     int lpr = 1;
     while (lpr * 4 < C) lpr *= 2;
-    ce_fwd_vec_kernel<<<grid, 256, 0, s>>>(logits, ld, y, mask, N, (int)C, lpr, scratch);
+    ce_fwd_vec_kernel<false><<<grid, 256, 0, s>>>(logits, ld, y, mask, N, (int)C, lpr, scratch, 0, 0, nullptr);
   } else {
     ce_fwd_kernel<<<grid, 256, 0, s>>>(logits, ld, y, mask, N, (int)C, scratch);
   }
   RGBX_CHECK_LAUNCH("ce_fwd_kernel");
+  nll_finish_kernel<<<1, 256, 0, s>>>(scratch, grid, stats);
+  RGBX_CHECK_LAUNCH("nll_finish_kernel");
+  return RGBX_OK;
+}
+
+extern "C" int rgbx_masked_ce_fwd_blocked_f32(const float* logits, int64_t blk_cols, int64_t blk_stride,
+                                              const float* bias, const int64_t* y, const uint8_t* mask, int64_t N,
+                                              int64_t C, double* stats, double* scratch, int64_t scratch_doubles,
+                                              rgbx_stream_t stream) {
+  if (N < 0 || C <= 0 || !stats) return fail(RGBX_E_ARG, "masked_ce_fwd_blocked: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0) {
+    RGBX_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(double), s));
+    return RGBX_OK;
+  }
+  if (!logits || !y) return fail(RGBX_E_ARG, "masked_ce_fwd_blocked: null pointer");
+  if (C % 4 || C > 256 || blk_cols <= 0 || blk_cols % 4 || C % blk_cols || blk_stride % 4 || !aligned16(logits))
+    return fail(RGBX_E_SHAPE, "masked_ce_fwd_blocked: needs C %% 4 == 0, C <= 256, block width %% 4 == 0 dividing C, "
+                              "16-byte aligned blocks (got C=%lld, blk_cols=%lld)", (long long)C, (long long)blk_cols);
+  int64_t need = 0;
+  if (int rc = rgbx_masked_nll_scratch_doubles(N, 1, &need)) return rc;
+  if (!scratch || scratch_doubles < need)
+    return fail(RGBX_E_WS, "masked_ce_fwd_blocked: scratch %lld < %lld doubles", (long long)scratch_doubles, (long long)need);
+  const int grid = (int)(need / 3);
+  int lpr = 1;
+  while (lpr * 4 < C) lpr *= 2;
+  ce_fwd_vec_kernel<true><<<grid, 256, 0, s>>>(logits, 0, y, mask, N, (int)C, lpr, scratch, blk_cols, blk_stride, bias);
+  RGBX_CHECK_LAUNCH("ce_fwd_vec_kernel (blocked)");
   nll_finish_kernel<<<1, 256, 0, s>>>(scratch, grid, stats);
   RGBX_CHECK_LAUNCH("nll_finish_kernel");
   return RGBX_OK;

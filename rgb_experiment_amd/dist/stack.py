@@ -104,6 +104,12 @@ class HipStackBackend:
         from .. import ops
         return ops.masked_ce_accuracy(logits, y, mask)
 
+    def ce_stats_blocked(self, blk, bias, y, mask):
+        """The same of logits = received slices + bias, read in place (selected rows only; C % 4 == 0, C <= 256: what
+        GridStack.build admits for the last layer)."""
+        from .. import ops
+        return ops.masked_ce_accuracy_blocked(blk, y, mask, bias=bias)
+
 
 class LayerSpec:
     """What GridStack needs of one conv layer: aggregation kind, rewrite mode, the parameters and how they enter
@@ -631,8 +637,8 @@ class GridStack:
             u = yield from self._propagate_g(i, "fwd", prev_blk, inbound)
             inbound = None
             root = dict(x_root=prev_blk, wt_root=wtr) if wtr is not None else {}
-            if i == L - 1 and wt is None:  # the transform ran before the exchange: logits = aggregate + bias
-                st = be.ce_stats(be.blocked_to_rows(u, bias=b), self.y, self.masks[which])
+            if i == L - 1 and wt is None:  # the transform ran before the exchange: logits = aggregate + bias, and the
+                st = be.ce_stats_blocked(u, b, self.y, self.masks[which])  # statistics read the received slices in place
                 return st[::2]
             if i == L - 1:
                 _, _, st = be.layer(u, wt, bias=b, ce=(self.y, self.masks[which], None), kind="return_linear_fwd", **root)

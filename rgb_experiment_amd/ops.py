@@ -1410,6 +1410,30 @@ def masked_ce_accuracy(logits, y, mask=None):
     return _ce_stats(logits, y, mask)[0]
 
 
+def masked_ce_accuracy_blocked(blk, y, mask=None, bias=None):
+    """masked_ce_accuracy of logits held BLOCKED ([B, n, C / B]: the column slices a node-partitioned run's exchange
+    delivers) plus `bias` per column, read in place — only the selected rows are touched (rgbx_masked_ce_fwd_blocked_f32)."""
+    _lib.require_device(blk, y, mask, bias)
+    if y.dtype != torch.int64:
+        raise RuntimeError(f"labels must be int64, got {y.dtype}")
+    if mask is not None and mask.dtype not in (torch.bool, torch.uint8):
+        raise RuntimeError(f"mask must be bool, got {mask.dtype}")
+    ptr, bc, bs = _blocked(blk, "logits")
+    n, C = blk.size(1), blk.size(0) * blk.size(2)
+    lib = _lib.load()
+    stats = torch.empty(3, dtype=torch.float64, device=blk.device)
+    n_scr = ctypes.c_int64(0)
+    _lib.check(lib.rgbx_masked_nll_scratch_doubles(n, 1, ctypes.byref(n_scr)), "rgbx_masked_nll_scratch_doubles")
+    scratch = torch.empty(n_scr.value, dtype=torch.float64, device=blk.device)
+    y = y.contiguous()
+    mask = None if mask is None else mask.contiguous()
+    b = None if bias is None else bias.detach().contiguous()
+    _lib.check(lib.rgbx_masked_ce_fwd_blocked_f32(ptr, bc, bs, _lib.ptr(b), _lib.ptr(y), _lib.ptr(mask), n, C,
+                                                  _lib.ptr(stats), _lib.ptr(scratch), n_scr.value, _lib.stream_ptr()),
+               "rgbx_masked_ce_fwd_blocked_f32")
+    return stats
+
+
 def masked_nll_accuracy(logp, y, mask=None):
     """(sum of -logp[i,y_i], selected-row count, correct arg-max count) as a float64 device tensor [3]."""
     logp = logp.detach()

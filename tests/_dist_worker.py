@@ -128,6 +128,9 @@ class TorchStackBackend:
     def run(self, handle, x, kind):
         return self.agg.run(handle, x)
 
+    def ce_stats_blocked(self, blk, bias, y, mask):
+        return self.ce_stats(_rows_of(blk) + bias, y, mask)
+
     def rows_ok(self, handle):
         """RGBX_TEST_HUB_RANK = r: rank r behaves like one whose CSRs carry a hub-row plan (no row-range launches) —
         which ranks do depends on the graph, and the schedule's collectives must not."""

@@ -860,6 +860,31 @@ def test_fused_kernel_takes_hub_rows_from_the_split_row_kernels(dev, K, n_out, k
     assert (xg.grad - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("C,B", [(128, 4), (32, 2), (64, 1), (96, 8)])
+def test_cross_entropy_statistics_from_blocked_logits(dev, C, B):
+    """rgbx_masked_ce_fwd_blocked_f32: [nll sum, selected rows, hits] of logits held as column slices (+ bias), read in
+    place, against the row-major kernel on the unpacked rows and against torch; row ranges of a bigger blocked buffer
+    (block stride > rows x cols), masks selecting few / all / no rows, labels out of range skipped."""
+    from rgb_experiment_amd import ops
+    n = 5000
+    gen = torch.Generator().manual_seed(C + B)
+    big = torch.randn(B, n + 200, C // B, generator=gen).to(dev)
+    blk = big[:, 100:100 + n]  # a view: the blocks are n x cols, 'block stride' is the base's
+    bias = torch.randn(C, generator=gen).to(dev)
+    y = torch.randint(-1, C + 1, (n,), generator=gen).to(dev)  # -1 and C: never selected
+    rows = ops.blocked_to_rows(blk, bias=bias)
+    for mask in (torch.rand(n, generator=gen).to(dev) < 0.2, None, torch.zeros(n, dtype=torch.bool, device=dev)):
+        got = ops.masked_ce_accuracy_blocked(blk, y, mask, bias=bias)
+        want = ops.masked_ce_accuracy(rows, y, mask)
+        assert got[1].item() == want[1].item() and got[2].item() == want[2].item()
+        assert abs(got[0].item() - want[0].item()) <= 1e-9 * max(1.0, abs(want[0].item()))
+        sel = (y >= 0) & (y < C) & (mask if mask is not None else torch.ones_like(y, dtype=torch.bool))
+        ref = torch.nn.functional.cross_entropy(rows[sel].double(), y[sel], reduction="sum").item() if sel.any() else 0.0
+        assert abs(got[0].item() - ref) < 1e-3 * max(1.0, abs(ref)) and got[1].item() == sel.sum().item()
+    nob = ops.masked_ce_accuracy_blocked(blk, y, None)
+    assert abs(nob[0].item() - ops.masked_ce_accuracy(ops.blocked_to_rows(blk), y, None)[0].item()) < 1e-6 * abs(nob[0].item())
+
+
 def _hub_graph(n, seed, hub_in=40000, hub_mid=3000, hub_out=15000, e=200000):
     gen = torch.Generator().manual_seed(seed)
     rnd = torch.randint(0, n, (2, e), generator=gen)
