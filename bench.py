@@ -665,8 +665,10 @@ def dist_alg_bytes(dgraph, kind, d, N, n_loc, world, K=10, replica=None):
             continue
         plan = gst["plan"]
         dc = d // C
-        if pieces == 1 and C == world:  # the APPNP plan: K whole-graph launches at width d / P
-            per = K * (spmm_alg_bytes(N, plan.fwd.nnz, dc) + N * 4 * dc)
+        if pieces == 1 and C == world:  # the APPNP plan: K whole-graph launches at width d / P (K - 1 when the last
+            # step returns in pieces: those launches are recorded as dist_*_colshard, below)
+            steps = K - 1 if getattr(dgraph, "_appnp_return_pieces", 1) > 1 else K
+            per = steps * (spmm_alg_bytes(N, plan.fwd.nnz, dc) + N * 4 * dc)
             out.update({"dist_fwd_appnp_colshard": per, "dist_bwd_appnp_colshard": per})
         else:
             for direction, half in (("fwd", plan.fwd), ("bwd", plan.bwd)):

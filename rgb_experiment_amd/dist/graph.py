@@ -151,6 +151,10 @@ class DistGraph:
     """
 
     is_distributed = True
+    # APPNP under the transpose: the last of the K steps returns in pieces behind their aggregation (_appnp_columns);
+    # False = all K steps in one call and one outbound exchange (round 2's form)
+    appnp_return_in_pieces = True
+    _appnp_return_pieces = 1
 
     def __init__(self, edge_index, num_nodes, loops_mode, comm=None, backend=None, exchange="auto", pieces=None):
         self.edge_index, self.N_global, self.loops_mode = edge_index, int(num_nodes), loops_mode
@@ -386,6 +390,17 @@ class DistGraph:
         P = self.comm.world
         half, handle = self._grid_half("gcn", P, 1, direction)
         cols = self._to_column_slice(h, 1, P)
+        m = self.pieces_for(h.size(1)) if (K >= 1 and self.appnp_return_in_pieces) else 1
+        if m > 1:
+            # The LAST step's aggregation runs over the piece-major CSR and returns piece by piece, each piece's exchange
+            # in flight while the next is aggregated (_aggregate_and_return, as every grid propagate): (m - 1) / m of the
+            # outbound transpose leaves the critical path. The teleport term of that step is the owner's business:
+            # z_K[own rows] = (1 - alpha) (A_hat z_{K-1})[own rows] + alpha h[own rows], on rows it holds anyway.
+            self._appnp_return_pieces = m
+            z = self.backend.appnp(handle, cols, K - 1, alpha, kind=f"dist_{direction}_appnp_colshard") if K > 1 else cols
+            half_m, handle_m = self._grid_half("gcn", P, m, direction)
+            ret = self._aggregate_and_return(half_m, handle_m, z, f"dist_{direction}_colshard")
+            return torch.add(h * alpha, ret, alpha=1.0 - alpha)
         out = self.backend.appnp(handle, cols, K, alpha, kind=f"dist_{direction}_appnp_colshard")
         n_loc, dc = self.n_local, out.size(1)
         back, work = self.comm.all_to_all_rows(out, self.row_counts, [n_loc] * P, tag="out 1/1")
