@@ -57,3 +57,19 @@ def test_latency_per_exchange_and_per_epoch_averages():
     assert abs(at["exposed_ms_per_epoch"] - 0.2) < 1e-9
     _, at = _replay(trace, steps=2, latency_us=50.0)
     assert abs(at["exposed_ms_per_epoch"] - 0.25) < 1e-9
+
+
+def test_where_the_epoch_is_split_by_task():
+    """dist.tasksplit.pays: every model at two ranks (one link between two GPUs: no partition scheme pays), APPNP stacks
+    on an even number of >= 4 ranks whose P column slices fall below 32 floats while P / 2 slices keep 16; nothing else."""
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import tasksplit
+    appnp = M.APPNPStack(hidden_unit=16, input_dim=12, output_dim=128, K=10, alpha=0.1, dropout_rate=0.5)
+    gcn = M.GCN(num_layers=2, hidden_unit=128, input_dim=128, output_dim=128, dropout_rate=0.5)
+    assert tasksplit.pays(gcn, 2) and tasksplit.pays(appnp, 2)
+    assert tasksplit.pays(appnp, 8) and tasksplit.pays(appnp, 6)          # 16- / 21-float slices; halves keep 32 / 42
+    assert not tasksplit.pays(appnp, 4) and not tasksplit.pays(appnp, 7)  # 32-float slices already; odd world
+    assert not tasksplit.pays(gcn, 8) and not tasksplit.pays(gcn, 4)
+    small = M.APPNPStack(hidden_unit=16, input_dim=12, output_dim=40, K=10, alpha=0.1, dropout_rate=0.5)
+    assert tasksplit.pays(small, 4) and not tasksplit.pays(small, 8)      # 40 classes: 10-float slices; 8 ranks: halves keep 10 only
+    assert tasksplit.pays(appnp, 8, width=128) and not tasksplit.pays(appnp, 8, width=512)
