@@ -17,7 +17,7 @@ class DistRunner:
 
     def __init__(self, model, edge_index, x, y, masks, rank, world, device, lr=0.01, weight_decay=0.0,
                  comm=None, backend=None, exchange="auto", resident_features=True, pieces=None,
-                 interleave_evals=True, fused=True, pieces_in=1, cache_input_aggregate=False, src_split=False,
+                 interleave_evals=True, fused=True, pieces_in=2, cache_input_aggregate=False, src_split=False,
                  pipeline=True):
         self.comm = comm or Comm()
         self.rank, self.world, self.device = rank, world, device
