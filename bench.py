@@ -417,11 +417,10 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
     ei_d, x_d, y_d = ei.to(dev), x.to(dev), y.to(dev)
     tm, vm, sm = (m.to(dev) for m in masks)
     # torch.optim.Adam as the reference builds it (itexperiments.py:391), in its fused form: one multi-tensor launch per
-    # step instead of seven. The fused step writes the parameters without moving their version counters, so what is
-    # cached per parameter version (ops.weight_t) is dropped after every step (drop_weight_cache).
+    # step instead of seven. The fused step writes the parameters without moving their version counters: the package's
+    # global optimizer post-hook (ops.note_weights_changed) retires what is cached per parameter state (ops.weight_t).
     params = list(model.parameters())
     opt = torch.optim.Adam(params, lr=0.01, fused=True)
-    drop_weight_cache = lambda: [p.__dict__.pop("_rgbx_wt", None) for p in params]
     graph = get_graph(ei_d, N, loops_mode)  # graph preparation happens once per edge_index, outside the loop
     _ = graph.bwd
     if kind == "gcn":
@@ -454,7 +453,6 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
         loss = masked_ce(model, fwd, y_d, tm)[0]  # = NLLLoss(log_softmax(model(x)['emb'])[mask], y[mask])
         loss.backward()
         opt.step()
-        drop_weight_cache()
         val, tst = evaluate(vm), evaluate(sm)
         s = torch.cat([loss.detach().double().reshape(1), val, tst]).tolist()  # the one host sync of the epoch
         return s[0], s[1] / s[2], s[3] / s[2], s[4] / s[5], s[6] / s[5]
@@ -466,7 +464,6 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
         loss = masked_ce(model, fwd, y_d, tm)[0]
         loss.backward()
         opt.step()
-        drop_weight_cache()
         return loss.detach()  # not the loss itself: a kept autograd graph would outlive the step (and the later capture)
 
     def graphed():

@@ -173,9 +173,8 @@ class DistRunner:
         self.opt.step()
         if self.engine is not None:
             self.engine.note_optimizer_step()
-        if self._fused_adam:  # the fused step writes the parameters without moving their version counters: whatever
-            for p in self._params:  # is cached per parameter version (ops.weight_t) must not survive it
-                p.__dict__.pop("_rgbx_wt", None)
+        # (a fused step writes the parameters without moving their version counters: ops.note_weights_changed, the
+        # global optimizer post-hook, retires what is cached per parameter state)
 
     def discard_speculation(self):
         """Drop the next epoch's training step if epoch(more=True) has computed one ahead (a loop that stops early,

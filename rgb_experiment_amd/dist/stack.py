@@ -526,9 +526,10 @@ class GridStack:
         b' = b scale + shift): made once per parameter state — the val and the test forward of an epoch share them."""
         # keyed by the training steps taken (a fused Adam step and the BatchNorm kernels write through raw pointers:
         # version counters do not see them) and, for changes from outside (load_state_dict), by the version counters
+        from .. import ops
         self._commit_if_due()
         tensors = [p for p in self.model.parameters()] + [t for bn in self.bns for t in (bn.running_mean, bn.running_var)]
-        key = (self._steps, self._opt_steps) + tuple(t._version for t in tensors)
+        key = (self._steps, self._opt_steps, ops.weights_epoch()) + tuple(t._version for t in tensors)
         if self._folded[0] != key:
             out = []
             L = len(self.specs)

@@ -19,6 +19,7 @@ Same five numbers per epoch as DistRunner.epoch, same arithmetic per step."""
 import torch
 import torch.distributed as dist
 
+from .. import ops
 from .comm import Comm, EmulatedComm
 from .runner import DistRunner
 
@@ -73,10 +74,7 @@ class WholeGraphRunner:
         return loss.detach().double().reshape(1)
 
     def _optimizer_step(self):
-        self.opt.step()
-        if self._fused_adam:  # see DistRunner._optimizer_step
-            for p in self._params:
-                p.__dict__.pop("_rgbx_wt", None)
+        self.opt.step()  # ops.note_weights_changed (global optimizer post-hook) retires the cached W^T
 
     def evaluate(self, which, sync=False):
         from ..models._stack import masked_ce
@@ -201,9 +199,7 @@ class TaskSplitRunner:
             v, s = zeros(2), zeros(2)
         else:
             self._hand_over()
-            if getattr(r, "_fused_adam", False):  # parameters written from outside: what is cached per version follows,
-                for p in r._params:               # what is cached per training step (none here) would not
-                    p.__dict__.pop("_rgbx_wt", None)
+            ops.note_weights_changed()  # parameters written from outside (broadcast into raw storage)
             r.model.eval()
             if r.interleave_evals and r._epochs_done > 0:
                 v, s = r._interleaved_evals()

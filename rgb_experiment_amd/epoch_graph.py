@@ -88,10 +88,9 @@ class GraphedEpoch:
 
     def run(self):
         self.graph.replay()
-        # a replay updates the parameters without moving their Python-side version counters: anything cached per
-        # parameter version (ops.weight_t) must not survive it
-        for p in self.net.parameters():
-            p.__dict__.pop("_rgbx_wt", None)
+        # a replay updates the parameters without moving their Python-side version counters and without running
+        # optimizer hooks: retire what is cached per parameter state (ops.weight_t, _eval_operands)
+        ops.note_weights_changed()
         s = self.stats.tolist()  # the one host sync of the epoch
         out = []
         for nll, cnt, correct in s:

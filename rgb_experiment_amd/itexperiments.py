@@ -11,9 +11,11 @@ dict / Correct & Smooth post-processing (reference :514-534). Out of scope and r
 Deliberate deviations from reference quirks:
   * ``compare_pred_label(need_all_metrics=False)`` returns zeros instead of raising
     ``UnboundLocalError`` (reference :658-664).
-  * the mask-validity test is ``not (valid_list or valid_tensor)``; the reference's
-    ``(not valid_list) or (not valid_tensor)`` (:210) is always true, so it remade masks always.
-    Pass ``remake_data_mask=True`` for the reference behaviour.
+
+Same results by default, fix as an opt-in: with ``specify_data=True`` the reference ALWAYS remakes the masks — its
+test ``(not valid_list) or (not valid_tensor)`` (:210) is true for every input, masks cannot be lists and tensors at
+once — and so does this function. ``keep_valid_data_mask=True`` (an addition) applies the test the code was
+evidently meant to make, ``not (valid_list or valid_tensor)``, and keeps supplied masks that pass it.
 """
 import os
 import random
@@ -117,6 +119,15 @@ def _masks_usable(data):
     return False
 
 
+def _must_remake_masks(data, remake_data_mask, keep_valid_data_mask):
+    """reference :210 `remake_data_mask or (not mask_exist) or (not valid_list) or (not valid_tensor)`: the last two
+    terms cannot both be false, so the reference remakes the masks of a supplied `data` on every call. The default
+    here is that behaviour; keep_valid_data_mask=True (opt-in fix) keeps masks that exist and are valid."""
+    if remake_data_mask or not keep_valid_data_mask:
+        return True
+    return not _masks_usable(data)
+
+
 def _as_bool_mask(mask, n, device):
     """The reference accepts masks as index lists, index tensors or boolean tensors (:193-209); the loop
     works on boolean masks of length N."""
@@ -178,6 +189,7 @@ def experiment(model_init_param: dict, *,
                num_train_per_class: int = 20, num_val: int = 500, num_test: int = 1000,
                dataset_split_seed: int = 123456789,
                specify_data: bool = False, data: Data = None, remake_data_mask: bool = False,
+               keep_valid_data_mask: bool = False,
                to_undirected_graph: bool = False,
                normalize_feature: str = None, normalize_feature_method: str = None,
                pta_loss_decay: float = 0.05,
@@ -252,7 +264,7 @@ def experiment(model_init_param: dict, *,
                      num_train_per_class=num_train_per_class, num_val=num_val, num_test=num_test).data
     else:
         data = data.clone()
-        if remake_data_mask or not _masks_usable(data):
+        if _must_remake_masks(data, remake_data_mask, keep_valid_data_mask):
             say("re-splitting the dataset (train/val/test masks)")
             data.train_mask, data.val_mask, data.test_mask = _make_masks(
                 data.y.cpu(), dataset_split_mode, dataset_split_ratio, num_train_per_class, num_val, num_test,

@@ -162,10 +162,12 @@ def _eval_operands(self):
     """Per conv layer the operands of its eval forward — W'^T, b', Wr'^T with the eval-mode BatchNorm behind the layer
     folded in (rgbx_fold_bn_linear_f32, one launch per layer) — or None for layers without that form. Made once per
     model state and shared by the val and the test forward of an epoch: keyed by the training forwards taken (BatchNorm's
-    kernels update the running statistics through raw pointers, and a fused optimizer step does not move version
-    counters either) plus every parameter's / buffer's version counter (load_state_dict and the like)."""
+    kernels update the running statistics through raw pointers), by ops.weights_epoch() (a fused optimizer step does not
+    move version counters; every optimizer step of the process moves that counter) plus every parameter's / buffer's
+    version counter (load_state_dict and the like)."""
     tensors = list(self.parameters()) + list(self.buffers())
-    key = (getattr(self, "_train_forwards", 0),) + tuple((t._version, t.data_ptr()) for t in tensors)
+    from .. import ops
+    key = (getattr(self, "_train_forwards", 0), ops.weights_epoch()) + tuple((t._version, t.data_ptr()) for t in tensors)
     cached = getattr(self, "_folded_eval", None)
     if cached is None or cached[0] != key:
         last = self.num_layers - 1

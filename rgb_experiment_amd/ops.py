@@ -169,16 +169,39 @@ def fused_linear_ok(graph, in_channels, out_channels, root=False, x=None):
     return bool(_lib.load().rgbx_spmm_linear_supported(in_channels, out_channels, int(root)))
 
 
+_WEIGHTS_EPOCH = [0]
+
+
+def note_weights_changed(*_args, **_kwargs):
+    """Parameters may have been written without their Python-side version counters moving: a fused / foreach /
+    capturable optimizer step (torch.optim.Adam(fused=True) writes through raw pointers), the replay of a captured
+    hipGraph. Everything this package caches per parameter state (weight_t, ConvStack._eval_operands,
+    dist.stack's folded operands) carries this counter in its key, so nothing made before the write is served after
+    it. Registered below as a GLOBAL optimizer step post-hook: every torch.optim step of the process bumps it,
+    whoever built the optimizer — a module of this package inside a foreign training loop needs no cooperation."""
+    _WEIGHTS_EPOCH[0] += 1
+
+
+def weights_epoch():
+    return _WEIGHTS_EPOCH[0]
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_post_hook  # noqa: E402
+
+_register_step_post_hook(note_weights_changed)
+
+
 def weight_t(weight):
     """W^T as the contiguous [K, Nout] operand rgbx_spmm_linear_f32 reads (its B fragments run along Nout). For an
-    nn.Parameter the transposed copy is kept on the parameter and reused until the parameter changes (in-place
-    version counter + storage address), instead of one `.t().contiguous()` per launch; temporaries (weights with a
-    folded BatchNorm) and launches being captured into a hipGraph (replays do not move version counters) always
-    transpose."""
+    nn.Parameter the transposed copy is kept on the parameter and reused until the parameter may have changed: the
+    in-place version counter, the storage address AND weights_epoch() (every optimizer step of the process, every
+    hipGraph replay of epoch_graph) are its tag, instead of one `.t().contiguous()` per launch; temporaries (weights
+    with a folded BatchNorm) and launches being captured into a hipGraph always transpose. Not seen: writes through
+    `param.data` outside an optimizer (a fresh version counter by PyTorch's rules) — call note_weights_changed()."""
     w = weight.detach()
     if not isinstance(weight, torch.nn.Parameter) or (w.is_cuda and torch.cuda.is_current_stream_capturing()):
         return w.t().contiguous()
-    tag = (weight._version, w.data_ptr(), tuple(w.shape))
+    tag = (weight._version, _WEIGHTS_EPOCH[0], w.data_ptr(), tuple(w.shape))
     cached = getattr(weight, "_rgbx_wt", None)
     if cached is None or cached[0] != tag:
         cached = (tag, w.t().contiguous())

@@ -370,7 +370,7 @@ def experiment_worker(rank, world, port, out_dir, model_name, on_gpu=False, clas
     params["hidden_unit"] = 32
     res = R.experiment(params, specify_data=True, data=data, model_name=model_name, learning_rate=0.01, epoch=6,
                        need_to_reappear=True, print_print=False, return_model=True, need_all_metrics=True,
-                       remake_data_mask=False)
+                       keep_valid_data_mask=True)
     torch.save({"metrics": {k: res[k] for k in ("ACC", "precision_score", "recall_score", "f1_macro", "f1_micro")},
                 "history": res["history"], "distributed": res["distributed"],
                 "state": {k: v.cpu().clone() for k, v in res["model"].state_dict().items()}},

@@ -98,7 +98,7 @@ def test_experiment_as_several_ranks_matches_one_gpu(model_name, tmp_path):
     params["hidden_unit"] = 32
     one = R.experiment(params, specify_data=True, data=data, model_name=model_name, learning_rate=0.01, epoch=6,
                        need_to_reappear=True, print_print=False, return_model=True, need_all_metrics=True,
-                       remake_data_mask=False, use_hip_graph=False)
+                       keep_valid_data_mask=True, use_hip_graph=False)
     a, b = parts[0]["history"], one["history"]
     # two ranks split the epoch by task, each on the whole graph with the single-GPU kernels and the same optimizer
     # (dist.tasksplit.WholeGraphRunner): the training rank's weights are the one-GPU run's bit for bit; the eval rank

@@ -1704,6 +1704,64 @@ def test_transposed_weight_cache_follows_the_parameter(dev):
     assert (eager.cpu() - O.gcn_forward(sd, x.cpu(), ei.cpu(), 2, False)["emb"]).abs().max().item() < TOL
 
 
+def test_fused_adam_outside_experiment(dev):
+    """A maintainer's own module and loop (the reference's models/gcn.py with the conv import
+    swapped) with torch.optim.Adam(fused=True), which writes the parameters through raw pointers and leaves their
+    version counters alone: nothing cached per parameter state (W^T of ops.weight_t, the folded eval operands) may
+    survive a step, with no cooperation from the loop. Three steps; train-mode logits of every step and the final
+    eval logits against the oracle's autograd run of the same three Adam steps."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.nn import GCNConv
+
+    class Net(torch.nn.Module):  # shaped like the reference's GCN (models/gcn.py:11-31); nothing of this package's stack
+        def __init__(self, f, hid, c):
+            super().__init__()
+            self.convs = torch.nn.ModuleList([GCNConv(f, hid), GCNConv(hid, c)])
+            self.bns = torch.nn.ModuleList([torch.nn.BatchNorm1d(hid)])
+
+        def forward(self, x, edge_index):
+            x = self.bns[0](self.convs[0](x, edge_index))
+            x = self.convs[1](x, edge_index)
+            return {"out": torch.log_softmax(x, dim=1), "emb": x}
+
+    n, f, hid, c = 3000, 64, 128, 16
+    gen = torch.Generator().manual_seed(11)
+    ei = rand_graph(n, 40000, 11, loops=5, dups=5)
+    x = torch.randn(n, f, generator=gen)
+    y = torch.randint(0, c, (n,), generator=gen)
+    torch.manual_seed(14530529)
+    net = Net(f, hid, c)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net.to(dev)
+    xd, eid, yd = x.to(dev), ei.to(dev), y.to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=0.01, fused=True)
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    ref_opt = torch.optim.Adam([v for v in ref_sd.values() if v.requires_grad], lr=0.01)
+    versions = [p._version for p in net.parameters()]
+    for step in range(3):
+        net.train()
+        opt.zero_grad()
+        out = net(xd, eid)
+        torch.nn.functional.nll_loss(out["out"], yd).backward()
+        opt.step()
+        ref_opt.zero_grad()
+        ref = O.gcn_forward(ref_sd, x, ei, 2, True)
+        torch.nn.functional.nll_loss(ref["out"], y).backward()
+        ref_opt.step()
+        assert (out["emb"].detach().cpu() - ref["emb"].detach()).abs().max().item() < TOL, step
+        net.eval()
+        with torch.no_grad():  # an eval forward between the steps, as the reference loop takes (itexperiments.py:464)
+            ev = net(xd, eid)["emb"].cpu()
+        ev_sd = {k: v.detach() for k, v in ref_sd.items()}  # the oracle keeps no running statistics: the module's own
+        ev_sd.update({k: v.cpu() for k, v in net.state_dict().items() if "running_" in k})
+        ref_ev = O.gcn_forward(ev_sd, x, ei, 2, False)["emb"]
+        assert (ev - ref_ev).abs().max().item() < 5 * TOL, step  # three Adam steps of rounding apart at most
+    w = net.convs[1].lin.weight
+    assert torch.equal(ops.weight_t(w), w.detach().t().contiguous())
+    if [p._version for p in net.parameters()] == versions:  # the hazard this test is about was live on this build
+        assert ops.weights_epoch() >= 3
+
+
 @pytest.mark.parametrize("graphed", [False, True])
 def test_shared_eval_forward_changes_nothing_but_the_forward_count(dev, graphed):
     """share_eval_forward=True: per-epoch test metrics from the val pass's outputs (the reference forwards a second

@@ -146,10 +146,36 @@ def test_experiment_mask_remake_rules():
     m = torch.zeros(60, dtype=torch.bool)
     d.train_mask, d.val_mask, d.test_mask = m.clone(), m.clone(), m.clone()
     d.train_mask[:30], d.val_mask[30:45], d.test_mask[45:] = True, True, True
-    from rgb_experiment_amd.itexperiments import _masks_usable
+    from rgb_experiment_amd.itexperiments import _masks_usable, _must_remake_masks
     assert _masks_usable(d)
+    # default = the reference (:210, a condition that is always true): supplied masks are remade, valid or not
+    assert _must_remake_masks(d, False, False) and _must_remake_masks(d, True, False)
+    # the opt-in fix keeps valid masks; remake_data_mask still wins
+    assert not _must_remake_masks(d, False, True) and _must_remake_masks(d, True, True)
     d.val_mask = None
-    assert not _masks_usable(d)
+    assert not _masks_usable(d) and _must_remake_masks(d, False, True)
+
+
+def test_experiment_remakes_supplied_masks_by_default():
+    """Same inputs, same results as the reference: with specify_data=True the masks the run uses are
+    get_whole_mask(y, ratio, seed) (reference :210-215), whatever the Data object carried."""
+    from rgb_experiment_amd.utils import get_whole_mask
+    d = _toy()
+    m = torch.zeros(60, dtype=torch.bool)
+    d.train_mask, d.val_mask, d.test_mask = m.clone(), m.clone(), m.clone()
+    d.train_mask[:2], d.val_mask[2:4], d.test_mask[4:6] = True, True, True  # 2 rows each: would show in the result
+    kw = dict(specify_data=True, model_name="MLP", epoch=3, learning_rate=0.01, use_cpu=True, print_print=False,
+              need_to_reappear=True, return_model=True)
+    res = R.experiment({"num_layers": 2, "hidden_unit": 8, "dropout_rate": 0.5}, data=d, **kw)
+    want = get_whole_mask(d.y, "6-2-2", 123456789)
+    assert int(want[2].sum()) > 2
+    fresh = _toy()
+    fresh.train_mask, fresh.val_mask, fresh.test_mask = want
+    kept = R.experiment({"num_layers": 2, "hidden_unit": 8, "dropout_rate": 0.5}, data=fresh,
+                        keep_valid_data_mask=True, **kw)
+    assert res["history"]["train_loss"] == kept["history"]["train_loss"] and res["ACC"] == kept["ACC"]
+    own = R.experiment({"num_layers": 2, "hidden_unit": 8, "dropout_rate": 0.5}, data=d, keep_valid_data_mask=True, **kw)
+    assert own["history"]["train_loss"] != res["history"]["train_loss"]  # the 2-row masks were honoured here
 
 
 def test_rd2pd_roundtrip(tmp_path):
@@ -243,7 +269,7 @@ def test_experiment_refuses_masks_that_select_unlabelled_nodes():
     d.test_mask[45:] = True
     with pytest.raises(RuntimeError, match="label is outside"):
         R.experiment({"num_layers": 2, "hidden_unit": 8, "dropout_rate": 0.5}, specify_data=True, data=d,
-                     model_name="MLP", epoch=2, use_cpu=True, print_print=False)
+                     model_name="MLP", epoch=2, use_cpu=True, print_print=False, keep_valid_data_mask=True)
 
 
 def test_experiment_accepts_index_list_masks():
@@ -251,7 +277,8 @@ def test_experiment_accepts_index_list_masks():
     d = _toy()
     d.train_mask, d.val_mask, d.test_mask = list(range(0, 30)), list(range(30, 45)), list(range(45, 60))
     res = R.experiment({"num_layers": 2, "hidden_unit": 8, "dropout_rate": 0.5}, specify_data=True, data=d,
-                       model_name="MLP", epoch=3, learning_rate=0.01, use_cpu=True, print_print=False)
+                       model_name="MLP", epoch=3, learning_rate=0.01, use_cpu=True, print_print=False,
+                       keep_valid_data_mask=True)
     assert 0.0 <= res["ACC"] <= 1.0
     from rgb_experiment_amd.itexperiments import _as_bool_mask
     m = _as_bool_mask([1, 3], 5, "cpu")
