@@ -26,6 +26,9 @@
  *                         graphsage.py:24,29; gat.py:23,29; appnp_stack.py:21,27), forward and backward.
  *   rgbx_masked_nll_*     nn.NLLLoss on out[mask] and the arg-max accuracy (itexperiments.py:400,
  *                         429,434,624-626,643).
+ *   rgbx_coalesce_* / rgbx_split_edge_keys_i64
+ *                         the one-shot edge-list edits in front of the path: torch_sparse.coalesce
+ *                         (rd2pd.py:92-93) and torch_geometric.utils.to_undirected (itexperiments.py:235-238) [PyG].
  *   rgbx_gather_rows_f32 / rgbx_scatter_add_rows_f32
  *                         halo pack / unpack for the 1-D node partition (new capability; the
  *                         reference is single-device, itexperiments.py:246).
@@ -51,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RGBX_VERSION 311 /* major*10000 + minor*100 + patch */
+#define RGBX_VERSION 400 /* major*10000 + minor*100 + patch */
 
 #define RGBX_OK 0
 #define RGBX_E_ARG (-1)    /* null pointer / negative size / bad enum */
@@ -492,6 +495,23 @@ int rgbx_masked_ce_fwd_blocked_f32(const float* logits, int64_t blk_cols, int64_
  * scale * stats[0] w.r.t. the logits, one pass. `scale` is a device scalar. */
 int rgbx_masked_ce_bwd_f32(const float* logits, int64_t ld, const int64_t* y, const uint8_t* mask, int64_t N,
                            int64_t C, const float* scale, float* grad, int64_t ldg, rgbx_stream_t stream);
+
+/* ---- edge-list ingest (before the path: rd2pd.py:92-93, itexperiments.py:235-238) ------------ */
+
+/* Sorted set of the pairs (row[e], col[e]) — with `mirror` != 0 also of their reverses (col[e], row[e]): coalesce and
+ * to_undirected. Two steps because the caller owns the output and its size is only known on the device:
+ *   1. rgbx_coalesce_keys_i64 writes the distinct keys row * N + col in ascending order to keys_out (capacity
+ *      M = mirror ? 2E : E) and counts[0] = their number, counts[1] = number of endpoints outside [0, N) (those are
+ *      clamped; a caller that sees counts[1] != 0 must discard the result). counts: 2 x uint64 on the device.
+ *   2. after reading counts[0] back and allocating int64 [2, count], rgbx_split_edge_keys_i64 writes the rows
+ *      (cap = the caller's capacity; min(cap, counts[0]) pairs are written).
+ * Workspace: rgbx_coalesce_workspace_bytes(E, N, mirror). Self-loops are kept (once), as both PyG helpers do. */
+int rgbx_coalesce_workspace_bytes(int64_t E, int64_t N, int mirror, size_t* bytes);
+int rgbx_coalesce_keys_i64(const int64_t* row, const int64_t* col, int64_t E, int64_t N, int mirror,
+                           uint64_t* keys_out, uint64_t* counts, void* workspace, size_t workspace_bytes,
+                           rgbx_stream_t stream);
+int rgbx_split_edge_keys_i64(const uint64_t* keys, const uint64_t* counts, int64_t cap, int64_t N, int64_t* out_row,
+                             int64_t* out_col, rgbx_stream_t stream);
 
 /* ---- halo pack / unpack (multi-GPU node partition) ----------------------------------------- */
 

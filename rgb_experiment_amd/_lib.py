@@ -87,6 +87,9 @@ SIGNATURES = {
     "rgbx_masked_ce_fwd_blocked_f32": [_P, _I64, _I64, _P, _P, _P, _I64, _I64, _P, _P, _I64, _P],
     "rgbx_masked_ce_bwd_f32": [_P, _I64, _P, _P, _I64, _I64, _P, _P, _I64, _P],
     "rgbx_masked_nll_bwd_f32": [_P, _P, _I64, _I64, _P, _P, _I64, _P],
+    "rgbx_coalesce_workspace_bytes": [_I64, _I64, _I, ctypes.POINTER(ctypes.c_size_t)],
+    "rgbx_coalesce_keys_i64": [_P, _P, _I64, _I64, _I, _P, _P, _P, ctypes.c_size_t, _P],
+    "rgbx_split_edge_keys_i64": [_P, _P, _I64, _I64, _P, _P, _P],
     "rgbx_gather_rows_f32": [_P, _I64, _P, _I64, _I64, _P, _I64, _P],
     "rgbx_scatter_add_rows_f32": [_P, _I64, _P, _I64, _I64, _P, _I64, _P],
 }

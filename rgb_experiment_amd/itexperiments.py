@@ -270,9 +270,6 @@ def experiment(model_init_param: dict, *,
                 data.y.cpu(), dataset_split_mode, dataset_split_ratio, num_train_per_class, num_val, num_test,
                 dataset_split_seed)
 
-    if to_undirected_graph:  # reference :235-238
-        data.edge_index = to_undirected(data.edge_index, num_nodes=data.num_nodes)
-
     # ---- device (reference :246-258): the message-passing path is HIP-only -------------------
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if distributed is None:  # one of several ranks a launcher started, and a model with a node-partitioned form
@@ -289,6 +286,8 @@ def experiment(model_init_param: dict, *,
     device = dist_ctx.device if dist_ctx is not None else torch.device(
         f"cuda:{cuda_index}" if (torch.cuda.is_available() and not use_cpu) else "cpu")
     data = data.to(device)
+    if to_undirected_graph:  # reference :235-238 (there on the CPU, before .to(device)); here on the run's device: the
+        data.edge_index = to_undirected(data.edge_index, num_nodes=data.num_nodes)  # HIP radix sort + unique on a GPU
     features = data.x
     if normalize_feature in ("row", "col", "all"):
         features = _normalize_features(features, normalize_feature, normalize_feature_method)

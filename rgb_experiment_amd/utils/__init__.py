@@ -1,6 +1,6 @@
 """Host-side helpers around the hot path: split masks (bit-exact with the reference's seeded splitters, golden
-G4), node-induced subgraphs (golden G5) and edge-list edits that run as torch ops on whichever device holds the
-edge list."""
+G4), node-induced subgraphs (golden G5) and the edge-list edits in front of the path (utils/edges.py: on a device
+tensor coalesce / to_undirected run in the HIP library, csrc/ingest.hip)."""
 from . import edges, mask, subgraph
 
 # split masks (reference utils/mask.py)

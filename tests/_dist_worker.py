@@ -386,6 +386,12 @@ def build_model(M, name, f, c):
         cls, layers = {"gcn_grid": (M.GCN, 2), "gcn3_grid": (M.GCN, 3), "graphsage_grid": (M.GraphSAGE, 2),
                        "graphsage2_grid": (M.GraphSAGE2, 3)}[name]
         return cls(num_layers=layers, hidden_unit=96, input_dim=f, output_dim=32, dropout_rate=0.5)
+    if name == "gcn_bench":  # the models bench.py times (in = hidden = classes = 128)
+        return M.GCN(num_layers=2, hidden_unit=128, input_dim=f, output_dim=c, dropout_rate=0.5)
+    if name == "graphsage_bench":
+        return M.GraphSAGE(num_layers=2, hidden_unit=128, input_dim=f, output_dim=c, dropout_rate=0.5)
+    if name == "appnpstack_bench":
+        return M.APPNPStack(hidden_unit=64, input_dim=f, output_dim=c, K=10, alpha=0.1, dropout_rate=0.5)
     if name == "gcn":
         return M.GCN(num_layers=3, hidden_unit=16, input_dim=f, output_dim=c, dropout_rate=0.5)
     if name == "graphsage":
@@ -399,6 +405,16 @@ def build_model(M, name, f, c):
     raise KeyError(name)
 
 
+def bench_problem_S():
+    """bench.py's workload S (BASELINE configs[1]: |V| = 200 k, |E| = 4 M, d = 128, 128 classes; same seeds)."""
+    n, e = 200_000, 4_000_000
+    ei = torch.randint(0, n, (2, e), generator=torch.Generator().manual_seed(1234567), dtype=torch.int64)
+    x = torch.randn(n, 128, generator=torch.Generator().manual_seed(1234568))
+    y = torch.randint(0, 128, (n,), generator=torch.Generator().manual_seed(1234569))
+    k = torch.arange(n) % 5
+    return ei, x, y, [k < 3, k == 3, k == 4]
+
+
 def hub_problem():
     """make_problem(n=5000, ...) plus two hub nodes: node 7 with 3000 extra in-edges, node 11 with 3000 extra
     out-edges — rows beyond LONG_ROW_SLOTS in the forward and in the transposed CSR (hub-row plans)."""
@@ -410,7 +426,7 @@ def hub_problem():
     return torch.cat([ei, extra], dim=1), x, y, masks
 
 
-def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", hub=False, ahead=True):
+def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", hub=False, ahead=True, size=None):
     """Rehearsal of the real per-rank HIP path: `world` ranks share cuda:0, collectives go through gloo
     with host staging (RCCL cannot put two ranks on one device). `ahead`: the first epoch announces the second
     (epoch(more=True): the fused schedule computes the second training step beside the first epoch's eval forwards)."""
@@ -418,7 +434,7 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", h
     from rgb_experiment_amd import models as M
     from rgb_experiment_amd.dist import Comm, DistRunner
     dev = torch.device("cuda:0")
-    ei, x, y, masks = hub_problem() if hub else make_problem(n=5000, e=60000, f=32, c=8)
+    ei, x, y, masks = bench_problem_S() if size == "S" else hub_problem() if hub else make_problem(n=5000, e=60000, f=32, c=8)
     torch.manual_seed(14530529)
     model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
     r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm(), exchange=exchange)

@@ -8,10 +8,15 @@ The PyG-dataflow oracle cannot hold these graphs ([E', d] temporaries of 32 GB),
     sampled target rows with the UNCHANGED oracle forward on the targets' in-neighbourhood (oracle/sampled.py);
   * APPNP at its stated K = 10 (whose ten hops cover the whole graph, so no neighbourhood can be cut out) is compared
     on ALL rows with ten iterations of the C restatement.
-Tolerance: 1e-4 absolute on logits (north_star)."""
+  * BACKWARD (reference itexperiments.py:439): one train-mode forward + backward of every BASELINE model, every
+    parameter's gradient — at S against the full oracle under torch autograd (its [E', d] temporaries fit the host
+    there), at L against oracle/large.py (propagate and its adjoint through the C restatement over the CSR and the
+    transposed CSR, dense layers / BatchNorm / loss under CPU autograd; pinned to ref_cpu by tests/test_oracle_large.py).
+Tolerance: 1e-4 absolute on logits (north_star); gradients 1e-4 * max(1, |g|_inf) AND 2e-3 relative to |g|_inf."""
 import pytest
 import torch
 
+from oracle import large as OL
 from oracle import ref_cpu as O
 from oracle import sampled as S
 
@@ -172,5 +177,92 @@ def test_model_logits_at_sampled_rows_of_the_benchmark_graph(dev, size, name):
     err = (got - want).abs().max().item()
     assert err < TOL, (name, size, err, info)
     del model, opt
+    clear_cache()
+    torch.cuda.empty_cache()
+
+
+# ---- backward at the BASELINE sizes -----------------------------------------------------------------------------
+
+GRAD_KW = dict(MODEL_KW, appnpstack=dict(hidden_unit=64, K=10, alpha=0.1, dropout_rate=0.5))  # config 5 as stated
+GRAD_TOL, GRAD_REL = 1e-4, 2e-3
+
+
+def _hip_training_step(dev, name, ei, x, y, mask, route):
+    """One train-mode forward + backward of the product model on the GPU. route 'kernel_loss': the loss inside the last
+    conv's kernel where the model has that form (what experiment() and bench.py run); 'logits': log-probabilities
+    materialised, NLLLoss on top (what a foreign loop runs). Returns (loss, {name: grad on the CPU}, initial state)."""
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.models._stack import masked_ce
+    cls = {"gcn": M.GCN, "graphsage": M.GraphSAGE, "graphsage2": M.GraphSAGE2, "gat": M.GAT,
+           "appnpstack": M.APPNPStack}[name]
+    torch.manual_seed(14530529)
+    model = cls(input_dim=128, output_dim=128, **GRAD_KW[name])
+    with torch.no_grad():  # biases and BatchNorm affine parameters off their zero / one initial values
+        g = torch.Generator().manual_seed(5)
+        for k, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(dev).train()
+    x_d, ei_d, y_d, m_d = x.to(dev), ei.to(dev), y.to(dev), mask.to(dev)
+    if route == "kernel_loss":
+        loss = masked_ce(model, {"x": x_d, "edge_index": ei_d}, y_d, m_d)[0]
+    else:
+        loss = torch.nn.functional.nll_loss(model(x_d, ei_d)["out"][m_d], y_d[m_d])
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
+    return float(loss.item()), grads, sd
+
+
+def _check(rep, loss, ref_loss, what):
+    print(f"gradient parity {what}: loss {loss:.7f} vs {ref_loss:.7f}; max |dg| {rep['max_abs']:.3e}, vs bound "
+          f"{rep['max_vs_bound']:.3e}, relative {rep['max_rel']:.3e} ({rep['worst']})")
+    assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (what, loss, ref_loss)
+    assert rep["max_vs_bound"] < GRAD_TOL, (what, rep)
+    assert rep["max_rel"] < GRAD_REL, (what, rep)
+
+
+@pytest.mark.parametrize("route", ["kernel_loss", "logits"])
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack"])
+def test_model_gradients_at_benchmark_size_S(dev, name, route):
+    """S (|V| = 200 k, |E| = 4 M, d = 128): every parameter gradient against the FULL oracle (oracle.ref_cpu, the PyG
+    dataflow under torch autograd: edge-sized temporaries of 2 GB each)."""
+    from rgb_experiment_amd.graph import clear_cache
+    ei, x, y = workload("S")
+    n = x.size(0)
+    mask = (torch.arange(n) % 5) < 3
+    loss, grads, sd = _hip_training_step(dev, name, ei, x, y, mask, route)
+    kw = GRAD_KW[name]
+    fwd = {"gcn": lambda p: O.gcn_forward(p, x, ei, 2, True), "graphsage": lambda p: O.graphsage_forward(p, x, ei, 2, True),
+           "graphsage2": lambda p: O.graphsage2_forward(p, x, ei, 2, True),
+           "gat": lambda p: O.gat_forward(p, x, ei, 2, kw.get("heads", 8), True),
+           "appnpstack": lambda p: O.appnp_stack_forward(p, x, ei, kw.get("K"), kw.get("alpha"), True)}[name]
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in sd.items()}
+    ref_loss = OL.masked_nll(fwd(ref_sd), y, mask)
+    ref_loss.backward()
+    rep = OL.compare_grads(grads, {k: v.grad for k, v in ref_sd.items() if v.requires_grad})
+    _check(rep, loss, ref_loss.item(), f"S {name} {route}")
+    clear_cache()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "appnpstack"])
+def test_model_gradients_at_benchmark_size_L(dev, name):
+    """L (|V| = 2 M, |E| = 60 M, d = 128; BASELINE configs 4 and 5 and the headline GCN): every parameter gradient
+    against oracle/large.py — propagate = C restatement over the CSR, its backward = the same over the transposed CSR,
+    dense layers / BatchNorm / loss under CPU autograd."""
+    from rgb_experiment_amd.graph import clear_cache
+    ei, x, y = workload("L")
+    n = x.size(0)
+    mask = (torch.arange(n) % 5) < 3
+    loss, grads, sd = _hip_training_step(dev, name, ei, x, y, mask, "kernel_loss")
+    torch.cuda.empty_cache()
+    graph = OL.graphs_for(name, ei, n, threads=O.c_threads())
+    kw = {k: v for k, v in GRAD_KW[name].items() if k in ("num_layers", "K", "alpha")}
+    ref_loss, ref_grads, _ = OL.loss_and_grads(name, sd, x, y, mask, graph, **kw)
+    rep = OL.compare_grads(grads, ref_grads)
+    _check(rep, loss, ref_loss, f"L {name}")
+    del graph
     clear_cache()
     torch.cuda.empty_cache()

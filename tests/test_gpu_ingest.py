@@ -1,0 +1,115 @@
+"""SURVEY 8(f3) on the device: the edge-list edits in front of the path — to_undirected (reference itexperiments.py:235-238),
+coalesce / remove_self_loops / add_remaining_self_loops (rd2pd.py:92-101) — on device tensors against the CPU result,
+BIT-EXACT (index work), from ragged toy cases to BASELINE sizes S and L (L mirrored + coalesced = 119 998 143 edges), and
+RD2PD's .npy triple -> Data -> get_graph end to end."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _cases():
+    g = torch.Generator().manual_seed(3)
+    yield "one edge", torch.tensor([[0], [1]]), 2
+    yield "one loop", torch.tensor([[0], [0]]), 1
+    yield "all duplicates", torch.tensor([[2, 2, 2, 2], [1, 1, 1, 1]]), 3
+    yield "already symmetric", torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]]), 3
+    for n, e in [(5, 40), (97, 900), (1000, 20000), (50000, 800000), (3, 500), (70000, 9)]:
+        ei = torch.randint(0, n, (2, e), generator=g)
+        loops = torch.randint(0, n, (7,), generator=g)
+        ei = torch.cat([ei, torch.stack([loops, loops]), ei[:, : e // 10]], dim=1)
+        yield f"random n={n} e={e}", ei[:, torch.randperm(ei.size(1), generator=g)], n
+
+
+@pytest.mark.parametrize("label,ei,n", list(_cases()), ids=[c[0] for c in _cases()])
+def test_edge_edits_on_the_device_are_bit_exact(dev, label, ei, n):
+    from rgb_experiment_amd import utils as U
+    d = ei.to(dev)
+    for fn in (lambda t: U.coalesce(t, n), lambda t: U.to_undirected(t, num_nodes=n), lambda t: U.to_undirected(t),
+               U.remove_self_loops, lambda t: U.add_remaining_self_loops(t, n)):
+        got, want = fn(d), fn(ei)
+        assert got.is_cuda and got.dtype == torch.int64 and got.is_contiguous()
+        assert torch.equal(got.cpu(), want), label
+    # composition, as rd2pd.py:92-101 applies them
+    got = U.add_remaining_self_loops(U.remove_self_loops(U.coalesce(d, n)), n)
+    want = U.add_remaining_self_loops(U.remove_self_loops(U.coalesce(ei, n)), n)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_edge_edits_empty_and_out_of_range(dev):
+    from rgb_experiment_amd import utils as U
+    empty = torch.empty((2, 0), dtype=torch.int64, device=dev)
+    assert U.coalesce(empty, 5).shape == (2, 0) and U.to_undirected(empty, num_nodes=5).shape == (2, 0)
+    bad = torch.tensor([[0, 7, 1], [1, 2, -1]], device=dev)
+    with pytest.raises(RuntimeError, match="outside"):
+        U.coalesce(bad, 5)
+    with pytest.raises(RuntimeError, match="outside"):
+        U.to_undirected(bad, num_nodes=5)
+    with pytest.raises(RuntimeError):
+        U.coalesce(torch.zeros((2, 3), dtype=torch.int32, device=dev), 5)
+
+
+@pytest.mark.parametrize("n,e", [(200_000, 4_000_000), (2_000_000, 60_000_000)])
+def test_edge_edits_at_benchmark_size(dev, n, e):
+    """bench.py's graphs S and L: to_undirected (the `undirected_same_run` block's input) and coalesce on the device
+    equal the CPU statement bit for bit; the CSR built from the device result equals the oracle's CSR of the CPU one."""
+    from rgb_experiment_amd import utils as U
+    from rgb_experiment_amd.graph import clear_cache, get_graph
+    ei = torch.randint(0, n, (2, e), generator=torch.Generator().manual_seed(1234567), dtype=torch.int64)
+    d = ei.to(dev)
+    und = U.to_undirected(d, num_nodes=n)
+    want = U.to_undirected(ei, num_nodes=n)
+    if n == 2_000_000:
+        assert want.size(1) == 119_998_143  # the figure DESIGN.md quotes for the undirected L graph
+    assert torch.equal(und.cpu(), want)
+    co = U.coalesce(d, n)
+    assert torch.equal(co.cpu(), U.coalesce(ei, n))
+    nl = U.remove_self_loops(d)
+    assert torch.equal(nl.cpu(), U.remove_self_loops(ei))
+    del co, nl
+    g = get_graph(und, n, 1)
+    rei, _ = O.rewrite_edges(want, n, 1)
+    rowptr, col, perm = O.csr_from_edges(rei[1], rei[0], torch.arange(rei.size(1)), n)
+    assert torch.equal(g.fwd.rowptr.cpu(), rowptr) and torch.equal(g.fwd.col.cpu(), col)
+    clear_cache()
+    torch.cuda.empty_cache()
+
+
+def test_rd2pd_npy_to_graph_on_the_device(dev, tmp_path):
+    """rd2pd.py:83-101 end to end: x int -> float, y -> long, edge_index -> long, the three edge edits, masks; with
+    device= the edits run in the HIP library and the Data lives on the GPU; get_graph on it equals the oracle's CSR of the
+    CPU-loaded Data."""
+    from rgb_experiment_amd import RD2PD
+    from rgb_experiment_amd.graph import clear_cache, get_graph
+    n, e = 30000, 400000
+    g = torch.Generator().manual_seed(8)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei = torch.cat([ei, ei[:, :5000], torch.arange(100).repeat(2, 1)], dim=1)
+    folder = tmp_path / "toy"
+    folder.mkdir()
+    np.save(folder / "x.npy", torch.randint(0, 3, (n, 16), generator=g).numpy().astype(np.int32))
+    np.save(folder / "y.npy", torch.randint(0, 6, (n,), generator=g).numpy().astype(np.int32))
+    np.save(folder / "edge_index.npy", ei.numpy().astype(np.int32))
+    kw = dict(dataset_name="toy", dataset_root=str(tmp_path), remove_duplicate_edges=True, remove_self_loop=True,
+              add_remaining_self_loop=True)
+    host = RD2PD(**kw).data
+    on_dev = RD2PD(device=dev, **kw).data
+    assert on_dev.x.is_cuda and on_dev.x.dtype == torch.float32 and on_dev.y.dtype == torch.int64
+    assert on_dev.edge_index.is_cuda and torch.equal(on_dev.edge_index.cpu(), host.edge_index)
+    for k in ("x", "y", "train_mask", "val_mask", "test_mask"):
+        assert torch.equal(getattr(on_dev, k).cpu(), getattr(host, k)), k
+    gr = get_graph(on_dev.edge_index, n, 1)
+    rei, w = O.gcn_norm(host.edge_index, None, n)
+    rowptr, col, perm = O.csr_from_edges(rei[1], rei[0], torch.arange(rei.size(1)), n)
+    assert torch.equal(gr.fwd.rowptr.cpu(), rowptr) and torch.equal(gr.fwd.col.cpu(), col)
+    assert (gr.w.cpu() - w[perm.long()]).abs().max().item() < 1e-6
+    clear_cache()

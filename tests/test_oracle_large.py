@@ -1,0 +1,72 @@
+"""oracle/large.py (the checker of the BASELINE-size gradient tests: propagate through the C restatement over a CSR, its
+adjoint over the transposed CSR) against oracle/ref_cpu.py (the PyG dataflow under torch autograd, pinned by the golden
+vectors), on graphs ref_cpu can hold: train-mode logits, loss and EVERY parameter gradient of the four models."""
+import pytest
+import torch
+
+from oracle import large as OL
+from oracle import ref_cpu as O
+
+CASES = {
+    "gcn": (lambda sd, x, ei, tr: O.gcn_forward(sd, x, ei, 2, tr), dict(num_layers=2)),
+    "graphsage": (lambda sd, x, ei, tr: O.graphsage_forward(sd, x, ei, 2, tr), dict(num_layers=2)),
+    "graphsage2": (lambda sd, x, ei, tr: O.graphsage2_forward(sd, x, ei, 2, tr), dict(num_layers=2)),
+    "appnpstack": (lambda sd, x, ei, tr: O.appnp_stack_forward(sd, x, ei, 10, 0.1, tr), dict(K=10, alpha=0.1)),
+}
+
+
+def _state(name, f, hid, c, gen):
+    r = lambda *s: torch.randn(*s, generator=gen) / max(s[-1], 1) ** 0.5
+    bn = lambda p, d: {p + "weight": 1 + 0.1 * r(d), p + "bias": 0.1 * r(d), p + "running_mean": torch.zeros(d),
+                       p + "running_var": torch.ones(d), p + "num_batches_tracked": torch.zeros((), dtype=torch.long)}
+    if name == "gcn":
+        sd = {"convs.0.lin.weight": r(hid, f), "convs.0.bias": 0.1 * r(hid), "convs.1.lin.weight": r(c, hid),
+              "convs.1.bias": 0.1 * r(c)}
+        sd.update(bn("bns.0.", hid))
+    elif name == "graphsage":
+        sd = {}
+        for i, (o, k) in enumerate([(hid, f), (c, hid)]):
+            sd.update({f"convs.{i}.lin_l.weight": r(o, k), f"convs.{i}.lin_l.bias": 0.1 * r(o),
+                       f"convs.{i}.lin_r.weight": r(o, k), f"convs.{i}.lin_r.bias": 0.1 * r(o)})
+        sd.update(bn("bns.0.", hid))
+    elif name == "graphsage2":
+        sd = {}
+        for i, (o, k) in enumerate([(hid, f), (c, hid)]):
+            sd.update({f"convs.{i}.lin_l.weight": r(o, k), f"convs.{i}.lin_l.bias": 0.1 * r(o),
+                       f"convs.{i}.lin_r.weight": r(o, k)})
+        sd.update(bn("bns.0.", hid))
+    else:
+        sd = {"lin1.weight": r(hid, f), "lin1.bias": 0.1 * r(hid), "lin2.weight": r(c, hid), "lin2.bias": 0.1 * r(c)}
+        sd.update(bn("bn.", hid))
+    return sd
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("n,e", [(300, 2500), (64, 40), (1, 0)])
+def test_large_graph_checker_equals_the_pinned_oracle(name, n, e):
+    gen = torch.Generator().manual_seed(n + e)
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    if e:  # self-loops and duplicates, the rewrite rules' cases
+        ei = torch.cat([ei, ei[:, :5], torch.arange(min(n, 4)).repeat(2, 1)], dim=1)
+    f, hid, c = 12, 16, 5
+    x = torch.randn(n, f, generator=gen)
+    y = torch.randint(0, c, (n,), generator=gen)
+    mask = torch.rand(n, generator=gen) < 0.6
+    mask[0] = True
+    sd = _state(name, f, hid, c, gen)
+    fwd, kw = CASES[name]
+    graph = OL.graphs_for(name, ei, n, threads=2)
+    loss, grads, emb = OL.loss_and_grads(name, sd, x, y, mask, graph, **kw)
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in sd.items()}
+    ref = fwd(ref_sd, x, ei, True)
+    ref_loss = OL.masked_nll(ref, y, mask)
+    ref_loss.backward()
+    assert (emb - ref["emb"].detach()).abs().max().item() < 2e-5
+    assert abs(loss - ref_loss.item()) < 1e-5
+    assert set(grads) == {k for k, v in ref_sd.items() if v.requires_grad}
+    for k, g in grads.items():
+        rg = ref_sd[k].grad
+        assert (g - rg).abs().max().item() < 2e-5 * max(1.0, rg.abs().max().item()), k
+    # eval mode too (running statistics)
+    ev = OL.forward(name, sd, x, graph, False, **kw)["emb"]
+    assert (ev - fwd(sd, x, ei, False)["emb"]).abs().max().item() < 2e-5
