@@ -125,16 +125,20 @@ def loss_and_grads(name, sd, x, y, mask, graph, **kw):
 
 def compare_grads(named_grads, ref_grads):
     """Per parameter max |g - g_ref|, relative to max(1, |g_ref|_inf) (the north-star style bound) and relative to
-    |g_ref|_inf alone (mean-reduced losses over 10^5..10^6 rows make small gradients: the second figure is the one a
-    wrong-but-small gradient cannot pass). Returns {'max_abs', 'max_vs_bound', 'max_rel', 'worst', 'per_param'}."""
+    the gradient's own scale (mean-reduced losses over 10^5..10^6 rows make small gradients: the second figure is the
+    one a wrong-but-small gradient cannot pass). The scale of a parameter is |g_ref|_inf, but not below 1 % of the
+    largest |g_ref|_inf of the model: a conv bias in front of a BatchNorm has a TRUE gradient of exactly zero and both
+    sides hold rounding noise there. Returns {'max_abs', 'max_vs_bound', 'max_rel', 'worst', 'per_param'}."""
     per, worst = {}, (0.0, None)
     assert set(named_grads) == set(ref_grads), (sorted(named_grads), sorted(ref_grads))
+    top = max([rg.abs().max().item() for rg in ref_grads.values() if rg.numel()] or [0.0])
     for k, rg in ref_grads.items():
         g = named_grads[k]
         assert g is not None and g.shape == rg.shape, k
         d = (g.double() - rg.double()).abs().max().item() if rg.numel() else 0.0
-        scale = rg.abs().max().item() if rg.numel() else 0.0
-        per[k] = {"abs": d, "ref_inf": scale, "rel": d / scale if scale > 0 else (0.0 if d == 0 else float("inf"))}
+        own = rg.abs().max().item() if rg.numel() else 0.0
+        scale = max(own, 0.01 * top)
+        per[k] = {"abs": d, "ref_inf": own, "rel": d / scale if scale > 0 else (0.0 if d == 0 else float("inf"))}
         if per[k]["rel"] > worst[0]:
             worst = (per[k]["rel"], k)
     return {"max_abs": max(v["abs"] for v in per.values()),

@@ -430,6 +430,9 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", h
     """Rehearsal of the real per-rank HIP path: `world` ranks share cuda:0, collectives go through gloo
     with host staging (RCCL cannot put two ranks on one device). `ahead`: the first epoch announces the second
     (epoch(more=True): the fused schedule computes the second training step beside the first epoch's eval forwards)."""
+    if size == "S" or os.environ.get("RGBX_TEST_DUMP_AFTER"):  # a stuck rank ends with the stacks of all its threads
+        import faulthandler                                     # on stderr instead of a silent hang of the test run
+        faulthandler.dump_traceback_later(int(os.environ.get("RGBX_TEST_DUMP_AFTER", "300")), exit=True)
     _init(rank, world, port)
     from rgb_experiment_amd import models as M
     from rgb_experiment_amd.dist import Comm, DistRunner
@@ -444,6 +447,8 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", h
                 "engine": r.engine is not None, "state": {k: v.cpu() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"gpu_{model_name}_{rank}.pt"))
     dist.destroy_process_group()
+    if size == "S" or os.environ.get("RGBX_TEST_DUMP_AFTER"):
+        faulthandler.cancel_dump_traceback_later()
 
 
 def gpu_tasksplit_worker(rank, world, port, out_dir, model_name, exchange="reshard"):

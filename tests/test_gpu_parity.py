@@ -1752,10 +1752,14 @@ def test_fused_adam_outside_experiment(dev):
         net.eval()
         with torch.no_grad():  # an eval forward between the steps, as the reference loop takes (itexperiments.py:464)
             ev = net(xd, eid)["emb"].cpu()
-        ev_sd = {k: v.detach() for k, v in ref_sd.items()}  # the oracle keeps no running statistics: the module's own
-        ev_sd.update({k: v.cpu() for k, v in net.state_dict().items() if "running_" in k})
-        ref_ev = O.gcn_forward(ev_sd, x, ei, 2, False)["emb"]
-        assert (ev - ref_ev).abs().max().item() < 5 * TOL, step  # three Adam steps of rounding apart at most
+        # eval logits against the oracle's forward of the module's OWN current state: a stale W^T / stale folded operand
+        # would show here at the size of one Adam step (lr = 0.01 per weight). (Against the oracle's independently trained
+        # weights the eval comparison is ill-conditioned: the conv bias in front of the BatchNorm has a true gradient of
+        # zero, Adam turns its rounding noise into +-lr steps, and running statistics do not cancel that shift; the
+        # train-mode logits above, where batch statistics do cancel it, are the comparison of the two trainings.)
+        own = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        ref_ev = O.gcn_forward(own, x, ei, 2, False)["emb"]
+        assert (ev - ref_ev).abs().max().item() < TOL, step
     w = net.convs[1].lin.weight
     assert torch.equal(ops.weight_t(w), w.detach().t().contiguous())
     if [p._version for p in net.parameters()] == versions:  # the hazard this test is about was live on this build
