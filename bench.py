@@ -375,6 +375,48 @@ def sampled_logit_parity(name, model, ei, x, x_d, ei_d, n_targets=None):
     return info
 
 
+def gradient_parity_S(dev, name="gcn"):
+    """BACKWARD parity at BASELINE workload S (|V| = 200 k, |E| = 4 M, d = 128; reference itexperiments.py:439): one
+    train-mode forward + backward of the benchmark's model on the GPU — loss inside the last conv's kernel, as the timed
+    region runs it — against the FULL oracle (oracle.ref_cpu: the PyG dataflow under torch autograd, 2 GB edge-sized
+    temporaries), every parameter's gradient. The L-size statement of the same check runs in `-m gpu`
+    (tests/test_gpu_fullsize.py::test_model_gradients_at_benchmark_size_L, against oracle/large.py)."""
+    from oracle import large as OL
+    from oracle import ref_cpu as O
+    from rgb_experiment_amd.graph import clear_cache
+    from rgb_experiment_amd.models._stack import masked_ce
+    t0 = time.perf_counter()
+    wl = WORKLOADS["S"]
+    ei, x, y = synth(wl["N"], wl["E"], wl["d"])
+    mask = split_masks(y)[0]
+    torch.manual_seed(14530529)
+    model = model_class(name)(input_dim=wl["d"], output_dim=wl["d"], **MODELS[name][0])
+    with torch.no_grad():  # biases / BatchNorm affine off their initial 0 / 1
+        g = torch.Generator().manual_seed(5)
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(dev).train()
+    loss = masked_ce(model, {"x": x.to(dev), "edge_index": ei.to(dev)}, y.to(dev), mask.to(dev))[0]
+    loss.backward()
+    grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
+    del model
+    clear_cache()
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in sd.items()}
+    torch.set_num_threads(host_cores())
+    ref_loss = OL.masked_nll(O.gcn_forward(ref_sd, x, ei, 2, True), y, mask)
+    ref_loss.backward()
+    rep = OL.compare_grads(grads, {k: ref_sd[k].grad for k in grads})
+    return {"workload": wl["name"], "loss_hip": float(loss.item()), "loss_oracle": float(ref_loss.item()),
+            "max_abs_grad_diff": rep["max_abs"], "max_grad_diff_over_max_1_ginf": rep["max_vs_bound"],
+            "max_rel_to_gradient_scale": rep["max_rel"], "worst_parameter": rep["worst"],
+            "tolerance": {"abs_over_max(1,|g|inf)": 1e-4, "relative": 2e-3}, "parameters": len(grads),
+            "seconds": time.perf_counter() - t0,
+            "what": "every parameter gradient of one training forward + backward (masked NLL on the G4 train split): "
+                    "HIP kernels vs oracle.ref_cpu under torch autograd on the CPU"}
+
+
 def appnp_full_graph_parity(model, ei, x, x_d, ei_d):
     """BASELINE config 5 as stated (APPNP K = 10, alpha = 0.1): eval-mode logits of ALL nodes of this run's trained
     APPNPStack against the same model on the CPU — dense layers in torch, the K propagates + teleport in the C
@@ -421,10 +463,18 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
     # global optimizer post-hook (ops.note_weights_changed) retires what is cached per parameter state (ops.weight_t).
     params = list(model.parameters())
     opt = torch.optim.Adam(params, lr=0.01, fused=True)
+    torch.cuda.synchronize()
+    t_ing = time.perf_counter()
     graph = get_graph(ei_d, N, loops_mode)  # graph preparation happens once per edge_index, outside the loop
     _ = graph.bwd
     if kind == "gcn":
         _ = graph.w, graph.w_t
+    torch.cuda.synchronize()
+    # int64 edge_index -> self-loop rewrite -> forward and transposed CSR (rgbx_csr_build: int32 radix
+    # sort) -> normalisation weights, once per edge_index (the reference redoes the rewrite + gcn_norm in every conv call)
+    ingest = {"csr_build_ms": (time.perf_counter() - t_ing) * 1e3,
+              "what": "rgbx_csr_build forward + transposed (stable int32 radix sort of E + N slots each) + degree "
+                      "normalisation + per-slot weights, wall clock with a device sync on both sides"}
     nnz_total = graph.fwd.nnz
     if kind == "gat":  # SURVEY §8d per-launch bytes, averaged over the 6 forward + 2 backward propagates
         alg = gat_alg_bytes(N, nnz_total, d)
@@ -473,8 +523,42 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
         gopt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
         return GraphedEpoch(model, gopt, {"x": x_d, "edge_index": ei_d}, y_d, (tm, vm, sm)).capture().run
 
+    def step_identical():
+        """The same epoch's five numbers with the two result-identical shortcuts experiment() takes by default
+        (share_eval_forward: val and test statistics from ONE eval forward — the reference's second eval forward,
+        itexperiments.py:470, recomputes the very same outputs; cache_input_aggregate is set on the model by the caller)."""
+        model.train()
+        opt.zero_grad()
+        loss = masked_ce(model, fwd, y_d, tm)[0]
+        loss.backward()
+        opt.step()
+        model.eval()
+        with torch.no_grad():
+            emb = model(**fwd)["emb"]
+            val, tst = ops.masked_ce_accuracy(emb, y_d, vm), ops.masked_ce_accuracy(emb, y_d, sm)
+        s = torch.cat([loss.detach().double().reshape(1), val, tst]).tolist()
+        return s[0], s[1] / s[2], s[3] / s[2], s[4] / s[5], s[6] / s[5]
+
+    def yardstick(reps=5):
+        """Box-speed yardstick: the PLAIN aggregation kernel (spmm_csr_kernel, no transform, no epilogue) over the same
+        forward CSR at the same width, timed with the same HIP events — a figure no fused-kernel change can move."""
+        w, rs = (graph.w, None) if kind == "gcn" else (None, graph.inv_deg) if kind == "mean" else (None, None)
+        sink = []
+        ops.spmm_raw(graph.fwd, w, rs, x_d, kind="yardstick")
+        ops.set_event_sink(sink)
+        for _ in range(reps):
+            ops.spmm_raw(graph.fwd, w, rs, x_d, kind="yardstick")
+        ops.set_event_sink(None)
+        torch.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) for _, a, b in sink)
+        return {"kernel": "spmm_csr_kernel", "avg_ms": sum(t) / len(t), "min_ms": t[0], "launches": len(t),
+                "what": "plain SpMM (no transform, no epilogue) over the same forward CSR, width d, same HIP-event timing"}
+
     step.graphed = graphed
     step.train_only = train_only
+    step.identical = step_identical
+    step.yardstick = yardstick
+    step.ingest = ingest
     step.device_inputs = (x_d, ei_d)
     return step, nnz_total, alg
 
@@ -516,7 +600,8 @@ def time_graphed(step, steps, warmup):
         return {"error": repr(exc)}
 
 
-def gcn_block(name, ei, x, y, dev, steps, warmup, d, note=None, replay=True, cache_input_aggregate=False):
+def gcn_block(name, ei, x, y, dev, steps, warmup, d, note=None, replay=True, cache_input_aggregate=False,
+              identical=False):
     """A 2-layer GCN epoch on another graph in the same process (secondary blocks of the line).
     `cache_input_aggregate`: the opt-in that keeps A_hat x of the static input features (4 aggregations per epoch, not
     7); `value` of that block counts the aggregations actually run."""
@@ -527,19 +612,24 @@ def gcn_block(name, ei, x, y, dev, steps, warmup, d, note=None, replay=True, cac
     model = model_class("gcn")(input_dim=d, output_dim=d, **MODELS["gcn"][0])
     model.cache_input_aggregate = cache_input_aggregate
     step, nnz, alg = build_single_gpu(model, ei, x, y, split_masks(y), dev, 1, "gcn", N, d)
+    ingest = step.ingest
+    if identical:  # share_eval_forward as well: one eval forward per epoch
+        step = step.identical
     for _ in range(warmup):
         step()
     events = []
     ops.set_event_sink(events)
     elapsed, _, per_step = time_steps(step, steps, 0)
     ops.set_event_sink(None)
-    n_prop = MODELS["gcn"][1] - (3 if cache_input_aggregate else 0)
+    n_prop = MODELS["gcn"][1] - (3 if cache_input_aggregate else 0) - (1 if identical and cache_input_aggregate else
+                                                                        2 if identical else 0)
     spmm_s = sum(s.elapsed_time(e) for k, s, e in events if k in AGG_KINDS) * 1e-3 / (n_prop * steps)
     out = {"workload": name, "edges_in": int(ei.size(1)), "edges_aggregated_per_propagate": nnz,
            "value": n_prop * nnz * steps / elapsed, "unit": "edges/s", "ms_per_step": elapsed / steps * 1e3,
            "median_ms_per_step": median(per_step), "epochs_per_s": steps / elapsed, "spmm_ms": spmm_s * 1e3,
-           "roofline_frac_algorithmic": alg / spmm_s / 1e9 / HBM_PEAK_GBS}
-    if replay:
+           "roofline_frac_algorithmic": alg / spmm_s / 1e9 / HBM_PEAK_GBS,
+           "aggregations_per_step": n_prop, "per_step_ms": [round(v, 3) for v in per_step], "ingest_ms": ingest}
+    if replay and not identical:
         out["hip_graph_replay"] = time_graphed(step, steps, warmup)
         if "ms_per_step" in out["hip_graph_replay"]:
             # what experiment() runs up to 20 M edges (use_hip_graph=True): the block's primary figure; the eager loop's
@@ -962,15 +1052,18 @@ def main():
 
     hbm_peak_gb = torch.cuda.max_memory_allocated(dev) / 1e9 if on_gpu else None  # structures + one epoch's tensors
     trace, events = events, [r for r in events if not r[0].startswith("@")]  # "@issue" / "@wait": the emulated comm's marks
-    by_kind = {}
+    by_kind, by_variant = {}, {}
     for k, s, e in events:
-        by_kind.setdefault(k, []).append(s.elapsed_time(e))
+        ms = s.elapsed_time(e)
+        by_kind.setdefault(str(k), []).append(ms)
+        if getattr(k, "variant", None) is not None:  # which form of the fused launch (ops.Kind)
+            by_variant.setdefault(f"{k}[{k.variant}]", []).append(ms)
     agg_total_ms = sum(sum(v) for k, v in by_kind.items() if k in AGG_KINDS)
     agg_total_ms *= args.steps / timed_steps_with_events  # scaled from the instrumented steps to all of them
     agg_avg_s = agg_total_ms * 1e-3 / (n_prop * args.steps)  # aggregation kernel time per propagate (this rank)
     dominant = max((k for k in by_kind if k in AGG_KINDS), key=lambda k: sum(by_kind[k]), default=None)
     kernel = KERNEL_OF_KIND.get(dominant, "none recorded")
-    achieved = None
+    achieved, roofline_launches = None, None
     if alg_by_kind and agg_total_ms:  # partitioned run: launches of different shapes, sum bytes over those made
         done = sum(alg_by_kind[k] * len(v) for k, v in by_kind.items() if k in alg_by_kind)
         achieved = done / (agg_total_ms * timed_steps_with_events / args.steps * 1e-3) / 1e9
@@ -988,9 +1081,18 @@ def main():
         elif dominant == "gat_linear_fwd":
             lin = gat_linear_launch_bytes(N, nnz_total, d)
             alg = (2 * lin["fwd_infer"] + lin["fwd_train"]) / 3
-        dom_s = sum(by_kind[dominant]) / len(by_kind[dominant]) / launches_per_event * 1e-3
+        # ONE convention for the dominant kernel's launch duration: the mean over EVERY launch of that kernel in the
+        # timed region (forward forms and the transposed launch alike: same kernel, same algorithmic bytes per launch),
+        # which for the conv stacks is what `spmm_ms` reports too
+        same_kernel = [k for k in by_kind if KERNEL_OF_KIND.get(k) == KERNEL_OF_KIND.get(dominant)
+                       and not dominant.startswith("gat")] or [dominant]
+        pooled = [v for k in same_kernel for v in by_kind[k]]
+        dom_s = sum(pooled) / len(pooled) / launches_per_event * 1e-3
         achieved = alg / dom_s / 1e9
+        roofline_launches = {"kinds": sorted(same_kernel), "launches_averaged": len(pooled)}
+    stat = lambda v: {"n": len(v), "avg_ms": sum(v) / len(v), "min_ms": min(v), "max_ms": max(v)}
     by_kind = {k: {"n": len(v), "avg_ms": sum(v) / len(v)} for k, v in sorted(by_kind.items())}
+    by_variant = {k: stat(v) for k, v in sorted(by_variant.items())}
     traffic, traffic_note = pmc_traffic(args.workload, args.model, kernel, parts)
     if args.degree != "uniform":
         traffic, traffic_note = None, "the committed PMC passes were taken on the uniform graph"
@@ -1027,13 +1129,17 @@ def main():
         "spmm_edges_per_s": nnz_total / agg_avg_s if parts == 1 and agg_avg_s else None,
         "spmm_ms": agg_avg_s * 1e3,
         "kernel_ms_by_kind": by_kind,
+        # the fused kernel's launches by FORM (template instantiation + what the launch also writes): z = the aggregate
+        # is stored for the weight gradient (+ N d 4 bytes), stats = BatchNorm column sums, pre = BatchNorm applied to
+        # the aggregate, ce_stats = loss statistics only (no output write), ce_grad = loss gradient written
+        "kernel_ms_by_variant": by_variant,
         "final_losses": {"train": last[0], "val": last[1], "test": last[3]},
         "hbm_allocated_peak_gb": hbm_peak_gb,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if achieved else None,
                      "traffic": traffic, "traffic_source": traffic_note,
                      "kernel": kernel, "kernel_source_hash": kernel_source_hash(kernel),
-                     "algorithmic_bytes_per_launch": alg,
+                     "algorithmic_bytes_per_launch": alg, "duration_over": roofline_launches,
                      "compulsory_bytes_per_launch": spmm_compulsory_bytes(N if parts == 1 else n_loc,
                                                                           nnz_total / group, d),
                      "note": ("an ideal 1/P share of one propagate" if parts > 1 and dgraph is not None
@@ -1102,6 +1208,19 @@ def main():
             if on_gpu:
                 torch.cuda.synchronize()
 
+    if parts == 1 and on_gpu:
+        result["ingest_ms"] = step.ingest
+
+        def yardstick_leg():
+            y = step.yardstick()
+            if y["avg_ms"] > 0:  # every form of the fused launch relative to the plain SpMM of the same box and run
+                y["launch_over_yardstick"] = {k: v["avg_ms"] / y["avg_ms"] for k, v in
+                                              {**by_kind, **by_variant}.items()
+                                              if KERNEL_OF_KIND.get(k.split("[")[0]) == "spmm_linear_kernel"}
+            return y
+        if kind in ("gcn", "mean", "sum"):
+            secondary("yardstick", yardstick_leg)
+
     if rank == 0 and parts == 1 and on_gpu and not args.no_cpu_baseline:
         x_d, ei_d = step.device_inputs
 
@@ -1119,6 +1238,8 @@ def main():
         if args.model == "appnpstack":
             secondary("parity_k10_whole_graph", lambda: appnp_full_graph_parity(model, ei, x, x_d, ei_d))
         secondary("cpu_baseline", lambda: cpu_baseline(ei, x, N, fused=fused_output()))
+        if args.model == "gcn" and args.workload in ("L", "S") and not args.primary_only:
+            secondary("parity_gradients_at_S", lambda: gradient_parity_S(dev))
 
     if parts == 1 and on_gpu and not args.primary_only:
         # SURVEY 8d secondary: the training step without the two eval forwards (after the headline: it moves the
@@ -1138,8 +1259,17 @@ def main():
 
         def undirected_leg():
             # SURVEY 8d secondary run: the mirrored / coalesced variant of the same graph (itexperiments.py:235-238)
-            ei_u = to_undirected(ei.to(dev), N).cpu()
-            return gcn_block(wl["name"] + ", to_undirected", ei_u, x, y, dev, args.steps, args.warmup, d, replay=False)
+            ei_dev = ei.to(dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ei_u = to_undirected(ei_dev, N)  # rgbx_coalesce_keys_i64 (mirror, 64-bit radix sort, unique) + split
+            torch.cuda.synchronize()
+            t_und = (time.perf_counter() - t0) * 1e3
+            ei_u = ei_u.cpu()
+            del ei_dev
+            out = gcn_block(wl["name"] + ", to_undirected", ei_u, x, y, dev, args.steps, args.warmup, d, replay=False)
+            out["ingest_ms"] = dict(out["ingest_ms"], to_undirected_ms=t_und, edges_out=int(ei_u.size(1)))
+            return out
 
         def configs_1_leg():
             s = WORKLOADS["S"]
@@ -1163,6 +1293,21 @@ def main():
                            "in all three forwards as the reference does")
             return out
 
+        def identical_leg():
+            # what experiment() runs BY DEFAULT (round 4): the two shortcuts whose results are bit-identical to the
+            # reference-shaped epoch (tests test_shared_eval_forward_changes_nothing_but_the_forward_count,
+            # test_cached_input_aggregate_changes_nothing_but_the_aggregation_count): A_hat x of the static features kept,
+            # val and test statistics from one eval forward — 3 aggregations per epoch instead of 7. `value` of the line
+            # stays on the reference-equivalent 7-propagate epoch.
+            out = gcn_block(wl["name"] + ", cache_input_aggregate + share_eval_forward (experiment() defaults)", ei, x, y,
+                            dev, args.steps, args.warmup, d, replay=False, cache_input_aggregate=True, identical=True)
+            out["note"] = ("same five numbers per epoch as the headline's epoch, bit for bit; 3 aggregations per epoch "
+                           "(training layer 2, its transposed backward, the one eval forward's layer 2)")
+            return out
+
+        secondary("identical_results_same_run", identical_leg)
+        if isinstance(result.get("identical_results_same_run"), dict) and "epochs_per_s" in result["identical_results_same_run"]:
+            result["epochs_per_s_identical_results"] = result["identical_results_same_run"]["epochs_per_s"]
         secondary("cached_input_aggregate_same_run", cached_leg)
         secondary("undirected_same_run", undirected_leg)
         secondary("powerlaw_same_run", powerlaw_leg)

@@ -221,8 +221,8 @@ def experiment(model_init_param: dict, *,
                begin_early_stopping: int = 20,
                return_model: bool = False,
                use_hip_graph: bool = True,
-               share_eval_forward: bool = False,
-               cache_input_aggregate: bool = False,
+               share_eval_forward: bool = True,
+               cache_input_aggregate="auto",
                distributed=None):
     """Train + evaluate one model on one graph; returns {'ACC', 'precision_score', 'recall_score',
     'f1_macro', 'f1_micro'} (reference :603-605). ``return_model=True`` (an addition) also returns
@@ -231,14 +231,17 @@ def experiment(model_init_param: dict, *,
     arithmetic is unchanged, only launch latency and host round-trips go away; on graphs beyond
     ``HIP_GRAPH_MAX_EDGES`` edges, where the kernels and not the launches set the epoch time (replay measured 3 %
     faster at 4 M edges, 4 % slower at 60 M), the eager loop runs instead unless ``use_hip_graph="always"``.
-    ``share_eval_forward=True``
-    (an addition, off by default) takes the per-epoch test metrics from the val pass's eval-mode outputs
-    instead of running the reference's second, identical eval forward (itexperiments.py:464-473): same
-    numbers, two forwards per epoch instead of three. ``cache_input_aggregate=True`` (an addition, off by default)
-    keeps the first conv layer's aggregate of the input features — the same matrix in every forward of every epoch,
-    because features and graph are static (itexperiments.py:417-473 recomputes it three times per epoch) — so that a
-    2-layer GCN / GraphSAGE epoch runs 4 aggregations instead of 7; models whose first layer has no aggregate-first
-    form (in > out) ignore it. ``distributed`` (an addition; the reference is single-device, :246): None = take the
+    ``share_eval_forward`` (an addition, ON by default since round 4: results are bit-identical,
+    test_shared_eval_forward_changes_nothing_but_the_forward_count) takes the per-epoch test metrics from the val pass's
+    eval-mode outputs instead of running the reference's second, identical eval forward (itexperiments.py:464-473): same
+    numbers, two forwards per epoch instead of three; ``False`` forwards twice as the reference does.
+    ``cache_input_aggregate`` (an addition; "auto" = on when HBM allows, also bit-identical,
+    test_cached_input_aggregate_changes_nothing_but_the_aggregation_count) keeps the first conv layer's aggregate of
+    the input features — the same matrix in every forward of every epoch, because features and graph are static
+    (itexperiments.py:417-473 recomputes it three times per epoch) — so that together with the shared eval forward a
+    2-layer GCN / GraphSAGE epoch runs 3 aggregations instead of 7; models whose first layer has no aggregate-first
+    form (in > out) ignore it; "auto" turns it off when the kept [N, F] matrix would take more than a quarter of the free
+    HBM (the memory guard); ``True`` / ``False`` force it. ``distributed`` (an addition; the reference is single-device, :246): None = take the
     node-partitioned route when the script runs as one of several ranks (``torchrun --nproc-per-node N script.py``:
     WORLD_SIZE > 1 in the environment, one process per GPU, device = LOCAL_RANK); every rank calls experiment() with
     the same arguments and the same data and gets the same result dict. Models: gcn / graphsage / graphsage2 / gat /
@@ -324,6 +327,9 @@ def experiment(model_init_param: dict, *,
         net = REGISTRY[name](input_dim=input_dim, output_dim=output_dim, **model_init_param)
         fwd = {"x": features} if name == "mlp" else {"x": features, "edge_index": data.edge_index}
     net.to(device)
+    if cache_input_aggregate == "auto":  # memory guard: the kept aggregate is one more [N, F] fp32 matrix in HBM
+        cache_input_aggregate = (device.type == "cuda" and name != "mlp" and dist_ctx is None  # partitioned: opt-in only
+                                 and features.numel() * 4 <= torch.cuda.mem_get_info(device)[0] // 4)
     if cache_input_aggregate:
         net.cache_input_aggregate = True  # read by models/_stack.ConvStack; other models have no such form
     runner = None

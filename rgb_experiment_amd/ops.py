@@ -21,8 +21,17 @@ def set_event_sink(sink):
     _EVENT_SINK = sink
 
 
+class Kind(str):
+    """Event kind that also says WHICH FORM of the launch it was (`variant`: the epilogues / extra outputs that select
+    the kernel's template instantiation and add to its bytes); equal to, and hashed as, the plain kind string."""
+    variant = None
+
+
 class _Timed:
-    def __init__(self, kind):
+    def __init__(self, kind, variant=None):
+        if variant is not None and _EVENT_SINK is not None:
+            kind = Kind(kind)
+            kind.variant = variant
         self.kind = kind
 
     def __enter__(self):
@@ -334,7 +343,14 @@ def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_roo
         keep.append(ws)
         L.out_colsums, L.stats_ws, L.stats_ws_bytes = colsums.data_ptr(), ws.data_ptr(), nbytes.value
     L.N, L.K, L.Nout = N, K, n_out
-    with _Timed(kind):
+    variant = None
+    if _EVENT_SINK is not None:  # which form this launch is (bench.py's per-variant table)
+        variant = "+".join([name for name, on in (
+            ("dense", dense), ("pre", pre is not None), ("root", wt_root is not None), ("z", z is not None),
+            ("zpos", w_pos is not None), ("stats", want_colsums), ("ce_stats", ce is not None and ce[2] is None),
+            ("ce_grad", ce is not None and ce[2] is not None), ("noout", out is None and out_blocked is None and ce is None),
+            ("blk", out_blocked is not None)) if on]) or "plain"
+    with _Timed(kind, variant):
         _lib.check(lib.rgbx_fused_layer_f32(ctypes.byref(L), _lib.stream_ptr()), "rgbx_fused_layer_f32")
     del keep
     return out, (z if w_pos is None else (z, z_pos)), (ce_stats if ce is not None else colsums)
