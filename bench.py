@@ -956,7 +956,9 @@ def main():
         common = dict(lr=0.01, comm=comm_obj, backend=test_backend, exchange=args.exchange, pieces=args.pieces,
                       interleave_evals=not args.no_interleave, fused=not args.no_fused, pieces_in=args.pieces_in,
                       cache_input_aggregate=args.cache_input_aggregate, src_split=args.src_split)
-        task_split = args.task_split == "on" or (args.task_split == "auto" and tasksplit.pays(model, parts, d))
+        # auto: where it pays; on two ranks (whole graph on both GPUs: no memory scaling) only when one GPU can hold it
+        task_split = args.task_split == "on" or (args.task_split == "auto" and tasksplit.pays(model, parts, d) and (
+            parts != 2 or bool(emu) or tasksplit.whole_graph_fits(N, E, [d], dev)))
         if task_split:
             # training steps on ranks [0, P/2), eval forwards on ranks [P/2, P), each group with the whole graph
             # (dist/tasksplit.py); an emulated run stands for rank 0 of the group --emulate-role names

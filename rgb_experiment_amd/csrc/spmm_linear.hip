@@ -813,6 +813,12 @@ extern "C" int rgbx_fused_layer_f32(const rgbx_fused_layer_t* Lp, rgbx_stream_t 
                 "Nout=%lld)", (long long)K, (long long)Nout);
   const bool x_blk = dense && L.x_blk_cols > 0, xr_blk = L.x_root && L.xr_blk_cols > 0;
   if (!dense && L.x_blk_cols) return fail(RGBX_E_ARG, "fused_layer: a blocked x needs DENSE mode (rowptr == NULL)");
+  // an AGGREGATING launch with per-slot weights and the loss epilogue, or with a second aggregate, has no instantiation
+  // that honours blocked root rows (launch(): the CE / POS branches compile without BLK): refuse instead of reading the
+  // blocked buffer as row-major
+  if (!dense && xr_blk && ((ce && L.w) || L.w_pos))
+    return fail(RGBX_E_ARG, "fused_layer: blocked root rows (xr_blk_cols) cannot be combined with per-slot weights plus "
+                            "the cross-entropy epilogue, or with w_pos, on an aggregating launch");
   if ((x_blk && (L.x_blk_cols % 4 || L.x_blk_stride % 4 || K % L.x_blk_cols)) ||
       (xr_blk && (L.xr_blk_cols % 4 || L.xr_blk_stride % 4 || K % L.xr_blk_cols)) ||
       (L.out_blk && (L.ob_cols <= 0 || Nout % L.ob_cols)))

@@ -158,7 +158,8 @@ class Comm:
     def self_test_views(self, device):
         """One small view exchange with a known answer, before the fused schedule relies on `all_to_all_views`: blocks
         of one buffer handed to several peers (the same view in more than one slot), row ranges of one buffer as
-        receive targets, and EMPTY entries for some pairs — what the schedule does, at 8 rows. Every rank checks what it
+        receive targets, and EMPTY entries for some pairs — what the schedule does, at 8 rows; then the same with several
+        works IN FLIGHT at once and waited for out of order (_self_test_in_flight). Every rank checks what it
         received, the verdict is all-reduced (MIN) so that all ranks agree; False means this backend / build does not
         deliver the views as assumed and the caller must stay on the single-buffer exchanges."""
         P, r = self.world, self.rank
@@ -176,6 +177,7 @@ class Comm:
         for q in range(P):
             want = torch.full((rows, w), -1.0, device=device) if silent(r, q) else base[r % C] + 1000.0 * q
             ok = ok and bool(torch.equal(dst[q], want))
+        ok = ok and self._self_test_in_flight(device)
         verdict = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
         if self.backend == "nccl" or not verdict.is_cuda:
             dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=self.group)
@@ -185,6 +187,33 @@ class Comm:
             verdict.copy_(h)
         self.bytes_sent, self.exchanges = 0, 0
         return bool(verdict.item() == 1.0)
+
+    def _self_test_in_flight(self, device):
+        """What the fused schedule actually does with the communicator (dist/stack.py GridStack._interleave), at 8 rows,
+        with a known answer: TWO piece-wise view exchanges (row pieces of one blocked send buffer into row ranges of one
+        receive buffer) and an async all-reduce outstanding TOGETHER on the same communicator, waited for OUT of issue
+        order (second piece, the all-reduce, first piece). A backend that serialises, reorders or mis-pairs grouped
+        send / recv lists under several works in flight shows here, before the first epoch, not in trained weights."""
+        P, r = self.world, self.rank
+        rows, w, pieces = 8, 4, 2
+        half = rows // pieces
+        src = (torch.arange(P * rows * w, dtype=torch.float32, device=device).view(P, rows, w) + 1000.0 * r)
+        dst = torch.full((P, rows, w), -1.0, dtype=torch.float32, device=device)
+        red = torch.full((16,), float(r + 1), dtype=torch.float32, device=device)
+        works = []
+        for k in range(pieces):  # piece k: rows [k * half, (k + 1) * half) of every peer's block
+            lo, hi = k * half, (k + 1) * half
+            works.append(self.all_to_all_views([src[q, lo:hi] for q in range(P)], [dst[q, lo:hi] for q in range(P)],
+                                               tag=f"self-test piece {k}"))
+        red_work = self.all_reduce_sum_async(red)
+        works[1].wait()
+        red_work.wait()
+        works[0].wait()
+        base = torch.arange(P * rows * w, dtype=torch.float32, device=device).view(P, rows, w)
+        ok = bool(torch.equal(red, torch.full_like(red, P * (P + 1) / 2.0)))
+        for q in range(P):  # rank q sent its block number r
+            ok = ok and bool(torch.equal(dst[q], base[r] + 1000.0 * q))
+        return ok
 
     def measure_link_gbs(self, device, mb_per_peer=16, reps=3):
         """GB/s one xGMI link carries per direction under an all-to-all (every pair busy at once), measured: `reps`

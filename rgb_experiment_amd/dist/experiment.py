@@ -64,7 +64,7 @@ class DistContext:
         dist.broadcast(h, 0)
         return t.copy_(h)
 
-    def runner(self, net, edge_index, features, y, masks, lr, weight_decay, cache_input_aggregate):
+    def runner(self, net, edge_index, features, y, masks, lr, weight_decay, cache_input_aggregate, task_split="auto"):
         """DistRunner over this rank's node range. Parameters, buffers and masks are taken from rank 0, so that the
         ranks agree even when the caller seeded nothing (need_to_reappear=False, or a splitter that draws from the
         global generator: utils/mask.py get_random_mask's val / test shuffle, reference mask.py:133)."""
@@ -75,9 +75,11 @@ class DistContext:
             for t in list(net.parameters()) + list(net.buffers()):
                 self._from_rank0(t.data)
         masks = tuple(self._from_rank0(m.to(torch.uint8)).bool() for m in masks)
-        if tasksplit.pays(net, self.world):
+        widths = sorted({features.size(1)} | {p.size(0) for p in net.parameters() if p.dim() == 2})
+        if tasksplit.resolve(task_split, net, self.world, features.size(0), edge_index.size(1), widths, self.device):
             # training steps on one half of the ranks, eval forwards on the other (APPNP stacks whose column slices
-            # would fall below the 128-byte line: dist/tasksplit.py); same loop, same numbers
+            # would fall below the 128-byte line; two ranks when one GPU can hold the whole graph: dist/tasksplit.py);
+            # same loop, same numbers. task_split="off" (or a graph one GPU cannot hold) = the partitioned DistRunner
             return tasksplit.TaskSplitRunner(net, edge_index, features, y, masks, self.rank, self.world, self.device,
                                              lr=lr, weight_decay=weight_decay, comm=Comm(), backend=self.test_backend)
         return DistRunner(net, edge_index, features, y, masks, self.rank, self.world, self.device, lr=lr,

@@ -101,6 +101,35 @@ def _wait_for(paths, timeout):
         time.sleep(0.05)
 
 
+def _mtime(path):
+    try:
+        return os.stat(path).st_mtime
+    except OSError:
+        return None
+
+
+def _await_rank0(d, k, paths, quiet_limit, hard_limit):
+    """A rank other than 0 waits for rank 0's decision: the first existing path of `paths`, for as long as rank 0 shows
+    signs of life — its supervisor touches `sup.0` once a second, its worker of attempt k the heartbeat `attempt{k}.hb.0`
+    — and no longer than `hard_limit` seconds. Returns the path, or None (rank 0 silent for `quiet_limit` s, or the
+    hard limit passed). Rank 0 alone decides how a run ends; the others never give up on it while it is alive."""
+    t0 = time.monotonic()
+    while True:
+        for p in paths:
+            hit = glob.glob(p)
+            if hit:
+                return hit[0]
+        now = time.monotonic()
+        if now - t0 > hard_limit:
+            return None
+        seen = [m for m in (_mtime(os.path.join(d, "sup.0")), _mtime(os.path.join(d, f"attempt{k}.hb.0"))) if m]
+        if seen and time.time() - max(seen) > quiet_limit:
+            return None
+        if not seen and now - t0 > quiet_limit:
+            return None
+        time.sleep(0.05)
+
+
 def die_with_parent(sig=signal.SIGKILL):
     """preexec_fn for a child that must not outlive this process (PR_SET_PDEATHSIG): a launcher or supervisor that is
     killed outright (SIGKILL: no handler runs) would otherwise leave ranks behind that hold their GPUs."""
@@ -202,12 +231,16 @@ def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
     for k, (name, flags) in enumerate(attempts):
         port_file = os.path.join(d, f"attempt{k}.port")
         if rank == 0:
+            _write(os.path.join(d, "sup.0"), str(k))
             with socket.socket() as s:
                 s.bind(("127.0.0.1", 0))
                 port = s.getsockname()[1]
             _write(port_file, str(port))
-        elif _wait_for([port_file, os.path.join(d, "gave_up")], 180) != port_file:
+        elif _await_rank0(d, max(k - 1, 0), [port_file, os.path.join(d, "gave_up")], stall_s + import_s,
+                          deadline_s + 60) != port_file:
+            # rank 0 has given up (its line, a diagnostic one, is out) or is gone: only then does this rank leave
             print(f"[bench supervisor rank {rank}] no rendezvous port for attempt {k}: leaving", file=sys.stderr)
+            time.sleep(1.0)  # rank 0 writes `gave_up` and then prints: do not make the agent end it in between
             return 1
         port = int(_read(port_file))
         hb = os.path.join(d, f"attempt{k}.hb.{rank}")
@@ -225,10 +258,14 @@ def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
         failed_glob = os.path.join(d, f"attempt{k}.failed.*")
         ok_file = os.path.join(d, f"attempt{k}.ok")
         reason = None
+        sup_beat = 0.0
         while True:
             rc = proc.poll()
             if rc is not None:
                 break
+            if rank == 0 and time.monotonic() - sup_beat > 1.0:  # what the other ranks' supervisors watch (_await_rank0)
+                sup_beat = time.monotonic()
+                _write(os.path.join(d, "sup.0"), str(k))
             if os.getppid() != agent:  # the launcher above is gone (killed outright): nobody is waiting for a line
                 kill_group(proc, grace=2.0)
                 print(f"[bench supervisor rank {rank}] the launcher is gone: worker ended, leaving", file=sys.stderr)
@@ -258,10 +295,17 @@ def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
         done = (_read(hb) or "").startswith("done")
         good = ((reason is None and rc == 0) or done) and (rank != 0 or line is not None)
         if good and rank != 0:
-            # my worker is through; the attempt counts if rank 0 got its line (a peer may still have failed)
-            hit = _wait_for([ok_file, os.path.join(d, f"attempt{k}.failed.0"), os.path.join(d, f"attempt{k + 1}.port")], 120)
-            if hit == ok_file or hit is None:
+            # my worker is through; the attempt counts only if rank 0 got its line (a peer may still have failed, rank 0's
+            # worker may still be busy): wait for rank 0's verdict while it is alive, and report success on `ok` alone
+            hit = _await_rank0(d, k, [ok_file, os.path.join(d, f"attempt{k}.failed.0"),
+                                      os.path.join(d, f"attempt{k + 1}.port"), os.path.join(d, "gave_up")],
+                               stall_s + import_s, max(deadline_s - (time.monotonic() - t0), 0) + 60)
+            if hit == ok_file:
                 return 0
+            if hit is None or hit.endswith("gave_up"):
+                print(f"[bench supervisor rank {rank}] no verdict from rank 0 for attempt {k}: leaving", file=sys.stderr)
+                time.sleep(1.0)
+                return 1
             history.append({"attempt": k, "flags": flags, "reason": "rank 0 did not get its line"})
             continue
         if good:
@@ -278,18 +322,19 @@ def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
         _write(os.path.join(d, f"attempt{k}.failed.{rank}"), reason)
         print(f"[bench supervisor rank {rank}] attempt {k} ({name}) failed: {reason}", file=sys.stderr, flush=True)
         if rank != 0:  # rank 0 decides: its line (-> done) or the next attempt's port (-> again)
-            hit = _wait_for([ok_file, os.path.join(d, f"attempt{k + 1}.port"), os.path.join(d, "gave_up")],
-                            deadline_s + 60)
+            hit = _await_rank0(d, k, [ok_file, os.path.join(d, f"attempt{k + 1}.port"), os.path.join(d, "gave_up")],
+                               stall_s + import_s, deadline_s + 60)
             if hit == ok_file:
                 return 0
             if hit is None or hit.endswith("gave_up"):
+                time.sleep(1.0)  # rank 0 prints its (diagnostic) line right after `gave_up`
                 return 1
     if rank == 0:
-        _write(os.path.join(d, "gave_up"), "1")
         print(json.dumps({"metric": "aggregated edges/sec (multi-GPU run failed in every attempt)", "value": None,
                           "unit": "edges/s", "n_gpus": world, "higher_is_better": True,
                           "error": "no attempt produced a benchmark line",
                           "launcher": {"attempts_made": len(attempts), "supervised": True, "failed": history}}),
               file=out, flush=True)
+        _write(os.path.join(d, "gave_up"), "1")  # after the line: the other ranks leave (non-zero) only now
     return 1
 

@@ -40,6 +40,49 @@ def pays(model, world, width=None):
     return width // world < 32 and width // (world // 2) >= 16
 
 
+def whole_graph_bytes(n, e, widths):
+    """HBM one rank needs to hold the WHOLE graph and run the single-GPU kernels on it (the world == 2 task split):
+    int64 edge_index, forward + transposed CSR (col, perm, weight per slot, rowptr), and per layer width the
+    activations an epoch keeps (input, aggregate, output, their gradients: 6 matrices of [n, width] fp32, measured
+    9.7 GB peak at n = 2 M, e = 60 M, widths 128: this estimate gives 9.9)."""
+    slots = e + n
+    return 16 * e + 2 * (12 * slots + 4 * (n + 1)) + sum(6 * 4 * n * w for w in widths)
+
+
+def whole_graph_fits(n, e, widths, device, comm=None):
+    """Every rank must take the same decision: the smallest free HBM over the ranks decides (one small all-reduce)."""
+    if device.type != "cuda":
+        return True
+    free = torch.tensor([float(torch.cuda.mem_get_info(device)[0])], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(free, op=dist.ReduceOp.MIN)
+        else:
+            h = free.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MIN)
+            free = h
+    return whole_graph_bytes(n, e, widths) <= 0.8 * float(free.item())
+
+
+def resolve(mode, model, world, n, e, widths, device):
+    """task_split = 'auto' | 'on' | 'off' (experiment(task_split=...), bench.py --task-split, environment
+    RGBX_TASK_SPLIT overrides 'auto'). auto: where it pays (`pays`), except that on TWO ranks — where the split means
+    the whole graph on both GPUs, i.e. no memory scaling — it is taken only when one GPU can hold the whole graph;
+    otherwise the node-partitioned DistRunner runs (each rank holds half of everything)."""
+    import os
+    if mode in (None, "auto"):
+        mode = os.environ.get("RGBX_TASK_SPLIT", "auto")
+    if mode not in ("auto", "on", "off"):
+        raise ValueError(f"task_split must be 'auto', 'on' or 'off', got {mode!r}")
+    if mode == "off" or world < 2 or world % 2:
+        return False
+    if mode == "on":
+        return True
+    if not pays(model, world):
+        return False
+    return world != 2 or whole_graph_fits(n, e, widths, device)
+
+
 class WholeGraphRunner:
     """What TaskSplitRunner needs of a group of ONE rank: the reference's training step and eval forwards on the whole
     graph, on this rank's GPU, with the single-GPU kernels (fused aggregate + transform, loss inside the last layer's

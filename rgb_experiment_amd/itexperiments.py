@@ -223,7 +223,8 @@ def experiment(model_init_param: dict, *,
                use_hip_graph: bool = True,
                share_eval_forward: bool = True,
                cache_input_aggregate="auto",
-               distributed=None):
+               distributed=None,
+               task_split: str = "auto"):
     """Train + evaluate one model on one graph; returns {'ACC', 'precision_score', 'recall_score',
     'f1_macro', 'f1_micro'} (reference :603-605). ``return_model=True`` (an addition) also returns
     the trained module and the per-epoch curves under 'model' / 'history'. ``use_hip_graph=True`` (an
@@ -245,7 +246,11 @@ def experiment(model_init_param: dict, *,
     node-partitioned route when the script runs as one of several ranks (``torchrun --nproc-per-node N script.py``:
     WORLD_SIZE > 1 in the environment, one process per GPU, device = LOCAL_RANK); every rank calls experiment() with
     the same arguments and the same data and gets the same result dict. Models: gcn / graphsage / graphsage2 / gat /
-    appnpstack (rgb_experiment_amd.dist.DistRunner); no hipGraph, no post_cs there."""
+    appnpstack (rgb_experiment_amd.dist.DistRunner); no hipGraph, no post_cs there. ``task_split`` (distributed runs):
+    "auto" | "on" | "off" — whether the epoch is split by task over two groups of ranks (dist/tasksplit.py). On TWO ranks
+    the split puts the WHOLE graph on both GPUs (one trains, one evaluates: fastest, but no memory scaling): "auto" takes
+    it only when one GPU can hold the whole graph and falls back to the node partition (half of everything per rank)
+    otherwise; "off" always partitions; the environment variable RGBX_TASK_SPLIT overrides "auto"."""
     say = print if print_print else (lambda *a, **k: None)
     say(f"running node classification: {'custom' if specify_data else dataset_name} data, model {model_name}")
 
@@ -337,7 +342,7 @@ def experiment(model_init_param: dict, *,
         # 1-D node partition: this rank keeps its node range of features / labels / masks and the structures of its
         # share of the graph; parameters are replicated (the seeds above made them equal on every rank)
         runner = dist_ctx.runner(net, data.edge_index, features, y, (train_mask, val_mask, test_mask), learning_rate,
-                                 weight_decay, cache_input_aggregate)
+                                 weight_decay, cache_input_aggregate, task_split)
         use_hip_graph = False
     graphed = None
     # capturable Adam keeps its step count on the device: required for graph capture, and used for the

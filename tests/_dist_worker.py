@@ -468,3 +468,24 @@ def gpu_tasksplit_worker(rank, world, port, out_dir, model_name, exchange="resha
                 "state": {k: v.cpu() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"gpusplit_{model_name}_{rank}.pt"))
     dist.destroy_process_group()
+
+
+def comm_selftest_worker(rank, world, port, out_dir, sabotage=False):
+    """Comm.self_test_views (view exchange with aliased / empty entries + several works in flight waited out of order)."""
+    _init(rank, world, port)
+    from rgb_experiment_amd.dist import Comm
+    comm = Comm()
+    if sabotage and rank == 1:  # a backend that pairs the second piece's views wrongly: the self-test must say no
+        real = comm.all_to_all_views
+
+        def wrong(send, recv, tag=None):
+            work = real(send, recv, tag)
+            if tag == "self-test piece 1":
+                for t in recv:
+                    if t.numel():
+                        t.add_(1.0)
+            return work
+        comm.all_to_all_views = wrong
+    ok = comm.self_test_views(torch.device("cpu"))
+    torch.save({"ok": ok, "exchanges": comm.exchanges}, os.path.join(out_dir, f"selftest_{rank}.pt"))
+    dist.destroy_process_group()

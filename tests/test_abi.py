@@ -96,6 +96,20 @@ def test_shape_and_alignment_errors_of_the_fused_and_dense_entry_points():
     assert layer(out=None, out_blk=p, ob_cols=48, ob_stride=480) == -1            # 48 does not divide Nout
     assert layer(out_blk=p, ob_cols=32, ob_stride=320, ce=ctypes.addressof(ce)) == -1   # loss epilogue: no blocked output
     assert layer(K=130) == -5
+    # an aggregating launch with per-slot weights + loss epilogue (or a second aggregate) has no blocked-root form
+    agg = dict(rowptr=p, col=p, w=p, x_root=p, wt_root=p, xr_blk_cols=32, xr_blk_stride=320)
+    assert layer(ce=ctypes.addressof(ce), out=None, **agg) == -1 and b"blocked root" in lib.rgbx_last_error_string()
+    assert layer(w_pos=p, z_pos_out=p, z_out=p, ldz=128, **agg) == -1
+    # new in 4.0.0: edge-list ingest
+    n = ctypes.c_size_t(0)
+    assert lib.rgbx_coalesce_workspace_bytes(-1, 4, 0, ctypes.byref(n)) == -1
+    assert lib.rgbx_coalesce_workspace_bytes(10, 2**31, 0, ctypes.byref(n)) == -2
+    rc = lib.rgbx_coalesce_workspace_bytes(1000, 100, 1, ctypes.byref(n))  # rocPRIM's size query of `unique` asks the
+    assert (rc == 0 and n.value >= 2 * 2000 * 8) or rc > 0                  # device for its configuration: a hipError here
+    assert lib.rgbx_coalesce_keys_i64(None, None, 5, 10, 0, p, p, p, 1 << 20, None) == -1
+    assert lib.rgbx_coalesce_keys_i64(p, p, 5, 10, 0, p, None, p, 1 << 20, None) == -1    # no counts
+    assert lib.rgbx_split_edge_keys_i64(None, p, 5, 10, p, p, None) == -1
+    assert lib.rgbx_split_edge_keys_i64(p, p, 0, 10, p, p, None) == 0                      # nothing to do
     assert lib.rgbx_blocked_to_rows_f32(p, 32, 320, p, 128, 10, 100, None, None) == -1  # 32 does not divide d = 100
     assert lib.rgbx_blocked_to_rows_f32(p, 32, 320, p, 64, 10, 128, None, None) == -1   # ldd < d
     assert lib.rgbx_blocked_to_rows_f32(None, 32, 320, p, 128, 10, 128, None, None) == -1

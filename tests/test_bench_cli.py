@@ -203,3 +203,42 @@ def test_ending_the_launcher_ends_every_rank():
                 break
             time.sleep(0.5)
         assert not alive, alive
+
+
+def test_other_ranks_wait_for_rank_0_while_it_is_alive(tmp_path):
+    """supervise._await_rank0: a rank whose own worker is through does not decide the run's end — it waits for rank 0's
+    verdict for as long as rank 0's supervisor (`sup.0`) or worker (`attempt{k}.hb.0`) keeps moving, well past the quiet
+    limit, and gives up (non-zero exit in supervise) only when rank 0 has been silent for that long or the hard limit
+    has passed."""
+    import threading
+    import time
+    from rgb_experiment_amd.dist import supervise as sv
+    d = str(tmp_path)
+    ok = os.path.join(d, "attempt0.ok")
+    # rank 0 silent from the start: None after the quiet limit
+    t0 = time.monotonic()
+    assert sv._await_rank0(d, 0, [ok], quiet_limit=0.3, hard_limit=5.0) is None
+    assert 0.25 < time.monotonic() - t0 < 2.0
+    # rank 0 alive (its supervisor keeps touching sup.0) for 4 quiet limits, then the verdict: the waiter is still there
+    stop = threading.Event()
+
+    def rank0():
+        t_end = time.monotonic() + 1.2
+        while time.monotonic() < t_end and not stop.is_set():
+            sv._write(os.path.join(d, "sup.0"), "0")
+            time.sleep(0.05)
+        sv._write(ok, "ok")
+
+    th = threading.Thread(target=rank0)
+    th.start()
+    try:
+        assert sv._await_rank0(d, 0, [ok, os.path.join(d, "gave_up")], quiet_limit=0.3, hard_limit=10.0) == ok
+    finally:
+        stop.set()
+        th.join()
+    # alive but never deciding: the hard limit ends the wait
+    os.remove(ok)
+    sv._write(os.path.join(d, "attempt0.hb.0"), "timed step")
+    t0 = time.monotonic()
+    assert sv._await_rank0(d, 0, [ok], quiet_limit=30.0, hard_limit=0.4) is None
+    assert time.monotonic() - t0 < 2.0

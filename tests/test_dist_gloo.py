@@ -448,6 +448,18 @@ def test_pipelined_reshard_equals_the_single_exchange(world, exchange, tmp_path)
             assert torch.equal(outs[chunks][0], outs[1][0]) and torch.equal(outs[chunks][1], outs[1][1]), (r, chunks)
 
 
+@pytest.mark.parametrize("world,sabotage", [(2, False), (3, False), (4, False), (4, True)])
+def test_communicator_self_test_before_the_fused_schedule(world, sabotage, tmp_path):
+    """Comm.self_test_views, run by DistRunner before the fused schedule's first epoch: aliased / empty / row-range views
+    in one exchange, then two piece-wise view exchanges plus an async all-reduce in flight together and waited for out of
+    issue order, each with a known answer; every rank gets the same verdict, and a rank that receives wrong rows in the
+    second piece turns it into False for ALL ranks (the runner then stays on the single-buffer exchanges)."""
+    mp.spawn(W.comm_selftest_worker, args=(world, _free_port(), str(tmp_path), sabotage), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"selftest_{r}.pt")) for r in range(world)]
+    assert [p["ok"] for p in parts] == [not sabotage] * world
+    assert all(p["exchanges"] == 0 for p in parts)  # the self-test leaves the traffic counters clean
+
+
 def test_dist_batchnorm_matches_full_batch_bn():
     """world = 1 (no process group): DistBatchNorm1d == nn.BatchNorm1d incl. running stats and grads."""
     from rgb_experiment_amd.dist import Comm, DistBatchNorm1d

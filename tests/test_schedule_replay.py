@@ -2,6 +2,9 @@
 import os
 import sys
 
+import pytest
+import torch
+
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 
 
@@ -73,3 +76,25 @@ def test_where_the_epoch_is_split_by_task():
     small = M.APPNPStack(hidden_unit=16, input_dim=12, output_dim=40, K=10, alpha=0.1, dropout_rate=0.5)
     assert tasksplit.pays(small, 4) and not tasksplit.pays(small, 8)      # 40 classes: 10-float slices; 8 ranks: halves keep 10 only
     assert tasksplit.pays(appnp, 8, width=128) and not tasksplit.pays(appnp, 8, width=512)
+
+
+def test_task_split_resolution_and_memory_guard(monkeypatch):
+    """experiment(task_split=...) / RGBX_TASK_SPLIT: 'off' always partitions, 'on' always splits (even worlds), 'auto' =
+    pays() — and on TWO ranks, where the split keeps the whole graph on both GPUs, only when one GPU can hold it."""
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import tasksplit
+    gcn = M.GCN(num_layers=2, hidden_unit=128, input_dim=128, output_dim=128, dropout_rate=0.5)
+    cpu = torch.device("cpu")
+    args = (2_000_000, 60_000_000, [128], cpu)
+    assert tasksplit.resolve("auto", gcn, 2, *args) and tasksplit.resolve("on", gcn, 2, *args)
+    assert not tasksplit.resolve("off", gcn, 2, *args) and not tasksplit.resolve("auto", gcn, 8, *args)
+    assert not tasksplit.resolve("on", gcn, 3, *args)  # odd world: no two equal groups
+    monkeypatch.setenv("RGBX_TASK_SPLIT", "off")
+    assert not tasksplit.resolve("auto", gcn, 2, *args) and tasksplit.resolve("on", gcn, 2, *args)
+    monkeypatch.delenv("RGBX_TASK_SPLIT")
+    monkeypatch.setattr(tasksplit, "whole_graph_fits", lambda *a, **k: False)  # a graph one GPU cannot hold
+    assert not tasksplit.resolve("auto", gcn, 2, *args) and tasksplit.resolve("on", gcn, 2, *args)
+    with pytest.raises(ValueError):
+        tasksplit.resolve("maybe", gcn, 2, *args)
+    # the footprint estimate against the measured peak of the benchmark epoch (9.7 GB at L, DESIGN.md 3)
+    assert 8e9 < tasksplit.whole_graph_bytes(2_000_000, 60_000_000, [128]) < 12e9
