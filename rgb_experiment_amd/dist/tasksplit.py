@@ -173,15 +173,14 @@ class TaskSplitRunner:
     # ---- hand-over of the model state -----------------------------------------------------------------------------
     def _hand_over(self):
         """Parameters and buffers of the training group's model -> every rank (source: rank 0; the training ranks hold
-        identical copies, the eval ranks install what arrives). One flat float32 buffer + one for the integer
-        counters."""
+        identical copies, the eval ranks install what arrives)."""
         if isinstance(self.world, EmulatedComm):
             return
-        for floats in (True, False):
-            ts = [t for t in self._state if t.is_floating_point() == floats]
-            if not ts:
-                continue
-            flat = torch.cat([t.detach().reshape(-1).to(torch.float32 if floats else torch.int64) for t in ts])
+        # one flat buffer per dtype present: every tensor travels in ITS OWN dtype (a float64 or bfloat16 buffer of a
+        # user's module is not squeezed through float32)
+        for dtype in sorted({t.dtype for t in self._state}, key=str):
+            ts = [t for t in self._state if t.dtype == dtype]
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
             self._broadcast(flat)
             if self.role == "eval":
                 off = 0
@@ -244,18 +243,28 @@ class TaskSplitRunner:
             self._hand_over()
             ops.note_weights_changed()  # parameters written from outside (broadcast into raw storage)
             r.model.eval()
-            if r.interleave_evals and r._epochs_done > 0:
+            e0 = time.perf_counter()
+            if getattr(r, "engine", None) is not None and r._epochs_done > 0:
+                # a fused schedule inside the group (--task-split on for a conv stack): its ONE-thread interleave of the
+                # two forwards; the two-thread path below would run over engine state that is not thread-safe
+                v, s = r.engine.eval_pair(1, 2)
+            elif r.interleave_evals and r._epochs_done > 0:
                 v, s = r._interleaved_evals()
             else:
                 v, _ = r.evaluate(1, sync=False)
                 s, _ = r.evaluate(2, sync=False)
             r._epochs_done += 1
             tl = zeros(1)
+            eval_enqueue_s = time.perf_counter() - e0
         # the five numbers of the epoch: the loss shares come from the training ranks, the eval statistics from the eval
         # ranks (everybody else adds zeros): ONE all-reduce over all ranks, one read-back
         packed = self.world.all_reduce_sum_(torch.cat([tl.reshape(1).double(), v.double(), s.double()]))
         self.host_enqueue_s += time.perf_counter() - t0
         p = packed.tolist()
+        if self.role == "eval" and hasattr(r, "_settle_interleave"):
+            # the host-bound fallback of DistRunner.epoch (two eval threads cost host time): decided once, over the eval
+            # group's communicator, from the time it took to enqueue the two forwards against the epoch's wall time
+            r._settle_interleave(eval_enqueue_s, time.perf_counter() - t0)
         cv, cs = self.mask_counts[1], self.mask_counts[2]
         return p[0], p[1] / cv, p[2] / cv, p[3] / cs, p[4] / cs
 
