@@ -95,6 +95,11 @@ __device__ __forceinline__ void load_b_batch(float (&b)[KB], const float* __rest
   for (int i = 0; i < KB; ++i) b[i] = wt[(int64_t)(2 * (s0 + i) + kr) * Nout + n0 + cc];
 }
 
+// (The 4-byte A reads at a row stride of K + 4 floats are 4-way bank-conflicted. Round 4 tried the permuted tile of
+// dense_stream_kernel here — one ds_read_b128 per four MFMAs: the float4 in flight next to 2 x KB B values pushed the
+// 64-VGPR instantiations into 3-8 spills and the launches got SLOWER, plain + 2.4 %, loss statistics + 12 %
+// (profiles/r04_ab_fused_forms_permuted_tile.txt): this kernel's MFMA phase hides under the other workgroups' gathers,
+// its register budget does not.)
 __device__ __forceinline__ void mfma_batch(f32x16& acc, const float (&b)[KB], const float* __restrict__ zt, int ldz,
                                            int s0, int kr, int cc) {
 #pragma unroll
@@ -578,15 +583,56 @@ __global__ void __launch_bounds__(256, POS ? 7 : (NT == 2 ? 5 : 8)) spmm_linear_
   }
 }
 
+// LDS tile layout of dense_stream_kernel (round 4). A lane's A values of MFMA steps 4 j .. 4 j + 3 are
+// k = 8 j + kr + {0, 2, 4, 6}: every OTHER float of its tile row. Read one by one that is a 4-byte ds_read per MFMA at a
+// row stride of K + 4 floats, 4-way bank-conflicted (round 3: SQ_LDS_BANK_CONFLICT 12.0 M of 17.0 M LDS cycles). The
+// tile is therefore stored with the columns of every group of 8 permuted to [k0 k2 k4 k6 | k1 k3 k5 k7]: the four values
+// are then four CONSECUTIVE floats at 8 j + 4 kr — one conflict-free ds_read_b128 per four MFMAs (16 lanes x 4 banks
+// cover the 64 banks once per lane group). Writers hold four consecutive k (a float4 of a row) and store them as two
+// float2 (park4). K order, B operands and therefore every result bit are those of spmm_linear_kernel<.., DENSE>.
+// v = columns c4 .. c4 + 3 (c4 % 4 == 0) of a tile row -> their permuted places
+__device__ __forceinline__ void park4(float* __restrict__ row, int c4, const float (&v)[4]) {
+  float* p = row + (c4 & ~7) + ((c4 & 4) >> 1);
+  *reinterpret_cast<float2*>(p) = make_float2(v[0], v[2]);
+  *reinterpret_cast<float2*>(p + 4) = make_float2(v[1], v[3]);
+}
+
 // The DENSE form for the widths a partitioned run lives on (K = 64 / 128), as a STREAMING kernel: a workgroup walks
 // many 32-row tiles and keeps its waves' W^T fragments in registers (K / 2 values per lane and 32-column tile; the
 // root term's Wr^T likewise), so W is read once per workgroup instead of once per tile — the per-tile 4-byte L2
 // fetches are what held the one-tile-per-workgroup form at 0.12-0.20 ms for 250 k rows against 0.05 ms of streaming.
-// Same tile loads, epilogues (blocked store, column sums, loss) and numbers as spmm_linear_kernel<.., DENSE>.
+// Same tile loads, epilogues (blocked store, column sums, loss), K order and numbers as
+// spmm_linear_kernel<.., DENSE>.
+//
+// Round 4: (1) A fragments by ds_read_b128 from the permuted tile (one conflict-free 16-byte read per four MFMAs; the
+// 4-byte reads at stride K + 4 were 4-way conflicted and one per MFMA); (2) the plain forms (no root term, no loss
+// epilogue) are software-pipelined over TWO LDS tiles: the next tile's rows are fetched into registers before the
+// MFMA loop of the current one and written to the other tile after it, one barrier per tile — the load of tile t + 1
+// and the stores of tile t - 1 travel under tile t's 64 MFMAs instead of between two barriers. Measured (tools/dense_bench.py,
+// profiles/r04_dense_bench.txt): K = Nout = 128, 2 M rows 0.94 -> 0.70 ms (94 TF = 0.60 of the fp32 MFMA peak; hipBLASLt
+// 0.63), 250 k rows 0.102 -> 0.092; K = 64, 2 M rows 0.53 -> 0.34 ms. K = 128 runs 3 workgroups per CU (146 VGPRs: 64 W^T
+// values + 16 for the tile in flight; at 128 VGPRs it spilled 16 and was slower than round 3), K = 64 four.
+template <int KC>
+__device__ __forceinline__ void stream_tile_mfma(f32x16& acc, const float* __restrict__ zt, const float (&breg)[KC / 2],
+                                                 int kr, int cc) {
+  constexpr int ldz = KC + 4;
+#pragma unroll
+  for (int j = 0; j < KC / 8; ++j) {
+    const float4 a = *reinterpret_cast<const float4*>(&zt[cc * ldz + 8 * j + 4 * kr]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, breg[4 * j], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, breg[4 * j + 1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, breg[4 * j + 2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, breg[4 * j + 3], acc, 0, 0, 0);
+  }
+}
+
 template <int KC, int NT, bool CE, bool ROOT>
-__global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE ? 3 : 4)) dense_stream_kernel(const FusedArgs A, int tiles) {
-  extern __shared__ float zt[];  // [TM][KC + 4] (the loss epilogue re-uses it as [TM][Nout + 4])
+__global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE || KC > 64 ? 3 : 4)) dense_stream_kernel(const FusedArgs A, int tiles) {
+  extern __shared__ float zt[];  // [TM][KC + 4] (the loss epilogue re-uses it as [TM][Nout + 4]); pipelined forms: two
   constexpr int ldz = KC + 4, k4 = KC / 4, S = KC / 2;
+  constexpr bool PIPE = !CE && !ROOT && NT == 1;  // NT = 2 keeps 128 W^T values per lane: no room for a tile in flight
+  constexpr int VPT = (TM * k4) / 256;  // float4 per thread and tile (KC = 128: 4, KC = 64: 2)
+  static_assert((TM * k4) % 256 == 0, "tile loads are spread evenly over the workgroup");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kr = lane >> 5, cc = lane & 31;
   float breg[NT][S];
@@ -601,6 +647,72 @@ __global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE ? 3 : 4)) dense_
         if constexpr (ROOT) rreg[tt][i] = A.wtr[(int64_t)(2 * i + kr) * A.Nout + n0 + cc];
       }
     }
+  }
+  if constexpr (PIPE) {
+    // this thread's VPT float4 of a tile: element idx = threadIdx.x + u * 256 -> row idx / k4, columns 4 * (idx % k4)
+    float pv[VPT][4];
+    auto fetch = [&](int tile) {
+      const int row_base = tile * TM;
+#pragma unroll
+      for (int u = 0; u < VPT; ++u) {
+        const int idx = threadIdx.x + u * 256;
+        const int r = idx / k4, c4 = (idx - r * k4) * 4;
+        const int row = row_base + r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pv[u][i] = 0.f;
+        if (row < A.N) load_vec<4>(pv[u], blocked_at(A.x, A.x_bc, A.x_bs, A.ldx, row, c4));
+      }
+    };
+    auto park = [&](int tile, float* buf) {  // pre-affine map, optional z_out, then into the LDS tile
+      const int row_base = tile * TM;
+#pragma unroll
+      for (int u = 0; u < VPT; ++u) {
+        const int idx = threadIdx.x + u * 256;
+        const int r = idx / k4, c4 = (idx - r * k4) * 4;
+        const int row = row_base + r;
+        if (row < A.N) {
+          if (A.pre_scale) {
+            float ps[4], pt[4];
+            load_vec<4>(ps, A.pre_scale + c4);
+            load_vec<4>(pt, A.pre_shift + c4);
+            const float rsum = A.pre_rowsum[row];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pv[u][i] = fmaf(pv[u][i], ps[i], pt[i] * rsum);
+          }
+          if (A.z_out) store_vec<4>(A.z_out + (int64_t)row * A.ldz + c4, pv[u]);
+        }
+        park4(&buf[r * ldz], c4, pv[u]);
+      }
+    };
+    int cur = 0;  // the tile being multiplied lives at zt + cur * TM * ldz, the one being filled at the other half
+    int tile = blockIdx.x;
+    if (tile < tiles) {
+      fetch(tile);
+      park(tile, zt);
+    }
+    __syncthreads();
+    for (; tile < tiles; tile += gridDim.x) {
+      const int next = tile + gridDim.x;
+      if (next < tiles) fetch(next);  // in flight during this tile's MFMAs
+      f32x16 acc[NT];
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+        if (wave * 32 + tt * 128 < A.Nout) stream_tile_mfma<KC>(acc[tt], zt + cur * (TM * ldz), breg[tt], kr, cc);
+      }
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const int n0 = wave * 32 + tt * 128;
+        if (n0 < A.Nout)
+          store_tile<true>(acc[tt], A.bias, A.out, A.ldo, tile * TM, A.N, n0, kr, cc, A.stats_part, A.Nout, A.out_blk,
+                           A.ob_c, A.ob_s, tile);
+      }
+      if (next < tiles) park(next, zt + (cur ^ 1) * (TM * ldz));
+      __syncthreads();  // the other tile is complete, and every wave is done reading this one
+      cur ^= 1;
+    }
+    return;
   }
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int row_base = tile * TM;
@@ -620,7 +732,7 @@ __global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE ? 3 : 4)) dense_
         }
         if (A.z_out) store_vec<4>(A.z_out + (int64_t)row * A.ldz + c4, v);
       }
-      store_vec<4>(&zt[r * ldz + c4], v);
+      park4(&zt[r * ldz], c4, v);
     }
     __syncthreads();
     f32x16 acc[NT];
@@ -628,11 +740,7 @@ __global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE ? 3 : 4)) dense_
     for (int tt = 0; tt < NT; ++tt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
-      if (wave * 32 + tt * 128 < A.Nout) {
-#pragma unroll
-        for (int i = 0; i < S; ++i)
-          acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zt[cc * ldz + 2 * i + kr], breg[tt][i], acc[tt], 0, 0, 0);
-      }
+      if (wave * 32 + tt * 128 < A.Nout) stream_tile_mfma<KC>(acc[tt], zt, breg[tt], kr, cc);
     }
     if constexpr (ROOT) {
       __syncthreads();  // every wave is done reading the loaded tile
@@ -650,16 +758,12 @@ __global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE ? 3 : 4)) dense_
             for (int i = 0; i < 4; ++i) v[i] = fmaf(v[i], ps[i], pt[i]);
           }
         }
-        store_vec<4>(&zt[r * ldz + c4], v);
+        park4(&zt[r * ldz], c4, v);
       }
       __syncthreads();
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
-        if (wave * 32 + tt * 128 < A.Nout) {
-#pragma unroll
-          for (int i = 0; i < S; ++i)
-            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zt[cc * ldz + 2 * i + kr], rreg[tt][i], acc[tt], 0, 0, 0);
-        }
+        if (wave * 32 + tt * 128 < A.Nout) stream_tile_mfma<KC>(acc[tt], zt, rreg[tt], kr, cc);
       }
     }
     if constexpr (CE) {
@@ -689,16 +793,17 @@ bool launch_dense_stream(const FusedArgs& A, hipStream_t s) {
   // behind: measured at 250 k rows, K = Nout = 128: 0.144 / 0.202 ms (eval / training) there against 0.180 / 0.269 here;
   // the plain forms gain: 0.120 -> 0.100 ms
   if (A.ce_part) return false;
-  const int per_cu = (root || nt > 1) ? 2 : (A.ce_part ? 3 : 4);
+  const int per_cu = (root || nt > 1) ? 2 : (A.ce_part || KC > 64 ? 3 : 4);  // = the kernel's __launch_bounds__
   const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+  const size_t lds2 = 2 * (size_t)TM * (KC + 4) * sizeof(float);  // the pipelined forms keep two tiles
   if (A.ce_part) {
     if (root) dense_stream_kernel<KC, 1, true, true><<<grid, 256, lds, s>>>(A, tiles);
     else dense_stream_kernel<KC, 1, true, false><<<grid, 256, lds, s>>>(A, tiles);
   } else if (nt == 1) {
     if (root) dense_stream_kernel<KC, 1, false, true><<<grid, 256, lds, s>>>(A, tiles);
-    else dense_stream_kernel<KC, 1, false, false><<<grid, 256, lds, s>>>(A, tiles);
+    else dense_stream_kernel<KC, 1, false, false><<<grid, 256, lds2, s>>>(A, tiles);
   } else {
-    dense_stream_kernel<KC, 2, false, false><<<grid, 256, lds, s>>>(A, tiles);
+    dense_stream_kernel<KC, 2, false, false><<<grid, 256, lds2, s>>>(A, tiles);
   }
   return true;
 }
