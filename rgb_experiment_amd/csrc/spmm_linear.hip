@@ -23,6 +23,18 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// Output stores of the aggregating kernel are NON-TEMPORAL (global_store ... nt): the rows it writes (out, the stored
+// aggregate, the loss gradient: 1-2 GB per launch at L) are read by nobody in this launch and compete in L2 / Infinity
+// Cache with the gathered table, a quarter of which is served from those caches. Measured on one box, all forms gathering
+// the same matrix (tools/ab_fused_forms.py, profiles/r04_ab_nt_stores.txt): plain - 0.9 %, z + stats - 2.2 %,
+// pre + z + ce_grad - 1.3 %; at S (everything cache-resident) + - 0.5 %.
+using f4v = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ void nt_store4(float* p, const float (&v)[4]) {
+  f4v t = {v[0], v[1], v[2], v[3]};
+  __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(p));
+}
+__device__ __forceinline__ void nt_store1(float* p, float v) { __builtin_nontemporal_store(v, p); }
+
 struct FusedArgs {
   const int* rowptr;
   const int* col;
@@ -157,7 +169,7 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __res
     const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * kr;
     if (row < N) {
       const float v = acc[r] + bb;
-      if (!BLK || out) out[(int64_t)row * ldo + n0 + cc] = v;
+      if (!BLK || out) nt_store1(&out[(int64_t)row * ldo + n0 + cc], v);
       if constexpr (BLK) { if (ob) ob[(int64_t)row * ob_c] = v; }
       s1 += v;
       s2 = fmaf(v, v, s2);
@@ -265,8 +277,8 @@ __device__ __forceinline__ void ce_epilogue(const FusedArgs& A, const f32x16& ac
     }
     if (A.ce_scale) {
       float* orow = A.out + (int64_t)row * A.ldo;
-      if (c0) orow[lane] = t >= 0 ? sc * (expf(v0 - lse) - (lane == t ? 1.f : 0.f)) : 0.f;
-      if (c1) orow[lane + 64] = t >= 0 ? sc * (expf(v1 - lse) - (lane + 64 == t ? 1.f : 0.f)) : 0.f;
+      if (c0) nt_store1(&orow[lane], t >= 0 ? sc * (expf(v0 - lse) - (lane == t ? 1.f : 0.f)) : 0.f);
+      if (c1) nt_store1(&orow[lane + 64], t >= 0 ? sc * (expf(v1 - lse) - (lane + 64 == t ? 1.f : 0.f)) : 0.f);
     }
   }
   __shared__ double cew[4][3];
@@ -458,7 +470,7 @@ __global__ void __launch_bounds__(256, POS ? 7 : (NT == 2 ? 5 : 8)) spmm_linear_
         for (int i = 0; i < 4; ++i) acc[i] = fmaf(acc[i], ps[i], pt[i] * rsum);
       }
       store_vec<4>(&zt[lr * ldz + c], acc);
-      if (A.z_out && row < A.N) store_vec<4>(A.z_out + (int64_t)row * A.ldz + c, acc);
+      if (A.z_out && row < A.N) nt_store4(A.z_out + (int64_t)row * A.ldz + c, acc);
       if constexpr (POS) {
         if (row < A.N) store_vec<4>(A.zpos_out + (int64_t)row * A.ldz + c, accp);
       }
