@@ -864,6 +864,11 @@ def main():
                          "forwards and epochs (experiment(cache_input_aggregate=True)); the line says so in its metric")
     ap.add_argument("--emulate-rank", type=int, default=0, metavar="P",
                     help="one GPU: rank 0's launches of a P-rank job, exchanges replaced by stand-in rows")
+    ap.add_argument("--emulate-contend", type=float, default=60.0, metavar="GBS",
+                    help="--emulate-rank: after the compute-only timing, time the same steps again with every exchange's "
+                         "bytes actually MOVED on this GPU at GBS per link and direction by a paced copy on a second stream "
+                         "and WAITED for (HBM / cache / CU contention and exposed exchange time inside the measured step); "
+                         "0 = skip")
     ap.add_argument("--degree", choices=("uniform", "powerlaw"), default="uniform",
                     help="powerlaw: secondary run on a hub-heavy graph of the same size (row-split plans at work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1199,6 +1204,46 @@ def main():
                 trace, timed_steps_with_events, latency_us=30.0)["by_link_rate"]
             result["emulated"]["next_step_ahead"] = ahead
         result["metric"] = "EMULATED rank compute, not a benchmark value: " + result["metric"]
+        if on_gpu and args.emulate_contend > 0:
+            def contended_leg():
+                # the PESSIMISTIC one-GPU figure (round 4): the same steps with the exchanges' bytes moved on this GPU at
+                # the assumed link rate x (P - 1) peers while the rank computes, and waited for where the schedule
+                # depends on them — what the step costs including exposed exchange time and the contention for HBM,
+                # caches and CUs that bench.replay_schedule's link model leaves out
+                cal = comm_obj.enable_contention(dev, args.emulate_contend)
+                warm = []
+                for i in range(4):  # (the first instrumented step under contention pays one-off event / stream set-up)
+                    ops.set_event_sink(warm if i == 0 else None)
+                    step()
+                ops.set_event_sink(None)
+                del warm
+                ev = []
+                calls2 = [0]
+
+                def step2():
+                    ops.set_event_sink(ev if calls2[0] % every == 0 else None)
+                    calls2[0] += 1
+                    return step()
+                dt, _, per = time_steps(step2, args.steps, 0, fence)
+                ops.set_event_sink(None)
+                waits = [a.elapsed_time(b) for k, a, b in [r for r in ev if not r[0].startswith("@")] if k == "exchange_wait"]
+                n_ev = len(range(0, args.steps, every))
+                free_ms = elapsed / args.steps * 1e3
+                return {"assumed_link_gbs_per_direction": args.emulate_contend, "paced_copy": cal,
+                        "ms_per_step": dt / args.steps * 1e3, "median_ms_per_step": median(per),
+                        "per_step_ms": [round(v, 3) for v in per], "compute_only_ms_per_step": free_ms,
+                        "compute_only_median_ms_per_step": median(step_ms),
+                        "exposed_exchange_wait_ms_per_step": sum(waits) / max(n_ev, 1),
+                        "contention_and_exposure_over_compute": median(per) / median(step_ms),
+                        "value_edges_per_s_with_exchanges": n_prop * nnz_total / (median(per) * 1e-3),
+                        "what": "rank 0's epoch with every exchange's bytes copied device-to-device on a second stream at "
+                                "the assumed link rate x (P - 1) while the compute stream runs, consumers waiting for the "
+                                "copy: compute + exposed exchange + contention, measured on ONE GPU; no RCCL, no real link"}
+            try:
+                result["emulated"]["contended"] = contended_leg()
+            except Exception as exc:  # noqa: BLE001
+                result["emulated"]["contended"] = {"error": repr(exc)}
+                torch.cuda.synchronize()
 
     def secondary(key, fn):
         """A leg after the timed region must never cost the line its headline: its failure is recorded under its key

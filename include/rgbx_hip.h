@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RGBX_VERSION 400 /* major*10000 + minor*100 + patch */
+#define RGBX_VERSION 401 /* major*10000 + minor*100 + patch */
 
 #define RGBX_OK 0
 #define RGBX_E_ARG (-1)    /* null pointer / negative size / bad enum */
@@ -522,6 +522,11 @@ int rgbx_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, int6
 /* dst[idx[r],:] += src[r,:] for r in [0,n); idx entries must be unique (no atomics). */
 int rgbx_scatter_add_rows_f32(const float* src, int64_t lds, const int32_t* idx, int64_t n,
                               int64_t d, float* dst, int64_t ldd, rgbx_stream_t stream);
+
+/* Measurement aid, not on the path: dst[0:n] = src[0:n] by `workgroups` workgroups only, i.e. at a rate the caller
+ * calibrates — the stand-in for an exchange's memory traffic when ONE GPU emulates a rank of a partitioned job
+ * (bench.py --emulate-rank P --emulate-contend GBS). n % 4 == 0, 16-byte aligned pointers. */
+int rgbx_paced_copy_f32(const float* src, float* dst, int64_t n, int workgroups, rgbx_stream_t stream);
 
 #ifdef __cplusplus
 }

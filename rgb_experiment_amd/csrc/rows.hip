@@ -71,8 +71,39 @@ blocked_to_rows_kernel(const float* __restrict__ src, int64_t bc, int64_t bs, fl
   }
 }
 
+// Stand-in for the memory traffic of an exchange on a ONE-GPU emulation of a partitioned rank (bench.py --emulate-rank
+// with --emulate-contend): `workgroups` workgroups copy n floats, eight independent 16-byte loads in flight per thread. Few
+// workgroups move the bytes at a link-like rate (calibrated by the caller) while the rank's own kernels run on another
+// stream, so that the HBM / L2 / CU time a real exchange takes from them is IN the measured step time.
+__global__ void __launch_bounds__(256)
+paced_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+  constexpr int U = 8;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + (U - 1) * stride < n4; i += U * stride) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) dst[i + u * stride] = v[u];
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
+
 }  // namespace
 }  // namespace rgbx
+
+extern "C" int rgbx_paced_copy_f32(const float* src, float* dst, int64_t n, int workgroups, rgbx_stream_t stream) {
+  using namespace rgbx;
+  if (n < 0 || workgroups <= 0) return fail(RGBX_E_ARG, "paced_copy: bad size");
+  if (n == 0) return RGBX_OK;
+  if (!src || !dst) return fail(RGBX_E_ARG, "paced_copy: null pointer");
+  if (n % 4 || !aligned16(src) || !aligned16(dst)) return fail(RGBX_E_ALIGN, "paced_copy: n % 4 == 0 and 16-byte alignment");
+  paced_copy_kernel<<<workgroups < kMaxGrid ? workgroups : kMaxGrid, 256, 0, (hipStream_t)stream>>>(
+      reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n / 4);
+  RGBX_CHECK_LAUNCH("paced_copy");
+  return RGBX_OK;
+}
 
 extern "C" int rgbx_blocked_to_rows_f32(const float* src, int64_t blk_cols, int64_t blk_stride, float* dst, int64_t ldd,
                                         int64_t n, int64_t d, const float* bias, rgbx_stream_t stream) {

@@ -312,13 +312,17 @@ class _TracedDone:
     schedule (which kernels were enqueued between an exchange's issue and the wait for it) can be replayed against a
     link model."""
 
-    def __init__(self, xid):
+    def __init__(self, xid, done=None):
         self.xid = xid
+        self.done = done  # HIP event on the emulated link stream (contended emulation), else None
 
     def wait(self):
         from .. import ops
         if ops._EVENT_SINK is not None:
             ops._EVENT_SINK.append(("@wait", self.xid))
+        if self.done is not None:  # contended emulation: the waiting stream stands still until "the links" have delivered
+            with ops._Timed("exchange_wait"):
+                torch.cuda.current_stream().wait_event(self.done)
         return None
 
 
@@ -391,7 +395,61 @@ class EmulatedComm(Comm):
         self._xid = getattr(self, "_xid", 0) + 1
         if ops._EVENT_SINK is not None:
             ops._EVENT_SINK.append(("@issue", self._xid, tag, link_bytes))
-        return _TracedDone(self._xid)
+        return _TracedDone(self._xid, self._contend_issue(link_bytes))
+
+    # ---- contended emulation (bench.py --emulate-contend GBS) ---------------------------------------------------------
+    def enable_contention(self, device, link_gbs, max_bytes=1 << 30):
+        """From now on every exchange MOVES its bytes on this GPU while the rank computes: a paced device-to-device copy
+        of (world - 1) x [bytes on the busiest link] on a separate "link" stream, at (world - 1) x link_gbs GB/s — the
+        inbound rows written into this rank's HBM plus as many outbound bytes read from it, through `wgs` workgroups
+        (RCCL's copy kernels run on CUs too) — started when the launches enqueued before the exchange's issue have
+        finished (FIFO over one stream, like the link model of bench.replay_schedule), and the consumer WAITS for it.
+        The measured step time then contains the exposed exchange time AND what the traffic costs the kernels it runs
+        beside (HBM bandwidth, L2 / Infinity Cache space, CU slots): the pessimistic one-GPU figure."""
+        from .. import _lib
+        import time
+        self._link = torch.cuda.Stream(device)
+        n = max_bytes // 4
+        self._paced_src = torch.empty(n, dtype=torch.float32, device=device).normal_()
+        self._paced_dst = torch.empty(n, dtype=torch.float32, device=device)
+        target = (self.world - 1) * float(link_gbs)
+        lib = _lib.load()
+
+        def rate(wgs, nbytes=256 << 20):
+            k = min(nbytes // 4, n) // 4 * 4
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            with torch.cuda.stream(self._link):
+                for _ in range(3):
+                    _lib.check(lib.rgbx_paced_copy_f32(self._paced_src.data_ptr(), self._paced_dst.data_ptr(), k, wgs,
+                                                       self._link.cuda_stream), "rgbx_paced_copy_f32")
+            self._link.synchronize()
+            return 3 * k * 4 / (time.perf_counter() - t0) / 1e9
+
+        rate(64)  # warm-up
+        table = {w: rate(w) for w in (4, 8, 16, 32, 64, 128, 256)}
+        # the smallest workgroup count that reaches the target rate (copy kernels cannot be slowed below one workgroup's
+        # rate; a rate above the target ends an exchange early, i.e. errs towards LESS exposure but MORE contention)
+        wgs = next((w for w in sorted(table) if table[w] >= target), max(table))
+        self._contend = {"link_gbs": float(link_gbs), "target_copy_gbs": target, "workgroups": wgs,
+                         "copy_gbs_measured": table[wgs], "calibration_gbs_by_workgroups": table}
+        return self._contend
+
+    def _contend_issue(self, link_bytes):
+        c = getattr(self, "_contend", None)
+        if c is None or link_bytes <= 0:
+            return None
+        from .. import _lib
+        n = min(int(link_bytes) * (self.world - 1) // 4, self._paced_src.numel()) // 4 * 4
+        if n == 0:
+            return None
+        cur = torch.cuda.current_stream()
+        self._link.wait_stream(cur)  # an exchange starts when its producers (everything enqueued so far) are done
+        _lib.check(_lib.load().rgbx_paced_copy_f32(self._paced_src.data_ptr(), self._paced_dst.data_ptr(), n,
+                                                   c["workgroups"], self._link.cuda_stream), "rgbx_paced_copy_f32")
+        done = torch.cuda.Event()
+        done.record(self._link)
+        return done
 
     def all_reduce_sum_(self, t):
         return t.mul_(self.world)  # as if every rank had contributed this rank's share
