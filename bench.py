@@ -483,7 +483,7 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
     else:
         alg = spmm_alg_bytes(N, nnz_total, d)
 
-    from rgb_experiment_amd.models._stack import masked_ce
+    from rgb_experiment_amd.models._stack import masked_ce, masked_ce_pair
     fwd = {"x": x_d, "edge_index": ei_d}
 
     def evaluate(mask):
@@ -534,8 +534,7 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
         opt.step()
         model.eval()
         with torch.no_grad():
-            emb = model(**fwd)["emb"]
-            val, tst = ops.masked_ce_accuracy(emb, y_d, vm), ops.masked_ce_accuracy(emb, y_d, sm)
+            val, tst = masked_ce_pair(model, fwd, y_d, vm, sm).unbind(0)  # one forward, both statistics sets
         s = torch.cat([loss.detach().double().reshape(1), val, tst]).tolist()
         return s[0], s[1] / s[2], s[3] / s[2], s[4] / s[5], s[6] / s[5]
 

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RGBX_VERSION 401 /* major*10000 + minor*100 + patch */
+#define RGBX_VERSION 402 /* major*10000 + minor*100 + patch */
 
 #define RGBX_OK 0
 #define RGBX_E_ARG (-1)    /* null pointer / negative size / bad enum */
@@ -175,8 +175,12 @@ typedef struct rgbx_ce_epilogue {
   const int64_t* y;        /* [N] labels */
   const uint8_t* mask;     /* [N] or NULL = all rows */
   const float* grad_scale; /* device scalar or NULL */
-  double* stats;           /* [3] */
-  double* scratch;         /* [(ceil(N / 32) + 64) * 3] */
+  double* stats;           /* [3]; [6] with mask_groups == 2 */
+  double* scratch;         /* [(ceil(N / 32) + 64) * 3]; * 6 with mask_groups == 2 */
+  /* 0 / 1: `mask` is a boolean. 2 (since 4.0.2; statistics only, mask required): bit 0 / bit 1 of mask[i] select row i
+   * for statistics set 0 / set 1 — stats[0:3] and stats[3:6] — so that ONE eval forward serves the val and the test
+   * metrics of an epoch (itexperiments.py:464-473 runs two identical forwards for them). */
+  int32_t mask_groups;
 } rgbx_ce_epilogue_t;
 
 int rgbx_spmm_linear_supported(int64_t K, int64_t Nout, int has_root);

@@ -28,7 +28,7 @@ class RowSplit(ctypes.Structure):
 class CeEpilogue(ctypes.Structure):
     """rgbx_ce_epilogue_t"""
     _fields_ = [("y", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("grad_scale", ctypes.c_void_p),
-                ("stats", ctypes.c_void_p), ("scratch", ctypes.c_void_p)]
+                ("stats", ctypes.c_void_p), ("scratch", ctypes.c_void_p), ("mask_groups", ctypes.c_int32)]
 
 
 class FusedLayer(ctypes.Structure):

@@ -71,6 +71,8 @@ struct FusedArgs {
   const uint8_t* ce_mask;
   const float* ce_scale;
   double* ce_part;
+  int ce_groups;  // 1: ce_mask is a boolean; 2: bit 0 / bit 1 of ce_mask[row] select the row for statistics set 0 / 1
+                  // (ce_part records are then 6 wide: one forward, the statistics of two masks — val and test)
   // node-partitioned runs (rgbx_fused_layer_f32). Blocked layout: element (i, c) at base + (c / cols) * stride +
   // i * cols + c % cols — column slices stored one after the other, the form the exchange sends and receives.
   // x_bc / x_bs: layout of x in DENSE mode (0 = row-major ldx); xr_bc / xr_bs: of the root rows; out_blk: a blocked
@@ -242,7 +244,9 @@ __device__ __forceinline__ void ce_epilogue(const FusedArgs& A, const f32x16& ac
     for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2) + 4 * kr) * ldq + n0 + cc] = acc[r] + bb;
   }
   __syncthreads();
-  double nll = 0.0, cnt = 0.0, hit = 0.0;
+  double nll = 0.0, nll2 = 0.0;  // nll2 / cnt2 / hit2: the second statistics set (ce_groups == 2)
+  int cnt = 0, hit = 0, cnt2 = 0, hit2 = 0;  // row counts as integers: one register each, exact
+  const int W = 3 * A.ce_groups;
   const float sc = A.ce_scale ? A.ce_scale[0] : 0.f;
   const bool c0 = lane < A.Nout, c1 = lane + 64 < A.Nout;
   for (int rr = 0; rr < TM / 4; ++rr) {
@@ -250,7 +254,9 @@ __device__ __forceinline__ void ce_epilogue(const FusedArgs& A, const f32x16& ac
     const int row = row_base + rl;
     if (row >= A.N) break;  // wave-uniform
     int t = -1;
-    if (!A.ce_mask || A.ce_mask[row]) {
+    int bits = A.ce_mask ? (int)A.ce_mask[row] : 1;
+    bits = A.ce_groups == 2 ? (bits & 3) : (bits ? 1 : 0);
+    if (bits) {
       const int64_t ti = A.ce_y[row];
       if (ti >= 0 && ti < A.Nout) t = (int)ti;
     }
@@ -271,9 +277,18 @@ __device__ __forceinline__ void ce_epilogue(const FusedArgs& A, const f32x16& ac
     for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off);
     const float lse = best + logf(se);
     if (t >= 0) {
-      nll += (double)(lse - ot[rl * ldq + t]);
-      cnt += 1.0;
-      hit += arg == t ? 1.0 : 0.0;
+      const double term = (double)(lse - ot[rl * ldq + t]);
+      const int h = arg == t ? 1 : 0;
+      if (bits & 1) {
+        nll += term;
+        cnt += 1;
+        hit += h;
+      }
+      if (bits & 2) {
+        nll2 += term;
+        cnt2 += 1;
+        hit2 += h;
+      }
     }
     if (A.ce_scale) {
       float* orow = A.out + (int64_t)row * A.ldo;
@@ -281,16 +296,19 @@ __device__ __forceinline__ void ce_epilogue(const FusedArgs& A, const f32x16& ac
       if (c1) nt_store1(&orow[lane + 64], t >= 0 ? sc * (expf(v1 - lse) - (lane + 64 == t ? 1.f : 0.f)) : 0.f);
     }
   }
-  __shared__ double cew[4][3];
+  __shared__ double cew[4][6];
   if (lane == 0) {
     cew[wave][0] = nll;
-    cew[wave][1] = cnt;
-    cew[wave][2] = hit;
+    cew[wave][1] = (double)cnt;
+    cew[wave][2] = (double)hit;
+    cew[wave][3] = nll2;
+    cew[wave][4] = (double)cnt2;
+    cew[wave][5] = (double)hit2;
   }
   __syncthreads();
-  if (threadIdx.x < 3) {
+  if ((int)threadIdx.x < W) {
     const int k = threadIdx.x;
-    A.ce_part[(int64_t)tile * 3 + k] = (cew[0][k] + cew[1][k]) + (cew[2][k] + cew[3][k]);
+    A.ce_part[(int64_t)tile * W + k] = (cew[0][k] + cew[1][k]) + (cew[2][k] + cew[3][k]);
   }
 }
 
@@ -311,23 +329,23 @@ __device__ __forceinline__ double block_tree_sum(double v, double* sh) {
 }
 
 __global__ void __launch_bounds__(256)
-ce_tiles_gather_kernel(const double* __restrict__ part, int n_tiles, double* __restrict__ part2) {
+ce_tiles_gather_kernel(const double* __restrict__ part, int n_tiles, double* __restrict__ part2, int W) {
   __shared__ double sh[256];
   const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
   const int b0 = blockIdx.x * per, b1 = min(n_tiles, b0 + per);
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < W; ++k) {
     double v = 0.0;
-    for (int b = b0 + threadIdx.x; b < b1; b += 256) v += part[(int64_t)b * 3 + k];
+    for (int b = b0 + threadIdx.x; b < b1; b += 256) v += part[(int64_t)b * W + k];
     v = block_tree_sum(v, sh);
-    if (threadIdx.x == 0) part2[blockIdx.x * 3 + k] = v;
+    if (threadIdx.x == 0) part2[blockIdx.x * W + k] = v;
   }
 }
 
 __global__ void __launch_bounds__(256)
-ce_tiles_finish_kernel(const double* __restrict__ part2, int n, double* __restrict__ stats) {
+ce_tiles_finish_kernel(const double* __restrict__ part2, int n, double* __restrict__ stats, int W) {
   __shared__ double sh[256];
-  for (int k = 0; k < 3; ++k) {
-    const double v = block_tree_sum((int)threadIdx.x < n ? part2[threadIdx.x * 3 + k] : 0.0, sh);
+  for (int k = 0; k < W; ++k) {
+    const double v = block_tree_sum((int)threadIdx.x < n ? part2[threadIdx.x * W + k] : 0.0, sh);
     if (threadIdx.x == 0) stats[k] = v;
   }
 }
@@ -906,6 +924,10 @@ extern "C" int rgbx_fused_layer_f32(const rgbx_fused_layer_t* Lp, rgbx_stream_t 
     if (L.out_colsums) return fail(RGBX_E_ARG, "spmm_linear: out_colsums and the cross-entropy epilogue exclude each other");
     if (L.out_blk) return fail(RGBX_E_ARG, "spmm_linear: a blocked output and the cross-entropy epilogue exclude each other");
     if (ce->grad_scale && !L.out) return fail(RGBX_E_ARG, "spmm_linear: the loss gradient needs `out`");
+    if (ce->mask_groups < 0 || ce->mask_groups > 2)
+      return fail(RGBX_E_ARG, "spmm_linear: mask_groups must be 0, 1 or 2 (got %d)", (int)ce->mask_groups);
+    if (ce->mask_groups == 2 && (ce->grad_scale || !ce->mask))
+      return fail(RGBX_E_ARG, "spmm_linear: two statistics sets (mask_groups == 2) need a mask and no loss gradient");
   }
   if ((L.w_pos != nullptr) != (L.z_pos_out != nullptr))
     return fail(RGBX_E_ARG, "fused_layer: w_pos and z_pos_out go together");
@@ -981,6 +1003,7 @@ extern "C" int rgbx_fused_layer_f32(const rgbx_fused_layer_t* Lp, rgbx_stream_t 
               L.ldx, L.ldo, L.ldz, L.ldr, long_row, zlong, threshold, n_long, (int)N, (int)K, (int)Nout,
               L.pre_scale, L.pre_shift, L.pre_rowsum, stats_part,
               ce ? ce->y : nullptr, ce ? ce->mask : nullptr, ce ? ce->grad_scale : nullptr, ce ? ce->scratch : nullptr,
+              ce && ce->mask_groups == 2 ? 2 : 1,
               x_blk ? L.x_blk_cols : 0, L.x_blk_stride, xr_blk ? L.xr_blk_cols : 0, L.xr_blk_stride,
               L.out_blk, L.ob_cols, L.ob_stride, L.w_pos, L.z_pos_out, zlong_pos};
   const int lanes = (int)(K / 4);
@@ -1006,10 +1029,11 @@ extern "C" int rgbx_fused_layer_f32(const rgbx_fused_layer_t* Lp, rgbx_stream_t 
   if (rc) return rc;
   if (ce) {
     const int tiles = (int)cdiv(N, TM);
-    double* part2 = ce->scratch + (size_t)tiles * 3;  // [kCeGather, 3] behind the tile records
-    ce_tiles_gather_kernel<<<kCeGather, 256, 0, s>>>(ce->scratch, tiles, part2);
+    const int W = ce->mask_groups == 2 ? 6 : 3;
+    double* part2 = ce->scratch + (size_t)tiles * W;  // [kCeGather, W] behind the tile records
+    ce_tiles_gather_kernel<<<kCeGather, 256, 0, s>>>(ce->scratch, tiles, part2, W);
     RGBX_CHECK_LAUNCH("ce_tiles_gather_kernel");
-    ce_tiles_finish_kernel<<<1, 256, 0, s>>>(part2, kCeGather, ce->stats);
+    ce_tiles_finish_kernel<<<1, 256, 0, s>>>(part2, kCeGather, ce->stats, W);
     RGBX_CHECK_LAUNCH("ce_tiles_finish_kernel");
   }
   if (!L.out_colsums) return RGBX_OK;

@@ -44,10 +44,9 @@ class GraphedEpoch:
         self.opt.step()
         net.eval()
         with torch.no_grad():
-            if self.share_eval_forward:  # one eval forward, two masks: the logits are needed twice
-                res = net(**self.fwd)
-                val_stats = ops.masked_ce_accuracy(res["emb"], y, self.val_mask)
-                test_stats = ops.masked_ce_accuracy(res["emb"], y, self.test_mask)
+            if self.share_eval_forward:  # one eval forward, two masks: both statistics sets from the last conv's kernel
+                from .models._stack import masked_ce_pair  # where it takes the loss (else from the one set of logits)
+                val_stats, test_stats = masked_ce_pair(net, self.fwd, y, self.val_mask, self.test_mask).unbind(0)
             else:  # the reference's two identical eval forwards (itexperiments.py:464,470)
                 val_stats = masked_ce(net, self.fwd, y, self.val_mask)[1]
                 test_stats = masked_ce(net, self.fwd, y, self.test_mask)[1]

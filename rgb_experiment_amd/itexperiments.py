@@ -410,6 +410,22 @@ def experiment(model_init_param: dict, *,
         hist["train_loss"].append(loss.item())
         loss.backward()
         optimizer.step()
+        if device.type == "cuda":
+            # the eval forwards reduced to what the loop reads of them (loss and accuracy per mask), by the same kernels
+            # as the captured epoch: NLL sum / rows / arg-max hits from the last conv's kernel where the model has that
+            # form, else from its logits; one forward for both masks under share_eval_forward
+            from .models._stack import masked_ce, masked_ce_pair
+            net.eval()
+            with torch.no_grad():
+                if share_eval_forward:
+                    st = masked_ce_pair(net, fwd, y, val_mask, test_mask)
+                else:
+                    st = torch.stack([masked_ce(net, fwd, y, val_mask)[1], masked_ce(net, fwd, y, test_mask)[1]])
+            (vn, vc, vh), (sn, sc, sh) = st.tolist()  # the epoch's one read-back of the eval side
+            nan = float("nan")
+            hist["test_acc"].append(sh / sc if sc else nan)
+            hist["test_loss"].append(sn / sc if sc else nan)
+            return (vh / vc if vc else nan), (vn / vc if vc else nan), None
         val = test(net, fwd, y, val_mask, loop_metrics)
         val_loss = criterion(val["test_op"][val_mask], y[val_mask]).item()
         if share_eval_forward:  # same eval-mode outputs, second mask (opt-in: the reference forwards twice)

@@ -99,6 +99,13 @@ class ConvStack(nn.Module):
         the loss itself may be None (nobody reads it there): it is stats[0] / stats[1]."""
         return self._run(x, edge_index, ce=(y, mask))
 
+    def masked_ce_pair(self, x, edge_index, y, mask_a, mask_b):
+        """[2, 3] statistics ([nll sum, selected rows, correct] under mask_a and under mask_b) of ONE eval forward: the val
+        and the test metrics of an epoch, for which the reference runs two identical eval forwards
+        (itexperiments.py:464-473). Where the last conv takes the loss into its kernel both sets come out of that one
+        launch (rgbx_ce_epilogue_t.mask_groups = 2) and the logits are never written; otherwise from the logits."""
+        return self._run(x, edge_index, ce=(y, (mask_a, mask_b)))[1]
+
     def _run(self, x, edge_index, ce=None):
         """x = bns[i](convs[i](x)) ... convs[-1](x) (models/gcn.py:25-31). A BatchNorm is never a pass of its own
         where a neighbouring conv can absorb it: under no_grad its eval-mode affine map goes into the PRECEDING conv's
@@ -136,7 +143,8 @@ class ConvStack(nn.Module):
             if (bn is not None and bn.training and torch.is_grad_enabled() and getattr(conv, "emits_colsums", False)
                     and hasattr(bn, "begin_training_step")):
                 extra["want_colsums"] = True
-            if i == last and ce is not None and getattr(conv, "accepts_ce", False):
+            if (i == last and ce is not None and getattr(conv, "accepts_ce", False)
+                    and not isinstance(ce[1], (tuple, list))):  # (a pair of masks: the folded eval route above, or the logits)
                 extra["ce"] = ce  # the last conv returns (loss, stats) instead of the logits
             if pending is not None:
                 sums = getattr(x, ops.COLSUMS, None)
@@ -204,6 +212,17 @@ def _input_aggregate(self, x, edge_index):
 
 
 ConvStack._input_aggregate = _input_aggregate
+
+
+def masked_ce_pair(model, fwd, y, mask_a, mask_b):
+    """[2, 3] eval statistics of `model(**fwd)` under two masks from ONE forward (ConvStack.masked_ce_pair where the model
+    has it, the logits otherwise): what share_eval_forward runs per epoch."""
+    from .. import ops
+    fn = getattr(model, "masked_ce_pair", None)
+    if fn is not None and set(fwd) == {"x", "edge_index"} and fwd["x"].is_cuda:
+        return fn(fwd["x"], fwd["edge_index"], y, mask_a, mask_b)
+    emb = model(**fwd)["emb"]
+    return torch.stack([ops.masked_ce_accuracy(emb, y, mask_a), ops.masked_ce_accuracy(emb, y, mask_b)])
 
 
 def masked_ce(model, fwd, y, mask):

@@ -290,8 +290,13 @@ def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_roo
         keep += [ps, pt, pr]
         L.pre_scale, L.pre_shift, L.pre_rowsum = ps.data_ptr(), pt.data_ptr(), pr.data_ptr()
     ce_stats = None
+    groups = 1
     if ce is not None:
         y, mask, grad_scale = ce
+        if isinstance(mask, (tuple, list)):  # two masks, one forward: statistics set 0 / 1 = bit 0 / 1 of the grouped mask
+            if grad_scale is not None:
+                raise RuntimeError("fused_layer: two masks are for statistics only (no loss gradient)")
+            mask, groups = group_masks(*mask), 2
         _lib.require_device(y, mask, grad_scale)
         if y.dtype != torch.int64:
             raise RuntimeError(f"labels must be int64, got {y.dtype}")
@@ -299,10 +304,10 @@ def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_roo
             raise RuntimeError(f"mask must be bool, got {mask.dtype}")
         y = y.contiguous()
         mask = None if mask is None else mask.contiguous()
-        ce_stats = torch.empty(3, dtype=torch.float64, device=x.device)
-        ce_scratch = torch.empty(3 * ((N + 31) // 32 + 64), dtype=torch.float64, device=x.device)
+        ce_stats = torch.empty(3 * groups, dtype=torch.float64, device=x.device)
+        ce_scratch = torch.empty(3 * groups * ((N + 31) // 32 + 64), dtype=torch.float64, device=x.device)
         ce_arg = _lib.CeEpilogue(_lib.ptr(y), _lib.ptr(mask), _lib.ptr(grad_scale), _lib.ptr(ce_stats),
-                                 _lib.ptr(ce_scratch))
+                                 _lib.ptr(ce_scratch), groups)
         keep += [y, mask, ce_scratch, ce_arg]
         L.ce = ctypes.addressof(ce_arg)
         want_out = grad_scale is not None  # statistics only: the logits are never written
@@ -353,6 +358,8 @@ def fused_layer(x, wt, csr=None, w=None, rs=None, bias=None, x_root=None, wt_roo
     with _Timed(kind, variant):
         _lib.check(lib.rgbx_fused_layer_f32(ctypes.byref(L), _lib.stream_ptr()), "rgbx_fused_layer_f32")
     del keep
+    if groups == 2:
+        ce_stats = ce_stats.view(2, 3)  # row k = [nll sum, selected rows, correct] under mask k
     return out, (z if w_pos is None else (z, z_pos)), (ce_stats if ce is not None else colsums)
 
 
@@ -601,9 +608,30 @@ def mask_scale(y, mask, C):
     return hit[0]
 
 
+_GROUP_MASKS = {}
+
+
+def group_masks(mask_a, mask_b):
+    """uint8 [N] with bit 0 = mask_a, bit 1 = mask_b (rgbx_ce_epilogue_t.mask_groups == 2): made once per pair of mask
+    tensors (address + version), masks are fixed for a run."""
+    _lib.require_device(mask_a, mask_b)
+    key = (mask_a.data_ptr(), mask_a._version, mask_b.data_ptr(), mask_b._version, mask_a.numel())
+    hit = _GROUP_MASKS.get(key)
+    if hit is None:
+        g = (mask_a.bool().to(torch.uint8) | (mask_b.bool().to(torch.uint8) << 1)).contiguous()
+        hit = (g, mask_a, mask_b)  # the mask tensors stay alive with their addresses
+        _GROUP_MASKS[key] = hit
+        while len(_GROUP_MASKS) > 16:
+            _GROUP_MASKS.pop(next(iter(_GROUP_MASKS)))
+    return hit[0]
+
+
 def ce_from_logits(logits, y, mask):
     """(loss, stats) of the masked cross-entropy taken from materialised logits: the unfused route of the *_ce
-    entry points. loss = NLLLoss(log_softmax(logits)[mask], y[mask]); stats = [nll sum, selected rows, correct]."""
+    entry points. loss = NLLLoss(log_softmax(logits)[mask], y[mask]); stats = [nll sum, selected rows, correct].
+    `mask` = (mask_a, mask_b): (None, [2, 3] stats) of both masks from the one set of logits."""
+    if isinstance(mask, (tuple, list)):
+        return None, torch.stack([masked_ce_accuracy(logits, y, m) for m in mask])
     if torch.is_grad_enabled() and logits.requires_grad:
         return masked_ce_loss(logits, y, mask, with_stats=True)
     stats = masked_ce_accuracy(logits, y, mask)

@@ -1766,6 +1766,39 @@ def test_fused_adam_outside_experiment(dev):
         assert ops.weights_epoch() >= 3
 
 
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack"])
+def test_two_masks_from_one_eval_forward(dev, name):
+    """rgbx_ce_epilogue_t.mask_groups = 2 / models._stack.masked_ce_pair: the val and the test statistics of an epoch
+    (NLL sum, rows, arg-max hits) from ONE eval forward equal, bit for bit, what two forwards with one mask each give
+    (what the reference runs, itexperiments.py:464-473) — masks that overlap and rows that neither selects included;
+    the conv stacks take both sets out of the last layer's kernel, GAT / APPNP from the one set of logits."""
+    from rgb_experiment_amd.models._stack import masked_ce, masked_ce_pair
+    cls, kw, _ = _model_case(name)
+    n, f, c = 3001, 48, 11
+    gen = torch.Generator().manual_seed(21)
+    ei = rand_graph(n, 30000, 21, loops=5, dups=5).to(dev)
+    x = torch.randn(n, f, generator=gen).to(dev)
+    y = torch.randint(0, c, (n,), generator=gen)
+    y[::97] = -1  # unlabelled rows inside the masks are skipped by both routes
+    y = y.to(dev)
+    r = torch.rand(n, generator=gen)
+    ma, mb = (r < 0.5).to(dev), ((r > 0.4) & (r < 0.8)).to(dev)  # overlap on (0.4, 0.5), nobody on (0.8, 1)
+    torch.manual_seed(3)
+    model = cls(input_dim=f, output_dim=c, **kw).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    fwd = {"x": x, "edge_index": ei}
+    model.train()
+    sel = ma & (y >= 0)
+    torch.nn.functional.nll_loss(model(**fwd)["out"][sel], y[sel]).backward()
+    opt.step()  # BatchNorm statistics and weights off their initial values
+    model.eval()
+    with torch.no_grad():
+        one = torch.stack([masked_ce(model, fwd, y, ma)[1], masked_ce(model, fwd, y, mb)[1]])
+        pair = masked_ce_pair(model, fwd, y, ma, mb)
+    assert pair.shape == (2, 3) and torch.equal(pair, one), (pair, one)
+    assert pair[0, 1].item() == float((ma & (y >= 0)).sum()) and pair[1, 1].item() == float((mb & (y >= 0)).sum())
+
+
 @pytest.mark.parametrize("graphed", [False, True])
 def test_shared_eval_forward_changes_nothing_but_the_forward_count(dev, graphed):
     """share_eval_forward=True: per-epoch test metrics from the val pass's outputs (the reference forwards a second
