@@ -99,14 +99,17 @@ EXPORTS = ["rgbx_version", "rgbx_last_error_string"] + list(SIGNATURES)
 _lib = None
 
 
-def bind(path):
-    """ctypes handle of a build of the library with every entry point's signature declared."""
+def bind(path, strict=True):
+    """ctypes handle of a build of the library with every entry point's signature declared. strict=False (kernel A/B
+    tools binding an OLDER build): entry points that build does not have are skipped."""
     lib = ctypes.CDLL(path)
     lib.rgbx_version.restype = _I
     lib.rgbx_version.argtypes = []
     lib.rgbx_last_error_string.restype = ctypes.c_char_p
     lib.rgbx_last_error_string.argtypes = []
     for name, argtypes in SIGNATURES.items():
+        if not strict and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         fn.restype = _I
         fn.argtypes = argtypes

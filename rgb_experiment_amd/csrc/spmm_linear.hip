@@ -660,7 +660,7 @@ template <int KC, int NT, bool CE, bool ROOT>
 __global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE || KC > 64 ? 3 : 4)) dense_stream_kernel(const FusedArgs A, int tiles) {
   extern __shared__ float zt[];  // [TM][KC + 4] (the loss epilogue re-uses it as [TM][Nout + 4]); pipelined forms: two
   constexpr int ldz = KC + 4, k4 = KC / 4, S = KC / 2;
-  constexpr bool PIPE = !CE && !ROOT && NT == 1;  // NT = 2 keeps 128 W^T values per lane: no room for a tile in flight
+  constexpr bool PIPE = !CE && NT == 1;  // NT = 2 keeps 128 W^T values per lane: no room for a tile in flight
   constexpr int VPT = (TM * k4) / 256;  // float4 per thread and tile (KC = 128: 4, KC = 64: 2)
   static_assert((TM * k4) % 256 == 0, "tile loads are spread evenly over the workgroup");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -680,7 +680,10 @@ __global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE || KC > 64 ? 3 :
   }
   if constexpr (PIPE) {
     // this thread's VPT float4 of a tile: element idx = threadIdx.x + u * 256 -> row idx / k4, columns 4 * (idx % k4)
+    // (ROOT: the same for the workgroup's own rows x_root, parked into a second pair of tiles behind the first pair)
     float pv[VPT][4];
+    float pr[ROOT ? VPT : 1][4];
+    constexpr int kRootTiles = 2 * TM * ldz;  // offset of the root rows' tiles
     auto fetch = [&](int tile) {
       const int row_base = tile * TM;
 #pragma unroll
@@ -691,6 +694,11 @@ __global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE || KC > 64 ? 3 :
 #pragma unroll
         for (int i = 0; i < 4; ++i) pv[u][i] = 0.f;
         if (row < A.N) load_vec<4>(pv[u], blocked_at(A.x, A.x_bc, A.x_bs, A.ldx, row, c4));
+        if constexpr (ROOT) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pr[u][i] = 0.f;
+          if (row < A.N) load_vec<4>(pr[u], blocked_at(A.xr, A.xr_bc, A.xr_bs, A.ldr, row, c4));
+        }
       }
     };
     auto park = [&](int tile, float* buf) {  // pre-affine map, optional z_out, then into the LDS tile
@@ -708,10 +716,15 @@ __global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE || KC > 64 ? 3 :
             const float rsum = A.pre_rowsum[row];
 #pragma unroll
             for (int i = 0; i < 4; ++i) pv[u][i] = fmaf(pv[u][i], ps[i], pt[i] * rsum);
+            if constexpr (ROOT) {  // the root rows are rows of the same affinely mapped matrix (no row-sum factor)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) pr[u][i] = fmaf(pr[u][i], ps[i], pt[i]);
+            }
           }
           if (A.z_out) store_vec<4>(A.z_out + (int64_t)row * A.ldz + c4, pv[u]);
         }
         park4(&buf[r * ldz], c4, pv[u]);
+        if constexpr (ROOT) park4(&buf[kRootTiles + r * ldz], c4, pr[u]);
       }
     };
     int cur = 0;  // the tile being multiplied lives at zt + cur * TM * ldz, the one being filled at the other half
@@ -729,7 +742,10 @@ __global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE || KC > 64 ? 3 :
       for (int tt = 0; tt < NT; ++tt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
-        if (wave * 32 + tt * 128 < A.Nout) stream_tile_mfma<KC>(acc[tt], zt + cur * (TM * ldz), breg[tt], kr, cc);
+        if (wave * 32 + tt * 128 < A.Nout) {
+          stream_tile_mfma<KC>(acc[tt], zt + cur * (TM * ldz), breg[tt], kr, cc);
+          if constexpr (ROOT) stream_tile_mfma<KC>(acc[tt], zt + kRootTiles + cur * (TM * ldz), rreg[tt], kr, cc);
+        }
       }
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
@@ -830,7 +846,14 @@ bool launch_dense_stream(const FusedArgs& A, hipStream_t s) {
     if (root) dense_stream_kernel<KC, 1, true, true><<<grid, 256, lds, s>>>(A, tiles);
     else dense_stream_kernel<KC, 1, true, false><<<grid, 256, lds, s>>>(A, tiles);
   } else if (nt == 1) {
-    if (root) dense_stream_kernel<KC, 1, false, true><<<grid, 256, lds, s>>>(A, tiles);
+    if (root) {  // + two tiles of root rows: 4 x 32 x (KC + 4) floats = 67.6 KB at KC = 128, beyond the 64 KB a launch
+      // may ask for without saying so
+      static const hipError_t allow = hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&dense_stream_kernel<KC, 1, false, true>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds2));
+      if (allow != hipSuccess) return false;  // the one-tile-per-workgroup form takes the launch
+      dense_stream_kernel<KC, 1, false, true><<<grid, 256, 2 * lds2, s>>>(A, tiles);
+    }
     else dense_stream_kernel<KC, 1, false, false><<<grid, 256, lds2, s>>>(A, tiles);
   } else {
     dense_stream_kernel<KC, 2, false, false><<<grid, 256, lds2, s>>>(A, tiles);
