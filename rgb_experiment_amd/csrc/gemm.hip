@@ -184,7 +184,11 @@ gemm_tn_reduce_kernel(const float* __restrict__ part, int S, int64_t MN, float* 
 
 int choose_splits(int64_t K, int M, int N) {
   const int64_t tiles = cdiv(M, BM) * cdiv(N, BN);
-  int64_t s = cdiv(1024, tiles);            // ~4 workgroups per CU over the whole grid
+  // ONE round of workgroups over the chip: the kernel's registers (66 VGPRs + 64 accumulators) allow 3 workgroups per
+  // CU, so 256 x 3 K-slabs; 1024 (round 3) left a second round of 256 workgroups on an otherwise idle chip:
+  // 2 M x 128 x 128: 0.710 -> 0.656 ms (tools/dense_bench.py, profiles/r04_gemm_tn_variants.txt; 4 waves per SIMD by
+  // __launch_bounds__ spills 7 registers and gains less)
+  int64_t s = cdiv(768, tiles);
   const int64_t max_s = cdiv(K, 16 * KT);   // at least 16 staged tiles per slab: fewer, longer slabs for small K
                                             // (K = 200 k: 391 partial tiles to reduce instead of 1024)
   if (s > max_s) s = max_s;
