@@ -529,8 +529,9 @@ int rgbx_scatter_add_rows_f32(const float* src, int64_t lds, const int32_t* idx,
 
 /* Measurement aid, not on the path: dst[0:n] = src[0:n] by `workgroups` workgroups only, i.e. at a rate the caller
  * calibrates — the stand-in for an exchange's memory traffic when ONE GPU emulates a rank of a partitioned job
- * (bench.py --emulate-rank P --emulate-contend GBS). n % 4 == 0, 16-byte aligned pointers. */
-int rgbx_paced_copy_f32(const float* src, float* dst, int64_t n, int workgroups, rgbx_stream_t stream);
+ * (bench.py --emulate-rank P --emulate-contend GBS). nontemporal != 0: loads and stores that do not allocate in the caches
+ * (the optimistic bracket of what a real exchange's DMA traffic does to them). n % 4 == 0, 16-byte aligned pointers. */
+int rgbx_paced_copy_f32(const float* src, float* dst, int64_t n, int workgroups, int nontemporal, rgbx_stream_t stream);
 
 #ifdef __cplusplus
 }

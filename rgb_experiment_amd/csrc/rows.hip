@@ -75,17 +75,24 @@ blocked_to_rows_kernel(const float* __restrict__ src, int64_t bc, int64_t bs, fl
 // with --emulate-contend): `workgroups` workgroups copy n floats, eight independent 16-byte loads in flight per thread. Few
 // workgroups move the bytes at a link-like rate (calibrated by the caller) while the rank's own kernels run on another
 // stream, so that the HBM / L2 / CU time a real exchange takes from them is IN the measured step time.
+// NT: non-temporal loads and stores — traffic that does not allocate in L2 / Infinity Cache, the optimistic end of what
+// inbound DMA writes and outbound reads of a real exchange may do to the caches (the plain form is the pessimistic end).
+using f4v = __attribute__((ext_vector_type(4))) float;
+template <bool NT>
 __global__ void __launch_bounds__(256)
-paced_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+paced_copy_kernel(const f4v* __restrict__ src, f4v* __restrict__ dst, int64_t n4) {
   constexpr int U = 8;
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   for (; i + (U - 1) * stride < n4; i += U * stride) {
-    float4 v[U];
+    f4v v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
+    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
 #pragma unroll
-    for (int u = 0; u < U; ++u) dst[i + u * stride] = v[u];
+    for (int u = 0; u < U; ++u) {
+      if constexpr (NT) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+      else dst[i + u * stride] = v[u];
+    }
   }
   for (; i < n4; i += stride) dst[i] = src[i];
 }
@@ -93,14 +100,20 @@ paced_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int6
 }  // namespace
 }  // namespace rgbx
 
-extern "C" int rgbx_paced_copy_f32(const float* src, float* dst, int64_t n, int workgroups, rgbx_stream_t stream) {
+extern "C" int rgbx_paced_copy_f32(const float* src, float* dst, int64_t n, int workgroups, int nontemporal,
+                                   rgbx_stream_t stream) {
   using namespace rgbx;
   if (n < 0 || workgroups <= 0) return fail(RGBX_E_ARG, "paced_copy: bad size");
   if (n == 0) return RGBX_OK;
   if (!src || !dst) return fail(RGBX_E_ARG, "paced_copy: null pointer");
   if (n % 4 || !aligned16(src) || !aligned16(dst)) return fail(RGBX_E_ALIGN, "paced_copy: n % 4 == 0 and 16-byte alignment");
-  paced_copy_kernel<<<workgroups < kMaxGrid ? workgroups : kMaxGrid, 256, 0, (hipStream_t)stream>>>(
-      reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n / 4);
+  const int grid = workgroups < kMaxGrid ? workgroups : kMaxGrid;
+  if (nontemporal)
+    paced_copy_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const f4v*>(src),
+                                                                   reinterpret_cast<f4v*>(dst), n / 4);
+  else
+    paced_copy_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const f4v*>(src),
+                                                                    reinterpret_cast<f4v*>(dst), n / 4);
   RGBX_CHECK_LAUNCH("paced_copy");
   return RGBX_OK;
 }

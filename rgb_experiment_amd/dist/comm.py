@@ -114,12 +114,51 @@ class Comm:
             if send.is_cuda:
                 work = _TimedWait(work)
             return recv, (work if self.turns is None else _TurnWork(work, self.turns))
-        host_recv = torch.empty(recv.shape, dtype=recv.dtype)
-        dist.all_to_all_single(host_recv, send.cpu().contiguous(), list(recv_counts), list(send_counts),
-                               group=self.group)
-        recv.copy_(host_recv)
+        host_recv = self._host_buffer(recv.shape, recv.dtype, recv.is_cuda)
+        dist.all_to_all_single(host_recv, self._to_host(send), list(recv_counts), list(send_counts), group=self.group)
+        self._from_host(recv, host_recv)
         done = _TimedWait(_Done()) if send.is_cuda else _Done()  # same wrappers as the RCCL path (rehearsals run them)
         return recv, (done if self.turns is None else _TurnWork(done, self.turns))
+
+    def _to_host(self, t):
+        """gloo rehearsals with device tensors: the rows go through a PINNED staging buffer, copied on the caller's
+        current stream and waited for on that stream alone. (A pageable `.cpu()` takes the runtime's own staging path;
+        with several ranks sharing one GPU and two host threads per rank — the interleaved eval forwards on their side
+        streams — that copy was seen to stall for minutes on some ranks of a 4-rank S-size run while the peers sat in the
+        collective: tests/test_gpu_dist.py's APPNP reshard(4) case at workload S, twice in a row inside the suite.)"""
+        if not t.is_cuda:
+            return t.contiguous()
+        t = t.contiguous()
+        pool = self.__dict__.setdefault("_pinned", {})
+        key = (threading.get_ident(), t.dtype)
+        buf = pool.get(key)
+        if buf is None or buf.numel() < t.numel():
+            buf = torch.empty(max(t.numel(), 1 << 20), dtype=t.dtype, pin_memory=True)
+            pool[key] = buf
+        host = buf[:t.numel()].view(t.shape)
+        host.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return host
+
+    def _host_buffer(self, shape, dtype, pinned):
+        """Receive side of the same staging: one pinned buffer per host thread and dtype, grown on demand."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if not pinned:
+            return torch.empty(shape, dtype=dtype)
+        pool = self.__dict__.setdefault("_pinned", {})
+        key = (threading.get_ident(), dtype, "recv")
+        buf = pool.get(key)
+        if buf is None or buf.numel() < n:
+            buf = torch.empty(max(n, 1 << 20), dtype=dtype, pin_memory=True)
+            pool[key] = buf
+        return buf[:n].view(shape)
+
+    def _from_host(self, dst, host):
+        dst.copy_(host, non_blocking=True)
+        if dst.is_cuda:
+            torch.cuda.current_stream(dst.device).synchronize()
 
     def all_to_all_views(self, send, recv, tag=None):
         """All-to-all of tensors where they lie: `send[q]` (contiguous, possibly empty) goes to rank q, `recv[q]`
@@ -144,13 +183,15 @@ class Comm:
         sc = [t.numel() for t in send]
         rc = [t.numel() for t in recv]
         flat = torch.cat([t.reshape(-1) for t in send]) if sum(sc) else send[0].new_empty(0)
-        host_recv = torch.empty(sum(rc), dtype=flat.dtype)
-        dist.all_to_all_single(host_recv, flat.cpu().contiguous(), rc, sc, group=self.group)
+        host_recv = self._host_buffer((sum(rc),), flat.dtype, cuda)
+        dist.all_to_all_single(host_recv, self._to_host(flat), rc, sc, group=self.group)
         off = 0
         for t, n in zip(recv, rc):
             if n:
-                t.copy_(host_recv[off:off + n].view(t.shape))
+                t.copy_(host_recv[off:off + n].view(t.shape), non_blocking=True)
             off += n
+        if cuda:
+            torch.cuda.current_stream().synchronize()  # the pinned buffer is handed out again by the next exchange
         del width
         done = _TimedWait(_Done()) if cuda else _Done()
         return done if self.turns is None else _TurnWork(done, self.turns)
@@ -398,7 +439,7 @@ class EmulatedComm(Comm):
         return _TracedDone(self._xid, self._contend_issue(link_bytes))
 
     # ---- contended emulation (bench.py --emulate-contend GBS) ---------------------------------------------------------
-    def enable_contention(self, device, link_gbs, max_bytes=1 << 30):
+    def enable_contention(self, device, link_gbs, max_bytes=1 << 30, nontemporal=False):
         """From now on every exchange MOVES its bytes on this GPU while the rank computes: a paced device-to-device copy
         of (world - 1) x [bytes on the busiest link] on a separate "link" stream, at (world - 1) x link_gbs GB/s — the
         inbound rows written into this rank's HBM plus as many outbound bytes read from it, through `wgs` workgroups
@@ -408,10 +449,11 @@ class EmulatedComm(Comm):
         beside (HBM bandwidth, L2 / Infinity Cache space, CU slots): the pessimistic one-GPU figure."""
         from .. import _lib
         import time
-        self._link = torch.cuda.Stream(device)
         n = max_bytes // 4
-        self._paced_src = torch.empty(n, dtype=torch.float32, device=device).normal_()
-        self._paced_dst = torch.empty(n, dtype=torch.float32, device=device)
+        if getattr(self, "_link", None) is None:
+            self._link = torch.cuda.Stream(device)
+            self._paced_src = torch.empty(n, dtype=torch.float32, device=device).normal_()
+            self._paced_dst = torch.empty(n, dtype=torch.float32, device=device)
         target = (self.world - 1) * float(link_gbs)
         lib = _lib.load()
 
@@ -422,7 +464,7 @@ class EmulatedComm(Comm):
             with torch.cuda.stream(self._link):
                 for _ in range(3):
                     _lib.check(lib.rgbx_paced_copy_f32(self._paced_src.data_ptr(), self._paced_dst.data_ptr(), k, wgs,
-                                                       self._link.cuda_stream), "rgbx_paced_copy_f32")
+                                                       int(nontemporal), self._link.cuda_stream), "rgbx_paced_copy_f32")
             self._link.synchronize()
             return 3 * k * 4 / (time.perf_counter() - t0) / 1e9
 
@@ -432,6 +474,7 @@ class EmulatedComm(Comm):
         # rate; a rate above the target ends an exchange early, i.e. errs towards LESS exposure but MORE contention)
         wgs = next((w for w in sorted(table) if table[w] >= target), max(table))
         self._contend = {"link_gbs": float(link_gbs), "target_copy_gbs": target, "workgroups": wgs,
+                         "nontemporal": bool(nontemporal),
                          "copy_gbs_measured": table[wgs], "calibration_gbs_by_workgroups": table}
         return self._contend
 
@@ -446,7 +489,8 @@ class EmulatedComm(Comm):
         cur = torch.cuda.current_stream()
         self._link.wait_stream(cur)  # an exchange starts when its producers (everything enqueued so far) are done
         _lib.check(_lib.load().rgbx_paced_copy_f32(self._paced_src.data_ptr(), self._paced_dst.data_ptr(), n,
-                                                   c["workgroups"], self._link.cuda_stream), "rgbx_paced_copy_f32")
+                                                   c["workgroups"], int(c["nontemporal"]), self._link.cuda_stream),
+                   "rgbx_paced_copy_f32")
         done = torch.cuda.Event()
         done.record(self._link)
         return done

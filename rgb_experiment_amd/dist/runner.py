@@ -212,7 +212,14 @@ class DistRunner:
         import threading
         from .comm import TakeTurns
         cuda = self.device.type == "cuda"
-        if cuda and self._streams is None:
+        # one side stream per forward where an exchange can be in flight beside kernels (RCCL; the emulated rank). The
+        # gloo rehearsal stages every exchange through the host and blocks in it: nothing overlaps there, and with several
+        # ranks SHARING one GPU the extra hardware queues (3 per rank, 4 ranks + the test's parent process) were seen to
+        # leave two ranks' side streams unscheduled for minutes while their peers sat in the collective
+        # (tests/test_gpu_dist.py, APPNP reshard(4) at workload S inside the suite; never alone) — there both forwards
+        # enqueue on the caller's stream, still taking turns at their exchanges
+        side = cuda and getattr(self.comm, "backend", "nccl") != "gloo"
+        if side and self._streams is None:
             self._streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
         turns = TakeTurns(2)
         out, err = [None, None], [None, None]
@@ -232,8 +239,12 @@ class DistRunner:
             try:
                 if cuda:
                     torch.cuda.set_device(self.device)
+                if side:
                     self._streams[i].wait_stream(main)
                     with torch.cuda.stream(self._streams[i]):
+                        out[i] = self.evaluate(1 + i, sync=False)[0]
+                elif cuda:
+                    with torch.cuda.stream(main):  # a new thread starts on the default stream: stay on the caller's
                         out[i] = self.evaluate(1 + i, sync=False)[0]
                 else:
                     out[i] = self.evaluate(1 + i, sync=False)[0]
@@ -260,7 +271,7 @@ class DistRunner:
         for e in err:
             if e is not None:
                 raise e
-        if cuda:
+        if side:
             for s in self._streams:
                 main.wait_stream(s)
         return out
