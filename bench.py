@@ -1204,12 +1204,12 @@ def main():
             result["emulated"]["next_step_ahead"] = ahead
         result["metric"] = "EMULATED rank compute, not a benchmark value: " + result["metric"]
         if on_gpu and args.emulate_contend > 0:
-            def contended_leg(nontemporal=False):
+            def contended_leg(nontemporal=False, sync_only=False):
                 # the PESSIMISTIC one-GPU figure (round 4): the same steps with the exchanges' bytes moved on this GPU at
                 # the assumed link rate x (P - 1) peers while the rank computes, and waited for where the schedule
                 # depends on them — what the step costs including exposed exchange time and the contention for HBM,
                 # caches and CUs that bench.replay_schedule's link model leaves out
-                cal = comm_obj.enable_contention(dev, args.emulate_contend, nontemporal=nontemporal)
+                cal = comm_obj.enable_contention(dev, args.emulate_contend, nontemporal=nontemporal, sync_only=sync_only)
                 warm = []
                 for i in range(4):  # (the first instrumented step under contention pays one-off event / stream set-up)
                     ops.set_event_sink(warm if i == 0 else None)
@@ -1238,11 +1238,13 @@ def main():
                         "what": "rank 0's epoch with every exchange's bytes copied device-to-device on a second stream at "
                                 "the assumed link rate x (P - 1) while the compute stream runs, consumers waiting for the "
                                 "copy: compute + exposed exchange + contention, measured on ONE GPU; no RCCL, no real link"}
-            for key, nt in (("contended", False), ("contended_cache_bypassing_traffic", True)):
-                # two brackets of what the exchanges' traffic does to the caches the gathers live on: plain loads / stores
-                # (allocating in L2 / Infinity Cache: pessimistic) and non-temporal ones (optimistic)
+            for key, nt, so in (("contended", False, False), ("contended_cache_bypassing_traffic", True, False),
+                                ("contended_control_sync_only", False, True)):
+                # plain loads / stores (allocating in L2 / Infinity Cache: pessimistic), non-temporal ones (optimistic), and
+                # a CONTROL that keeps every stream hand-over and launch of the emulation but moves 4 KB per exchange: what
+                # of the slowdown is cross-stream synchronisation rather than traffic
                 try:
-                    result["emulated"][key] = contended_leg(nt)
+                    result["emulated"][key] = contended_leg(nt, so)
                 except Exception as exc:  # noqa: BLE001
                     result["emulated"][key] = {"error": repr(exc)}
                     torch.cuda.synchronize()

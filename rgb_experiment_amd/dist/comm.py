@@ -439,7 +439,7 @@ class EmulatedComm(Comm):
         return _TracedDone(self._xid, self._contend_issue(link_bytes))
 
     # ---- contended emulation (bench.py --emulate-contend GBS) ---------------------------------------------------------
-    def enable_contention(self, device, link_gbs, max_bytes=1 << 30, nontemporal=False):
+    def enable_contention(self, device, link_gbs, max_bytes=1 << 30, nontemporal=False, sync_only=False):
         """From now on every exchange MOVES its bytes on this GPU while the rank computes: a paced device-to-device copy
         of (world - 1) x [bytes on the busiest link] on a separate "link" stream, at (world - 1) x link_gbs GB/s — the
         inbound rows written into this rank's HBM plus as many outbound bytes read from it, through `wgs` workgroups
@@ -474,7 +474,7 @@ class EmulatedComm(Comm):
         # rate; a rate above the target ends an exchange early, i.e. errs towards LESS exposure but MORE contention)
         wgs = next((w for w in sorted(table) if table[w] >= target), max(table))
         self._contend = {"link_gbs": float(link_gbs), "target_copy_gbs": target, "workgroups": wgs,
-                         "nontemporal": bool(nontemporal),
+                         "nontemporal": bool(nontemporal), "sync_only": bool(sync_only),
                          "copy_gbs_measured": table[wgs], "calibration_gbs_by_workgroups": table}
         return self._contend
 
@@ -486,6 +486,8 @@ class EmulatedComm(Comm):
         n = min(int(link_bytes) * (self.world - 1) // 4, self._paced_src.numel()) // 4 * 4
         if n == 0:
             return None
+        if c["sync_only"]:  # control: the same stream hand-overs and launches, 4 KB instead of the exchange's bytes
+            n = min(n, 1024)
         cur = torch.cuda.current_stream()
         self._link.wait_stream(cur)  # an exchange starts when its producers (everything enqueued so far) are done
         _lib.check(_lib.load().rgbx_paced_copy_f32(self._paced_src.data_ptr(), self._paced_dst.data_ptr(), n,
