@@ -101,7 +101,16 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs& A, int row, int c,
 #pragma unroll
     for (int i = 0; i < VEC; ++i) r[i] += bv[i];
   }
-  store_vec<VEC>(A.out + (int64_t)row * A.ldo + c, r);
+  // non-temporal for the 16-byte path: the output row is read by nobody in this launch and competes with the gathered table
+  // for L2 / Infinity Cache (plain SpMM at L 4.88 -> 4.80 ms; the APPNP K-loop, whose next step gathers what this one
+  // wrote, still gains: 48.2 -> 47.9 ms for K = 10; tools/ab_lib.py, profiles/r04_ab_nt_stores.txt)
+  if constexpr (VEC == 4) {
+    using f4v = __attribute__((ext_vector_type(4))) float;
+    f4v t = {r[0], r[1], r[2], r[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(A.out + (int64_t)row * A.ldo + c));
+  } else {
+    store_vec<VEC>(A.out + (int64_t)row * A.ldo + c, r);
+  }
 }
 
 // G lanes per neighbour row, VEC floats per lane; columns beyond G*VEC are covered by an outer

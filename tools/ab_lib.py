@@ -73,6 +73,9 @@ def main():
         g = get_graph(ei, N, 1)
         out = torch.empty_like(x)
         cases["gcn spmm"] = lambda: ops.spmm_raw(g.fwd, g.w, None, x, out=out)
+    if "appnp" in which:  # the K-loop: every step gathers the table the previous step wrote
+        g = get_graph(ei, N, 1)
+        cases["appnp K=10 forward"] = lambda: ops.appnp_raw(g.fwd, g.w, x, 10, 0.1)
     res = {k: {"A": [], "B": []} for k in cases}
     for tag, lib in (("A", lib_a), ("B", lib_b)):  # warm-up both (graph build, allocator)
         _lib.use(lib)
