@@ -621,10 +621,15 @@ __global__ void __launch_bounds__(256, POS ? 7 : (NT == 2 ? 5 : 8)) spmm_linear_
 // cover the 64 banks once per lane group). Writers hold four consecutive k (a float4 of a row) and store them as two
 // float2 (park4). K order, B operands and therefore every result bit are those of spmm_linear_kernel<.., DENSE>.
 // v = columns c4 .. c4 + 3 (c4 % 4 == 0) of a tile row -> their permuted places
+// (Which of the two 8-byte stores goes first alternates with bit 5 of c4: the 16 lanes of a ds_write_b64 lane group hold
+// c4 = 0, 4, .., 60; written in the same order, lanes 8..15 would hit the banks of lanes 0..7 again — the 2-way
+// conflicts that were 8.0 M of this kernel's 32.5 M LDS cycles per 2 M-row launch.)
 __device__ __forceinline__ void park4(float* __restrict__ row, int c4, const float (&v)[4]) {
   float* p = row + (c4 & ~7) + ((c4 & 4) >> 1);
-  *reinterpret_cast<float2*>(p) = make_float2(v[0], v[2]);
-  *reinterpret_cast<float2*>(p + 4) = make_float2(v[1], v[3]);
+  const bool swap = (c4 & 32) != 0;
+  const float2 even = make_float2(v[0], v[2]), odd = make_float2(v[1], v[3]);
+  *reinterpret_cast<float2*>(swap ? p + 4 : p) = swap ? odd : even;
+  *reinterpret_cast<float2*>(swap ? p : p + 4) = swap ? even : odd;
 }
 
 // The DENSE form for the widths a partitioned run lives on (K = 64 / 128), as a STREAMING kernel: a workgroup walks
