@@ -58,6 +58,22 @@ def test_edge_edits_empty_and_out_of_range(dev):
         U.coalesce(torch.zeros((2, 3), dtype=torch.int32, device=dev), 5)
 
 
+def test_edge_edits_at_the_largest_node_count(dev):
+    """N just below 2^31 (the library's index limit): keys row * N + col take 62 bits, the radix sort runs over all of
+    them; duplicates, mirrored pairs and self-loops at both ends of the id range."""
+    from rgb_experiment_amd import utils as U
+    n = 2**31 - 2
+    g = torch.Generator().manual_seed(5)
+    ei = torch.randint(0, n, (2, 5000), generator=g, dtype=torch.int64)
+    ends = torch.tensor([[0, n - 1, n - 1, 0, 7], [n - 1, 0, n - 1, 0, 7]])
+    ei = torch.cat([ei, ends, ei[:, :100], ei[:, :50].flip(0)], dim=1)
+    d = ei.to(dev)
+    assert torch.equal(U.coalesce(d, n).cpu(), U.coalesce(ei, n))
+    assert torch.equal(U.to_undirected(d, num_nodes=n).cpu(), U.to_undirected(ei, num_nodes=n))
+    with pytest.raises(RuntimeError):  # one node more: beyond int32 indices
+        U.coalesce(d, 2**31)
+
+
 @pytest.mark.parametrize("n,e", [(200_000, 4_000_000), (2_000_000, 60_000_000)])
 def test_edge_edits_at_benchmark_size(dev, n, e):
     """bench.py's graphs S and L: to_undirected (the `undirected_same_run` block's input) and coalesce on the device

@@ -1766,6 +1766,33 @@ def test_fused_adam_outside_experiment(dev):
         assert ops.weights_epoch() >= 3
 
 
+@pytest.mark.parametrize("dense,K,C", [(False, 128, 128), (False, 64, 32), (True, 128, 96), (True, 48, 32)])
+def test_loss_epilogue_with_two_statistics_sets(dev, dense, K, C):
+    """rgbx_ce_epilogue_t.mask_groups = 2 on the kernel itself, aggregating and DENSE launches, fixed-width and generic
+    instantiations: stats[0:3] / stats[3:6] equal the one-mask launches' bit for bit; a loss gradient together with two
+    sets is refused."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import get_graph
+    n = 4099
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(n, K, generator=gen).to(dev)
+    wt = (torch.randn(K, C, generator=gen) / K ** 0.5).to(dev)
+    b = torch.randn(C, generator=gen).to(dev)
+    y = torch.randint(-1, C, (n,), generator=gen).to(dev)
+    r = torch.rand(n, generator=gen)
+    ma, mb = (r < 0.6).to(dev), (r > 0.3).to(dev)
+    kw = {}
+    if not dense:
+        gr = get_graph(rand_graph(n, 30000, 32, loops=3, dups=3).to(dev), n, 1)
+        kw = dict(csr=gr.fwd, w=gr.w)
+    one = [ops.fused_layer(x, wt, bias=b, ce=(y, m, None), **kw)[2] for m in (ma, mb)]
+    out, _, pair = ops.fused_layer(x, wt, bias=b, ce=(y, (ma, mb), None), **kw)
+    assert out is None and pair.shape == (2, 3)
+    assert torch.equal(pair[0], one[0]) and torch.equal(pair[1], one[1])
+    with pytest.raises(RuntimeError, match="statistics only"):
+        ops.fused_layer(x, wt, bias=b, ce=(y, (ma, mb), ops.mask_scale(y, ma, C)), **kw)
+
+
 @pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack"])
 def test_two_masks_from_one_eval_forward(dev, name):
     """rgbx_ce_epilogue_t.mask_groups = 2 / models._stack.masked_ce_pair: the val and the test statistics of an epoch
