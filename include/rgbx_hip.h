@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RGBX_VERSION 402 /* major*10000 + minor*100 + patch */
+#define RGBX_VERSION 403 /* major*10000 + minor*100 + patch */
 
 #define RGBX_OK 0
 #define RGBX_E_ARG (-1)    /* null pointer / negative size / bad enum */
@@ -516,6 +516,12 @@ int rgbx_coalesce_keys_i64(const int64_t* row, const int64_t* col, int64_t E, in
                            rgbx_stream_t stream);
 int rgbx_split_edge_keys_i64(const uint64_t* keys, const uint64_t* counts, int64_t cap, int64_t N, int64_t* out_row,
                              int64_t* out_col, rgbx_stream_t stream);
+
+/* HOST function (the one entry point that takes a host pointer and runs on the CPU, synchronously): perm[0..n) =
+ * list(range(n)) after Python's `random.seed(seed); random.shuffle(...)`, bit for bit (MT19937 seeded by init_by_array over
+ * the 32-bit words of |seed|; randbelow by rejection over getrandbits(bit_length)) — the shuffle behind the reference's split
+ * masks (utils/mask.py:66-102; itexperiments.py:210-215). n < 2^32. */
+int rgbx_py_random_shuffle_i64(int64_t seed, int64_t n, int64_t* perm);
 
 /* ---- halo pack / unpack (multi-GPU node partition) ----------------------------------------- */
 

@@ -93,6 +93,7 @@ SIGNATURES = {
     "rgbx_gather_rows_f32": [_P, _I64, _P, _I64, _I64, _P, _I64, _P],
     "rgbx_scatter_add_rows_f32": [_P, _I64, _P, _I64, _I64, _P, _I64, _P],
     "rgbx_paced_copy_f32": [_P, _P, _I64, _I, _I, _P],
+    "rgbx_py_random_shuffle_i64": [_I64, _I64, _P],
 }
 EXPORTS = ["rgbx_version", "rgbx_last_error_string"] + list(SIGNATURES)
 

@@ -312,3 +312,27 @@ def test_model_output_is_the_reference_dict_with_lazy_log_probs():
     fresh = model_output(z)
     assert "'out'" in repr(fresh) and set(fresh.copy()) == {"out", "emb", "x"}
     assert torch.equal(model_output(z).pop("out"), want)
+
+
+def test_native_shuffle_is_pythons_random_shuffle_bit_for_bit():
+    """rgbx_py_random_shuffle_i64 (csrc/pyshuffle.hip, host code) against `random.seed(seed); random.shuffle(list(range(n)))`:
+    the shuffle behind the reference's split masks (utils/mask.py:66-102) — seeds below and above 2^32 (one and two key
+    words), negative, the int64 extremes; lengths around powers of two (the rejection loop of randbelow) and 0 / 1."""
+    import random
+    from rgb_experiment_amd.utils import mask as M
+    for seed in (0, 1, 123456789, 14530529, 2**32 - 1, 2**32, 2**40 + 7, -5, -2**63, 2**63 - 1, 1234567):
+        for n in (0, 1, 2, 3, 7, 100, 1000, 4097, 65536, 65537, 100003):
+            random.seed(seed)
+            ref = list(range(n))
+            random.shuffle(ref)
+            assert M._py_shuffled_range(n, seed).tolist() == ref, (seed, n)
+    # seeds the C++ path does not take (beyond int64, non-int) fall back to `random` itself
+    random.seed(2**70 + 1)
+    ref = list(range(50))
+    random.shuffle(ref)
+    assert M._py_shuffled_range(50, 2**70 + 1).tolist() == ref
+    # and the module-level generator is left seeded as the reference leaves it
+    M._py_shuffled_range(10, 42)
+    a = random.random()
+    random.seed(42)
+    assert a == random.random()
