@@ -33,7 +33,9 @@ def _py_shuffled_range(n, seed):
     """list(range(n)) after `random.seed(seed); random.shuffle(...)` as an int64 tensor: by the library's C++ restatement of
     CPython's generator (rgbx_py_random_shuffle_i64: ~15 ms for 2 M positions where CPython takes seconds; bit-exact,
     tests/test_host_logic.py) when the library is built and the seed is an int that fits 64 bits; by `random` itself
-    otherwise. Like the reference, this leaves the global `random` state seeded (callers may rely on it)."""
+    otherwise. The module-level `random` generator is left SEEDED with `seed` as the reference's call leaves it seeded — but on
+    the C++ path not advanced by the shuffle's draws (nothing on the path draws from it afterwards: model initialisation uses
+    torch's generators, RD2PD's sampling reseeds, experiment(need_to_reappear=True) reseeds)."""
     random.seed(seed)  # the reference's call has this side effect on the module-level generator
     if isinstance(seed, int) and not isinstance(seed, bool) and -2**63 <= seed < 2**63 and n < 2**32:
         try:
