@@ -845,7 +845,10 @@ bool launch_dense_stream(const FusedArgs& A, hipStream_t s) {
   // the plain forms gain: 0.120 -> 0.100 ms
   if (A.ce_part) return false;
   const int per_cu = (root || nt > 1) ? 2 : (A.ce_part || KC > 64 ? 3 : 4);  // = the kernel's __launch_bounds__
-  const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+  // as many workgroups as give every one of them the same number of tiles (± 1 on the last few): 7,813 tiles (250 k rows) over
+  // 768 workgroups would be 10 for most and 11 for some — a tenth of the launch spent with most of the chip idle
+  const int slots = 256 * per_cu;
+  const int grid = tiles <= slots ? tiles : (int)cdiv(tiles, cdiv(tiles, slots));
   const size_t lds2 = 2 * (size_t)TM * (KC + 4) * sizeof(float);  // the pipelined forms keep two tiles
   if (A.ce_part) {
     if (root) dense_stream_kernel<KC, 1, true, true><<<grid, 256, lds, s>>>(A, tiles);
