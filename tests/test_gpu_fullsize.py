@@ -45,6 +45,21 @@ def workload(size):
     return _CACHE[size]
 
 
+_CSR = {}
+
+
+def csr_graph(size, kind, loops_mode=1):
+    """oracle.large.CsrGraph (forward + transposed CSR with their weights) of the benchmark graph, kept across the tests of
+    this module: its two stable sorts of 62 M edge keys are a third of the CPU time of an L-size case."""
+    key = (size, kind, loops_mode)
+    if key not in _CSR:
+        for k in [k for k in _CSR if k[0] != size]:
+            del _CSR[k]
+        ei, x, _ = workload(size)
+        _CSR[key] = OL.CsrGraph(ei, x.size(0), kind, loops_mode=loops_mode, threads=O.c_threads())
+    return _CSR[key]
+
+
 @pytest.mark.parametrize("size", ["S", "L"])
 def test_fused_aggregate_transform_on_the_whole_benchmark_graph(dev, size):
     from rgb_experiment_amd import ops
@@ -87,16 +102,12 @@ def test_appnp_k10_on_the_whole_benchmark_graph(dev, size):
     ei, x, y = workload(size)
     n = x.size(0)
     K, alpha = 10, 0.1
-    threads = O.c_threads()
-    rei, w = O.gcn_norm(ei, None, n)
-    rowptr, col, perm = O.csr_from_edges(rei[1], rei[0], torch.arange(rei.size(1)), n)
-    ws = w[perm.long()].contiguous()
-    del rei, w, perm
+    cg = csr_graph(size, "gcn")  # gcn_norm + per-target CSR (oracle.large.CsrGraph, pinned by tests/test_oracle_large.py)
 
     def appnp_cpu(h):
         z = h
         for _ in range(K):
-            z = (1 - alpha) * O.propagate_c_csr(rowptr, col, ws, z, "add", threads) + alpha * h
+            z = (1 - alpha) * cg.forward(z) + alpha * h
         return z
 
     ei_d, x_d = ei.to(dev), x.to(dev)
@@ -267,11 +278,11 @@ def test_model_gradients_at_benchmark_size_L(dev, name):
     mask = (torch.arange(n) % 5) < 3
     loss, grads, sd = _hip_training_step(dev, name, ei, x, y, mask, "kernel_loss")
     torch.cuda.empty_cache()
-    graph = OL.graphs_for(name, ei, n, threads=O.c_threads())
+    graph = csr_graph("L", *{"gcn": ("gcn", 1), "appnpstack": ("gcn", 1), "graphsage": ("mean", 2),
+                             "graphsage2": ("mean", 0)}[name])
     kw = {k: v for k, v in GRAD_KW[name].items() if k in ("num_layers", "K", "alpha")}
     ref_loss, ref_grads, _ = OL.loss_and_grads(name, sd, x, y, mask, graph, **kw)
     rep = OL.compare_grads(grads, ref_grads)
     _check(rep, loss, ref_loss, f"L {name}")
-    del graph
     clear_cache()
     torch.cuda.empty_cache()
