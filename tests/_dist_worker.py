@@ -489,3 +489,87 @@ def comm_selftest_worker(rank, world, port, out_dir, sabotage=False):
     ok = comm.self_test_views(torch.device("cpu"))
     torch.save({"ok": ok, "exchanges": comm.exchanges}, os.path.join(out_dir, f"selftest_{rank}.pt"))
     dist.destroy_process_group()
+
+
+def gpu_runner_worker_multi(rank, world, port, out_dir, cases):
+    """gpu_runner_worker for SEVERAL (model_name, exchange) cases in one set of rank processes (one interpreter start-up, one
+    process group): every case builds its own model and DistRunner, runs its two epochs, saves
+    gpu_<model>_<exchange>_<rank>.pt, and leaves nothing behind for the next one (graph caches dropped)."""
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("RGBX_TEST_DUMP_AFTER", "420")), exit=True)
+    _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import Comm, DistRunner
+    from rgb_experiment_amd.graph import clear_cache
+    dev = torch.device("cuda:0")
+    for model_name, exchange in cases:
+        ei, x, y, masks = make_problem(n=5000, e=60000, f=32, c=8)
+        torch.manual_seed(14530529)
+        model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
+        r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm(), exchange=exchange)
+        hist = [r.epoch(more=True), r.epoch()]
+        torch.cuda.synchronize()
+        torch.save({"hist": hist, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi,
+                    "engine": r.engine is not None},
+                   os.path.join(out_dir, f"gpu_{model_name}_{exchange}_{rank}.pt"))
+        del r, model
+        clear_cache()
+        torch.cuda.empty_cache()
+        dist.barrier()
+    dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+
+
+def single_gpu_worker(rank, out_path, jobs):
+    """The ONE-GPU reference runs of tests/test_gpu_dist.py, in a process of their own: the test's parent process then never
+    holds a GPU context, so a set of N ranks sharing the card is N processes on it, not N + 1 (beyond the hardware's queue
+    slots the driver time-slices the queues of processes that wait on one another through gloo: the same S-size case took
+    15 s on one box and 96 s on another, and minutes with side streams on top). jobs = [(key, model_name, hub, size)]."""
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.graph import clear_cache
+    dev = torch.device("cuda:0")
+    out = {}
+    nll = torch.nn.functional.nll_loss
+    for key, model_name, hub, size in jobs:
+        ei, x, y, masks = (bench_problem_S() if size == "S" else hub_problem() if hub
+                           else make_problem(n=5000, e=60000, f=32, c=8))
+        torch.manual_seed(14530529)
+        model = build_model(M, model_name, x.size(1), int(y.max()) + 1).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01)
+        ei, x, y = ei.to(dev), x.to(dev), y.to(dev)
+        masks = [m.to(dev) for m in masks]
+        hist = []
+        for _ in range(2):
+            model.train()
+            opt.zero_grad()
+            o = model(x, ei)["out"]
+            loss = nll(o[masks[0]], y[masks[0]])
+            loss.backward()
+            opt.step()
+            model.eval()
+            with torch.no_grad():
+                ev = model(x, ei)["out"]
+            hist.append((loss.item(), nll(ev[masks[1]], y[masks[1]]).item(), nll(ev[masks[2]], y[masks[2]]).item()))
+        model.train()
+        with torch.no_grad():
+            out[key] = (hist, model(x, ei)["emb"].cpu())
+        del model, opt
+        clear_cache()
+    torch.save(out, out_path)
+
+
+def experiment_single_worker(rank, out_path, model_name):
+    """experiment() on one GPU with the data / arguments of experiment_worker(on_gpu=True), in a process of its own."""
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RGBX_DIST_BACKEND"):
+        os.environ.pop(key, None)
+    import rgb_experiment_amd as R
+    ei, x, y, masks = make_problem(n=5000, e=60000, f=32, c=8)
+    data = R.Data(x=x, y=y, edge_index=ei)
+    data.train_mask, data.val_mask, data.test_mask = masks
+    params = R.InitialParameters.defaults_for(model_name)
+    params["hidden_unit"] = 32
+    one = R.experiment(params, specify_data=True, data=data, model_name=model_name, learning_rate=0.01, epoch=6,
+                       need_to_reappear=True, print_print=False, return_model=True, need_all_metrics=True,
+                       keep_valid_data_mask=True, use_hip_graph=False)
+    torch.save({"history": one["history"], "ACC": one["ACC"],
+                "state": {k: v.cpu() for k, v in one["model"].state_dict().items()}}, out_path)
