@@ -910,10 +910,15 @@ def main():
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     on_gpu = dev.type == "cuda"
+    shared_devices = False
     if world > 1:
         # RGBX_DIST_BACKEND=gloo rehearses the N>1 code path with several ranks on ONE GPU (host-staged
         # collectives) or on the CPU (above); the real runs use RCCL ("nccl").
         if backend == "nccl":
+            from rgb_experiment_amd.dist import sharing
+            # more ranks than visible GPUs (a one-GPU box): RCCL over its socket transport, a different NCCL_HOSTID per rank
+            # (dist/sharing.py) — the product's backend and code path, NOT a scaling measurement; the line says so
+            shared_devices = sharing.prepare_rccl(rank, world, torch.cuda.device_count())
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
@@ -1190,6 +1195,13 @@ def main():
         result["modelled_seconds_per_epoch_first_two_layers"] = getattr(runner, "replicate_costs", None)
         result["link_gbs_measured"] = getattr(comm_obj, "link_gbs", None)  # 16 MB-per-peer all-to-all at start-up
         result["small_all_to_all_us_measured"] = getattr(comm_obj, "link_latency_us", None)  # one row per peer
+    if shared_devices:
+        result["ranks_share_devices"] = {
+            "ranks": world, "visible_gpus": torch.cuda.device_count(),
+            "what": "RCCL with a different NCCL_HOSTID per rank (rgb_experiment_amd/dist/sharing.py): the ranks time-slice the "
+                    "visible GPU(s) and exchange through RCCL's socket transport on the loopback interface — the product's "
+                    "backend and code path end to end, NOT a scaling measurement; `value` says nothing about N GPUs"}
+        result["metric"] = f"REHEARSAL ({world} ranks on {torch.cuda.device_count()} GPU), not a benchmark value: " + result["metric"]
     if emu:
         result["n_gpus"] = 1
         result["emulated"] = {"rank": 0, "of": emu, "scheme": scheme,

@@ -50,6 +50,10 @@ class DistContext:
                                "no visible GPU / use_cpu=True is not supported (no CPU fallback)")
         if not dist.is_initialized():
             if backend == "nccl":
+                from . import sharing
+                if sharing.prepare_rccl(int(os.environ.get("RANK", "0")), world, torch.cuda.device_count()):
+                    print(f"rgb_experiment_amd: {world} ranks on {torch.cuda.device_count()} visible GPU(s) - RCCL over its "
+                          "socket transport (dist/sharing.py): a rehearsal of the distributed path, not a faster run", flush=True)
                 dist.init_process_group("nccl", device_id=device)
             else:
                 dist.init_process_group(backend)

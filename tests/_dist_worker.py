@@ -183,10 +183,25 @@ def make_problem(n=97, e=900, f=12, c=5, seed=0):
     return ei, x, y, masks
 
 
+def rccl_on_one_gpu_env(rank):
+    """Environment of a rank that shares cuda:0 with the other ranks UNDER RCCL (rgb_experiment_amd/dist/sharing.py)."""
+    from rgb_experiment_amd.dist.sharing import rccl_env
+    return rccl_env(rank)
+
+
 def _init(rank, world, port):
+    """Process group of a test rank: gloo, or — RGBX_TEST_BACKEND=rccl, GPU tests only — RCCL with the ranks sharing cuda:0."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("RGBX_TEST_BACKEND") == "rccl":
+        import faulthandler
+        if not os.environ.get("RGBX_TEST_DUMP_AFTER"):  # a rank stuck in a collective ends with its stacks, not silently
+            faulthandler.dump_traceback_later(300, exit=True)
+        os.environ.update(rccl_on_one_gpu_env(rank))
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
 
 
@@ -358,6 +373,12 @@ def experiment_worker(rank, world, port, out_dir, model_name, on_gpu=False, clas
     route of rgb_experiment_amd.itexperiments.experiment."""
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
                        "MASTER_PORT": str(port), "RGBX_DIST_BACKEND": "gloo"})
+    if on_gpu and os.environ.get("RGBX_TEST_BACKEND") == "rccl":
+        # the product's own backend, the ranks sharing cuda:0: experiment() sees WORLD_SIZE > visible GPUs and prepares RCCL for
+        # it by itself (dist/sharing.py) - nothing but the backend's name is set here
+        import faulthandler
+        faulthandler.dump_traceback_later(300, exit=True)
+        os.environ["RGBX_DIST_BACKEND"] = "nccl"
     if not on_gpu:
         os.environ["RGBX_TEST_AGGREGATOR"] = "_dist_worker:OracleAggregator"
     torch.set_num_threads(1)
@@ -443,7 +464,7 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", h
     r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm(), exchange=exchange)
     hist = [r.epoch(more=ahead), r.epoch()]
     torch.cuda.synchronize()
-    torch.save({"hist": hist, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi,
+    torch.save({"hist": hist, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi, "backend": dist.get_backend(),
                 "engine": r.engine is not None, "state": {k: v.cpu() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"gpu_{model_name}_{rank}.pt"))
     dist.destroy_process_group()
@@ -510,7 +531,7 @@ def gpu_runner_worker_multi(rank, world, port, out_dir, cases):
         hist = [r.epoch(more=True), r.epoch()]
         torch.cuda.synchronize()
         torch.save({"hist": hist, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi,
-                    "engine": r.engine is not None},
+                    "engine": r.engine is not None, "backend": dist.get_backend()},
                    os.path.join(out_dir, f"gpu_{model_name}_{exchange}_{rank}.pt"))
         del r, model
         clear_cache()
@@ -573,3 +594,22 @@ def experiment_single_worker(rank, out_path, model_name):
                        keep_valid_data_mask=True, use_hip_graph=False)
     torch.save({"history": one["history"], "ACC": one["ACC"],
                 "state": {k: v.cpu() for k, v in one["model"].state_dict().items()}}, out_path)
+
+
+def rccl_probe_worker(rank, world, port, out_dir):
+    """Does RCCL come up with `world` ranks on cuda:0 on this box (dist/sharing.py)? One all-reduce and one grouped
+    send / recv list with an empty entry; a file per rank says yes."""
+    os.environ["RGBX_TEST_BACKEND"] = "rccl"
+    _init(rank, world, port)
+    dev = torch.device("cuda", 0)
+    t = torch.full((1024,), float(rank + 1), device=dev)
+    dist.all_reduce(t)
+    send = [torch.full((4, 8), float(10 * rank + q), device=dev) if q != rank else torch.empty((0, 8), device=dev)
+            for q in range(world)]
+    recv = [torch.empty((4, 8), device=dev) if q != rank else torch.empty((0, 8), device=dev) for q in range(world)]
+    dist.all_to_all(recv, send, async_op=True).wait()
+    torch.cuda.synchronize()
+    ok = t[0].item() == world * (world + 1) / 2 and all(bool((recv[q] == 10 * q + rank).all()) for q in range(world) if q != rank)
+    if ok:
+        torch.save({"backend": dist.get_backend(), "nccl": torch.cuda.nccl.version()}, os.path.join(out_dir, f"probe_{rank}.pt"))
+    dist.destroy_process_group()
