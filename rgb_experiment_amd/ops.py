@@ -200,6 +200,29 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _register
 _register_step_post_hook(note_weights_changed)
 
 
+class _MadeOn:
+    """A device tensor kept for reuse, with the stream it was made on. Whoever takes it on ANOTHER stream first makes that
+    stream wait for the making — the interleaved eval forwards of a multi-rank run (dist/runner.py, one HIP stream per
+    forward, two host threads) share W^T copies, mask bitmaps and loss divisors: the forward that finds one cached must not
+    launch on it before the other stream's transpose kernel has run. (Found by the first RCCL run with the ranks sharing a
+    GPU, round 4: the replicate scheme's test loss, second forward, came out of the PREVIOUS step's W^T in the recycled block.)"""
+    __slots__ = ("value", "stream", "event")
+
+    def __init__(self, value):
+        self.value, self.stream, self.event = value, None, None
+        if value.is_cuda and not torch.cuda.is_current_stream_capturing():
+            self.stream = torch.cuda.current_stream(value.device)
+            self.event = torch.cuda.Event()
+            self.event.record(self.stream)
+
+    def get(self):
+        if self.event is not None:
+            cur = torch.cuda.current_stream(self.value.device)
+            if cur != self.stream and not torch.cuda.is_current_stream_capturing():
+                cur.wait_event(self.event)
+        return self.value
+
+
 def weight_t(weight):
     """W^T as the contiguous [K, Nout] operand rgbx_spmm_linear_f32 reads (its B fragments run along Nout). For an
     nn.Parameter the transposed copy is kept on the parameter and reused until the parameter may have changed: the
@@ -213,9 +236,9 @@ def weight_t(weight):
     tag = (weight._version, _WEIGHTS_EPOCH[0], w.data_ptr(), tuple(w.shape))
     cached = getattr(weight, "_rgbx_wt", None)
     if cached is None or cached[0] != tag:
-        cached = (tag, w.t().contiguous())
+        cached = (tag, _MadeOn(w.t().contiguous()))
         weight._rgbx_wt = cached
-    return cached[1]
+    return cached[1].get()
 
 
 def _blocked(t, what):
@@ -601,11 +624,11 @@ def mask_scale(y, mask, C):
         sel = (y >= 0) & (y < C)
         if mask is not None:
             sel = sel & mask.bool()
-        hit = ((1.0 / sel.sum().double()).float().reshape(1), y, mask)  # the tensors stay alive with their addresses
+        hit = (_MadeOn((1.0 / sel.sum().double()).float().reshape(1)), y, mask)  # the tensors stay alive with their addresses
         _SCALE_CACHE[key] = hit
         while len(_SCALE_CACHE) > 32:
             _SCALE_CACHE.pop(next(iter(_SCALE_CACHE)))
-    return hit[0]
+    return hit[0].get()
 
 
 _GROUP_MASKS = {}
@@ -619,11 +642,11 @@ def group_masks(mask_a, mask_b):
     hit = _GROUP_MASKS.get(key)
     if hit is None:
         g = (mask_a.bool().to(torch.uint8) | (mask_b.bool().to(torch.uint8) << 1)).contiguous()
-        hit = (g, mask_a, mask_b)  # the mask tensors stay alive with their addresses
+        hit = (_MadeOn(g), mask_a, mask_b)  # the mask tensors stay alive with their addresses
         _GROUP_MASKS[key] = hit
         while len(_GROUP_MASKS) > 16:
             _GROUP_MASKS.pop(next(iter(_GROUP_MASKS)))
-    return hit[0]
+    return hit[0].get()
 
 
 def ce_from_logits(logits, y, mask):

@@ -1994,3 +1994,38 @@ def test_full_size_properties(dev, n, e):
     aty = ops.spmm_raw(g.bwd, g.w_t, None, y)
     lhs, rhs = (ax.double() * y.double()).sum().item(), (x.double() * aty.double()).sum().item()
     assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))
+
+
+def test_cached_operands_are_safe_across_streams(dev):
+    """ops.weight_t / mask_scale / group_masks keep a device tensor for reuse; the interleaved eval forwards of a multi-rank
+    run take them on two HIP streams. The stream that finds the copy cached must wait for the stream that is still making it
+    (ops._MadeOn): here stream A is kept busy, makes W^T behind that work, and stream B takes the cached W^T at once. Without the
+    wait B reads the block before the transpose has run (round 4, the first RCCL run: the replicate scheme's test loss came out
+    of the previous step's W^T)."""
+    from rgb_experiment_amd import ops
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(128, 96, device=dev))
+    a, b = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    big = torch.randn(6144, 6144, device=dev)
+    y = torch.randint(0, 7, (4096,), device=dev)
+    for step in range(4):
+        with torch.no_grad():
+            w.add_(1.0 + step)
+        ops.note_weights_changed()
+        mask_a = torch.rand(4096, device=dev) < 0.5  # fresh tensors: the caches below miss
+        mask_b = torch.rand(4096, device=dev) < 0.3
+        torch.cuda.synchronize()
+        with torch.cuda.stream(a):
+            for _ in range(6):
+                big @ big  # a few ms in front of the makers
+            ops.weight_t(w)
+            ops.mask_scale(y, mask_a, 7)
+            ops.group_masks(mask_a, mask_b)
+        with torch.cuda.stream(b):
+            got_w = ops.weight_t(w).clone()
+            got_s = ops.mask_scale(y, mask_a, 7).clone()
+            got_g = ops.group_masks(mask_a, mask_b).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got_w, w.detach().t()), step
+        assert got_s.item() == pytest.approx(1.0 / int(mask_a.sum()), rel=1e-6)
+        assert torch.equal(got_g, mask_a.to(torch.uint8) | (mask_b.to(torch.uint8) << 1))
