@@ -613,3 +613,30 @@ def rccl_probe_worker(rank, world, port, out_dir):
     if ok:
         torch.save({"backend": dist.get_backend(), "nccl": torch.cuda.nccl.version()}, os.path.join(out_dir, f"probe_{rank}.pt"))
     dist.destroy_process_group()
+
+
+def gpu_interleave_worker(rank, world, port, out_dir, model_name, exchange, size):
+    """The same three epochs twice in one set of ranks: val and test forwards issued by two host threads on two HIP streams
+    (DistRunner's default from the second epoch on) and one after the other on the caller's stream. Saved: both histories and
+    both sets of train-mode logits."""
+    os.environ["RGBX_INTERLEAVE"] = "always"  # no host-bound verdict in between (DistRunner._settle_interleave)
+    _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import Comm, DistRunner
+    from rgb_experiment_amd.graph import clear_cache
+    dev = torch.device("cuda:0")
+    ei, x, y, masks = bench_problem_S() if size == "S" else make_problem(n=5000, e=60000, f=32, c=8)
+    res = {"backend": dist.get_backend()}
+    for tag, inter in (("interleaved", True), ("sequential", False)):
+        torch.manual_seed(14530529)
+        model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
+        r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm(), exchange=exchange,
+                       interleave_evals=inter, fused=False)
+        hist = [r.epoch(), r.epoch(), r.epoch()]
+        torch.cuda.synchronize()
+        res[tag] = {"hist": hist, "logits": r.logits(True).cpu(), "threads": bool(r.interleave_evals and r.engine is None)}
+        del r, model
+        clear_cache()
+        dist.barrier()
+    torch.save(res, os.path.join(out_dir, f"inter_{model_name}_{rank}.pt"))
+    dist.destroy_process_group()

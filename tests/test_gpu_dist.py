@@ -241,3 +241,20 @@ def test_gloo_staging_of_device_tensors(tmp_path):
         hist, emb = _single_gpu(model_name)
         assert abs(parts[0]["hist"][0][0] - hist[0][0]) < 1e-4
         assert (torch.cat([p["logits_train"] for p in parts]) - emb).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("model_name,world,exchange,size", [("gcn_bench", 2, "replicate", "S"), ("gcn_bench", 3, "halo", "S"),
+                                                             ("graphsage_bench", 2, "reshard", "S"),
+                                                             ("appnpstack_bench", 4, "reshard", "S"), ("gat", 3, "auto", None)])
+def test_eval_forwards_on_two_streams_give_the_same_bits(model_name, world, exchange, size, tmp_path, rank_backend):
+    """The val and the test forward issued by two host threads on two HIP streams (RCCL: one forward's exchange in flight beside
+    the other's kernels) against the same forwards one after the other: same launches on the same operands, so every loss,
+    every accuracy and every logit is bit-identical. Tolerances elsewhere in this file (5e-3 on eval losses: BatchNorm's
+    conditioning) would not see a forward that ran on the previous step's operands — this does (round 4: the cached W^T)."""
+    mp.spawn(W.gpu_interleave_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, size), nprocs=world,
+             join=True)
+    for r in range(world):
+        p = torch.load(os.path.join(tmp_path, f"inter_{model_name}_{r}.pt"))
+        assert p["interleaved"]["threads"] and not p["sequential"]["threads"]
+        assert p["interleaved"]["hist"] == p["sequential"]["hist"], (r, p["interleaved"]["hist"], p["sequential"]["hist"])
+        assert torch.equal(p["interleaved"]["logits"], p["sequential"]["logits"])
