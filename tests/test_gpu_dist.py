@@ -143,7 +143,7 @@ def test_partitioned_hip_run_matches_single_gpu_at_S(model_name, world, exchange
     assert err < 1e-3
 
 
-@pytest.mark.parametrize("model_name", ["gcn", "graphsage"])
+@pytest.mark.parametrize("model_name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack"])
 def test_experiment_as_several_ranks_matches_one_gpu(model_name, tmp_path):
     """experiment() under WORLD_SIZE = 2 (the ranks share the one GPU, gloo staging) against experiment() on one GPU:
     same loss curves (train tightly; eval within the +-lr noise of pre-BatchNorm biases, see above), same accuracy to a
@@ -180,14 +180,17 @@ def test_fused_schedule_with_hub_rows(model_name, world, exchange, tmp_path):
     assert (torch.cat([p["logits_train"] for p in parts]) - emb).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("model_name,world,exchange", [("gcn_grid", 4, "2x2"), ("graphsage2_grid", 2, "reshard")])
-def test_step_computed_ahead_gives_the_same_bits(model_name, world, exchange, tmp_path):
+@pytest.mark.parametrize("model_name,world,exchange,size", [("gcn_grid", 4, "2x2", None), ("graphsage2_grid", 2, "reshard", None),
+                                                             ("gcn_bench", 4, "2x2", "S"), ("graphsage_bench", 2, "reshard", "S")])
+def test_step_computed_ahead_gives_the_same_bits(model_name, world, exchange, size, tmp_path):
     """Real kernels: the second training step computed beside the first epoch's eval forwards (epoch(more=True), the
     default of every other case in this file) against the plain sequence of the same run — same launches on the same
-    operands, so every number and every tensor of the state_dict is bit-identical."""
+    operands, so every number and every tensor of the state_dict is bit-identical. At workload S too (round 4): two separate
+    sets of ranks on RCCL, exchanges of 25-50 MB in flight beside the kernels — a send buffer overwritten before its exchange
+    has read it, or a receive view read before it has landed, would show as a difference between the two runs."""
     runs = []
     for ahead in (True, False):
-        mp.spawn(W.gpu_runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, False, ahead),
+        mp.spawn(W.gpu_runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, False, ahead, size),
                  nprocs=world, join=True)
         runs.append([torch.load(os.path.join(tmp_path, f"gpu_{model_name}_{r}.pt")) for r in range(world)])
     for p, q in zip(*runs):
