@@ -916,10 +916,10 @@ def main():
         # collectives) or on the CPU (above); the real runs use RCCL ("nccl").
         if backend == "nccl":
             from rgb_experiment_amd.dist import sharing
-            # more ranks than visible GPUs (a one-GPU box): RCCL over its socket transport, a different NCCL_HOSTID per rank
-            # (dist/sharing.py) — the product's backend and code path, NOT a scaling measurement; the line says so
-            shared_devices = sharing.prepare_rccl(rank, world, torch.cuda.device_count())
-            dist.init_process_group("nccl", device_id=dev)
+            # two ranks on the SAME device (a one-GPU box; told from the PCI identities the ranks publish, not from counts):
+            # RCCL over its socket transport, a different NCCL_HOSTID per rank (dist/sharing.py) — the product's backend and
+            # code path, NOT a scaling measurement; the line says so
+            shared_devices = sharing.init_rccl(dev)
         else:
             dist.init_process_group(backend)
         sv.beat("process group up")

@@ -51,10 +51,9 @@ class DistContext:
         if not dist.is_initialized():
             if backend == "nccl":
                 from . import sharing
-                if sharing.prepare_rccl(int(os.environ.get("RANK", "0")), world, torch.cuda.device_count()):
-                    print(f"rgb_experiment_amd: {world} ranks on {torch.cuda.device_count()} visible GPU(s) - RCCL over its "
-                          "socket transport (dist/sharing.py): a rehearsal of the distributed path, not a faster run", flush=True)
-                dist.init_process_group("nccl", device_id=device)
+                if sharing.init_rccl(device) and int(os.environ.get("RANK", "0")) == 0:
+                    print(f"rgb_experiment_amd: some of the {world} ranks share a GPU - RCCL over its socket transport "
+                          "(dist/sharing.py): a rehearsal of the distributed path, not a faster run", flush=True)
             else:
                 dist.init_process_group(backend)
         return cls(dist.get_rank(), dist.get_world_size(), device, test_backend)

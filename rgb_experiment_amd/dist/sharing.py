@@ -7,12 +7,13 @@ socket -> host buffer -> GPU). Nothing about the RATE of such a run means anythi
 HBM — but everything about its BEHAVIOUR is the product's: torch.distributed's nccl backend with more than one rank,
 communicator set-up, grouped send / recv lists on views (Comm.all_to_all_views), async works on RCCL's stream waited for out of
 order, two host threads issuing in turns (TakeTurns), the side streams of the interleaved eval forwards. tests/test_gpu_dist.py
-runs on it; bench.py --gpus N and experiment() take it when N exceeds the visible devices and say so on their output."""
+runs on it; bench.py --gpus N and experiment() take it when two of their ranks sit on the same device and say so on their output.
+
+Whether ranks share a device is decided by what they actually opened, not by counting: every rank publishes the identity of its
+device (host name + PCI domain:bus:device) through the rendezvous store BEFORE the communicator exists, and only when two ranks
+name the same device do the ranks take the socket route. A launcher that gives each rank ONE visible GPU (HIP_VISIBLE_DEVICES
+per rank: eight ranks, device_count() == 1 everywhere) therefore stays on xGMI."""
 import os
-
-
-def ranks_share_devices(world, n_devices):
-    return world > max(int(n_devices), 1)
 
 
 def rccl_env(rank):
@@ -21,11 +22,53 @@ def rccl_env(rank):
             "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
 
 
-def prepare_rccl(rank, world, n_devices):
-    """Called by every rank before dist.init_process_group("nccl"): when the ranks must share devices, put rccl_env()
-    into this process's environment (values the caller exported stay). Returns whether the ranks share devices."""
-    if not ranks_share_devices(world, n_devices):
-        return False
+def share_a_device(identities):
+    """True when two ranks named the same device."""
+    return len(set(identities)) < len(identities)
+
+
+def apply_env(rank):
+    """rccl_env(rank) into this process's environment; values the caller exported stay."""
     for k, v in rccl_env(rank).items():
         os.environ.setdefault(k, v)
-    return True
+
+
+def device_identity(device):
+    import socket
+
+    import torch
+    p = torch.cuda.get_device_properties(device)
+    return f"{socket.gethostname()}|{p.pci_domain_id:x}:{p.pci_bus_id:x}:{p.pci_device_id:x}"
+
+
+def rendezvous_store(timeout_s=600):
+    """(store, rank, world) of the launcher's environment (env://: a torchrun agent's store when there is one), BEFORE any
+    process group exists."""
+    import datetime
+
+    from torch.distributed import rendezvous
+    timeout = datetime.timedelta(seconds=timeout_s)
+    store, rank, world = next(iter(rendezvous("env://", int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]),
+                                              timeout=timeout)))
+    store.set_timeout(timeout)
+    return store, rank, world
+
+
+def exchange_identities(store, rank, world, identity):
+    store.set(f"rgbx/device/{rank}", identity)
+    return [store.get(f"rgbx/device/{r}").decode() for r in range(world)]  # blocks until rank r has published
+
+
+def init_rccl(device, timeout_s=600):
+    """dist.init_process_group("nccl", device_id=device) from the launcher's environment (RANK / WORLD_SIZE / MASTER_*), with the
+    device identities exchanged through the rendezvous store first (module docstring). Returns whether ranks share a device."""
+    import datetime
+
+    import torch.distributed as dist
+    store, rank, world = rendezvous_store(timeout_s)
+    shared = share_a_device(exchange_identities(store, rank, world, device_identity(device)))
+    if shared:
+        apply_env(rank)
+    dist.init_process_group("nccl", store=store, rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=timeout_s), device_id=device)
+    return shared

@@ -640,3 +640,19 @@ def gpu_interleave_worker(rank, world, port, out_dir, model_name, exchange, size
         dist.barrier()
     torch.save(res, os.path.join(out_dir, f"inter_{model_name}_{rank}.pt"))
     dist.destroy_process_group()
+
+
+def identity_exchange_worker(rank, world, port, out_dir, idents):
+    """dist/sharing.py's store exchange as init_rccl does it (env:// rendezvous, identities through the store, then a process
+    group made FROM that store) — on gloo, with made-up identities."""
+    import datetime
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    from rgb_experiment_amd.dist import sharing
+    store, r, w = sharing.rendezvous_store(120)
+    got = sharing.exchange_identities(store, r, w, idents[rank])
+    dist.init_process_group("gloo", store=store, rank=r, world_size=w, timeout=datetime.timedelta(seconds=120))
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    torch.save({"got": got, "shared": sharing.share_a_device(got), "sum": t.item(), "rank": r, "world": w},
+               os.path.join(out_dir, f"ident_{rank}.pt"))
+    dist.destroy_process_group()

@@ -483,3 +483,15 @@ def test_dist_batchnorm_matches_full_batch_bn():
     assert torch.allclose(ref.running_var, mine.running_var, atol=1e-5)
     ref.eval(), mine.eval()
     assert torch.allclose(ref(x), mine(x), atol=1e-6)
+
+
+@pytest.mark.parametrize("idents,shared", [(["box|0:5:0", "box|0:15:0", "box|0:25:0"], False),
+                                           (["box|0:5:0", "box|0:5:0", "box|0:25:0"], True)])
+def test_device_identities_through_the_rendezvous_store(idents, shared, tmp_path):
+    """dist/sharing.py: the ranks publish what device they opened through the env:// rendezvous store before any communicator
+    exists, every rank reads every identity, and the process group is then made from that same store (the route init_rccl
+    takes; here on gloo). One visible GPU per rank with DIFFERENT identities is not 'sharing'."""
+    mp.spawn(W.identity_exchange_worker, args=(3, _free_port(), str(tmp_path), idents), nprocs=3, join=True)
+    for r in range(3):
+        p = torch.load(os.path.join(tmp_path, f"ident_{r}.pt"))
+        assert p["got"] == idents and p["shared"] is shared and p["sum"] == 6.0 and (p["rank"], p["world"]) == (r, 3)

@@ -339,18 +339,19 @@ def test_native_shuffle_is_pythons_random_shuffle_bit_for_bit():
 
 
 def test_rccl_environment_for_ranks_that_share_a_device(monkeypatch):
-    """dist/sharing.py: nothing is touched when every rank has a GPU of its own; with more ranks than devices every rank
-    names its own NCCL_HOSTID (RCCL's duplicate-GPU check compares host identities) and the loopback interface; values the
-    caller exported stay."""
+    """dist/sharing.py: ranks share a device when two of them published the same identity (not when counts say so); then
+    every rank names its own NCCL_HOSTID (RCCL's duplicate-GPU check compares host identities) and the loopback interface;
+    values the caller exported stay."""
     import os
 
     from rgb_experiment_amd.dist import sharing
+    assert not sharing.share_a_device(["h|0:5:0", "h|0:15:0", "h|0:65:0"])
+    assert sharing.share_a_device(["h|0:5:0", "h|0:15:0", "h|0:5:0"])
+    assert not sharing.share_a_device(["h|0:5:0"])
     for k in sharing.rccl_env(0):
         monkeypatch.delenv(k, raising=False)
-    assert not sharing.prepare_rccl(3, 8, 8) and "NCCL_HOSTID" not in os.environ
-    assert not sharing.ranks_share_devices(1, 0)
     monkeypatch.setenv("NCCL_SOCKET_IFNAME", "eth7")
-    assert sharing.prepare_rccl(1, 2, 1)
+    sharing.apply_env(1)
     assert os.environ["NCCL_HOSTID"] == sharing.rccl_env(1)["NCCL_HOSTID"] != sharing.rccl_env(0)["NCCL_HOSTID"]
     assert os.environ["NCCL_SOCKET_IFNAME"] == "eth7" and os.environ["NCCL_IB_DISABLE"] == "1"
     for k in sharing.rccl_env(0):
