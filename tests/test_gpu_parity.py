@@ -2029,3 +2029,56 @@ def test_cached_operands_are_safe_across_streams(dev):
         assert torch.equal(got_w, w.detach().t()), step
         assert got_s.item() == pytest.approx(1.0 / int(mask_a.sum()), rel=1e-6)
         assert torch.equal(got_g, mask_a.to(torch.uint8) | (mask_b.to(torch.uint8) << 1))
+
+
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack"])
+@pytest.mark.parametrize("graph", ["no_edges", "one_node", "star_in", "star_out", "only_self_loops", "two_components_ragged"])
+def test_models_on_degenerate_graphs(dev, name, graph):
+    """Whole models where the CSR degenerates: an empty edge list (every row empty before self-loop completion, GAT / SAGE
+    rows with NO in-edge at all), a single node, every edge into one node / out of one node (one 300-slot row beside 299 empty
+    ones), self-loops only (already complete), and 33 + 1 nodes (one full 32-row tile + a ragged one-row tile) in two
+    components. Eval logits and one training step's loss + every gradient against the oracle, as the regular case."""
+    cls, kw, oracle_fwd = _model_case(name)
+    n = {"one_node": 1, "two_components_ragged": 34}.get(graph, 300)
+    f, c = 32, 5
+    if graph == "no_edges":
+        ei = torch.empty((2, 0), dtype=torch.int64)
+    elif graph == "one_node":
+        ei = torch.tensor([[0], [0]])
+    elif graph == "star_in":
+        ei = torch.stack([torch.arange(1, n), torch.zeros(n - 1, dtype=torch.int64)])
+    elif graph == "star_out":
+        ei = torch.stack([torch.zeros(n - 1, dtype=torch.int64), torch.arange(1, n)])
+    elif graph == "only_self_loops":
+        ei = torch.stack([torch.arange(n), torch.arange(n)])
+    else:
+        a = torch.arange(0, 32)
+        ei = torch.cat([torch.stack([a, a + 1]), torch.stack([a + 1, a]), torch.tensor([[33], [33]])], dim=1)
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(n, f, generator=gen)
+    y = torch.randint(0, c, (n,), generator=gen)
+    torch.manual_seed(14530529)
+    model = cls(input_dim=f, output_dim=c, **kw)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(dev)
+    model.eval()
+    with torch.no_grad():
+        out = model(x.to(dev), ei.to(dev))
+    ref = oracle_fwd(sd, x, ei, False)
+    assert torch.isfinite(out["emb"]).all()
+    assert (out["emb"].cpu() - ref["emb"]).abs().max().item() < TOL
+    if n == 1:
+        return  # a training-mode BatchNorm over one row raises in torch, here and in the reference alike
+    model.train()
+    out = model(x.to(dev), ei.to(dev))
+    loss = torch.nn.functional.nll_loss(out["out"], y.to(dev))
+    loss.backward()
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    ref = oracle_fwd(ref_sd, x, ei, True)
+    ref_loss = torch.nn.functional.nll_loss(ref["out"], y)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    for pname, p in model.named_parameters():
+        rg = ref_sd[pname].grad
+        assert rg is not None and torch.isfinite(p.grad).all(), pname
+        assert (p.grad.cpu() - rg).abs().max().item() < 1e-4 * max(1.0, rg.abs().max().item()), pname
