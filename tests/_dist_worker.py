@@ -426,6 +426,22 @@ def build_model(M, name, f, c):
     raise KeyError(name)
 
 
+def lopsided_problem():
+    """make_problem's sizes with every edge inside the first 40 % of the nodes: under a 1-D partition over 2-4 ranks the last
+    rank(s) own rows WITHOUT any edge (only the self-loops a GCN adds), send nothing and receive nothing in every exchange —
+    empty entries of the grouped send / recv lists, empty halo plans, zero-row pieces."""
+    ei, x, y, masks = make_problem(n=5000, e=60000, f=32, c=8)
+    return ei % 2000, x, y, masks
+
+
+def problem_of(model_name):
+    """'gcn@lopsided' -> ('gcn', the lopsided problem); plain names -> make_problem(n=5000, ...)."""
+    base, _, variant = model_name.partition("@")
+    if variant == "lopsided":
+        return base, lopsided_problem()
+    return base, make_problem(n=5000, e=60000, f=32, c=8)
+
+
 def bench_problem_S():
     """bench.py's workload S (BASELINE configs[1]: |V| = 200 k, |E| = 4 M, d = 128, 128 classes; same seeds)."""
     n, e = 200_000, 4_000_000
@@ -524,9 +540,9 @@ def gpu_runner_worker_multi(rank, world, port, out_dir, cases):
     from rgb_experiment_amd.graph import clear_cache
     dev = torch.device("cuda:0")
     for model_name, exchange in cases:
-        ei, x, y, masks = make_problem(n=5000, e=60000, f=32, c=8)
+        base, (ei, x, y, masks) = problem_of(model_name)
         torch.manual_seed(14530529)
-        model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
+        model = build_model(M, base, x.size(1), int(y.max()) + 1)
         r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm(), exchange=exchange)
         hist = [r.epoch(more=True), r.epoch()]
         torch.cuda.synchronize()
@@ -552,10 +568,10 @@ def single_gpu_worker(rank, out_path, jobs):
     out = {}
     nll = torch.nn.functional.nll_loss
     for key, model_name, hub, size in jobs:
-        ei, x, y, masks = (bench_problem_S() if size == "S" else hub_problem() if hub
-                           else make_problem(n=5000, e=60000, f=32, c=8))
+        base, small = problem_of(model_name)
+        ei, x, y, masks = bench_problem_S() if size == "S" else hub_problem() if hub else small
         torch.manual_seed(14530529)
-        model = build_model(M, model_name, x.size(1), int(y.max()) + 1).to(dev)
+        model = build_model(M, base, x.size(1), int(y.max()) + 1).to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=0.01)
         ei, x, y = ei.to(dev), x.to(dev), y.to(dev)
         masks = [m.to(dev) for m in masks]
