@@ -196,7 +196,9 @@ def test_dist_runner_training_matches_single_process(model_name, world, exchange
 
 
 @pytest.mark.parametrize("model_name,world,exchange,stop_early", [("appnpstack", 4, "reshard", True),
-                                                                   ("gcn", 2, "halo", True), ("gcn", 6, "halo", False)])
+                                                                   ("gcn", 2, "halo", True), ("gcn", 6, "halo", False),
+                                                                   # BASELINE configs[4] as the 8-GPU tier runs it: 4 + 4
+                                                                   ("appnpstack", 8, "reshard", False)])
 def test_epoch_split_by_task_over_two_groups(model_name, world, exchange, stop_early, tmp_path):
     """dist.TaskSplitRunner: ranks [0, P/2) run the training steps, ranks [P/2, P) the val and test forwards, each group
     with the whole graph partitioned over its ranks; the training group computes step t + 1 ahead while the eval group
@@ -233,7 +235,9 @@ def test_epoch_split_by_task_over_two_groups(model_name, world, exchange, stop_e
 
 @pytest.mark.parametrize("model_name,world,exchange,pieces,also_modules", [
     ("gcn_grid", 2, "reshard", 1, True), ("gcn3_grid", 4, "2x2", 3, False), ("graphsage_grid", 2, "reshard", 2, False),
-    ("graphsage_grid", 6, "2x3", 1, False), ("graphsage2_grid", 4, "2x2", 4, True), ("gcn3_grid", 6, "3x2", 2, False)])
+    ("graphsage_grid", 6, "2x3", 1, False), ("graphsage2_grid", 4, "2x2", 4, True), ("gcn3_grid", 6, "3x2", 2, False),
+    # the world size the 8-GPU tier runs, the scheme the cost model picks there for the benchmark (2 row groups x 4 slices)
+    ("gcn_grid", 8, "2x4", 2, False), ("graphsage_grid", 8, "2x4", 4, False)])
 def test_fused_grid_schedule_matches_single_process(model_name, world, exchange, pieces, also_modules, tmp_path):
     """dist/stack.py GridStack (layer outputs written blocked into the send buffers, BatchNorm / transform / loss in the
     return stage, manual backward, view exchanges) trains exactly like one process running the oracle under autograd:
