@@ -13,6 +13,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: a long-running case (still part of -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The multi-rank GPU module runs LAST: it is the one part of `-m gpu` that depends on more than this process and the card
+    (rank processes, RCCL's socket transport or gloo, rendezvous ports), and under `-x` a failure there must not keep the
+    parity modules from running. (Stable sort: everything else keeps its order.)"""
+    items.sort(key=lambda it: it.fspath.basename == "test_gpu_dist.py")
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
