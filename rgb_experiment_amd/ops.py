@@ -220,6 +220,7 @@ class _MadeOn:
             cur = torch.cuda.current_stream(self.value.device)
             if cur != self.stream and not torch.cuda.is_current_stream_capturing():
                 cur.wait_event(self.event)
+                self.value.record_stream(cur)  # when the copy is replaced, its block is not handed out under this stream
         return self.value
 
 

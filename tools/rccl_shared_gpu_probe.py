@@ -40,6 +40,22 @@ def child():
     dist.all_to_all_single(r, s, sizes_in, sizes_out)
     torch.cuda.synchronize()
     dist.barrier()
+    if rank == 0 and os.environ.get("RGBX_PROBE_PROFILE"):
+        # which GPU kernels carry the collectives (torch's own profiler, inside this process: no launcher to profile)
+        from torch.profiler import ProfilerActivity, profile
+        big = torch.randn(4 << 20, device=dev)
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            for _ in range(3):
+                dist.all_reduce(big)
+                dist.all_to_all_single(recv, send)
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=12, max_name_column_width=90), flush=True)
+    elif os.environ.get("RGBX_PROBE_PROFILE"):
+        big = torch.randn(4 << 20, device=dev)
+        for _ in range(3):
+            dist.all_reduce(big)
+            dist.all_to_all_single(recv, send)
+        torch.cuda.synchronize()
     print(f"rank {rank}/{world}: nccl backend ok (all_reduce, all_to_all_single even + ragged, barrier); "
           f"version {torch.cuda.nccl.version()}", flush=True)
     dist.destroy_process_group()
