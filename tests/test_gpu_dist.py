@@ -264,3 +264,27 @@ def test_eval_forwards_on_two_streams_give_the_same_bits(model_name, world, exch
         assert p["interleaved"]["threads"] and not p["sequential"]["threads"]
         assert p["interleaved"]["hist"] == p["sequential"]["hist"], (r, p["interleaved"]["hist"], p["sequential"]["hist"])
         assert torch.equal(p["interleaved"]["logits"], p["sequential"]["logits"])
+
+
+def test_bench_gpus_2_as_typed_on_the_one_gpu(rank_backend):
+    """`python bench.py --gpus 2` end to end on this box: the launcher starts its two ranks (supervised), they find out that they
+    sit on the same device, take RCCL's socket route (dist/sharing.py) — or gloo where RCCL did not come up — and rank 0 prints
+    ONE JSON line that says what it is."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("RGBX_TEST_BACKEND", None)
+    if rank_backend != "rccl":
+        env["RGBX_DIST_BACKEND"] = "gloo"
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "S", "--steps", "3",
+                           "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=420)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["value"] > 0 and res["launcher"]["attempt"] == 0
+    assert all(abs(v - 4.85) < 0.1 for v in res["final_losses"].values()), res["final_losses"]  # ln(128) = 4.852 at the start
+    if rank_backend == "rccl":
+        assert res["ranks_share_devices"]["ranks"] == 2 and res["metric"].startswith("REHEARSAL")
