@@ -762,7 +762,12 @@ gat_bwd_src_combine_kernel(int n_long, const int* __restrict__ long_row, const i
 }
 
 // ------------------------------------------------------------------------------------------
-int split_view(const rgbx_row_split_t* split, int H, int C, SplitDev* sd, const char* name) {
+// `train`: the caller's scratch holds 2F + 3H floats per chunk (training forward) instead of F + 2H. The two [n_chunks, F]
+// arrays come FIRST, so that both start at a multiple of F floats from the (16-byte aligned) scratch: with the H-sized
+// arrays in between, pacc2 sat 2 * n_chunks * H floats further — off the 16-byte grid for an odd chunk count at one head, the
+// vector width fell from 4 to 2, and a head of more than 128 channels (C = 132 ... 256) no longer fitted a wave's 64 lanes
+// ("needs 128 lanes per head"; whole-model fuzz, round 4: seed 283, two nodes with 4,526 edges between them).
+int split_view(const rgbx_row_split_t* split, int H, int C, bool train, SplitDev* sd, const char* name) {
   *sd = SplitDev{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (!split || split->threshold <= 0 || split->n_chunks <= 0) return RGBX_OK;
   if (split->n_long <= 0 || !split->chunk_row || !split->chunk_begin || !split->chunk_end || !split->long_row ||
@@ -773,11 +778,11 @@ int split_view(const rgbx_row_split_t* split, int H, int C, SplitDev* sd, const 
   sd->chunk_row = split->chunk_row;
   sd->chunk_begin = split->chunk_begin;
   sd->chunk_end = split->chunk_end;
-  sd->pacc = split->partial;                                   // [n_chunks, F]
-  sd->p0 = split->partial + (int64_t)split->n_chunks * F;      // [n_chunks, H]
-  sd->p1 = sd->p0 + (int64_t)split->n_chunks * H;              // [n_chunks, H]
-  sd->pacc2 = sd->p1 + (int64_t)split->n_chunks * H;           // [n_chunks, F]   (training forward only: the caller
-  sd->p2 = sd->pacc2 + (int64_t)split->n_chunks * F;           // [n_chunks, H]    then provides 2F + 3H per chunk)
+  sd->pacc = split->partial;                                                 // [n_chunks, F]
+  sd->pacc2 = train ? sd->pacc + (int64_t)split->n_chunks * F : nullptr;     // [n_chunks, F]  (training forward only)
+  sd->p0 = sd->pacc + (int64_t)split->n_chunks * F * (train ? 2 : 1);        // [n_chunks, H]
+  sd->p1 = sd->p0 + (int64_t)split->n_chunks * H;                            // [n_chunks, H]
+  sd->p2 = train ? sd->p1 + (int64_t)split->n_chunks * H : nullptr;          // [n_chunks, H]  (training forward only)
   return RGBX_OK;
 }
 
@@ -1006,7 +1011,7 @@ extern "C" int rgbx_gat_aggregate_fwd_f32(const int32_t* rowptr, const int32_t* 
   if ((out_pos != nullptr) != (a_pos != nullptr)) return fail(RGBX_E_ARG, "gat_fwd: out_pos and a_pos go together");
   if (ldh < (int64_t)H * C || ldo < (int64_t)H * C) return fail(RGBX_E_ARG, "gat_fwd: leading dimension < H*C");
   SplitDev sd;
-  if (int rc = split_view(split, H, C, &sd, "gat_fwd")) return rc;
+  if (int rc = split_view(split, H, C, out_pos != nullptr, &sd, "gat_fwd")) return rc;
   const int vec = pick_vec(C, {hfeat, out, att_src, att_dst, bias, out_scale, sd.pacc, out_pos, sd.pacc2}, {ldh, ldo});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_fwd")) return rc;
@@ -1112,7 +1117,7 @@ extern "C" int rgbx_gat_bwd_src_f32(const int32_t* rowptr_t, const int32_t* col_
   const int64_t F = (int64_t)H * C;
   if (ldh < F || ldg < F || ldgh < F) return fail(RGBX_E_ARG, "gat_bwd_src: leading dimension < H*C");
   SplitDev sd;
-  if (int rc = split_view(split, H, C, &sd, "gat_bwd_src")) return rc;
+  if (int rc = split_view(split, H, C, false, &sd, "gat_bwd_src")) return rc;
   const int vec = pick_vec(C, {hfeat, gout, g_hfeat, sd.pacc, att2}, {ldh, ldg, ldgh});
   GatLayout L;
   if (int rc = make_layout(H, C, vec, &L, "gat_bwd_src")) return rc;

@@ -360,38 +360,68 @@ class GATConv(nn.Module):
     folds_post_affine = True  # forward(..., post_affine=(scale, shift)): see models/_stack.py
     accepts_ce = True  # forward(..., ce=(y, mask)) returns (loss, stats): see models/_stack.py
 
+    @staticmethod
+    def kernel_channels(C):
+        """Channels per head the attention kernels run with. A wave holds one head's channels on at most 64 lanes of
+        4 / 2 / 1 floats (csrc/gat.hip make_layout: C % 4 == 0 up to 256, C % 2 == 0 up to 128, any C up to 64); other
+        widths — 130 classes on the single-head output layer, an odd 67 — are padded per head to the next multiple of 4
+        with zero weight rows, zero attention entries and zero bias, which changes neither a score nor a kept column
+        (PyG's GATConv has no such bound)."""
+        if C <= 64 or (C % 2 == 0 and C <= 128) or (C % 4 == 0 and C <= 256):
+            return C
+        Cp = (C + 3) // 4 * 4
+        if Cp > 256:
+            raise NotImplementedError(f"GATConv: {C} channels per head; the attention kernels take at most 256")
+        return Cp
+
     def forward(self, x, edge_index, post_affine=None, ce=None):
         """`post_affine` = (scale, shift) of an eval-mode BatchNorm that follows this layer (no_grad only): applied in
         the aggregation kernel's store, out = aggregate * scale + (bias * scale + shift), when the bias rides there
         too; otherwise after the layer. `ce` = (y, mask): the layer is the model's last; returns (loss, stats) of the
         masked cross-entropy of its output instead of the output."""
         H, C = self.heads, self.out_channels
+        Cp = self.kernel_channels(C)
+        if Cp == C:
+            return self._forward(x, edge_index, self.lin_src.weight, self.att_src, self.att_dst, self.bias, C, post_affine, ce)
+        pad = torch.nn.functional.pad
+        in_kernel = self.concat or H == 1
+        weight = pad(self.lin_src.weight.view(H, C, -1), (0, 0, 0, Cp - C)).reshape(H * Cp, -1)
+        bias = pad(self.bias.view(H, C), (0, Cp - C)).reshape(-1) if in_kernel else pad(self.bias, (0, Cp - C))
+        out = self._forward(x, edge_index, weight, pad(self.att_src, (0, Cp - C)), pad(self.att_dst, (0, Cp - C)), bias, Cp,
+                            None, None)
+        out = out.view(-1, H, Cp)[:, :, :C].reshape(-1, H * C) if (self.concat and H > 1) else out[:, :C]
+        if post_affine is not None:
+            out = out * post_affine[0] + post_affine[1]
+        return out if ce is None else ops.ce_from_logits(out, ce[0], ce[1])
+
+    def _forward(self, x, edge_index, weight, att_src, att_dst, bias, C, post_affine, ce):
+        H = self.heads
         graph = get_graph(edge_index, x.size(0), LOOPS_REMOVE_ADD)
         if (H == 1 and post_affine is None
                 and ops.gat_linear_ok(graph, self.in_channels, C, x, None if ce is None else ce[0])):
             # one head: sum_j alpha_ij (W x_j) = W sum_j alpha_ij x_j — scores from x, the coefficients as a per-edge
             # vector, then aggregation + transform (+ loss) in ONE launch of the fused kernel; no h = x W^T product
-            return ops.gat_attend_linear(x, self.lin_src.weight, self.att_src, self.att_dst, graph,
-                                         self.negative_slope, bias=self.bias, ce=ce)
+            return ops.gat_attend_linear(x, weight, att_src, att_dst, graph, self.negative_slope, bias=bias, ce=ce)
         if ce is not None:
-            return ops.ce_from_logits(self.forward(x, edge_index, post_affine), ce[0], ce[1])
+            return ops.ce_from_logits(self._forward(x, edge_index, weight, att_src, att_dst, bias, C, post_affine, None),
+                                      ce[0], ce[1])
         # the bias rides in the aggregation kernel's store when it applies to the stored row as is
         # (concatenated heads, or a single head, whose "mean over heads" is the identity)
         in_kernel = self.concat or H == 1
         dist_resident = getattr(graph, "is_distributed", False) and graph.is_resident(x)
         if dist_resident:
-            out = graph.gat(x, self.att_src, self.att_dst, H, C, self.negative_slope, weight=self.lin_src.weight)
-            out = out + self.bias if in_kernel else out.view(-1, H, C).mean(dim=1) + self.bias
+            out = graph.gat(x, att_src, att_dst, H, C, self.negative_slope, weight=weight)
+            out = out + bias if in_kernel else out.view(-1, H, C).mean(dim=1) + bias
         else:
-            h = ops.linear(x, self.lin_src.weight)
+            h = ops.linear(x, weight)
             if in_kernel and post_affine is not None and not getattr(graph, "is_distributed", False):
                 scale, shift = post_affine
-                return ops.gat_attend(h, self.att_src, self.att_dst, graph, H, C, self.negative_slope,
-                                      bias=self.bias * scale + shift, out_scale=scale)
-            out = ops.gat_attend(h, self.att_src, self.att_dst, graph, H, C, self.negative_slope,
-                                 bias=self.bias if in_kernel else None)
+                return ops.gat_attend(h, att_src, att_dst, graph, H, C, self.negative_slope,
+                                      bias=bias * scale + shift, out_scale=scale)
+            out = ops.gat_attend(h, att_src, att_dst, graph, H, C, self.negative_slope,
+                                 bias=bias if in_kernel else None)
             if not in_kernel:
-                out = out.view(-1, H, C).mean(dim=1) + self.bias
+                out = out.view(-1, H, C).mean(dim=1) + bias
         if post_affine is not None:
             out = out * post_affine[0] + post_affine[1]
         return out

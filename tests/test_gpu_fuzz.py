@@ -184,3 +184,140 @@ def run_case(dev, seed, ref_dtype=torch.float32):
 def test_conv_layers_against_the_oracle_on_random_shapes(dev, block):
     for seed in range(block * 40, block * 40 + 40):
         run_case(dev, 9000 + seed)
+
+
+# ---- whole models through the routes experiment() takes: loss inside the last conv's kernel, BatchNorm handed to the
+# following conv, column statistics from the producing launch, two statistics sets from one eval forward -----------
+
+MODEL_KINDS = ["gcn", "graphsage", "graphsage2", "gat", "appnpstack"]
+
+
+def _close(name, got, ref64, ref32, scale_floor=0.0, rel=3e-4, own_factor=16.0):
+    """|HIP - float64 oracle| within rel x the reference's scale — or within own_factor x what the float32 ORACLE itself is off
+    from the float64 one: a badly conditioned case (BatchNorm over a handful of rows, rank-one inputs, thousands of duplicate edges
+    between two nodes) moves every float32 implementation, and the bound then follows the case instead of failing it."""
+    got = got.detach().cpu().double()
+    err = (got - ref64).abs().max().item() if ref64.numel() else 0.0
+    scale = max(ref64.abs().max().item() if ref64.numel() else 0.0, scale_floor, 1e-30)
+    own = (ref32.double() - ref64).abs().max().item() if ref64.numel() else 0.0
+    bound = max(rel * scale, own_factor * own)
+    assert err <= bound, (name, err, bound, "float32 oracle off by", own)
+
+
+def make_model_case(seed):
+    """(description, model on the CPU, oracle forward (sd, x, training) -> dict, edge_index, x, y, masks) of a seed."""
+    from rgb_experiment_amd import models as M
+    rng = random.Random(seed)
+    kind = MODEL_KINDS[seed % len(MODEL_KINDS)]
+    n = rng.choice([2, 3, 33, 64, 100, 257, 700, 2000])
+    f_in = rng.choice([1, 3, 8, 12, 32, 33, 64, 100, 128, 160])
+    classes = rng.choice([2, 3, 7, 32, 40, 128, 130])
+    hidden = rng.choice([4, 16, 32, 64, 96, 100, 128])
+    layers = rng.choice([2, 2, 3, 4])
+    ei = make_graph(rng, n)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, f_in, generator=g)
+    y = torch.randint(0, classes, (n,), generator=g)
+    r = torch.rand(n, generator=g)
+    masks = [r < 0.5, (r >= 0.5) & (r < 0.75), r >= 0.75]
+    masks[0][rng.randrange(n)] = True  # at least one training row
+    desc = f"seed={seed} model={kind} n={n} E={ei.size(1)} in={f_in} hidden={hidden} classes={classes} layers={layers}"
+    torch.manual_seed(seed)
+    if kind == "gcn":
+        model = M.GCN(num_layers=layers, hidden_unit=hidden, input_dim=f_in, output_dim=classes, dropout_rate=0.5)
+        ref_fn = lambda sd, xc, tr: O.gcn_forward(sd, xc, ei, layers, tr)
+    elif kind == "graphsage":
+        model = M.GraphSAGE(num_layers=layers, hidden_unit=hidden, input_dim=f_in, output_dim=classes, dropout_rate=0.5)
+        ref_fn = lambda sd, xc, tr: O.graphsage_forward(sd, xc, ei, layers, tr)
+    elif kind == "graphsage2":
+        model = M.GraphSAGE2(num_layers=layers, hidden_unit=hidden, input_dim=f_in, output_dim=classes, dropout_rate=0.5)
+        ref_fn = lambda sd, xc, tr: O.graphsage2_forward(sd, xc, ei, layers, tr)
+    elif kind == "gat":
+        heads = rng.choice([1, 2, 8])
+        hidden = rng.choice([1, 4, 8, 16])
+        desc += f" heads={heads} per-head={hidden}"
+        model = M.GAT(num_layers=layers, hidden_unit=hidden, heads=heads, input_dim=f_in, output_dim=classes, dropout_rate=0.5)
+        ref_fn = lambda sd, xc, tr: O.gat_forward(sd, xc, ei, layers, heads, tr)
+    else:
+        K, alpha = rng.choice([1, 2, 10]), rng.choice([0.1, 0.5])
+        desc += f" K={K} alpha={alpha}"
+        model = M.APPNPStack(hidden_unit=hidden, input_dim=f_in, output_dim=classes, K=K, alpha=alpha, dropout_rate=0.5)
+        ref_fn = lambda sd, xc, tr: O.appnp_stack_forward(sd, xc, ei, K, alpha, tr)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:  # biases start at zero, BatchNorm weights at one: make them count
+                p.uniform_(0.5, 1.5) if p.mean().item() > 0.9 else p.uniform_(-0.5, 0.5)
+    return desc, model, ref_fn, ei, x, y, masks
+
+
+def run_model_case(dev, seed):
+    """One training step (loss + every parameter gradient) and one eval forward (val + test statistics from ONE forward, logits)
+    of a random model on a random graph, HIP vs the oracle under autograd — the oracle in float64 as the reference and in
+    float32 as the yardstick of the case's conditioning (_close). Gradients: 3e-4 of the parameter's largest reference entry,
+    floored at 1 % of the model's largest gradient entry (a bias in front of a BatchNorm has a TRUE gradient of zero)."""
+    from rgb_experiment_amd.graph import clear_cache
+    from rgb_experiment_amd.models._stack import masked_ce, masked_ce_pair
+    desc, model, ref_fn, ei, x, y, masks = make_model_case(seed)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    nll = torch.nn.functional.nll_loss
+    # BatchNorm over two or three rows, or over rank-one features (one input column: every hidden column is the same
+    # normalised vector up to sign, and what reaches the first layers' parameters is the rounding left of a projection that
+    # cancels): such cases stay in — they are where shapes degenerate — but only as a detector of gross errors
+    # (tools/fuzz_soak.py --models 0 1500, round 4: 60 of 67 exceedances at 2e-4 had n <= 3, 6 of the other 7 one input column)
+    conditioned = x.size(0) >= 33 and x.size(1) >= 3
+    tol = dict(rel=3e-4, own_factor=16.0) if conditioned else dict(rel=5e-2, own_factor=64.0)
+
+    def oracle_step(dtype):
+        sd = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point())
+              for k, v in sd0.items()}
+        ref = ref_fn(sd, x.to(dtype), True)
+        loss = nll(ref["out"][masks[0]], y[masks[0]])
+        loss.backward()
+        return loss.detach(), {k: v.grad.detach() for k, v in sd.items() if v.is_floating_point() and v.grad is not None}
+
+    def oracle_eval(sd1, dtype):
+        sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd1.items()}
+        ref = ref_fn(sd, x.to(dtype), False)
+        sums = [nll(ref["out"][m], y[m], reduction="sum") if int(m.sum()) else torch.zeros((), dtype=dtype) for m in masks[1:]]
+        hits = [int((ref["out"][m].argmax(1) == y[m]).sum()) for m in masks[1:]]
+        return ref["emb"].detach(), torch.stack(sums).detach(), hits
+
+    model.to(dev)
+    clear_cache()
+    xd, eid, yd = x.to(dev), ei.to(dev), y.to(dev)
+    md = [m.to(dev) for m in masks]
+    try:
+        model.train()
+        loss, stats = masked_ce(model, {"x": xd, "edge_index": eid}, yd, md[0])
+        loss.backward()
+        (l32, g32), (l64, g64) = oracle_step(torch.float32), oracle_step(torch.float64)
+        _close("loss", loss, l64, l32, scale_floor=1.0, rel=tol["rel"] / 10, own_factor=tol["own_factor"])
+        assert int(stats[1].item()) == int(masks[0].sum())
+        floor = 0.01 * max(v.abs().max().item() for v in g64.values())
+        for name, p in model.named_parameters():
+            if name in g64:
+                assert p.grad is not None, name
+                _close(name + ".grad", p.grad, g64[name], g32[name], scale_floor=floor, **tol)
+        # eval forward on the model as the training forward left it (running statistics moved): both masks from one forward
+        sd1 = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        model.eval()
+        with torch.no_grad():
+            pair = masked_ce_pair(model, {"x": xd, "edge_index": eid}, yd, md[1], md[2]).cpu()
+            emb = model(xd, eid)["emb"]
+        (e32, s32, _), (e64, s64, hits) = oracle_eval(sd1, torch.float32), oracle_eval(sd1, torch.float64)
+        _close("eval logits", emb, e64, e32, scale_floor=1.0, **tol)
+        _close("eval nll sums", pair[:, 0], s64, s32, scale_floor=1.0, **tol)
+        for i, m in enumerate(masks[1:]):
+            cnt = int(m.sum())
+            assert int(pair[i, 1].item()) == cnt, ("count", i)
+            assert abs(int(pair[i, 2].item()) - hits[i]) <= max(1, cnt // 200), ("hits", i, pair[i, 2].item(), hits[i])
+    except AssertionError as exc:
+        raise AssertionError(f"{desc}: {exc}") from exc
+    except RuntimeError as exc:
+        raise RuntimeError(f"{desc}: {exc}") from exc
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_whole_models_against_the_oracle_on_random_shapes(dev, block):
+    for seed in range(block * 25, block * 25 + 25):
+        run_model_case(dev, seed)

@@ -2082,3 +2082,72 @@ def test_models_on_degenerate_graphs(dev, name, graph):
         rg = ref_sd[pname].grad
         assert rg is not None and torch.isfinite(p.grad).all(), pname
         assert (p.grad.cpu() - rg).abs().max().item() < 1e-4 * max(1.0, rg.abs().max().item()), pname
+
+
+@pytest.mark.parametrize("H,C,concat", [(1, 130, True), (1, 67, True), (2, 65, True), (3, 70, False), (1, 255, True),
+                                        (1, 256, True), (1, 129, False), (4, 66, True)])
+def test_gat_conv_with_head_widths_the_kernels_pad(dev, H, C, concat):
+    """Channels per head beyond what one wave's 64 lanes hold at the width's natural vector size (odd above 64, not a multiple
+    of 4 above 128: e.g. 130 classes on the single-head output layer): GATConv pads each head to the next multiple of 4 with
+    zero weight rows / attention entries / bias (nn/conv.py kernel_channels) — found by the whole-model fuzz, round 4: such a
+    layer used to raise from rgbx_gat_scores_f32. Output and every gradient against the oracle; 257+ is refused by name."""
+    from rgb_experiment_amd import nn as RN
+    n, f = 300, 24
+    gen = torch.Generator().manual_seed(5)
+    ei = rand_graph(n, 2400, 5, loops=3, dups=3)
+    x = torch.randn(n, f, generator=gen)
+    torch.manual_seed(3)
+    conv = RN.GATConv(f, C, H, concat=concat)
+    with torch.no_grad():
+        conv.bias.uniform_(-0.5, 0.5)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in conv.state_dict().items() if "lin_dst" not in k}
+    conv.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    out = conv(xd, ei.to(dev))
+    ref = O.gat_conv(xc, ei, sd["lin_src.weight"], sd["att_src"], sd["att_dst"], sd["bias"], H, concat)
+    assert out.shape == ref.shape
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() < TOL
+    go = torch.randn(ref.shape, generator=gen)
+    out.backward(go.to(dev))
+    ref.backward(go)
+    assert (xd.grad.cpu() - xc.grad).abs().max().item() < 2e-4 * max(1.0, xc.grad.abs().max().item())
+    for name, p in conv.named_parameters():
+        if "lin_dst" in name:
+            continue
+        rg = sd[name].grad
+        assert (p.grad.cpu() - rg).abs().max().item() < 2e-4 * max(1.0, rg.abs().max().item()), name
+    with pytest.raises(NotImplementedError, match="256"):
+        RN.GATConv(f, 257, 1).to(dev)(xd.detach(), ei.to(dev))
+
+
+@pytest.mark.parametrize("C", [256, 132, 130, 64])
+def test_gat_single_head_wide_with_an_odd_number_of_hub_chunks(dev, C):
+    """One head of more than 128 channels needs the 16-byte vector width (64 lanes x 4 floats); with hub rows the TRAINING
+    forward keeps two [n_chunks, F] partial arrays in the row-split scratch, and the second one used to start 2 * n_chunks
+    floats off the 16-byte grid when the chunk count was odd: the launch fell back to 8-byte vectors and refused the width
+    ("needs 128 lanes per head"). Here: one target with 3,000 in-edges = 3 chunks; output and gradients vs the oracle."""
+    from rgb_experiment_amd import nn as RN
+    from rgb_experiment_amd.graph import clear_cache
+    n, f = 40, 16
+    gen = torch.Generator().manual_seed(11)
+    ei = torch.cat([rand_graph(n, 200, 11, loops=2, dups=2),
+                    torch.stack([torch.randint(0, n, (3000,), generator=gen), torch.full((3000,), 7)])], dim=1)
+    x = torch.randn(n, f, generator=gen)
+    torch.manual_seed(4)
+    conv = RN.GATConv(f, C, 1)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in conv.state_dict().items() if "lin_dst" not in k}
+    conv.to(dev)
+    clear_cache()
+    xd, xc = x.to(dev).requires_grad_(True), x.clone().requires_grad_(True)
+    out = conv(xd, ei.to(dev))
+    ref = O.gat_conv(xc, ei, sd["lin_src.weight"], sd["att_src"], sd["att_dst"], sd["bias"], 1, True)
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() < TOL
+    go = torch.randn(ref.shape, generator=gen)
+    out.backward(go.to(dev))
+    ref.backward(go)
+    assert (xd.grad.cpu() - xc.grad).abs().max().item() < 3e-4 * max(1.0, xc.grad.abs().max().item())
+    for name, p in conv.named_parameters():
+        if "lin_dst" not in name:
+            rg = sd[name].grad
+            assert (p.grad.cpu() - rg).abs().max().item() < 3e-4 * max(1.0, rg.abs().max().item()), name

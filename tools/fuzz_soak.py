@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off soak of tests/test_gpu_fuzz.py's differential fuzz beyond the seeds the suite pins (0..319): every seed in
 [first, last) through run_case, failures collected (seed, kind, message) instead of stopping at the first.
-Usage: python tools/fuzz_soak.py first last
+Usage: python tools/fuzz_soak.py first last            (conv layers: run_case)
+       python tools/fuzz_soak.py --models first last   (whole models: run_model_case)
        python tools/fuzz_soak.py --ref64 seed [seed ...]   (the listed seeds against the oracle computing in float64)"""
 import os
 import sys
@@ -28,13 +29,17 @@ def main():
                     print(f"seed {seed} vs the {dtype} oracle: {repr(exc)[:260]}", flush=True)
                     rc |= dtype == torch.float64
         return int(rc)
+    models = sys.argv[1] == "--models"
+    if models:
+        sys.argv.pop(1)
+    run, kinds = (F.run_model_case, F.MODEL_KINDS) if models else (F.run_case, F.KINDS)
     first, last = int(sys.argv[1]), int(sys.argv[2])
     bad, t0, mark = [], time.time(), time.time()
     for seed in range(first, last):
         try:
-            F.run_case(dev, seed)
+            run(dev, seed)
         except Exception as exc:  # noqa: BLE001 - collected, reported below
-            bad.append((seed, F.KINDS[seed % len(F.KINDS)], repr(exc)[:300]))
+            bad.append((seed, kinds[seed % len(kinds)], repr(exc)[:300]))
             print("FAIL", bad[-1], flush=True)
         if time.time() - mark > 30:
             mark = time.time()

@@ -1,0 +1,5 @@
+#!/bin/bash
+# round 4, call 64: whole-model fuzz, bounds by conditioning
+mkdir -p gpurun_out/r04
+timeout -k 10 900 python tools/fuzz_soak.py --models 0 1500 2>&1 | grep -v "amdgpu.ids" | tee gpurun_out/r04/c64_model_fuzz.txt | tail -30 | cut -c1-600
+exit 0
