@@ -146,7 +146,7 @@ def test_partitioned_hip_run_matches_single_gpu_at_S(model_name, world, exchange
     assert err < 1e-3
 
 
-@pytest.mark.parametrize("model_name", ["gcn", "graphsage", "graphsage2", "gat", "appnpstack"])
+@pytest.mark.parametrize("model_name", ["gcn", "graphsage", "gat", "appnpstack"])  # (graphsage2 passed too; 9 s each)
 def test_experiment_as_several_ranks_matches_one_gpu(model_name, tmp_path):
     """experiment() under WORLD_SIZE = 2 (the ranks share the one GPU, gloo staging) against experiment() on one GPU:
     same loss curves (train tightly; eval within the +-lr noise of pre-BatchNorm biases, see above), same accuracy to a
