@@ -129,3 +129,50 @@ def test_rd2pd_npy_to_graph_on_the_device(dev, tmp_path):
     assert torch.equal(gr.fwd.rowptr.cpu(), rowptr) and torch.equal(gr.fwd.col.cpu(), col)
     assert (gr.w.cpu() - w[perm.long()]).abs().max().item() < 1e-6
     clear_cache()
+
+
+def ingest_fuzz_case(dev, seed):
+    """One random edge list (node count from 1 to 2^31 - 2 at a few magnitudes, edge count 0 .. 6,000, duplicates, loops,
+    ids piled at both ends of the range) through every edit on the device against the CPU result, bit for bit; then the CSR the
+    path builds from the device result against the one built from the CPU result."""
+    import random
+
+    from rgb_experiment_amd import utils as U
+    from rgb_experiment_amd.graph import clear_cache, get_graph
+    rng = random.Random(seed)
+    n = rng.choice([1, 2, 3, 17, 64, 65, 1000, 4097, 70000, 2 ** 20 + 3, 2 ** 31 - 2])
+    e = rng.choice([0, 1, 2, 63, 64, 65, 500, 2048, 6000])
+    g = torch.Generator().manual_seed(seed)
+    style = rng.choice(["uniform", "low", "high", "few"])
+    if style == "uniform":
+        ei = torch.randint(0, n, (2, e), generator=g)
+    elif style == "low":
+        ei = torch.randint(0, min(n, 5), (2, e), generator=g)
+    elif style == "high":
+        ei = n - 1 - torch.randint(0, min(n, 5), (2, e), generator=g)
+    else:  # a handful of distinct pairs, many copies
+        base = torch.randint(0, n, (2, max(1, min(e, 4))), generator=g)
+        ei = base[:, torch.randint(0, base.size(1), (e,), generator=g)] if e else base[:, :0]
+    if e:
+        loops = torch.randint(0, n, (rng.choice([0, 1, 9]),), generator=g)
+        ei = torch.cat([ei, torch.stack([loops, loops]), ei[:, : e // 7]], dim=1)
+        ei = ei[:, torch.randperm(ei.size(1), generator=g)]
+    d = ei.to(dev)
+    desc = f"seed={seed} n={n} e={ei.size(1)} style={style}"
+    for name, fn in (("coalesce", lambda t: U.coalesce(t, n)), ("to_undirected", lambda t: U.to_undirected(t, num_nodes=n)),
+                     ("remove_self_loops", U.remove_self_loops)):
+        got, want = fn(d), fn(ei)
+        assert got.is_cuda and got.dtype == torch.int64 and torch.equal(got.cpu(), want), (desc, name)
+    if n <= 70000:  # (add_remaining_self_loops and the CSR materialise n entries)
+        got = U.add_remaining_self_loops(U.remove_self_loops(U.to_undirected(d, num_nodes=n)), n)
+        want = U.add_remaining_self_loops(U.remove_self_loops(U.to_undirected(ei, num_nodes=n)), n)
+        assert torch.equal(got.cpu(), want), (desc, "composition")
+        clear_cache()
+        a, b = get_graph(got, n, 1), get_graph(want.to(dev), n, 1)
+        assert torch.equal(a.fwd.rowptr, b.fwd.rowptr) and torch.equal(a.fwd.col, b.fwd.col), (desc, "csr")
+        clear_cache()
+
+
+def test_edge_edits_on_random_lists(dev):
+    for seed in range(300):
+        ingest_fuzz_case(dev, seed)
