@@ -321,3 +321,131 @@ def run_model_case(dev, seed):
 def test_whole_models_against_the_oracle_on_random_shapes(dev, block):
     for seed in range(block * 25, block * 25 + 25):  # 75 pinned seeds; tools/fuzz_soak.py --models soaked 3,500
         run_model_case(dev, seed)
+
+
+# ---- rgbx_fused_layer_f32 by option: dense or aggregating, blocked or plain rows, pre-affine, root term, stored z, column
+# sums, blocked output, loss statistics (one or two masks) or loss gradient -----------------------------------------------
+
+def _to_blocked(m, B):
+    n, d = m.shape
+    return m.view(n, B, d // B).permute(1, 0, 2).contiguous()
+
+
+def run_fused_layer_case(dev, seed):
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import LOOPS_ADD_REMAINING, clear_cache, get_graph
+    rng = random.Random(seed)
+    n = rng.choice([1, 2, 31, 32, 33, 64, 97, 257, 1013, 4100])
+    K = rng.choice([4, 8, 12, 32, 48, 64, 96, 128, 160, 256])
+    n_out = rng.choice([32, 64, 96, 128, 160, 256])
+    dense = rng.random() < 0.6
+    g = torch.Generator().manual_seed(seed)
+    d = lambda t: t.to(dev)
+    x = torch.randn(n, K, generator=g)
+    W = torch.randn(n_out, K, generator=g) / K ** 0.5
+    bias = torch.randn(n_out, generator=g) if rng.random() < 0.8 else None
+    pre = None
+    if rng.random() < 0.5:
+        pre = (torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g), torch.rand(n, generator=g))
+    root = rng.random() < 0.4
+    xr = torch.randn(n, K, generator=g) if root else None
+    Wr = torch.randn(n_out, K, generator=g) / K ** 0.5 if root else None
+    in_blocks = [b for b in (1, 2, 4, 8) if K % b == 0 and (K // b) % 4 == 0]
+    B = rng.choice(in_blocks) if dense else 1
+    Br = rng.choice(in_blocks)
+    out_blocks = [b for b in (1, 2, 3, 4, 5, 8) if n_out % b == 0 and (n_out // b) % 8 == 0]
+    Bo = rng.choice(out_blocks)
+    mode = rng.choice(["out", "out+z", "out+colsums", "out+blocked", "blocked only", "ce stats", "ce two masks", "ce grad"])
+    if mode.startswith("ce") and n_out > 128:
+        mode = "out+z"
+    desc = (f"seed={seed} n={n} K={K} Nout={n_out} {'dense' if dense else 'aggregating'} B={B} Br={Br if root else '-'} "
+            f"Bo={Bo} pre={pre is not None} root={root} bias={bias is not None} mode={mode}")
+    # reference in float64
+    x64 = x.double()
+    if dense:
+        z = x64
+        csr = w = None
+        rowsum_ref = None
+    else:
+        ei = make_graph(rng, n)
+        clear_cache()
+        gr = get_graph(ei.to(dev), n, LOOPS_ADD_REMAINING)
+        csr, w = gr.fwd, gr.w
+        e2, wn = O.gcn_norm(ei, None, n)
+        z = O.propagate(e2, x64, n, wn.double(), "add")
+        if pre is not None:  # the affine map of the aggregate needs the row sums of the operator (ops: graph.rowsum)
+            pre = (pre[0], pre[1], torch.zeros(n).index_add_(0, e2[1], wn))
+    if pre is not None:
+        z = z * pre[0].double() + pre[1].double() * pre[2].double()[:, None]
+    out = z @ W.double().t()
+    if bias is not None:
+        out = out + bias.double()
+    if root:
+        r = xr.double()
+        if pre is not None:
+            r = r * pre[0].double() + pre[1].double()
+        out = out + r @ Wr.double().t()
+    try:
+        kw = dict(bias=None if bias is None else d(bias), pre=None if pre is None else tuple(d(t) for t in pre))
+        if not dense:
+            kw.update(csr=csr, w=w)
+        if root:
+            kw.update(x_root=_to_blocked(d(xr), Br) if (Br > 1 and (dense or not mode.startswith("ce"))) else d(xr),
+                      wt_root=d(Wr).t().contiguous())
+        xin = _to_blocked(d(x), B) if B > 1 else d(x)
+        wt = d(W).t().contiguous()
+        tol_out = 2e-4 * max(1.0, out.abs().max().item())
+        if mode.startswith("ce"):
+            y = torch.randint(0, n_out, (n,), generator=g)
+            if n > 2:
+                y[rng.randrange(n)] = -1  # an ignored row
+            ma, mb = torch.rand(n, generator=g) < 0.6, torch.rand(n, generator=g) < 0.3
+            logp = torch.log_softmax(out, 1)
+
+            def want_stats(m):
+                sel = m & (y >= 0)
+                nll = -logp[sel, y[sel]].sum().item() if int(sel.sum()) else 0.0
+                return nll, int(sel.sum()), int((out[sel].argmax(1) == y[sel]).sum())
+            if mode == "ce two masks":
+                _, _, st = ops.fused_layer(xin, wt, ce=(d(y), (d(ma), d(mb)), None), **kw)
+                for i, m in enumerate((ma, mb)):
+                    nll, cnt, hits = want_stats(m)
+                    assert int(st[i, 1].item()) == cnt and abs(st[i, 0].item() - nll) < 2e-4 * max(1.0, abs(nll)), (i, st[i], nll, cnt)
+                    assert abs(int(st[i, 2].item()) - hits) <= max(1, cnt // 100), ("hits", i)
+            else:
+                nll, cnt, hits = want_stats(ma)
+                scale = ops.mask_scale(d(y), d(ma), n_out) if (mode == "ce grad" and cnt) else None
+                dl, _, st = ops.fused_layer(xin, wt, ce=(d(y), d(ma), scale), **kw)
+                assert int(st[1].item()) == cnt and abs(st[0].item() - nll) < 2e-4 * max(1.0, abs(nll)), (st, nll, cnt)
+                if scale is not None:
+                    sel = ma & (y >= 0)
+                    want = torch.softmax(out, 1)
+                    want[torch.arange(n), y.clamp(min=0)] -= 1.0
+                    want = want * sel[:, None] / cnt
+                    assert (dl.cpu().double() - want).abs().max().item() < 1e-6 + 2e-4 * want.abs().max().item(), "loss gradient"
+            return
+        ob = torch.empty((Bo, n, n_out // Bo), device=dev) if "blocked" in mode else None
+        got, zz, cs = ops.fused_layer(xin, wt, want_out=mode != "blocked only", out_blocked=ob, want_z=mode == "out+z",
+                                      want_colsums=mode == "out+colsums", **kw)
+        if mode != "blocked only":
+            assert (got.cpu().double() - out).abs().max().item() < tol_out, "out"
+        if ob is not None:
+            rows = ob.permute(1, 0, 2).reshape(n, n_out)
+            assert (rows.cpu().double() - out).abs().max().item() < tol_out, "blocked out"
+            if got is not None:
+                assert torch.equal(rows, got), "blocked copy differs from the rows"
+        if mode == "out+z":
+            assert (zz.cpu().double() - z).abs().max().item() < 2e-5 * max(1.0, z.abs().max().item()), "z"
+        if mode == "out+colsums":
+            want_cs = torch.stack([out.sum(0), (out ** 2).sum(0)])
+            assert (cs.cpu() - want_cs).abs().max().item() < 2e-4 * max(1.0, want_cs.abs().max().item()), "colsums"
+    except AssertionError as exc:
+        raise AssertionError(f"{desc}: {exc}") from exc
+    except RuntimeError as exc:
+        raise RuntimeError(f"{desc}: {exc}") from exc
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_fused_layer_forms_on_random_shapes(dev, block):
+    for seed in range(block * 100, block * 100 + 100):
+        run_fused_layer_case(dev, seed)

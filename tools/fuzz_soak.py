@@ -3,6 +3,7 @@
 [first, last) through run_case, failures collected (seed, kind, message) instead of stopping at the first.
 Usage: python tools/fuzz_soak.py first last            (conv layers: run_case)
        python tools/fuzz_soak.py --models first last   (whole models: run_model_case)
+       python tools/fuzz_soak.py --fused first last    (rgbx_fused_layer_f32 by option: run_fused_layer_case)
        python tools/fuzz_soak.py --ref64 seed [seed ...]   (the listed seeds against the oracle computing in float64)"""
 import os
 import sys
@@ -29,10 +30,11 @@ def main():
                     print(f"seed {seed} vs the {dtype} oracle: {repr(exc)[:260]}", flush=True)
                     rc |= dtype == torch.float64
         return int(rc)
-    models = sys.argv[1] == "--models"
-    if models:
+    which = sys.argv[1] if sys.argv[1].startswith("--") else ""
+    if which:
         sys.argv.pop(1)
-    run, kinds = (F.run_model_case, F.MODEL_KINDS) if models else (F.run_case, F.KINDS)
+    run, kinds = {"--models": (F.run_model_case, F.MODEL_KINDS), "--fused": (F.run_fused_layer_case, ["fused_layer"]),
+                  "": (F.run_case, F.KINDS)}[which]
     first, last = int(sys.argv[1]), int(sys.argv[2])
     bad, t0, mark = [], time.time(), time.time()
     for seed in range(first, last):
