@@ -435,10 +435,12 @@ def lopsided_problem():
 
 
 def problem_of(model_name):
-    """'gcn@lopsided' -> ('gcn', the lopsided problem); plain names -> make_problem(n=5000, ...)."""
+    """'gcn@lopsided' -> ('gcn', the lopsided problem), 'gcn@hub' -> hub_problem(); plain names -> make_problem(n=5000, ...)."""
     base, _, variant = model_name.partition("@")
     if variant == "lopsided":
         return base, lopsided_problem()
+    if variant == "hub":
+        return base, hub_problem()
     return base, make_problem(n=5000, e=60000, f=32, c=8)
 
 

@@ -89,6 +89,10 @@ CASES = [("gcn", 2, "halo"), ("gcn", 3, "halo"), ("graphsage", 2, "halo"), ("app
          ("gat@lopsided", 3, "auto"), ("appnpstack@lopsided", 4, "reshard"), ("gcn_wide@lopsided", 3, "replicate")]
 
 
+if os.environ.get("RGBX_DIST_SWEEP"):  # one-off sweep (tools/gpu4/call75.sh): every case again on the lopsided and the hub problem
+    CASES = CASES + [(f"{m}@{v}", w, x) for m, w, x in CASES if "@" not in m for v in ("lopsided", "hub")]
+
+
 @pytest.mark.parametrize("world", [2, 3, 4])
 def test_partitioned_hip_run_matches_single_gpu(world, tmp_path, rank_backend):
     """Every (model, scheme) case of this world size in ONE set of rank processes (the interpreter start-up of 2-4 ranks is
