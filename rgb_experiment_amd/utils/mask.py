@@ -63,10 +63,23 @@ def get_whole_mask(y, ratio, seed=1234567):
     """Ratio split over all labelled nodes; the seed is bumped by one until the train part holds
     every class (reference utils/mask.py:10-22)."""
     labelled = torch.arange(len(y), dtype=torch.int64)[y != -1]
+    classes, first_seed = None, seed
     while True:
         masks = get_order(ratio, labelled, len(y), seed)
         if check_train_containing(masks[0], y):
             return masks
+        if seed - first_seed >= 20000:
+            # feasible on paper, hopeless in practice (130 classes of two nodes each and a 60 % train part: one seed in 1e10)
+            raise ValueError(f"get_whole_mask: 20000 seeds tried from {first_seed}, none puts every class into the train "
+                             f"part of ratio {ratio!r} (the reference's loop over seeds would never end in practice)")
+        if classes is None:
+            # no seed can succeed when the train part has fewer rows than there are classes: the reference spins here for
+            # ever (mask.py:16-21, `seed += 1` without an end); the same inputs get an error instead of a hang
+            classes = int((torch.unique(y) != -1).sum())
+            if int(masks[0].sum()) < classes:
+                raise ValueError(f"get_whole_mask: the train part of ratio {ratio!r} holds {int(masks[0].sum())} of "
+                                 f"{labelled.numel()} labelled nodes, fewer than the {classes} classes it must contain "
+                                 "(the reference's loop over seeds would never end)")
         seed += 1
 
 

@@ -356,3 +356,18 @@ def test_rccl_environment_for_ranks_that_share_a_device(monkeypatch):
     assert os.environ["NCCL_SOCKET_IFNAME"] == "eth7" and os.environ["NCCL_IB_DISABLE"] == "1"
     for k in sharing.rccl_env(0):
         monkeypatch.delenv(k, raising=False)
+
+
+def test_whole_mask_with_more_classes_than_training_rows_raises_instead_of_spinning():
+    """Reference utils/mask.py:16-21 bumps the seed until the train part contains every class — for ever when it has fewer
+    rows than there are classes (found by a random sweep of experiment(): 33 nodes, 130 classes). Same inputs: a ValueError."""
+    import pytest
+    import torch
+
+    from rgb_experiment_amd.utils import mask as M
+    y = torch.arange(40) % 30  # 30 classes on 40 nodes
+    with pytest.raises(ValueError, match="never end"):
+        M.get_whole_mask(y, "6-2-2", seed=1)
+    y2 = torch.arange(400) % 3  # feasible: returns after a few seeds at most
+    tr, va, te = M.get_whole_mask(y2, "6-2-2", seed=1)
+    assert M.check_train_containing(tr, y2) and int(tr.sum() + va.sum() + te.sum()) == 400
