@@ -674,3 +674,69 @@ def identity_exchange_worker(rank, world, port, out_dir, idents):
     torch.save({"got": got, "shared": sharing.share_a_device(got), "sum": t.item(), "rank": r, "world": w},
                os.path.join(out_dir, f"ident_{rank}.pt"))
     dist.destroy_process_group()
+
+
+def propagate_fuzz_worker(rank, world, port, out_dir, seeds):
+    """Distributed propagate (every loops mode / kind) + K-step APPNP, forward and backward, on RANDOM problems: node counts from
+    `world` itself (one row per rank) upward, edge lists from empty to hub-heavy (tests/test_gpu_fuzz.make_graph), widths that do
+    and do not divide by the world size or the grid's column count (the scheme then falls back to halo for that width), every
+    exchange scheme and piece count. Every rank computes the single-process oracle itself and compares its own rows."""
+    import random
+
+    import test_gpu_fuzz as F
+    from oracle import ref_cpu as O
+    _init(rank, world, port)
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.dist import Comm, DistGraph, partition_bounds
+    grids = [f"{r}x{world // r}" for r in range(1, world) if world % r == 0 and world // r > 1]
+    bad = []
+    for seed in seeds:
+        rng = random.Random(seed)
+        n = rng.choice([world, world + 1, 2 * world + 1, 17, 64, 97, 300, 1000])
+        n = max(n, world)
+        f = rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 24, 30, 32, 48])
+        exchange = rng.choice(["halo", "reshard", "auto"] + grids)
+        pieces = rng.choice([None, 1, 2, 3, 4])
+        ei = F.make_graph(rng, n)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(n, f, generator=g)
+        go = torch.randn(n, f, generator=g)
+        lo, hi = partition_bounds(n, world)[rank:rank + 2]
+        desc = f"seed={seed} world={world} n={n} E={ei.size(1)} f={f} exchange={exchange} pieces={pieces}"
+
+        def chk(ok, what):  # (recorded, never raised: a rank that left a case early would miss its peers' next collective)
+            if not ok:
+                bad.append((desc, repr(what)))
+        if True:
+            for mode, kind in ((1, "gcn"), (2, "mean"), (0, "mean"), (0, "sum")):
+                dg = DistGraph(ei, n, mode, Comm(), OracleAggregator(), exchange, pieces=pieces)
+                xl = x[lo:hi].clone().requires_grad_(True)
+                out = dg.propagate(xl, kind)
+                out.backward(go[lo:hi])
+                rei, _ = O.rewrite_edges(ei, n, mode)
+                xr = x.double().requires_grad_(True)  # the oracle in float64: thousands of duplicate edges between a handful
+                if kind == "gcn":                       # of nodes are summed one by one by its index_add_ (2e-4 off in float32)
+                    _, w = O.gcn_norm(ei, None, n)
+                    want = O.propagate(rei, xr, n, w.double(), "add")
+                else:
+                    want = O.propagate(rei, xr, n, None, "add" if kind == "sum" else "mean")
+                want.backward(go.double())
+                tol = 1e-4 * max(1.0, want.detach().abs().max().item(), xr.grad.abs().max().item())  # (the CPU aggregator of this rehearsal sums in float32, one term at a time)
+                if hi > lo:
+                    chk((out.detach().double() - want.detach()[lo:hi]).abs().max().item() <= tol, (mode, kind, "out"))
+                    chk((xl.grad.double() - xr.grad[lo:hi]).abs().max().item() <= tol, (mode, kind, "grad"))
+            K, alpha = rng.choice([1, 2, 4]), rng.choice([0.0, 0.15])
+            dg = DistGraph(ei, n, 1, Comm(), OracleAggregator(), exchange, pieces=pieces)
+            xl = x[lo:hi].clone().requires_grad_(True)
+            out = ops.appnp_propagate(xl, dg, K, alpha)
+            out.backward(go[lo:hi])
+            xr = x.double().requires_grad_(True)
+            want = O.appnp(xr, ei, K, alpha)
+            want.backward(go.double())
+            tol = 1e-4 * max(1.0, want.detach().abs().max().item(), xr.grad.abs().max().item())
+            if hi > lo:
+                chk((out.detach().double() - want.detach()[lo:hi]).abs().max().item() <= tol, ("appnp out", K, alpha))
+                chk((xl.grad.double() - xr.grad[lo:hi]).abs().max().item() <= tol, ("appnp grad", K, alpha))
+        # (an exception ends this rank; its peers then fail in the next collective and the spawn reports it)
+    torch.save(bad, os.path.join(out_dir, f"propfuzz_{rank}.pt"))
+    dist.destroy_process_group()

@@ -499,3 +499,15 @@ def test_device_identities_through_the_rendezvous_store(idents, shared, tmp_path
     for r in range(3):
         p = torch.load(os.path.join(tmp_path, f"ident_{r}.pt"))
         assert p["got"] == idents and p["shared"] is shared and p["sum"] == 6.0 and (p["rank"], p["world"]) == (r, 3)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 6, 8])
+def test_distributed_propagate_on_random_problems(world, tmp_path):
+    """The partition plans and exchange schemes on random problems (W.propagate_fuzz_worker): 12 pinned seeds per world size
+    in one set of rank processes; RGBX_DIST_FUZZ_SEEDS=<count> soaks more."""
+    count = int(os.environ.get("RGBX_DIST_FUZZ_SEEDS", "12"))
+    first = int(os.environ.get("RGBX_DIST_FUZZ_FIRST", "0"))
+    seeds = list(range(first + 1000 * world, first + 1000 * world + count))
+    mp.spawn(W.propagate_fuzz_worker, args=(world, _free_port(), str(tmp_path), seeds), nprocs=world, join=True)
+    bad = [b for r in range(world) for b in torch.load(os.path.join(tmp_path, f"propfuzz_{r}.pt"))]
+    assert not bad, bad[:5]
