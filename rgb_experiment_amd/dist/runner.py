@@ -323,7 +323,9 @@ class DistRunner:
         self._epochs_done += 1
         self._settle_interleave(self.host_enqueue_s - enq0, time.perf_counter() - t0)
         cv, cs = self.mask_counts[1], self.mask_counts[2]
-        return p[0], p[1] / cv, p[2] / cv, p[3] / cs, p[4] / cs
+        # (an eval mask without a row: nan, as the mean over an empty selection is on one GPU — not a ZeroDivisionError)
+        nan = float("nan")
+        return (p[0], p[1] / cv if cv else nan, p[2] / cv if cv else nan, p[3] / cs if cs else nan, p[4] / cs if cs else nan)
 
     def _settle_interleave(self, enqueue_s, wall_s):
         """Two host threads issuing the eval forwards hide one forward's exchange behind the other's aggregation, but

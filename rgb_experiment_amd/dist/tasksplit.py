@@ -266,7 +266,9 @@ class TaskSplitRunner:
             # group's communicator, from the time it took to enqueue the two forwards against the epoch's wall time
             r._settle_interleave(eval_enqueue_s, time.perf_counter() - t0)
         cv, cs = self.mask_counts[1], self.mask_counts[2]
-        return p[0], p[1] / cv, p[2] / cv, p[3] / cs, p[4] / cs
+        # (an eval mask without a row: nan, as the mean over an empty selection is on one GPU — not a ZeroDivisionError)
+        nan = float("nan")
+        return (p[0], p[1] / cv if cv else nan, p[2] / cv if cv else nan, p[3] / cs if cs else nan, p[4] / cs if cs else nan)
 
     # what bench.py reads of a runner
     graphs = property(lambda self: self.inner.graphs)

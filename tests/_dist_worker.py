@@ -676,7 +676,7 @@ def identity_exchange_worker(rank, world, port, out_dir, idents):
     dist.destroy_process_group()
 
 
-def propagate_fuzz_worker(rank, world, port, out_dir, seeds):
+def propagate_fuzz_worker(rank, world, port, out_dir, seeds, own_group=True):
     """Distributed propagate (every loops mode / kind) + K-step APPNP, forward and backward, on RANDOM problems: node counts from
     `world` itself (one row per rank) upward, edge lists from empty to hub-heavy (tests/test_gpu_fuzz.make_graph), widths that do
     and do not divide by the world size or the grid's column count (the scheme then falls back to halo for that width), every
@@ -685,7 +685,8 @@ def propagate_fuzz_worker(rank, world, port, out_dir, seeds):
 
     import test_gpu_fuzz as F
     from oracle import ref_cpu as O
-    _init(rank, world, port)
+    if own_group:
+        _init(rank, world, port)
     from rgb_experiment_amd import ops
     from rgb_experiment_amd.dist import Comm, DistGraph, partition_bounds
     grids = [f"{r}x{world // r}" for r in range(1, world) if world % r == 0 and world // r > 1]
@@ -739,4 +740,115 @@ def propagate_fuzz_worker(rank, world, port, out_dir, seeds):
                 chk((xl.grad.double() - xr.grad[lo:hi]).abs().max().item() <= tol, ("appnp grad", K, alpha))
         # (an exception ends this rank; its peers then fail in the next collective and the spawn reports it)
     torch.save(bad, os.path.join(out_dir, f"propfuzz_{rank}.pt"))
+    if own_group:
+        dist.destroy_process_group()
+
+
+def runner_fuzz_worker(rank, world, port, out_dir, seeds, own_group=True):
+    """DistRunner (fused per-rank schedule where the widths allow it, the modules otherwise) for two epochs on RANDOM problems
+    and models, against the same two epochs of single-process oracle training that every rank runs for itself: train losses
+    (the second one sees the first update: gradients, their all-reduce and Adam are in it), eval losses and hit counts."""
+    import random
+
+    import test_gpu_fuzz as F
+    from oracle import ref_cpu as O
+    if own_group:
+        _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import Comm, DistRunner
+    from rgb_experiment_amd.graph import clear_cache
+    grids = [f"{r}x{world // r}" for r in range(1, world) if world % r == 0 and world // r > 1]
+    nll = torch.nn.functional.nll_loss
+    bad = []
+    for seed in seeds:
+        rng = random.Random(seed)
+        n = rng.choice([4 * world + 1, 97, 150, 400])
+        f = rng.choice([8, 12, 16, 24, 32, 48])
+        c = rng.choice([4, 8, 24, 32])
+        hidden = rng.choice([8, 16, 24, 32, 48, 96])
+        layers = rng.choice([2, 2, 3])
+        kind = rng.choice(["gcn", "gcn", "graphsage", "graphsage", "graphsage2", "appnpstack", "gat"])
+        exchange = rng.choice(["halo", "reshard", "auto", "replicate"] + grids)
+        pieces = rng.choice([None, 1, 2, 3])
+        ei = F.make_graph(rng, n)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(n, f, generator=g)
+        y = torch.randint(0, c, (n,), generator=g)
+        r_ = torch.rand(n, generator=g)
+        masks = [r_ < 0.5, (r_ >= 0.5) & (r_ < 0.75), r_ >= 0.75]
+        masks[0][0] = True  # (val / test may stay empty on the smallest graphs: nan there, compared as "no rows")
+        desc = f"seed={seed} world={world} {kind} n={n} E={ei.size(1)} f={f} hidden={hidden} classes={c} layers={layers} exchange={exchange} pieces={pieces}"
+        torch.manual_seed(seed)
+        if kind == "gcn":
+            model = M.GCN(num_layers=layers, hidden_unit=hidden, input_dim=f, output_dim=c, dropout_rate=0.5)
+            fwd = lambda p, tr: O.gcn_forward(p, x, ei, layers, tr)
+        elif kind == "graphsage":
+            model = M.GraphSAGE(num_layers=layers, hidden_unit=hidden, input_dim=f, output_dim=c, dropout_rate=0.5)
+            fwd = lambda p, tr: O.graphsage_forward(p, x, ei, layers, tr)
+        elif kind == "graphsage2":
+            model = M.GraphSAGE2(num_layers=layers, hidden_unit=hidden, input_dim=f, output_dim=c, dropout_rate=0.5)
+            fwd = lambda p, tr: O.graphsage2_forward(p, x, ei, layers, tr)
+        elif kind == "gat":
+            heads = rng.choice([1, 2, 4])
+            model = M.GAT(num_layers=layers, hidden_unit=max(hidden // 8, 1), heads=heads, input_dim=f, output_dim=c, dropout_rate=0.5)
+            fwd = lambda p, tr: O.gat_forward(p, x, ei, layers, heads, tr)
+        else:
+            K = rng.choice([1, 3])
+            model = M.APPNPStack(hidden_unit=hidden, input_dim=f, output_dim=c, K=K, alpha=0.1, dropout_rate=0.5)
+            fwd = lambda p, tr: O.appnp_stack_forward(p, x, ei, K, 0.1, tr)
+        if exchange == "replicate" and (kind in ("gat", "appnpstack") or f > hidden):
+            exchange = "auto"  # (the replicate scheme serves conv stacks whose first layer aggregates before it transforms)
+        params = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()
+                  if "lin_dst" not in k}
+        trainable = [k for k, _ in model.named_parameters() if "lin_dst" not in k]
+        opt = torch.optim.Adam([params[k] for k in trainable], lr=0.01)
+        want = []
+        for _ in range(2):
+            opt.zero_grad()
+            out = fwd(params, True)["out"]
+            loss = nll(out[masks[0]], y[masks[0]])
+            loss.backward()
+            opt.step()
+            with torch.no_grad():
+                ev = fwd(params, False)["out"]
+            want.append((loss.item(),
+                         [nll(ev[m], y[m]).item() if int(m.sum()) else 0.0 for m in masks[1:]],
+                         [int((ev[m].argmax(1) == y[m]).sum()) for m in masks[1:]]))
+        clear_cache()
+        try:
+            r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
+                           backend=OracleAggregator(), exchange=exchange, pieces=pieces, pieces_in=pieces or 1)
+            hist = [r.epoch(more=True), r.epoch()]
+        except (NotImplementedError, ValueError) as exc:  # a combination the runner refuses by name, on every rank alike
+            bad.append((desc, "refused: " + repr(exc)[:160])) if "refus" in os.environ.get("RGBX_FUZZ_SHOW", "") else None
+            continue
+        for step in range(2):
+            tl, wl = hist[step][0], want[step][0]
+            if abs(tl - wl) > 5e-5 * max(1.0, abs(wl)):
+                bad.append((desc, f"train loss of epoch {step}: {tl} vs {wl}", r.engine is not None))
+        # eval numbers of the last epoch against the oracle's eval forward on THIS run's trained weights (two separately
+        # trained runs differ by Adam's +-lr steps on the biases in front of a BatchNorm, whose true gradient is zero)
+        own = {k: v.detach().clone() for k, v in r.model.state_dict().items() if "lin_dst" not in k}
+        with torch.no_grad():
+            ev = fwd(own, False)["out"]
+        _, vl, va, sl, sa = hist[1]
+        for name, m, got_l, got_a in (("val", masks[1], vl, va), ("test", masks[2], sl, sa)):
+            cnt = int(m.sum())
+            if not cnt:
+                continue
+            wl_, wa_ = nll(ev[m], y[m]).item(), int((ev[m].argmax(1) == y[m]).sum()) / cnt
+            if abs(got_l - wl_) > 1e-4 * max(1.0, abs(wl_)) or abs(got_a - wa_) > 1.5 / cnt:
+                bad.append((desc, f"{name} loss / accuracy of the last epoch: {(got_l, got_a)} vs {(wl_, wa_)}", r.engine is not None))
+        del r
+    torch.save(bad, os.path.join(out_dir, f"runfuzz_{rank}.pt"))
+    if own_group:
+        dist.destroy_process_group()
+
+
+def dist_fuzz_worker(rank, world, port, out_dir, prop_seeds, run_seeds):
+    """propagate_fuzz_worker and runner_fuzz_worker in ONE set of rank processes (the interpreter start-up of the ranks is most
+    of a short fuzz's time)."""
+    _init(rank, world, port)
+    propagate_fuzz_worker(rank, world, port, out_dir, prop_seeds, own_group=False)
+    runner_fuzz_worker(rank, world, port, out_dir, run_seeds, own_group=False)
     dist.destroy_process_group()
