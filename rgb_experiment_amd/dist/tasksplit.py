@@ -143,6 +143,14 @@ class TaskSplitRunner:
         if world < 2 or world % 2:
             raise RuntimeError(f"task split needs an even number of ranks, got {world}")
         half = world // 2
+        ex = str(runner_kw.get("exchange", "auto"))
+        if "x" in ex:
+            # refused HERE, by every rank at once: left to the first propagate, the training group would raise while the eval
+            # group already waits in the hand-over broadcast (found by the gloo fuzz, round 4: "2x2" on 4 ranks = groups of 2)
+            R, C = (int(v) for v in ex.split("x"))
+            if R * C != half:
+                raise ValueError(f"exchange={ex!r} does not factor the {half} ranks of a task-split group "
+                                 f"({world} ranks = 2 groups of {half})")
         self.rank, self.world_size, self.device = rank, world, device
         self.role = role or ("train" if rank < half else "eval")
         if isinstance(comm, EmulatedComm):  # bench.py --emulate-rank: one process stands for one rank of one group

@@ -815,17 +815,33 @@ def runner_fuzz_worker(rank, world, port, out_dir, seeds, own_group=True):
                          [nll(ev[m], y[m]).item() if int(m.sum()) else 0.0 for m in masks[1:]],
                          [int((ev[m].argmax(1) == y[m]).sum()) for m in masks[1:]]))
         clear_cache()
+        if "desc" in os.environ.get("RGBX_FUZZ_SHOW", ""):
+            print(f"[rank {rank}] {desc}", flush=True)
+        # the epoch split by task on an even world (half the ranks train, half evaluate; 2 ranks: each on the whole graph)
+        split = world % 2 == 0 and exchange != "replicate" and rng.random() < 0.3
+        if split and "x" in exchange:  # a grid must factor the GROUP (TaskSplitRunner refuses anything else by name)
+            half = world // 2
+            fits = [f"{a}x{half // a}" for a in range(1, half) if half % a == 0 and half // a > 1]
+            exchange = rng.choice(fits) if fits else "auto"
         try:
-            r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
-                           backend=OracleAggregator(), exchange=exchange, pieces=pieces, pieces_in=pieces or 1)
+            if split:
+                from rgb_experiment_amd.dist import TaskSplitRunner
+                r = TaskSplitRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01,
+                                    backend=OracleAggregator(), exchange=exchange)
+                desc += " task-split"
+            else:
+                r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
+                               backend=OracleAggregator(), exchange=exchange, pieces=pieces, pieces_in=pieces or 1)
             hist = [r.epoch(more=True), r.epoch()]
+            if split:
+                r.discard_speculation()
         except (NotImplementedError, ValueError) as exc:  # a combination the runner refuses by name, on every rank alike
             bad.append((desc, "refused: " + repr(exc)[:160])) if "refus" in os.environ.get("RGBX_FUZZ_SHOW", "") else None
             continue
         for step in range(2):
             tl, wl = hist[step][0], want[step][0]
             if abs(tl - wl) > 5e-5 * max(1.0, abs(wl)):
-                bad.append((desc, f"train loss of epoch {step}: {tl} vs {wl}", r.engine is not None))
+                bad.append((desc, f"train loss of epoch {step}: {tl} vs {wl}", getattr(r, "engine", None) is not None))
         # eval numbers of the last epoch against the oracle's eval forward on THIS run's trained weights (two separately
         # trained runs differ by Adam's +-lr steps on the biases in front of a BatchNorm, whose true gradient is zero)
         own = {k: v.detach().clone() for k, v in r.model.state_dict().items() if "lin_dst" not in k}
@@ -838,7 +854,8 @@ def runner_fuzz_worker(rank, world, port, out_dir, seeds, own_group=True):
                 continue
             wl_, wa_ = nll(ev[m], y[m]).item(), int((ev[m].argmax(1) == y[m]).sum()) / cnt
             if abs(got_l - wl_) > 1e-4 * max(1.0, abs(wl_)) or abs(got_a - wa_) > 1.5 / cnt:
-                bad.append((desc, f"{name} loss / accuracy of the last epoch: {(got_l, got_a)} vs {(wl_, wa_)}", r.engine is not None))
+                bad.append((desc, f"{name} loss / accuracy of the last epoch: {(got_l, got_a)} vs {(wl_, wa_)}",
+                            getattr(r, "engine", None) is not None))
         del r
     torch.save(bad, os.path.join(out_dir, f"runfuzz_{rank}.pt"))
     if own_group:
@@ -848,7 +865,10 @@ def runner_fuzz_worker(rank, world, port, out_dir, seeds, own_group=True):
 def dist_fuzz_worker(rank, world, port, out_dir, prop_seeds, run_seeds):
     """propagate_fuzz_worker and runner_fuzz_worker in ONE set of rank processes (the interpreter start-up of the ranks is most
     of a short fuzz's time)."""
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("RGBX_TEST_DUMP_AFTER", "600")), exit=True)  # a hang ends with its stacks
     _init(rank, world, port)
     propagate_fuzz_worker(rank, world, port, out_dir, prop_seeds, own_group=False)
     runner_fuzz_worker(rank, world, port, out_dir, run_seeds, own_group=False)
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()

@@ -98,3 +98,14 @@ def test_task_split_resolution_and_memory_guard(monkeypatch):
         tasksplit.resolve("maybe", gcn, 2, *args)
     # the footprint estimate against the measured peak of the benchmark epoch (9.7 GB at L)
     assert 8e9 < tasksplit.whole_graph_bytes(2_000_000, 60_000_000, [128]) < 12e9
+
+
+def test_task_split_refuses_a_grid_that_does_not_factor_its_groups():
+    """TaskSplitRunner checks an explicit RxC exchange against the GROUP size in its constructor, before any rank creates a
+    group or waits for another: 4 ranks are 2 groups of 2, "2x2" cannot be laid over a group."""
+    import pytest
+    import torch
+
+    from rgb_experiment_amd.dist import TaskSplitRunner
+    with pytest.raises(ValueError, match="task-split group"):
+        TaskSplitRunner(None, None, None, None, None, 0, 4, torch.device("cpu"), exchange="2x2")
