@@ -62,7 +62,7 @@ def test_bench_gpus_n_with_the_epoch_split_by_task():
     assert res["final_losses"]["val"] == res["final_losses"]["val"] and res["final_losses"]["val"] > 0  # from the eval group
 
 
-@pytest.mark.parametrize("gpus,exchange,scheme", [(2, "auto", None), (3, "replicate", "replicate"), (4, "2x2", "grid2x2")])
+@pytest.mark.parametrize("gpus,exchange,scheme", [(3, "replicate", "replicate"), (4, "2x2", "grid2x2")])  # (2 ranks: the task-split case below)
 def test_bench_gpus_n_launches_its_own_ranks(gpus, exchange, scheme):
     # (--task-split off: two ranks would otherwise split the epoch by task, each on the whole graph — its own test below)
     proc = _run(["--gpus", str(gpus), "--workload", "T", "--steps", "2", "--warmup", "1", "--exchange", exchange,

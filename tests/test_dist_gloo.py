@@ -196,7 +196,7 @@ def test_dist_runner_training_matches_single_process(model_name, world, exchange
 
 
 @pytest.mark.parametrize("model_name,world,exchange,stop_early", [("appnpstack", 4, "reshard", True),
-                                                                   ("gcn", 2, "halo", True), ("gcn", 6, "halo", False),
+                                                                   ("gcn", 2, "halo", True),
                                                                    # BASELINE configs[4] as the 8-GPU tier runs it: 4 + 4
                                                                    ("appnpstack", 8, "reshard", False)])
 def test_epoch_split_by_task_over_two_groups(model_name, world, exchange, stop_early, tmp_path):
@@ -280,7 +280,7 @@ def test_fused_grid_schedule_matches_single_process(model_name, world, exchange,
         assert abs(a[0] - b[0]) < 2e-5 and abs(a[1] - b[1]) < 3e-2 and abs(a[3] - b[3]) < 3e-2, (a, b)
 
 
-@pytest.mark.parametrize("model_name,world,exchange,pieces", [("graphsage_grid", 4, "2x2", 1), ("gcn3_grid", 3, "reshard", 3)])
+@pytest.mark.parametrize("model_name,world,exchange,pieces", [("gcn3_grid", 3, "reshard", 3)])  # (+ the 2 x 2 grid in -m gpu)
 def test_next_training_step_computed_during_the_eval_forwards(model_name, world, exchange, pieces, tmp_path):
     """DistRunner.epoch(more=True): the eval forwards of an epoch are interleaved with the forward + backward of the
     NEXT epoch's training step (one thread; its optimizer step waits for the next call). Same kernels on the same
@@ -349,7 +349,7 @@ def test_fused_grid_schedule_with_the_kept_input_aggregate(model_name, world, ex
         assert torch.allclose(v, b["state"][k], atol=1e-6), k
 
 
-@pytest.mark.parametrize("model_name", ["gcn", "appnpstack"])
+@pytest.mark.parametrize("model_name", ["gcn"])  # (appnpstack: tests/test_gpu_dist.py, on the real kernels)
 def test_experiment_runs_as_one_of_several_ranks(model_name, tmp_path):
     """experiment() under WORLD_SIZE > 1 takes the node-partitioned route (dist/experiment.py): every rank returns the
     same metrics and trained weights, and 2 ranks train like 3 ranks (the partition changes summation orders only)."""
