@@ -840,7 +840,11 @@ def runner_fuzz_worker(rank, world, port, out_dir, seeds, own_group=True):
             continue
         for step in range(2):
             tl, wl = hist[step][0], want[step][0]
-            if abs(tl - wl) > 5e-5 * max(1.0, abs(wl)):
+            # the first loss is a pure forward; the second has ONE Adam step in it, and Adam turns the rounding noise of a
+            # parameter whose true gradient is ~0 (a bias in front of a BatchNorm, GAT's attention vectors once a hub has made
+            # the rows alike) into a +-lr step: two correct runs differ by O(lr) there (soak, round 4: 2 of 4,000 cases at
+            # 1e-4 and 3e-3 relative, a 17-node and a 33-node hub graph) — tight on the first, a gross-error bound on the second
+            if abs(tl - wl) > (5e-5 if step == 0 else 1e-2) * max(1.0, abs(wl)):
                 bad.append((desc, f"train loss of epoch {step}: {tl} vs {wl}", getattr(r, "engine", None) is not None))
         # eval numbers of the last epoch against the oracle's eval forward on THIS run's trained weights (two separately
         # trained runs differ by Adam's +-lr steps on the biases in front of a BatchNorm, whose true gradient is zero)
