@@ -21,6 +21,10 @@ class DistRunner:
                  pipeline=True):
         self.comm = comm or Comm()
         self.rank, self.world, self.device = rank, world, device
+        if "x" in str(exchange):  # an explicit R x C grid must factor the ranks: said before any structure is built
+            R, C = (int(v) for v in str(exchange).split("x"))
+            if R * C != world:
+                raise ValueError(f"exchange={exchange!r} does not factor the world size {world}")
         N = x.size(0)
         lo, hi = partition_bounds(N, world)[rank:rank + 2]
         self.lo, self.hi, self.N = lo, hi, N

@@ -109,3 +109,14 @@ def test_task_split_refuses_a_grid_that_does_not_factor_its_groups():
     from rgb_experiment_amd.dist import TaskSplitRunner
     with pytest.raises(ValueError, match="task-split group"):
         TaskSplitRunner(None, None, None, None, None, 0, 4, torch.device("cpu"), exchange="2x2")
+
+
+def test_dist_runner_refuses_a_grid_that_does_not_factor_the_world():
+    import pytest
+    import torch
+
+    from rgb_experiment_amd.dist import DistRunner
+    from rgb_experiment_amd.dist.comm import EmulatedComm
+    with pytest.raises(ValueError, match="does not factor the world size 4"):
+        DistRunner(None, None, torch.zeros(8, 4), torch.zeros(8), [], 0, 4, torch.device("cpu"), comm=EmulatedComm(4, 0),
+                   exchange="2x4")
