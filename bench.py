@@ -674,6 +674,66 @@ def cora_shaped(dev, epochs=60):
     return out
 
 
+def real_shape_block(dev, ei, N, F, C, names, steps, warmup):
+    """The epoch on the shapes the reference actually ships (initial_params.py:25-29: 2 layers, hidden 64; F > hidden > C
+    with C = 7 on Cora, 40 on ogbn-arxiv — 最终结果.csv), on the graph of workload L: every layer transforms first and
+    gathers at its OUTPUT width (64, then C padded to a multiple of 4), BatchNorm's column sums and the masked
+    cross-entropy come out of the gather kernel (rgbx_spmm_csr_epilogue_f32). Per model: ms per reference epoch (train
+    fwd + bwd + Adam + 2 eval fwd) and per identical-results epoch (one shared eval forward), the launches by kind and
+    form (HIP events on the launch stream), peak HBM, and the row-gather kernels' algorithmic-byte roofline by width."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import clear_cache, get_graph
+    gen = torch.Generator(device=dev).manual_seed(1234570)
+    x = torch.randn((N, F), generator=gen, device=dev)
+    y = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(1234571))
+    masks = split_masks(y)
+    out = {"nodes": N, "edges_in": int(ei.size(1)), "features": F, "hidden": 64, "classes": C,
+           "what": "reference default hyper-parameters (initial_params.py:25-29) on workload L's graph; features ~ N(0, 1) "
+                   "drawn on the device", "models": {}}
+    for name in names:
+        torch.manual_seed(14530529)
+        kwargs, n_prop, loops_mode, kind = MODELS[name]
+        kwargs = dict(kwargs, hidden_unit=64)
+        model = model_class(name)(input_dim=F, output_dim=C, **kwargs)
+        torch.cuda.reset_peak_memory_stats(dev)
+        step, nnz, _ = build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, C)
+        rec = {}
+        for label, fn in (("reference_epoch", step), ("identical_results_epoch", step.identical)):
+            for _ in range(warmup):
+                fn()
+            events = []
+            ops.set_event_sink(events)
+            dt, last, per = time_steps(fn, steps, 0)
+            ops.set_event_sink(None)
+            by = {}
+            for k, s, e in events:
+                key = f"{k}[{k.variant}]" if getattr(k, "variant", None) is not None else str(k)
+                by.setdefault(key, []).append(s.elapsed_time(e))
+            table = {k: {"n_per_epoch": len(v) / steps, "avg_ms": sum(v) / len(v), "ms_per_epoch": sum(v) / steps}
+                     for k, v in sorted(by.items())}
+            rec[label] = {"ms_per_epoch": dt / steps * 1e3, "median_ms_per_epoch": median(per), "epochs_per_s": steps / dt,
+                          "timed_launches_ms_per_epoch": sum(t["ms_per_epoch"] for t in table.values()),
+                          "launches": table, "final_train_loss": last[0]}
+        # the row-gather kernels by width: algorithmic bytes (SURVEY 8d formula; 'mean' / 'sum' carry no per-edge weight)
+        roof = {}
+        for key, t in rec["reference_epoch"]["launches"].items():
+            if "[rows+" not in key:
+                continue
+            d = int(key.split("+d")[-1].rstrip("]"))
+            alg = spmm_alg_bytes(N, nnz, d) - (0 if key.startswith("gcn") else 4 * nnz)  # per-edge weights: A_hat only
+            roof[key] = {"width": d, "algorithmic_bytes": alg, "avg_ms": t["avg_ms"],
+                         "achieved_gbs": alg / (t["avg_ms"] * 1e-3) / 1e9,
+                         "frac_of_8TBs": alg / (t["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        rec["row_gather_roofline"] = roof
+        rec["hbm_allocated_peak_gb"] = torch.cuda.max_memory_allocated(dev) / 1e9
+        rec["edges_aggregated_per_propagate"] = nnz
+        out["models"][name] = rec
+        del step, model
+        clear_cache()
+        torch.cuda.empty_cache()
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # N > 1
 
@@ -871,6 +931,9 @@ def main():
     ap.add_argument("--degree", choices=("uniform", "powerlaw"), default="uniform",
                     help="powerlaw: secondary run on a hub-heavy graph of the same size (row-split plans at work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--real-shape", default=None, metavar="MODEL:F:C",
+                    help="run ONLY the real-shape block (bench.real_shape_block) for one model on workload L's graph, "
+                         "e.g. gcn:1433:7 — the command profiled under rocprofv3 for profiles/r05_real_shape_*")
     ap.add_argument("--primary-only", action="store_true",
                     help="skip the secondary legs (hipGraph replay, configs[0]/[1] blocks, undirected run): clean "
                          "rocprofv3 runs")
@@ -932,6 +995,12 @@ def main():
     t_mark = time.perf_counter()
     ei, x, y = synth(N, E, d, args.degree)
     sv.beat("synthetic graph drawn")
+    if args.real_shape:
+        name, F, C = args.real_shape.split(":")
+        del x
+        print(json.dumps({"real_shape": real_shape_block(dev, ei, N, int(F), int(C), [name], args.steps, args.warmup)}),
+              flush=True)
+        return
     train_mask, val_mask, test_mask = split_masks(y)
     sv.beat("masks split")
     setup["synthetic_graph_and_masks_s"] = time.perf_counter() - t_mark
@@ -1368,6 +1437,12 @@ def main():
                            "(training layer 2, its transposed backward, the one eval forward's layer 2)")
             return out
 
+        def real_shape_leg():
+            # the reference's own shapes (in > out, small odd class counts): never the fused aggregate+transform kernel
+            names = ("gcn", "graphsage", "graphsage2")
+            return {"F1433_C7": real_shape_block(dev, ei, N, 1433, 7, names, max(3, args.steps // 2), 2),
+                    "F128_C40": real_shape_block(dev, ei, N, 128, 40, names, max(3, args.steps // 2), 2)}
+
         secondary("identical_results_same_run", identical_leg)
         if isinstance(result.get("identical_results_same_run"), dict) and "epochs_per_s" in result["identical_results_same_run"]:
             result["epochs_per_s_identical_results"] = result["identical_results_same_run"]["epochs_per_s"]
@@ -1376,6 +1451,7 @@ def main():
         secondary("powerlaw_same_run", powerlaw_leg)
         secondary("configs_1_same_run", configs_1_leg)
         secondary("configs_0_same_run", lambda: cora_shaped(dev))
+        secondary("real_shape_same_run", real_shape_leg)
     if rank == 0:
         print(json.dumps(result), flush=True)
     # from here on only the teardown is left: a supervisor that has to end this worker later (a process group that does

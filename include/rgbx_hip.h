@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RGBX_VERSION 403 /* major*10000 + minor*100 + patch */
+#define RGBX_VERSION 500 /* major*10000 + minor*100 + patch */
 
 #define RGBX_OK 0
 #define RGBX_E_ARG (-1)    /* null pointer / negative size / bad enum */
@@ -137,6 +137,36 @@ int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w,
                       const float* x, int64_t ldx, const float* y, int64_t ldy, const float* bias,
                       float* out, int64_t ldo, int64_t N, int64_t d, float a, float b,
                       const rgbx_row_split_t* split, rgbx_stream_t stream);
+
+/* rgbx_spmm_csr_f32 with an epilogue over the finished output rows, for layers that transform BEFORE they aggregate
+ * (in > out — every default configuration of the reference, initial_params.py:25-29: F -> 64 -> C with C = 7, 6, 3, 40 ...),
+ * whose last kernel is this gather and not the fused aggregate+transform one. A lane group holds a target's complete
+ * output row, so what the reference runs next as separate passes over [N, d] comes out of the registers:
+ *   out_colsums ([2, d] doubles): column sums of out and out^2 — the statistics of the training-mode BatchNorm1d
+ *     behind the layer (models/gcn.py:27 then :28); fp32 per 32-row tile, tiles added in fp64 in a fixed order;
+ *     stats_ws: rgbx_spmm_linear_stats_workspace_bytes(N, d) bytes, 8-byte aligned. `out` is written as usual.
+ *   ce: log_softmax + NLLLoss on out[mask] + arg-max (models/gcn.py:31, itexperiments.py:400,429,434,624-626) exactly as
+ *     rgbx_ce_epilogue_t describes: statistics only (out not written, may be NULL; rows no mask selects are not even
+ *     gathered) or, with grad_scale, `out` = the loss gradient w.r.t. the logits. n_classes = C <= d: columns [C, d) are
+ *     PADDING (rows padded to a multiple of 4 floats: C = 7 -> d = 8) — no part in max / sum-exp / arg-max, gradient 0;
+ *     0 = all d columns. Labels outside [0, C) deselect a row. ce->scratch as for rgbx_spmm_linear_f32.
+ * Exactly one of out_colsums / ce. d % 4 == 0, d <= 256 (rgbx_spmm_csr_epilogue_supported); x, y, out, bias 16-byte
+ * aligned, leading dimensions % 4 == 0. The logits are bit-identical to rgbx_spmm_csr_f32's (same summation order).
+ * `split`: as rgbx_spmm_linear_f32 — split->partial must hold (n_chunks + n_long) * d floats. */
+typedef struct rgbx_spmm_epilogue {
+  const struct rgbx_ce_epilogue* ce; /* or NULL */
+  int64_t n_classes;
+  double* out_colsums;               /* or NULL */
+  void* stats_ws;
+  size_t stats_ws_bytes;
+} rgbx_spmm_epilogue_t;
+
+int rgbx_spmm_csr_epilogue_supported(int64_t d);
+int rgbx_spmm_csr_epilogue_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
+                               const float* x, int64_t ldx, const float* y, int64_t ldy, const float* bias,
+                               float* out, int64_t ldo, int64_t N, int64_t d, float a, float b,
+                               const rgbx_row_split_t* split, const rgbx_spmm_epilogue_t* epi,
+                               rgbx_stream_t stream);
 
 /* Fused aggregate-then-transform for layers whose propagate commutes with their Linear
  * (GCNConv, the mean branch of SAGEConv / my_SAGEConv):

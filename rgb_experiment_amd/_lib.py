@@ -31,6 +31,12 @@ class CeEpilogue(ctypes.Structure):
                 ("stats", ctypes.c_void_p), ("scratch", ctypes.c_void_p), ("mask_groups", ctypes.c_int32)]
 
 
+class SpmmEpilogue(ctypes.Structure):
+    """rgbx_spmm_epilogue_t"""
+    _fields_ = [("ce", ctypes.c_void_p), ("n_classes", ctypes.c_int64), ("out_colsums", ctypes.c_void_p),
+                ("stats_ws", ctypes.c_void_p), ("stats_ws_bytes", ctypes.c_size_t)]
+
+
 class FusedLayer(ctypes.Structure):
     """rgbx_fused_layer_t"""
     _fields_ = [("rowptr", _P), ("col", _P), ("w", _P), ("rs", _P), ("x", _P), ("ldx", _I64),
@@ -50,6 +56,8 @@ SIGNATURES = {
     "rgbx_gcn_norm_f32": [_P, _P, _I64, _P, _P, _P],
     "rgbx_inv_degree_f32": [_P, _I64, _P, _P],
     "rgbx_spmm_csr_f32": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _F, _F, _P, _P],
+    "rgbx_spmm_csr_epilogue_supported": [_I64],
+    "rgbx_spmm_csr_epilogue_f32": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _F, _F, _P, _P, _P],
     "rgbx_spmm_linear_supported": [_I64, _I64, _I],
     "rgbx_spmm_linear_stats_workspace_bytes": [_I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
     "rgbx_spmm_linear_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P,

@@ -264,6 +264,196 @@ int launch(const SpmmArgs& A, const rgbx_row_split_t* sp, hipStream_t s) {
   return RGBX_OK;
 }
 
+// ---- the same row gather with an epilogue over the finished rows (rgbx_spmm_csr_epilogue_f32) --------------------
+// Layers that transform BEFORE they aggregate (in > out: every configuration the reference ships, initial_params.py:25-29 —
+// F = 1433 -> 64 -> C = 7) end in this kernel, not in the fused aggregate+transform one; what follows the layer in the
+// reference is then a pass over its [N, d] output: BatchNorm's column statistics (models/gcn.py:28) or log_softmax +
+// NLLLoss + arg-max (gcn.py:31, itexperiments.py:429,434,624-626). A lane group of the gather holds a target's COMPLETE
+// output row (d <= 256), so both come out of the registers here:
+//  - column sums: a wave adds its 8 rows per column, the 4 waves of a 32-row tile meet in LDS, one [2, d] fp32 record per
+//    tile; the records are added in fp64 in a fixed order (reduce_tile_stats) — as the fused kernel's MFMA-tile statistics;
+//  - masked cross-entropy: max / first arg-max / sum-exp go through the group's lanes with shuffles; per tile one record
+//    (nll sum, rows, hits) x mask groups; `out` receives the loss gradient, or nothing at all (statistics only).
+// Rows are assigned statically (wave w of a tile owns rows 8 w .. 8 w + 7) so that every sum has a fixed order.
+struct EpiArgs {
+  float* stats_part;  // [tiles][2 * d] or NULL
+  const int64_t* ce_y;
+  const uint8_t* ce_mask;
+  const float* ce_scale;
+  double* ce_part;    // [tiles][3 * ce_groups] or NULL
+  int ce_groups;
+  int C;              // columns [C, d) are padding: no part in the loss, gradient 0
+  // hub rows: RAW weighted sums finished by the split-row kernels, compact in hub order
+  const int* long_row;
+  const float* zlong;
+  int threshold, n_long;
+};
+
+template <int G, bool HAS_W, bool CE>
+__global__ void __launch_bounds__(256) spmm_tile_epilogue_kernel(const SpmmArgs A, const EpiArgs E) {
+  constexpr int VEC = 4;
+  constexpr int RPW = kTileRows / 4;  // rows per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / G, t = lane % G;
+  const int c = t * VEC;
+  const bool active = c < A.d;
+  const int row_base = blockIdx.x * kTileRows;
+  float s1[VEC] = {0.f, 0.f, 0.f, 0.f}, s2[VEC] = {0.f, 0.f, 0.f, 0.f};
+  double nll = 0.0, nll2 = 0.0;
+  int cnt = 0, hit = 0, cnt2 = 0, hit2 = 0;
+  const float sc = (CE && E.ce_scale) ? E.ce_scale[0] : 0.f;
+  float bv[VEC] = {0.f, 0.f, 0.f, 0.f};
+  if (A.bias && active) load_vec<VEC>(bv, A.bias + c);
+
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = row_base + wave * RPW + rr;
+    if (row >= A.N) break;  // wave-uniform
+    const int start = __builtin_amdgcn_readfirstlane(A.rowptr[row]);
+    const int end = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
+    int tgt = -1, bits = 1;
+    if constexpr (CE) {
+      bits = E.ce_mask ? (int)E.ce_mask[row] : 1;
+      bits = E.ce_groups == 2 ? (bits & 3) : (bits ? 1 : 0);
+      if (bits) {
+        const int64_t ti = E.ce_y[row];
+        if (ti >= 0 && ti < E.C) tgt = (int)ti;
+      }
+      if (tgt < 0 && !E.ce_scale) continue;  // not selected and nothing to store: the row is not even gathered
+    }
+    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+    if (E.threshold > 0 && end - start > E.threshold) {  // hub row (wave-uniform): finished by the split-row kernels
+      int lo = 0, hi = E.n_long - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (E.long_row[mid] < row) lo = mid + 1;
+        else hi = mid;
+      }
+      if (active) load_vec<VEC>(acc, E.zlong + (int64_t)lo * A.d + c);
+    } else if (!CE || tgt >= 0) {
+      accumulate_slots<G, VEC, HAS_W>(A, start, end, A.x + c, active, lane, g, acc);
+    }
+    // every lane group now holds the row: the epilogue of spmm_epilogue, same operation order (same bits)
+    const float scale = A.rs ? A.a * A.rs[row] : A.a;
+    float r[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] = scale * acc[i];
+    if (A.y && active) {
+      float yv[VEC];
+      load_vec<VEC>(yv, A.y + (int64_t)row * A.ldy + c);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) r[i] = fmaf(A.b, yv[i], r[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] += bv[i];
+    if constexpr (!CE) {
+      if (g == 0 && active) {
+        if (A.out) {
+          using f4v = __attribute__((ext_vector_type(4))) float;
+          f4v o = {r[0], r[1], r[2], r[3]};
+          __builtin_nontemporal_store(o, reinterpret_cast<f4v*>(A.out + (int64_t)row * A.ldo + c));
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          s1[i] += r[i];
+          s2[i] = fmaf(r[i], r[i], s2[i]);
+        }
+      }
+    } else {
+      float e[VEC] = {0.f, 0.f, 0.f, 0.f};
+      float lse = 0.f;
+      if (tgt >= 0) {
+        // NLLLoss(log_softmax(z))_i = lse_i - z[i, y_i]; arg-max = the first maximal column (rgbx_masked_ce_fwd_f32)
+        float best = -INFINITY;
+        int arg = INT32_MAX;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const bool valid = active && c + i < E.C;
+          if (valid && r[i] > best) { best = r[i]; arg = c + i; }
+        }
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) {
+          const float ob = __shfl_xor(best, off);
+          const int oa = __shfl_xor(arg, off);
+          if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+        }
+        float se = 0.f, tv = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const bool valid = active && c + i < E.C;
+          e[i] = valid ? expf(r[i] - best) : 0.f;
+          se += e[i];
+          if (valid && c + i == tgt) tv = r[i];
+        }
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) {
+          se += __shfl_xor(se, off);
+          tv += __shfl_xor(tv, off);  // exactly one lane of the group holds the target column
+        }
+        lse = best + logf(se);
+        const double term = (double)(lse - tv);
+        const int h = arg == tgt ? 1 : 0;
+        if (bits & 1) { nll += term; cnt += 1; hit += h; }
+        if (bits & 2) { nll2 += term; cnt2 += 1; hit2 += h; }
+      }
+      if (E.ce_scale && g == 0 && active) {  // grad_scale * (softmax - onehot) on selected rows, 0 elsewhere (rgbx_masked_ce_bwd_f32)
+        float gr[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const bool valid = c + i < E.C;
+          gr[i] = (tgt >= 0 && valid) ? sc * (expf(r[i] - lse) - (c + i == tgt ? 1.f : 0.f)) : 0.f;
+        }
+        using f4v = __attribute__((ext_vector_type(4))) float;
+        f4v o = {gr[0], gr[1], gr[2], gr[3]};
+        __builtin_nontemporal_store(o, reinterpret_cast<f4v*>(A.out + (int64_t)row * A.ldo + c));
+      }
+    }
+  }
+  if constexpr (!CE) {
+    if (!E.stats_part) return;
+    __shared__ float sh[4][512];
+    if (g == 0 && active) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        sh[wave][c + i] = s1[i];
+        sh[wave][A.d + c + i] = s2[i];
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * A.d; k += 256)
+      E.stats_part[(int64_t)blockIdx.x * 2 * A.d + k] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
+  } else {
+    __shared__ double cew[4][6];
+    if (lane == 0) {
+      cew[wave][0] = nll;
+      cew[wave][1] = (double)cnt;
+      cew[wave][2] = (double)hit;
+      cew[wave][3] = nll2;
+      cew[wave][4] = (double)cnt2;
+      cew[wave][5] = (double)hit2;
+    }
+    __syncthreads();
+    const int W = 3 * E.ce_groups;
+    if ((int)threadIdx.x < W) {
+      const int k = threadIdx.x;
+      E.ce_part[(int64_t)blockIdx.x * W + k] = (cew[0][k] + cew[1][k]) + (cew[2][k] + cew[3][k]);
+    }
+  }
+}
+
+template <int G>
+int launch_epilogue(const SpmmArgs& A, const EpiArgs& E, hipStream_t s) {
+  const int tiles = (int)cdiv(A.N, kTileRows);
+  if (E.ce_part) {
+    if (A.w) spmm_tile_epilogue_kernel<G, true, true><<<tiles, 256, 0, s>>>(A, E);
+    else spmm_tile_epilogue_kernel<G, false, true><<<tiles, 256, 0, s>>>(A, E);
+  } else {
+    if (A.w) spmm_tile_epilogue_kernel<G, true, false><<<tiles, 256, 0, s>>>(A, E);
+    else spmm_tile_epilogue_kernel<G, false, false><<<tiles, 256, 0, s>>>(A, E);
+  }
+  RGBX_CHECK_LAUNCH("spmm_tile_epilogue_kernel");
+  return RGBX_OK;
+}
+
 template <int VEC>
 int dispatch_groups(const SpmmArgs& A, const rgbx_row_split_t* sp, hipStream_t s) {
   const int lanes = (A.d + VEC - 1) / VEC;  // lanes needed to cover one row
@@ -365,4 +555,80 @@ extern "C" int rgbx_appnp_f32(const int32_t* rowptr, const int32_t* col, const f
     lds = ldo;
   }
   return RGBX_OK;
+}
+
+extern "C" int rgbx_spmm_csr_epilogue_supported(int64_t d) { return d >= 4 && d % 4 == 0 && d <= 256; }
+
+extern "C" int rgbx_spmm_csr_epilogue_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* rs,
+                                          const float* x, int64_t ldx, const float* y, int64_t ldy, const float* bias,
+                                          float* out, int64_t ldo, int64_t N, int64_t d, float a, float b,
+                                          const rgbx_row_split_t* split, const rgbx_spmm_epilogue_t* epi,
+                                          rgbx_stream_t stream) {
+  if (!epi || (!epi->ce && !epi->out_colsums)) return fail(RGBX_E_ARG, "spmm_epilogue: no epilogue given (use rgbx_spmm_csr_f32)");
+  if (epi->ce && epi->out_colsums) return fail(RGBX_E_ARG, "spmm_epilogue: out_colsums and the cross-entropy epilogue exclude each other");
+  if (N < 0 || d <= 0) return fail(RGBX_E_ARG, "spmm_epilogue: bad size");
+  if (N >= INT32_MAX) return fail(RGBX_E_RANGE, "spmm_epilogue: N exceeds int32");
+  if (!rgbx_spmm_csr_epilogue_supported(d))
+    return fail(RGBX_E_SHAPE, "spmm_epilogue: needs d %% 4 == 0 and d <= 256 (got %lld); pad the rows", (long long)d);
+  const rgbx_ce_epilogue_t* ce = epi->ce;
+  const bool stats_only = ce && !ce->grad_scale;
+  if (!rowptr || !col || !x || (!out && !stats_only)) return fail(RGBX_E_ARG, "spmm_epilogue: null pointer");
+  if (ldx < d || (out && ldo < d) || (y && ldy < d)) return fail(RGBX_E_ARG, "spmm_epilogue: leading dimension < d");
+  if (out == x) return fail(RGBX_E_ARG, "spmm_epilogue: out must not alias x");
+  if (!aligned16(x) || ldx % 4 || (y && (!aligned16(y) || ldy % 4)) || (out && (!aligned16(out) || ldo % 4)) ||
+      (bias && !aligned16(bias)))
+    return fail(RGBX_E_ALIGN, "spmm_epilogue: x / y / out / bias must be 16-byte aligned with ld %% 4 == 0");
+  int C = (int)d;
+  if (ce) {
+    if (!ce->y || !ce->stats || !ce->scratch) return fail(RGBX_E_ARG, "spmm_epilogue: incomplete cross-entropy epilogue");
+    if (ce->mask_groups < 0 || ce->mask_groups > 2)
+      return fail(RGBX_E_ARG, "spmm_epilogue: mask_groups must be 0, 1 or 2 (got %d)", (int)ce->mask_groups);
+    if (ce->mask_groups == 2 && (ce->grad_scale || !ce->mask))
+      return fail(RGBX_E_ARG, "spmm_epilogue: two statistics sets (mask_groups == 2) need a mask and no loss gradient");
+    if (epi->n_classes < 0 || epi->n_classes > d) return fail(RGBX_E_ARG, "spmm_epilogue: n_classes must lie in [0, d]");
+    if (epi->n_classes > 0) C = (int)epi->n_classes;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = (int)cdiv(N, kTileRows);
+  if (N == 0) {
+    if (ce) RGBX_HIP(hipMemsetAsync(ce->stats, 0, sizeof(double) * (ce->mask_groups == 2 ? 6 : 3), s));
+    if (epi->out_colsums) RGBX_HIP(hipMemsetAsync(epi->out_colsums, 0, sizeof(double) * 2 * d, s));
+    return RGBX_OK;
+  }
+  float* stats_part = nullptr;
+  double* stats_part2 = nullptr;
+  if (epi->out_colsums) {
+    size_t need = 0;
+    rgbx_spmm_linear_stats_workspace_bytes(N, d, &need);
+    if (!epi->stats_ws || epi->stats_ws_bytes < need)
+      return fail(RGBX_E_WS, "spmm_epilogue: statistics workspace %zu < %zu bytes", epi->stats_ws_bytes, need);
+    if (reinterpret_cast<uintptr_t>(epi->stats_ws) % 8) return fail(RGBX_E_ALIGN, "spmm_epilogue: stats_ws must be 8-byte aligned");
+    stats_part2 = static_cast<double*>(epi->stats_ws);
+    stats_part = reinterpret_cast<float*>(stats_part2 + (size_t)kStatsGather * 2 * d);
+  }
+  SpmmArgs A{rowptr, col, w, rs, x, y, bias, out, ldx, ldy, ldo, (int)N, (int)d, a, b, 0};
+  EpiArgs E{stats_part, ce ? ce->y : nullptr, ce ? ce->mask : nullptr, ce ? ce->grad_scale : nullptr,
+            ce ? ce->scratch : nullptr, ce && ce->mask_groups == 2 ? 2 : 1, C, nullptr, nullptr, 0, 0};
+  if (split && split->threshold > 0 && split->n_chunks > 0) {
+    // hub rows first: raw chunk sums + ordered combine into the tail of the caller's scratch ([n_long, d] behind the
+    // [n_chunks, d] partials); the tile kernel applies the epilogue to them like to any other row
+    float* zl = split->partial ? split->partial + (size_t)split->n_chunks * d : nullptr;
+    if (int rc = spmm_long_rows_compact(rowptr, col, w, nullptr, x, ldx, (int)d, split, zl, s)) return rc;
+    E.long_row = split->long_row;
+    E.zlong = zl;
+    E.threshold = split->threshold;
+    E.n_long = split->n_long;
+  }
+  const int lanes = (int)(d / 4);
+  int rc;
+  if (lanes <= 1) rc = launch_epilogue<1>(A, E, s);
+  else if (lanes <= 2) rc = launch_epilogue<2>(A, E, s);
+  else if (lanes <= 4) rc = launch_epilogue<4>(A, E, s);
+  else if (lanes <= 8) rc = launch_epilogue<8>(A, E, s);
+  else if (lanes <= 16) rc = launch_epilogue<16>(A, E, s);
+  else if (lanes <= 32) rc = launch_epilogue<32>(A, E, s);
+  else rc = launch_epilogue<64>(A, E, s);
+  if (rc) return rc;
+  if (ce) return reduce_ce_tiles(ce->scratch, tiles, ce->stats, ce->mask_groups == 2 ? 6 : 3, s);
+  return reduce_tile_stats(stats_part, tiles, (int)(2 * d), stats_part2, epi->out_colsums, s);
 }

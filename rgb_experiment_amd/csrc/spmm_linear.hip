@@ -92,7 +92,7 @@ __device__ __forceinline__ const float* blocked_at(const float* base, int64_t bc
   return bc ? base + (int64_t)(c / (int)bc) * bs + (int64_t)row * bc + (c % (int)bc) : base + (int64_t)row * ld + c;
 }
 
-constexpr int TM = 32;       // destination rows per workgroup = one MFMA row tile; 4 waves aggregate 8 rows each
+constexpr int TM = kTileRows;  // destination rows per workgroup = one MFMA row tile; 4 waves aggregate 8 rows each
                             // (64- and 128-row tiles, one B fragment feeding 2-4 MFMAs, measured slower: DESIGN 3.2a)
 constexpr int NT_ROOT = 2;  // 32-column output tiles a wave may own when a root term is present (Nout <= 256)
 // Registers: the row-per-wave gather needs ~47 VGPRs and is bound by how many waves keep loads in flight, so this
@@ -225,7 +225,6 @@ tile_stats_finish_kernel(const double* __restrict__ part2, int G, int width2, do
   }
 }
 
-constexpr int kStatsGather = 1024;  // workgroups of the second stage
 
 // Cross-entropy of the finished 32 x Nout tile (Nout <= 128), see FusedArgs::ce_part. The four waves park their 32 x 32
 // blocks in LDS (the aggregate tile is dead by now), then each wave takes 8 rows: a lane holds columns lane and
@@ -314,7 +313,6 @@ __device__ __forceinline__ void ce_epilogue(const FusedArgs& A, const f32x16& ac
 
 // stats[k] = sum over the tiles' records in a fixed order, two stages: kCeGather workgroups add a contiguous slice of
 // the records each (thread-strided, then a block tree), one workgroup adds their sums.
-constexpr int kCeGather = 64;
 
 __device__ __forceinline__ double block_tree_sum(double v, double* sh) {
   sh[threadIdx.x] = v;
@@ -836,7 +834,6 @@ __global__ void __launch_bounds__(256, ROOT || NT > 1 ? 2 : (CE || KC > 64 ? 3 :
 template <int KC>
 bool launch_dense_stream(const FusedArgs& A, hipStream_t s) {
   const int tiles = (int)cdiv(A.N, TM);
-  const size_t lds = (size_t)TM * ((A.ce_part && A.Nout > A.K ? A.Nout : A.K) + 4) * sizeof(float);
   const bool root = A.xr != nullptr;
   const int nt = A.Nout <= 128 ? 1 : 2;
   if (A.Nout > 256 || (root && nt == 2)) return false;  // register budget: the one-tile-per-workgroup form
@@ -844,16 +841,13 @@ bool launch_dense_stream(const FusedArgs& A, hipStream_t s) {
   // behind: measured at 250 k rows, K = Nout = 128: 0.144 / 0.202 ms (eval / training) there against 0.180 / 0.269 here;
   // the plain forms gain: 0.120 -> 0.100 ms
   if (A.ce_part) return false;
-  const int per_cu = (root || nt > 1) ? 2 : (A.ce_part || KC > 64 ? 3 : 4);  // = the kernel's __launch_bounds__
+  const int per_cu = (root || nt > 1) ? 2 : (KC > 64 ? 3 : 4);  // = the kernel's __launch_bounds__
   // as many workgroups as give every one of them the same number of tiles (± 1 on the last few): 7,813 tiles (250 k rows) over
   // 768 workgroups would be 10 for most and 11 for some — a tenth of the launch spent with most of the chip idle
   const int slots = 256 * per_cu;
   const int grid = tiles <= slots ? tiles : (int)cdiv(tiles, cdiv(tiles, slots));
   const size_t lds2 = 2 * (size_t)TM * (KC + 4) * sizeof(float);  // the pipelined forms keep two tiles
-  if (A.ce_part) {
-    if (root) dense_stream_kernel<KC, 1, true, true><<<grid, 256, lds, s>>>(A, tiles);
-    else dense_stream_kernel<KC, 1, true, false><<<grid, 256, lds, s>>>(A, tiles);
-  } else if (nt == 1) {
+  if (nt == 1) {
     if (root) {  // + two tiles of root rows: 4 x 32 x (KC + 4) floats = 67.6 KB at KC = 128, beyond the 64 KB a launch
       // may ask for without saying so
       static const hipError_t allow = hipFuncSetAttribute(
@@ -913,6 +907,25 @@ int launch(const FusedArgs& A, hipStream_t s) {
 }
 
 }  // namespace
+
+int reduce_ce_tiles(double* scratch, int tiles, double* stats, int W, hipStream_t s) {
+  double* part2 = scratch + (size_t)tiles * W;  // [kCeGather, W] behind the tile records
+  ce_tiles_gather_kernel<<<kCeGather, 256, 0, s>>>(scratch, tiles, part2, W);
+  RGBX_CHECK_LAUNCH("ce_tiles_gather_kernel");
+  ce_tiles_finish_kernel<<<1, 256, 0, s>>>(part2, kCeGather, stats, W);
+  RGBX_CHECK_LAUNCH("ce_tiles_finish_kernel");
+  return RGBX_OK;
+}
+
+int reduce_tile_stats(const float* part, int tiles, int width2, double* part2, double* sums, hipStream_t s) {
+  const int G = tiles < kStatsGather ? tiles : kStatsGather;
+  tile_stats_gather_kernel<<<G, 256, 0, s>>>(part, tiles, width2, part2);
+  RGBX_CHECK_LAUNCH("tile_stats_gather_kernel");
+  tile_stats_finish_kernel<<<(int)cdiv(width2, 8), 256, 0, s>>>(part2, G, width2, sums);
+  RGBX_CHECK_LAUNCH("tile_stats_finish_kernel");
+  return RGBX_OK;
+}
+
 }  // namespace rgbx
 
 using namespace rgbx;
@@ -1059,22 +1072,10 @@ extern "C" int rgbx_fused_layer_f32(const rgbx_fused_layer_t* Lp, rgbx_stream_t 
   else rc = launch<64, 0>(A, s);
   if (rc) return rc;
   if (ce) {
-    const int tiles = (int)cdiv(N, TM);
-    const int W = ce->mask_groups == 2 ? 6 : 3;
-    double* part2 = ce->scratch + (size_t)tiles * W;  // [kCeGather, W] behind the tile records
-    ce_tiles_gather_kernel<<<kCeGather, 256, 0, s>>>(ce->scratch, tiles, part2, W);
-    RGBX_CHECK_LAUNCH("ce_tiles_gather_kernel");
-    ce_tiles_finish_kernel<<<1, 256, 0, s>>>(part2, kCeGather, ce->stats, W);
-    RGBX_CHECK_LAUNCH("ce_tiles_finish_kernel");
+    if (int rc2 = reduce_ce_tiles(ce->scratch, (int)cdiv(N, TM), ce->stats, ce->mask_groups == 2 ? 6 : 3, s)) return rc2;
   }
   if (!L.out_colsums) return RGBX_OK;
-  const int tiles = (int)cdiv(N, TM), width2 = (int)(2 * Nout);
-  const int G = tiles < kStatsGather ? tiles : kStatsGather;
-  tile_stats_gather_kernel<<<G, 256, 0, s>>>(stats_part, tiles, width2, stats_part2);
-  RGBX_CHECK_LAUNCH("tile_stats_gather_kernel");
-  tile_stats_finish_kernel<<<(int)cdiv(width2, 8), 256, 0, s>>>(stats_part2, G, width2, L.out_colsums);
-  RGBX_CHECK_LAUNCH("tile_stats_finish_kernel");
-  return RGBX_OK;
+  return reduce_tile_stats(stats_part, (int)cdiv(N, TM), (int)(2 * Nout), stats_part2, L.out_colsums, s);
 }
 
 extern "C" int rgbx_spmm_linear_stats_workspace_bytes(int64_t N, int64_t Nout, size_t* bytes) {

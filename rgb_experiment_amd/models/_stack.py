@@ -144,8 +144,8 @@ class ConvStack(nn.Module):
                     and hasattr(bn, "begin_training_step")):
                 extra["want_colsums"] = True
             if (i == last and ce is not None and getattr(conv, "accepts_ce", False)
-                    and not isinstance(ce[1], (tuple, list))):  # (a pair of masks: the folded eval route above, or the logits)
-                extra["ce"] = ce  # the last conv returns (loss, stats) instead of the logits
+                    and (not isinstance(ce[1], (tuple, list)) or getattr(conv, "accepts_ce_pair", False))):
+                extra["ce"] = ce  # the last conv returns (loss, stats) instead of the logits (a pair of masks: (None, [2, 3]))
             if pending is not None:
                 sums = getattr(x, ops.COLSUMS, None)
                 after = getattr(conv, "forward_after_bn", None)

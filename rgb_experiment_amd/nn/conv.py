@@ -88,6 +88,7 @@ class GCNConv(nn.Module):
         nn.init.zeros_(self.bias)
 
     accepts_ce = True         # forward(..., ce=(y, mask)): the model's last layer may take the loss into its kernel
+    accepts_ce_pair = True    # ... and mask may be (mask_a, mask_b): (None, [2, 3] statistics) of one eval forward
 
     def forward(self, x, edge_index, post_affine=None, want_colsums=False, ce=None):
         """`post_affine` = (scale, shift) of an eval-mode BatchNorm that follows this layer (no_grad only): a
@@ -136,6 +137,11 @@ class GCNConv(nn.Module):
                                            colsums=colsums)
         if bn is not None:
             x = bn(x, colsums=colsums)
+        weight, bias, n = ops.pad_rows4(self.lin.weight, self.bias)
+        if ops.rows_epilogue_ok(graph, n, x, y) and not ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x):
+            # transform first (the reference's shapes: hidden 64 -> C = 7, initial_params.py:25), then aggregate the
+            # [N, 8] rows with the loss taken in the gather kernel: no logits, no log-softmax / NLL / arg-max passes
+            return ops.propagate_rows_ce(ops.linear(x, weight), graph, "gcn", n, self.out_channels, y, mask, bias=bias)
         return ops.ce_from_logits(self.forward(x, edge_index), y, mask)
 
     def forward_after_bn(self, x, edge_index, bn, colsums=None, want_colsums=False, ce=None):
@@ -164,6 +170,9 @@ class GCNConv(nn.Module):
             # step). On a partitioned graph the aggregated tensor is then the static feature matrix, whose
             # boundary rows are resident (dist.DistGraph.pin_resident): no exchange either.
             return ops.linear(ops.propagate_gcn(x, graph), weight, bias)
+        if want_colsums and ops.rows_epilogue_ok(graph, self.out_channels, x):
+            # transform first; the BatchNorm behind the layer gets its column sums from the gather kernel
+            return ops.propagate_rows(ops.linear(x, weight), graph, "gcn", bias=bias, want_colsums=True)
         return ops.propagate_gcn(ops.linear(x, weight), graph, bias=bias)
 
 
@@ -181,6 +190,7 @@ class SAGEConv(nn.Module):
         self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
 
     accepts_ce = True         # see GCNConv
+    accepts_ce_pair = True
 
     def eval_operands(self, bn=None):
         return ops.fold_bn_linear(self.lin_l.weight, self.lin_l.bias, root_weight=self.lin_r.weight, bn=bn)
@@ -208,7 +218,20 @@ class SAGEConv(nn.Module):
                                            mask, bn=bn, colsums=colsums)
         if bn is not None:
             x = bn(x, colsums=colsums)
+        if (ops.rows_epilogue_ok(graph, (self.out_channels + 3) // 4 * 4, x, y)
+                and not ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x)):
+            h, n = self._transform_first(x, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight)
+            return ops.propagate_rows_ce(h, graph, "mean", n, self.out_channels, y, mask)
         return ops.ce_from_logits(self.forward(x, edge_index), y, mask)
+
+    @staticmethod
+    def _transform_first(x, w_l, b_l, w_r):
+        """h = x [W_l; W_r]^T + [0; b_l] as ONE product ([N, 2 n], n = out rounded up to a multiple of 4): the left half is
+        what the mean runs over, the right half the root term plus lin_l's bias (which PyG adds after the aggregation:
+        a node without in-edges gets b_l + W_r x_i). The wide input (F = 1433 on Cora) is read once for both Linears."""
+        w_l, b_l, n = ops.pad_rows4(w_l, b_l)
+        w_r = ops.pad_rows4(w_r)[0]
+        return ops.linear(x, torch.cat([w_l, w_r]), torch.cat([torch.zeros_like(b_l), b_l])), n
 
     def forward_after_bn(self, x, edge_index, bn, colsums=None, want_colsums=False, ce=None):
         """See GCNConv.forward_after_bn; the root term lin_r(bn(x)_i) gets the affine map as its rows are loaded."""
@@ -232,9 +255,17 @@ class SAGEConv(nn.Module):
         if ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x):
             # lin_l(mean_j x_j) + lin_r(x_i) in one kernel: both products accumulate in the same MFMA tile
             return ops.propagate_linear(x, graph, "mean", w_l, b_l, root_weight=w_r, want_colsums=want_colsums)
+        if self.in_channels > self.out_channels and x.is_cuda and not getattr(graph, "is_distributed", False):
+            # in > out (the reference's defaults: F -> 64 -> C; graphsage2 at F = 1433 is the row its README marks OOM,
+            # README.md:74): mean_j(x_j) W_l^T = mean_j(x_j W_l^T) — transform first, gather at the OUTPUT width
+            h, n = self._transform_first(x, w_l, b_l, w_r)
+            out = ops.propagate_rows(h, graph, "mean", n=n, want_colsums=want_colsums and n == self.out_channels)
+            return out if n == self.out_channels else out[:, :self.out_channels]
         x_r = ops.linear(ops.target_rows(x, graph), w_r)  # the targets' own rows (all of x except on a dist.ReplicaGraph)
         if ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x):
             return ops.propagate_linear(x, graph, "mean", w_l, b_l) + x_r
+        if self.in_channels > self.out_channels:
+            return ops.propagate_mean(ops.linear(x, w_l), graph) + b_l + x_r
         agg = ops.propagate_mean(x, graph)
         return ops.linear(agg, w_l, b_l) + x_r
 
@@ -254,6 +285,7 @@ class MySAGEConv(nn.Module):
         self.lin_r = nn.Linear(in_channels, out_channels)
 
     accepts_ce = True         # see GCNConv
+    accepts_ce_pair = True
 
     def eval_operands(self, bn=None):
         if not self.add_self_loops:
@@ -288,7 +320,22 @@ class MySAGEConv(nn.Module):
                                                self.lin_r.weight, y, mask, bn=bn, colsums=colsums)
         if bn is not None:
             x = bn(x, colsums=colsums)
+        mode = LOOPS_REMOVE_ADD if self.add_self_loops else LOOPS_KEEP
+        graph = get_graph(edge_index, x.size(0), mode)
+        fused = self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x)
+        if ops.rows_epilogue_ok(graph, (self.out_channels + 3) // 4 * 4, x, y) and not fused:
+            h, n = self._transform_both(x, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, self.lin_r.bias)
+            return ops.propagate_rows_ce(h, graph, "mean", n, self.out_channels, y, mask)
         return ops.ce_from_logits(self.forward(x, edge_index), y, mask)
+
+    @staticmethod
+    def _transform_both(x, w_l, b_l, w_r, b_r):
+        """h = [lin_l(x), lin_r(x)] as ONE product (models/graphsage.py:49-50 runs two Linears over the same x): [N, 2 n],
+        n = out rounded up to a multiple of 4. b_l stays inside the mean, as in the reference (a row without entries —
+        add_self_loops=False and no in-edge — gets no b_l)."""
+        w_l, b_l, n = ops.pad_rows4(w_l, b_l)
+        w_r, b_r, _ = ops.pad_rows4(w_r, b_r)
+        return ops.linear(x, torch.cat([w_l, w_r]), torch.cat([b_l, b_r])), n
 
     def forward_after_bn(self, x, edge_index, bn, colsums=None, want_colsums=False, ce=None):
         """See GCNConv.forward_after_bn."""
@@ -322,16 +369,28 @@ class MySAGEConv(nn.Module):
         if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, root=True, x=x):
             # mean_j(lin_l(x_j)) + lin_r(x_i) = (mean_j x_j) Wl^T + x_i Wr^T + (b_l + b_r), one kernel
             return ops.propagate_linear(x, graph, "mean", w_l, b_l + b_r, root_weight=w_r, want_colsums=want_colsums)
+        fused_left = self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x)
+        input_layer = not x.requires_grad and self.add_self_loops and self.in_channels <= self.out_channels
+        if x.is_cuda and not getattr(graph, "is_distributed", False) and not fused_left and not input_layer:
+            # transform first, as the reference writes the layer (in > out is its default shape: F -> 64 -> C)
+            return self._conv_rows(x, graph, w_l, b_l, w_r, b_r, want_colsums)
         x_r = ops.linear(ops.target_rows(x, graph), w_r, b_r)
-        if self.add_self_loops and ops.fused_linear_ok(graph, self.in_channels, self.out_channels, x=x):
+        if fused_left:
             return ops.propagate_linear(x, graph, "mean", w_l, b_l) + x_r
-        if not x.requires_grad and self.add_self_loops and self.in_channels <= self.out_channels:
+        if input_layer:
             # Input layer (see GCNConv.forward): with the self-loop every row's mean weights
             # sum to 1, so mean_j(W x_j + b) = W mean_j(x_j) + b exactly; aggregating first removes the
             # transposed SpMM from this layer's backward.
             return ops.linear(ops.propagate_mean(x, graph), w_l, b_l) + x_r
         x_l = ops.linear(x, w_l, b_l)
         return ops.propagate_mean(x_l, graph) + x_r
+
+    def _conv_rows(self, x, graph, w_l, b_l, w_r, b_r, want_colsums):
+        """The layer as the reference writes it — transform, then the mean, then += x_r (graphsage.py:49-60) — on one
+        product and one gather: the add is the gather kernel's additive operand."""
+        h, n = self._transform_both(x, w_l, b_l, w_r, b_r)
+        out = ops.propagate_rows(h, graph, "mean", n=n, want_colsums=want_colsums and n == self.out_channels)
+        return out if n == self.out_channels else out[:, :self.out_channels]
 
 
 class GATConv(nn.Module):
@@ -457,6 +516,11 @@ class SGConv(nn.Module):
         if h is None:
             mode = LOOPS_ADD_REMAINING if self.add_self_loops else LOOPS_KEEP
             graph = get_graph(edge_index, x.size(0), mode)
+            if not self.cached and self.in_channels > self.out_channels:
+                # nothing is kept between calls, so A_hat^K (x W^T) = (A_hat^K x) W^T runs the K gathers at the
+                # OUTPUT width (F = 1433 -> C = 7 on Cora: 1/180 of the bytes)
+                out = ops.appnp_propagate(ops.linear(x, self.lin.weight), graph, self.K, 0.0)
+                return out if self.lin.bias is None else out + self.lin.bias
             h = ops.appnp_propagate(x, graph, self.K, 0.0)
             if self.cached:
                 self._cached_x = h if h.requires_grad else h.detach()
@@ -486,6 +550,16 @@ class GINConv(nn.Module):
             # written, no scale / add passes; eps gets its gradient through the root operand
             h = ops.propagate_linear(x, graph, "sum", first.weight, first.bias,
                                      root_weight=(1 + self.eps) * first.weight)
+            for layer in list(self.nn)[1:]:
+                h = layer(h)
+            return h
+        if isinstance(first, nn.Linear) and first.in_features > first.out_features:
+            # (sum_j x_j + (1 + eps) x_i) W^T + b = sum_j (x_j W^T) + (1 + eps) (x_i W^T) + b: transform first, gather at
+            # the output width of nn's first Linear (in > out: the reference's first block, F -> 64, models/gin.py:14-21)
+            h = ops.linear(x, first.weight)
+            h = ops.propagate_sum(h, graph) + (1 + self.eps) * h
+            if first.bias is not None:
+                h = h + first.bias
             for layer in list(self.nn)[1:]:
                 h = layer(h)
             return h

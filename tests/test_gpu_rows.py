@@ -1,0 +1,347 @@
+"""The layers as the reference's DEFAULT shapes run them (in > out: F -> hidden 64 -> C in {3, 6, 7, 40, 47},
+reference initial_params.py:25-29, 最终结果.csv): transform first, gather at the output width, BatchNorm's column sums
+and the masked cross-entropy taken inside the gather kernel (rgbx_spmm_csr_epilogue_f32). HIP path vs the CPU oracle.
+
+Tolerances: logits / losses 1e-4 absolute (the north-star bound) or tighter where stated; statistics counts exact; the
+epilogue kernel's output rows are BIT-identical to rgbx_spmm_csr_f32's (same summation order)."""
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def graph_with_isolated_nodes(n, e, seed, hub=0):
+    """Random directed edges among the first 90 % of the nodes' targets: the last tenth has no in-edge (isolated as
+    aggregation targets), node n - 1 has no edge at all; a few self-loops and duplicates; optionally one hub target."""
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n - 1, (e,), generator=g)
+    dst = torch.randint(0, max(1, n - n // 10), (e,), generator=g)
+    ei = torch.stack([src, dst])
+    k = torch.randint(0, n - 1, (7,), generator=g)
+    ei = torch.cat([ei, torch.stack([k, k]), ei[:, :5]], dim=1)
+    if hub:
+        ei = torch.cat([ei, torch.stack([torch.randint(0, n - 1, (hub,), generator=g), torch.full((hub,), 3)])], dim=1)
+    return ei
+
+
+def _kind_graph(dev, ei, n, kind):
+    from rgb_experiment_amd.graph import Graph
+    return Graph(ei.to(dev), n, {"gcn": 1, "mean": 0, "sum": 0}[kind])
+
+
+@pytest.mark.parametrize("d", [4, 8, 40, 64, 128, 256])
+@pytest.mark.parametrize("kind", ["gcn", "mean", "sum"])
+def test_row_kernel_column_sums(dev, d, kind, monkeypatch):
+    """out is bit-identical to the plain row gather's; colsums = [sum out, sum out^2] per column (fp64 reference of the
+    same out); with the additive operand, a bias, isolated targets and a hub row cut into chunks."""
+    from rgb_experiment_amd import graph as G
+    from rgb_experiment_amd import ops
+    monkeypatch.setattr(G, "LONG_ROW_SLOTS", 256)
+    n = 4133  # not a multiple of the 32-row tile
+    ei = graph_with_isolated_nodes(n, 30000, d, hub=1500)
+    g = _kind_graph(dev, ei, n, kind)
+    assert g.fwd.split is not None
+    gen = torch.Generator().manual_seed(d + 1)
+    h = torch.randn(n, 2 * d, generator=gen).to(dev)
+    bias = torch.randn(d, generator=gen).to(dev)
+    w, rs = ops._kind_weights(g, kind)
+    for y, b in ((None, None), (h[:, d:], bias)):
+        want = ops.spmm_raw(g.fwd, w, rs, h[:, :d], y=y, a=1.0, b=1.0, bias=b)
+        out, cs = ops.spmm_epilogue_raw(g.fwd, w, rs, h[:, :d], y=y, a=1.0, b=1.0, bias=b, want_colsums=True)
+        assert torch.equal(out, want)
+        ref = torch.stack([want.double().sum(0), (want.double() ** 2).sum(0)])
+        assert (cs - ref).abs().max().item() < 1e-6 * max(1.0, ref.abs().max().item())
+        again = ops.spmm_epilogue_raw(g.fwd, w, rs, h[:, :d], y=y, a=1.0, b=1.0, bias=b, want_colsums=True)[1]
+        assert torch.equal(cs, again)  # fixed summation order
+
+
+@pytest.mark.parametrize("C", [1, 3, 7, 40, 47, 128, 130, 256])
+@pytest.mark.parametrize("kind", ["gcn", "mean"])
+def test_row_kernel_cross_entropy(dev, C, kind, monkeypatch):
+    """Statistics and loss gradient of the masked cross-entropy from inside the gather, against the loss kernels run on
+    the materialised logits (rgbx_masked_ce_fwd_f32 / _bwd_f32, themselves checked against torch in test_gpu_parity):
+    padded class counts, labels out of range, isolated targets, a hub row, two masks from one launch."""
+    from rgb_experiment_amd import graph as G
+    from rgb_experiment_amd import ops
+    monkeypatch.setattr(G, "LONG_ROW_SLOTS", 256)
+    n = 3001
+    d = (C + 3) // 4 * 4
+    ei = graph_with_isolated_nodes(n, 25000, C, hub=1200)
+    g = _kind_graph(dev, ei, n, kind)
+    gen = torch.Generator().manual_seed(C)
+    h = torch.randn(n, 2 * d, generator=gen)
+    h[:, C:d] = 0  # pad columns, as pad_rows4 produces them
+    h = h.to(dev)
+    bias = torch.nn.functional.pad(torch.randn(C, generator=gen), (0, d - C)).to(dev)
+    y = torch.randint(0, C, (n,), generator=gen)
+    y[5], y[6] = -1, C  # unlabelled / out of range: deselected
+    mask = torch.rand(n, generator=gen) < 0.5
+    mask[3] = True  # the hub row is selected
+    mask[n - 1] = True  # a node without any edge is selected
+    mask2 = torch.rand(n, generator=gen) < 0.3
+    y, mask, mask2 = y.to(dev), mask.to(dev), mask2.to(dev)
+    w, rs = ops._kind_weights(g, kind)
+    logits = ops.spmm_raw(g.fwd, w, rs, h[:, :d], y=h[:, d:], a=1.0, b=1.0, bias=bias)[:, :C].contiguous()
+    want = ops.masked_ce_accuracy(logits, y, mask)
+    none, stats = ops.spmm_epilogue_raw(g.fwd, w, rs, h[:, :d], y=h[:, d:], a=1.0, b=1.0, bias=bias, ce=(y, mask, None),
+                                        n_classes=C)
+    assert none is None
+    assert torch.equal(stats[1:], want[1:])
+    assert abs(stats[0].item() - want[0].item()) < 1e-5 * max(1.0, want[0].item())
+    # no mask = every labelled row
+    _, stats_all = ops.spmm_epilogue_raw(g.fwd, w, rs, h[:, :d], y=h[:, d:], a=1.0, b=1.0, bias=bias, ce=(y, None, None),
+                                         n_classes=C)
+    want_all = ops.masked_ce_accuracy(logits, y, None)
+    assert torch.equal(stats_all[1:], want_all[1:]) and int(stats_all[1].item()) == n - 2
+    assert abs(stats_all[0].item() - want_all[0].item()) < 1e-5 * max(1.0, want_all[0].item())
+    # two masks, one launch
+    _, pair = ops.spmm_epilogue_raw(g.fwd, w, rs, h[:, :d], y=h[:, d:], a=1.0, b=1.0, bias=bias, ce=(y, (mask, mask2), None),
+                                    n_classes=C)
+    want2 = ops.masked_ce_accuracy(logits, y, mask2)
+    assert pair.shape == (2, 3) and torch.equal(pair[0], stats)
+    assert torch.equal(pair[1, 1:], want2[1:]) and abs(pair[1, 0].item() - want2[0].item()) < 1e-5 * max(1.0, want2[0].item())
+    # loss gradient in place of the logits
+    scale = ops.mask_scale(y, mask, C)
+    grad, stats_g = ops.spmm_epilogue_raw(g.fwd, w, rs, h[:, :d], y=h[:, d:], a=1.0, b=1.0, bias=bias, ce=(y, mask, scale),
+                                          n_classes=C)
+    assert torch.equal(stats_g, stats)
+    lg = logits.clone().requires_grad_(True)
+    ops.masked_ce_loss(lg, y, mask).backward()
+    assert (grad[:, :C] - lg.grad).abs().max().item() < 1e-6
+    assert torch.equal(grad[:, C:], torch.zeros(n, d - C, device=dev))
+    sel = (mask & (y >= 0) & (y < C))
+    assert torch.equal(grad[~sel], torch.zeros_like(grad[~sel]))
+
+
+def test_row_kernel_argument_checks(dev):
+    from rgb_experiment_amd import ops
+    n = 100
+    g = _kind_graph(dev, graph_with_isolated_nodes(n, 500, 0), n, "gcn")
+    y = torch.zeros(n, dtype=torch.int64, device=dev)
+    with pytest.raises(RuntimeError, match="d %% 4|pad the rows|d % 4"):
+        ops.spmm_epilogue_raw(g.fwd, g.w, None, torch.zeros(n, 7, device=dev), want_colsums=True)
+    with pytest.raises(RuntimeError, match="256"):
+        ops.spmm_epilogue_raw(g.fwd, g.w, None, torch.zeros(n, 260, device=dev), want_colsums=True)
+    with pytest.raises(RuntimeError, match="n_classes"):
+        ops.spmm_epilogue_raw(g.fwd, g.w, None, torch.zeros(n, 8, device=dev), ce=(y, None, None), n_classes=9)
+    with pytest.raises(RuntimeError, match="no epilogue"):
+        ops.spmm_epilogue_raw(g.fwd, g.w, None, torch.zeros(n, 8, device=dev))
+    with pytest.raises(RuntimeError, match="int64"):
+        ops.spmm_epilogue_raw(g.fwd, g.w, None, torch.zeros(n, 8, device=dev), ce=(y.int(), None, None), n_classes=7)
+
+
+# ---- whole models at the reference's default shapes ------------------------------------------------------------------
+
+def _default_shape_case(name):
+    from rgb_experiment_amd import models as M
+    kw = dict(num_layers=2, hidden_unit=64, dropout_rate=0.5)  # initial_params.py:25-29
+    if name == "gcn":
+        return M.GCN, kw, lambda sd, x, ei, tr: O.gcn_forward(sd, x, ei, 2, tr), "_PropagateRowsBackward"
+    if name == "graphsage":
+        return M.GraphSAGE, kw, lambda sd, x, ei, tr: O.graphsage_forward(sd, x, ei, 2, tr), "_PropagateRowsBackward"
+    if name == "graphsage2":
+        return M.GraphSAGE2, kw, lambda sd, x, ei, tr: O.graphsage2_forward(sd, x, ei, 2, tr), "_PropagateRowsBackward"
+    if name == "appnpstack":
+        return (M.APPNPStack, dict(hidden_unit=64, K=10, alpha=0.1, dropout_rate=0.5),
+                lambda sd, x, ei, tr: O.appnp_stack_forward(sd, x, ei, 10, 0.1, tr), "_APPNPCEBackward")
+    raise KeyError(name)
+
+
+class _GatherSpy:
+    """Records (width, epilogue?, wrote an output?) of every aggregation launch."""
+
+    def __init__(self, monkeypatch):
+        from rgb_experiment_amd import ops
+        self.calls = []
+        raw, epi, appnp = ops.spmm_raw, ops.spmm_epilogue_raw, ops.appnp_raw
+
+        def spy_raw(csr, w, rs, x, *a, **k):
+            self.calls.append((x.size(1), None, True))
+            return raw(csr, w, rs, x, *a, **k)
+
+        def spy_epi(csr, w, rs, x, *a, **k):
+            res = epi(csr, w, rs, x, *a, **k)
+            self.calls.append((x.size(1), "ce" if k.get("ce") is not None else "colsums", res[0] is not None))
+            return res
+
+        def spy_appnp(csr, w, h, *a, **k):
+            self.calls.append((h.size(1), None, True))
+            return appnp(csr, w, h, *a, **k)
+
+        monkeypatch.setattr(ops, "spmm_raw", spy_raw)
+        monkeypatch.setattr(ops, "appnp_raw", spy_appnp)
+        monkeypatch.setattr(ops, "spmm_epilogue_raw", spy_epi)
+
+
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "appnpstack"])
+@pytest.mark.parametrize("C", [3, 7, 40, 47])
+def test_models_at_the_reference_default_shapes(dev, name, C, monkeypatch):
+    """F = 1433 -> hidden 64 -> C: loss, statistics and every parameter gradient of one training step against the
+    oracle under autograd; eval statistics of both masks from one forward against the oracle's logits; every gather runs
+    at width <= 64 (graphsage2: not at F = 1433, the row the reference marks OOM, README.md:74) and the eval forward
+    writes no [N, C] matrix."""
+    cls, kw, oracle_fwd, grad_fn = _default_shape_case(name)
+    n, f = 2708, 1433
+    ei = graph_with_isolated_nodes(n, 10556, C)
+    gen = torch.Generator().manual_seed(C)
+    x = (torch.rand(n, f, generator=gen) < 0.0126).float()  # bag-of-words-like: ~18 ones per row
+    x = x / x.sum(1, keepdim=True).clamp(min=1)
+    y = torch.randint(0, C, (n,), generator=gen)
+    mask = torch.rand(n, generator=gen) < 0.6
+    mask[n - 1] = True  # a node without any edge
+    mask_b = ~mask
+    torch.manual_seed(14530529)
+    model = cls(input_dim=f, output_dim=C, **kw)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.5, 0.5) if ("bn" not in k or "bias" in k) else p.uniform_(0.5, 1.5)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    params = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd0.items()}
+    out_o = oracle_fwd(params, x, ei, True)["out"]
+    loss_o = torch.nn.functional.nll_loss(out_o[mask], y[mask])
+    loss_o.backward()
+
+    spy = _GatherSpy(monkeypatch)
+    model.to(dev).train()
+    xd, eid, yd, md, mbd = x.to(dev), ei.to(dev), y.to(dev), mask.to(dev), mask_b.to(dev)
+    loss, stats = model.masked_ce(xd, eid, yd, md)
+    assert type(loss.grad_fn).__name__ == grad_fn  # the loss came out of the gather kernel
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) < 1e-5
+    assert int(stats[1].item()) == int(mask.sum())
+    assert int(stats[2].item()) == int((out_o[mask].argmax(1) == y[mask]).sum())
+    for k, p in model.named_parameters():
+        want = params[k].grad
+        assert (p.grad.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item()), k
+    assert max(c[0] for c in spy.calls) <= 64, spy.calls
+    assert spy.calls and any(c[1] == "ce" for c in spy.calls)
+
+    # eval: both masks from one forward, no logits written; BatchNorm's running statistics moved once, as the oracle's did
+    sd1 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ref_sd = dict(sd0)
+    for k in sd1:
+        if "running_" in k or "num_batches" in k:
+            ref_sd[k] = sd1[k]
+    ref = oracle_fwd(ref_sd, x, ei, False)
+    spy.calls.clear()
+    model.eval()
+    with torch.no_grad():
+        model.load_state_dict({k: v.to(dev) for k, v in ref_sd.items()})
+        pair = model.masked_ce_pair(xd, eid, yd, md, mbd)
+        emb = model(xd, eid)["emb"]
+    last = [c for c in spy.calls if c[1] == "ce"]
+    assert len(last) == 1 and last[0][2] is False  # one loss launch, which wrote nothing
+    assert (emb.cpu() - ref["emb"]).abs().max().item() < TOL
+    for row, m in ((pair[0], mask), (pair[1], mask_b)):
+        nll = torch.nn.functional.nll_loss(ref["out"][m], y[m], reduction="sum").item()
+        assert int(row[1].item()) == int(m.sum())
+        assert abs(row[0].item() - nll) < 1e-4 * max(1.0, nll)
+        # arg-max ties aside (none on random data), the hit counts agree
+        assert abs(int(row[2].item()) - int((ref["emb"][m].argmax(1) == y[m]).sum())) <= 1
+
+
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2"])
+def test_hidden_layer_hands_batchnorm_its_column_sums_from_the_row_kernel(dev, name, monkeypatch):
+    """in > out hidden layer followed by a training-mode BatchNorm: the gather kernel's column sums replace the statistics
+    pass; outputs, running statistics and gradients equal the route with the statistics pass."""
+    from rgb_experiment_amd import ops
+    cls, kw, _, _ = _default_shape_case(name)
+    kw = dict(kw, num_layers=3)
+    n, f, C = 3000, 200, 16
+    ei = graph_with_isolated_nodes(n, 20000, 9)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(n, f, generator=gen).to(dev)
+    y = torch.randint(0, C, (n,), generator=gen).to(dev)
+    torch.manual_seed(5)
+    model = cls(input_dim=f, output_dim=C, **kw).to(dev).train()
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    spy = _GatherSpy(monkeypatch)
+    out = model(x, ei.to(dev))["emb"]
+    torch.nn.functional.cross_entropy(out, y).backward()
+    assert any(c[1] == "colsums" for c in spy.calls), spy.calls
+    got = {k: p.grad.clone() for k, p in model.named_parameters()}
+    sd1 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    monkeypatch.setattr(ops, "rows_epilogue_ok", lambda *a, **k: False)
+    model.load_state_dict(sd0)
+    model.zero_grad()
+    spy.calls.clear()
+    out2 = model(x, ei.to(dev))["emb"]
+    torch.nn.functional.cross_entropy(out2, y).backward()
+    assert not any(c[1] for c in spy.calls)
+    assert (out - out2).abs().max().item() < 1e-5
+    for k, p in model.named_parameters():
+        assert (p.grad - got[k]).abs().max().item() < 1e-5 * max(1.0, got[k].abs().max().item()), k
+    for k, v in model.state_dict().items():
+        if "running_" in k:
+            assert (v - sd1[k]).abs().max().item() < 1e-6, k
+
+
+@pytest.mark.parametrize("K", [1, 2, 10])
+@pytest.mark.parametrize("C", [7, 40])
+def test_appnp_with_the_loss_in_its_last_step(dev, K, C):
+    """ops.appnp_propagate_ce against APPNP followed by the loss kernels on its logits: loss, statistics, input gradient."""
+    from rgb_experiment_amd import ops
+    from rgb_experiment_amd.graph import Graph
+    n, d = 5000, (C + 3) // 4 * 4
+    ei = graph_with_isolated_nodes(n, 40000, K + C)
+    g = Graph(ei.to(dev), n, 1)
+    gen = torch.Generator().manual_seed(K)
+    h0 = torch.nn.functional.pad(torch.randn(n, C, generator=gen), (0, d - C)).to(dev)
+    y = torch.randint(0, C, (n,), generator=gen).to(dev)
+    mask = (torch.rand(n, generator=gen) < 0.5).to(dev)
+    h = h0.clone().requires_grad_(True)
+    loss, stats = ops.appnp_propagate_ce(h, g, K, 0.1, C, y, mask)
+    loss.backward()
+    h2 = h0.clone().requires_grad_(True)
+    logits = ops.appnp_propagate(h2, g, K, 0.1)[:, :C]
+    want, wstats = ops.masked_ce_loss(logits, y, mask, with_stats=True)
+    want.backward()
+    assert abs(loss.item() - want.item()) < 1e-6 and torch.equal(stats[1:], wstats[1:])
+    assert (h.grad - h2.grad).abs().max().item() < 1e-6
+    ref = O.appnp(h0[:, :C].cpu().double(), ei, K, 0.1)
+    sel = mask.cpu()
+    nll = torch.nn.functional.cross_entropy(ref[sel], y.cpu()[sel]).item()
+    assert abs(loss.item() - nll) < 1e-5
+
+
+def test_gin_and_uncached_sgc_transform_first(dev, monkeypatch):
+    """GINConv's first Linear with in > out and SGConv(cached=False) with in > out gather at the output width; logits and
+    gradients against the oracle."""
+    from rgb_experiment_amd import models as M
+    n, f, C = 2000, 300, 7
+    ei = graph_with_isolated_nodes(n, 12000, 4)
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(n, f, generator=gen)
+    y = torch.randint(0, C, (n,), generator=gen)
+    for name in ("gin", "sgc"):
+        torch.manual_seed(2)
+        if name == "gin":
+            model = M.GIN(input_dim=f, output_dim=C, hidden_unit=64, num_layers=2, dropout_rate=0.0)
+            fwd = lambda sd, tr: O.gin_forward(sd, x, ei, 2, tr)
+        else:
+            model = M.SGC(input_dim=f, output_dim=C, K=2, cached=False)
+            fwd = lambda sd, tr: O.sgc_forward(sd, x, ei, 2)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        params = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        ref = fwd(params, True)
+        torch.nn.functional.nll_loss(ref["out"], y).backward()
+        spy = _GatherSpy(monkeypatch)
+        model.to(dev).train()
+        out = model(x.to(dev), ei.to(dev))
+        torch.nn.functional.nll_loss(out["out"], y.to(dev)).backward()
+        assert max(c[0] for c in spy.calls) <= 64, (name, spy.calls)
+        assert (out["emb"].detach().cpu() - ref["emb"].detach()).abs().max().item() < TOL, name
+        for k, p in model.named_parameters():
+            want = params[k].grad
+            assert (p.grad.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item()), (name, k)
