@@ -684,7 +684,7 @@ def real_shape_block(dev, ei, N, F, C, names, steps, warmup):
     from rgb_experiment_amd import ops
     from rgb_experiment_amd.graph import clear_cache, get_graph
     gen = torch.Generator(device=dev).manual_seed(1234570)
-    x = torch.randn((N, F), generator=gen, device=dev)
+    x = ops.align_rows(torch.randn((N, F), generator=gen, device=dev))  # as experiment() lays the features out
     y = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(1234571))
     masks = split_masks(y)
     out = {"nodes": N, "edges_in": int(ei.size(1)), "features": F, "hidden": 64, "classes": C,

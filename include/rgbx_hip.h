@@ -428,6 +428,11 @@ int rgbx_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N, size_t* bytes)
 /* C[M,N] = alpha * A^T B, A [K,M] (lda), B [K,N] (ldb), fp32 row-major, K = node count (huge),
  * M,N = feature widths. Split-K over the whole chip on v_mfma_f32_32x32x2_f32 (exact fp32), partials
  * reduced in slab order (bitwise reproducible). This is dW = dY^T X of every Linear on the path.
+ * Alignment: when A and B are 16-byte aligned with lda % 4 == 0 and ldb % 4 == 0, rows are read in whole 16-byte groups —
+ * for M % 4 != 0 / N % 4 != 0 the last group of a row ends in the row's padding (columns [M, lda) / [N, ldb)), which
+ * must therefore be readable memory for EVERY row, the last included (any finite or non-finite contents: those products
+ * are never stored). F = 1433 feature rows kept at a stride of 1436 floats take this path; rows that are not 16-byte
+ * aligned take a 4-byte path several times slower.
  * `a_colsum` ([M], optional): also receives the column sums of A (unscaled) — the bias gradient
  * db = sum_rows dY, taken from the A tiles the kernel stages anyway. */
 int rgbx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,

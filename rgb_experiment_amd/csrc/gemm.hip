@@ -13,6 +13,14 @@
 // Kernel 2: sums the S partials in slab order (bitwise reproducible, no float atomics).
 // Optionally the column sums of A (= the bias gradient when A = dY) are taken from the staged A tiles by the
 // workgroups of the first N-tile and reduced the same way: dY is then read once for dW and db together.
+//
+// Round 5 — the reference's default shapes (initial_params.py:25-29: F = 1433 -> hidden 64 -> C = 7), where dW1 = dH^T X
+// is [64, 1433] over K = |V| rows and was 16.9 of the 42 ms epoch at |V| = 2 M:
+//  (1) the 16-byte path no longer needs M % 4 == 0 / N % 4 == 0, only 16-byte aligned ROWS (lda % 4 == 0, ldb % 4 == 0):
+//      a row's last float4 may reach into its padding (columns [N, ld)), whose products land in output columns that are
+//      never stored. A feature matrix with F = 1433 is kept with a row stride of 1436 floats (ops.align_rows);
+//  (2) M <= 64 runs a 64 x 128 tile (one 32-row MFMA block per wave instead of two): half the MFMAs and half the A-side
+//      LDS traffic of the 128 x 128 tile, which multiplied 64 rows of zeros.
 #include "rgbx_common.h"
 
 namespace rgbx {
@@ -21,123 +29,117 @@ namespace {
 constexpr int BM = 128, BN = 128, KT = 32;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-template <bool VEC4>
+// Scalar staging (rows that are not 16-byte aligned): [KT x W] tile, row-major in LDS; rows >= k_end and columns >= ncols
+// are zero-filled
+template <int W>
 __device__ __forceinline__ void stage_tile(float* __restrict__ lds, const float* __restrict__ src,
                                            int64_t ld, int64_t k0, int64_t k_end, int c0, int ncols) {
-  // [KT x 128] tile, row-major in LDS; rows >= k_end and columns >= ncols are zero-filled
   const int tid = threadIdx.x;
-  if constexpr (VEC4) {
-#pragma unroll
-    for (int p = 0; p < KT * 32 / 256; ++p) {
-      const int idx = p * 256 + tid;  // float4 index
-      const int r = idx >> 5, c = (idx & 31) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int64_t k = k0 + r;
-      if (k < k_end && c0 + c < ncols) {  // ncols % 4 == 0 on this path
-        v = *reinterpret_cast<const float4*>(src + k * ld + c0 + c);
-      }
-      *reinterpret_cast<float4*>(lds + r * 128 + c) = v;
-    }
-  } else {
 #pragma unroll 4
-    for (int p = 0; p < KT * 128 / 256; ++p) {
-      const int idx = p * 256 + tid;
-      const int r = idx >> 7, c = idx & 127;
-      const int64_t k = k0 + r;
-      lds[r * 128 + c] = (k < k_end && c0 + c < ncols) ? src[k * ld + c0 + c] : 0.f;
-    }
+  for (int p = 0; p < KT * W / 256; ++p) {
+    const int idx = p * 256 + tid;
+    const int r = idx / W, c = idx % W;
+    const int64_t k = k0 + r;
+    lds[r * W + c] = (k < k_end && c0 + c < ncols) ? src[k * ld + c0 + c] : 0.f;
   }
 }
 
-// Register-staged variant of stage_tile (16-byte path): fetch_tile issues the global loads of one [KT x 128] tile
+// Register-staged variant (16-byte path): fetch_tile issues the global loads of one [KT x W] tile
 // into registers, put_tile writes them to LDS. Splitting the two lets the loads of tile i+1 fly while the MFMAs
 // of tile i run (the plain loop waits for HBM once per 32 rows of K with nothing else to do).
-constexpr int kTileVecs = KT * 32 / 256;  // float4 per thread and tile
-
-__device__ __forceinline__ void fetch_tile(float4 (&regs)[kTileVecs], const float* __restrict__ src, int64_t ld,
+// W = tile width in floats (128, or 64 for the A side of the 64-row output tile); W / 4 float4 per tile row
+template <int W>
+__device__ __forceinline__ void fetch_tile(float4 (&regs)[KT * (W / 4) / 256], const float* __restrict__ src, int64_t ld,
                                            int64_t k0, int64_t k_end, int c0, int ncols) {
 #pragma unroll
-  for (int p = 0; p < kTileVecs; ++p) {
+  for (int p = 0; p < KT * (W / 4) / 256; ++p) {
     const int idx = p * 256 + threadIdx.x;
-    const int r = idx >> 5, c = (idx & 31) * 4;
+    const int r = idx / (W / 4), c = (idx % (W / 4)) * 4;
     const int64_t k = k0 + r;
     regs[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // c0 + c < ncols <= ld: the float4 may end in the row's padding (columns [ncols, ld)), never beyond the row
     if (k < k_end && c0 + c < ncols) regs[p] = *reinterpret_cast<const float4*>(src + k * ld + c0 + c);
   }
 }
 
-__device__ __forceinline__ void put_tile(float* __restrict__ lds, const float4 (&regs)[kTileVecs]) {
+template <int W>
+__device__ __forceinline__ void put_tile(float* __restrict__ lds, const float4 (&regs)[KT * (W / 4) / 256]) {
 #pragma unroll
-  for (int p = 0; p < kTileVecs; ++p) {
+  for (int p = 0; p < KT * (W / 4) / 256; ++p) {
     const int idx = p * 256 + threadIdx.x;
-    const int r = idx >> 5, c = (idx & 31) * 4;
-    *reinterpret_cast<float4*>(lds + r * 128 + c) = regs[p];
+    const int r = idx / (W / 4), c = (idx % (W / 4)) * 4;
+    *reinterpret_cast<float4*>(lds + r * W + c) = regs[p];
   }
 }
 
-template <bool VEC4>
+// MT = rows of the output tile a workgroup owns: 128 (each wave a 64 x 64 quadrant = 2 x 2 MFMA blocks) or 64 (each wave
+// 32 x 64 = 1 x 2 blocks; M <= 64)
+template <bool VEC4, int MT>
 __global__ void __launch_bounds__(256)
 gemm_tn_partial_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                        float* __restrict__ part, float* __restrict__ colpart, int64_t K, int M, int N,
                        int64_t slab) {
-  __shared__ float lds[2 * KT * 128];
+  constexpr int MI = MT / 64;  // 32-row MFMA blocks per wave along M
+  __shared__ float lds[KT * (MT + 128)];
   float* la = lds;
-  float* lb = lds + KT * 128;
+  float* lb = lds + KT * MT;
   const int split = blockIdx.x;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.z * BN;
+  const int m0 = blockIdx.y * MT, n0 = blockIdx.z * BN;
   const int64_t k_begin = (int64_t)split * slab;
   const int64_t k_end = k_begin + slab < K ? k_begin + slab : K;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * (MT / 2), wn = (wave & 1) * 64;
   const int kr = lane >> 5, cc = lane & 31;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const bool sums = colpart != nullptr && blockIdx.z == 0 && threadIdx.x < BM;
+  const bool sums = colpart != nullptr && blockIdx.z == 0 && threadIdx.x < MT;
   float csum = 0.f;
-  auto consume = [&]() {  // one staged [KT x 128] pair of tiles: column sums of A (optional) + 16 MFMA steps
+  auto consume = [&]() {  // one staged pair of tiles: column sums of A (optional) + 16 MFMA steps
     if (sums) {  // thread t owns column m0 + t of A (rows past k_end were zero-filled)
 #pragma unroll 8
-      for (int r = 0; r < KT; ++r) csum += la[r * 128 + threadIdx.x];
+      for (int r = 0; r < KT; ++r) csum += la[r * MT + threadIdx.x];
     }
 #pragma unroll 4
     for (int kk = 0; kk < KT; kk += 2) {
-      const float a0 = la[(kk + kr) * 128 + wm + cc];
-      const float a1 = la[(kk + kr) * 128 + wm + 32 + cc];
+      float a[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = la[(kk + kr) * MT + wm + i * 32 + cc];
       const float b0 = lb[(kk + kr) * 128 + wn + cc];
       const float b1 = lb[(kk + kr) * 128 + wn + 32 + cc];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b1, acc[i][1], 0, 0, 0);
+      }
     }
   };
   if constexpr (VEC4) {
-    float4 ra[kTileVecs], rb[kTileVecs];
-    fetch_tile(ra, A, lda, k_begin, k_end, m0, M);
-    fetch_tile(rb, B, ldb, k_begin, k_end, n0, N);
+    float4 ra[KT * (MT / 4) / 256], rb[KT * 32 / 256];
+    fetch_tile<MT>(ra, A, lda, k_begin, k_end, m0, M);
+    fetch_tile<128>(rb, B, ldb, k_begin, k_end, n0, N);
     for (int64_t k0 = k_begin; k0 < k_end; k0 += KT) {
       __syncthreads();  // the previous tile pair is fully consumed
-      put_tile(la, ra);
-      put_tile(lb, rb);
+      put_tile<MT>(la, ra);
+      put_tile<128>(lb, rb);
       __syncthreads();
       if (k0 + KT < k_end) {  // next pair in flight while this one is multiplied
-        fetch_tile(ra, A, lda, k0 + KT, k_end, m0, M);
-        fetch_tile(rb, B, ldb, k0 + KT, k_end, n0, N);
+        fetch_tile<MT>(ra, A, lda, k0 + KT, k_end, m0, M);
+        fetch_tile<128>(rb, B, ldb, k0 + KT, k_end, n0, N);
       }
       consume();
     }
   } else {
     for (int64_t k0 = k_begin; k0 < k_end; k0 += KT) {
       __syncthreads();
-      stage_tile<false>(la, A, lda, k0, k_end, m0, M);
-      stage_tile<false>(lb, B, ldb, k0, k_end, n0, N);
+      stage_tile<MT>(la, A, lda, k0, k_end, m0, M);
+      stage_tile<128>(lb, B, ldb, k0, k_end, n0, N);
       __syncthreads();
       consume();
     }
@@ -147,7 +149,7 @@ gemm_tn_partial_kernel(const float* __restrict__ A, int64_t lda, const float* __
   // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   float* out = part + (int64_t)split * M * N;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -182,13 +184,15 @@ gemm_tn_reduce_kernel(const float* __restrict__ part, int S, int64_t MN, float* 
   }
 }
 
+int tile_rows(int M) { return M <= 64 ? 64 : BM; }
+
 int choose_splits(int64_t K, int M, int N) {
-  const int64_t tiles = cdiv(M, BM) * cdiv(N, BN);
+  const int64_t tiles = cdiv(M, tile_rows(M)) * cdiv(N, BN);
   // ONE round of workgroups over the chip: the kernel's registers (66 VGPRs + 64 accumulators) allow 3 workgroups per
   // CU, so 256 x 3 K-slabs; 1024 (round 3) left a second round of 256 workgroups on an otherwise idle chip:
   // 2 M x 128 x 128: 0.710 -> 0.656 ms (tools/dense_bench.py, profiles/r04_gemm_tn_variants.txt; 4 waves per SIMD by
   // __launch_bounds__ spills 7 registers and gains less)
-  int64_t s = cdiv(768, tiles);
+  int64_t s = cdiv(tile_rows(M) == 64 ? 1024 : 768, tiles);  // the 64-row tile (32 accumulators) fits 4 workgroups per CU
   const int64_t max_s = cdiv(K, 16 * KT);   // at least 16 staged tiles per slab: fewer, longer slabs for small K
                                             // (K = 200 k: 391 partial tiles to reduce instead of 1024)
   if (s > max_s) s = max_s;
@@ -226,12 +230,16 @@ extern "C" int rgbx_gemm_tn_f32(const float* A, int64_t lda, const float* B, int
   const int64_t slab = cdiv(cdiv(K > 0 ? K : 1, S), KT) * KT;
   float* part = static_cast<float*>(workspace);
   float* colpart = a_colsum ? part + (size_t)S * M * N : nullptr;
-  dim3 grid(S, (unsigned)cdiv(M, BM), (unsigned)cdiv(N, BN));
-  const bool v4 = aligned16(A) && aligned16(B) && lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0;
-  if (v4)
-    gemm_tn_partial_kernel<true><<<grid, 256, 0, s>>>(A, lda, B, ldb, part, colpart, K, (int)M, (int)N, slab);
-  else
-    gemm_tn_partial_kernel<false><<<grid, 256, 0, s>>>(A, lda, B, ldb, part, colpart, K, (int)M, (int)N, slab);
+  const int mt = tile_rows((int)M);
+  dim3 grid(S, (unsigned)cdiv(M, mt), (unsigned)cdiv(N, BN));
+  // 16-byte path: aligned ROWS are enough — a row's last float4 may end in its padding (header: "rows are read in whole
+  // 16-byte groups")
+  const bool v4 = aligned16(A) && aligned16(B) && lda % 4 == 0 && ldb % 4 == 0;
+#define RGBX_GEMM_TN(V4, MT) \
+  gemm_tn_partial_kernel<V4, MT><<<grid, 256, 0, s>>>(A, lda, B, ldb, part, colpart, K, (int)M, (int)N, slab)
+  if (v4) { if (mt == 64) RGBX_GEMM_TN(true, 64); else RGBX_GEMM_TN(true, 128); }
+  else { if (mt == 64) RGBX_GEMM_TN(false, 64); else RGBX_GEMM_TN(false, 128); }
+#undef RGBX_GEMM_TN
   RGBX_CHECK_LAUNCH("gemm_tn_partial_kernel");
   const int64_t MN = M * N;
   int64_t rb = cdiv(MN, 32);

@@ -124,6 +124,31 @@ def target_rows(x, graph):
     return x if fn is None else fn(x)
 
 
+def align_rows(x):
+    """`x` ([N, F] float32 on the device) as a view whose ROWS start on 16-byte boundaries: F % 4 != 0 (Cora's 1433) ->
+    a fresh [N, F4] buffer (F4 = F rounded up to 4, pad columns zero) viewed as [:, :F]. Same values, same shape; dense
+    products over it read whole float4s (rgbx_gemm_tn_f32's aligned-row path, hipBLASLt with lda = F4) and _pad4 finds the
+    padded matrix already there. Costs one copy, once per feature matrix (the reference moves / normalises the features
+    once as well, itexperiments.py:258-299); returns `x` itself where nothing is to do."""
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda or x.size(1) % 4 == 0:
+        return x
+    n, f = x.shape
+    base = torch.zeros((n, (f + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+    view = base[:, :f]
+    view.copy_(x)
+    view._rgbx_base = base  # (this Python object only: views of it are ordinary strided tensors)
+    return view
+
+
+def _rows_padded_readable(t):
+    """A [K, n] matrix whose 16-byte-aligned rows may be read up to the next multiple of 4 columns (rgbx_gemm_tn_f32's
+    contract): contiguous rows, stride % 4 == 0, and the storage holds the last row's padding too."""
+    if t.dim() != 2 or t.size(1) % 4 == 0 or t.stride(0) % 4 or t.data_ptr() % 16:
+        return True  # nothing is read beyond the columns (or the rows are unaligned: the 4-byte path)
+    last = t.storage_offset() + (t.size(0) - 1) * t.stride(0) + (t.size(1) + 3) // 4 * 4
+    return last * 4 <= t.untyped_storage().nbytes()
+
+
 def _pad4(x):
     """Feature widths that are no multiple of 4 (C = 7 classes on Cora, 41 on Reddit, 47 on ogbn-products) run on
     zero-padded rows: 16-byte aligned rows take the float4 gather path and straddle fewer 128-byte lines. Measured at
@@ -133,6 +158,9 @@ def _pad4(x):
     d = x.size(1)
     if d % 4 == 0 or not x.is_cuda:
         return x, d
+    base = getattr(x, "_rgbx_base", None)
+    if base is not None and not x.requires_grad:  # align_rows made the padded matrix already (pad columns zero)
+        return base, d
     return torch.nn.functional.pad(x, (0, 4 - d % 4)), d
 
 
@@ -1560,8 +1588,8 @@ def gemm_tn(a, b, alpha=1.0, colsum=False, out=None, sums_out=None):
     ([M], from the same pass): returns (a^T b, a.sum(0)). `out` ([M, N] contiguous) / `sums_out` ([M]): write there
     (e.g. views of one flat gradient buffer)."""
     _lib.require_device(a, b)
-    a = a if a.stride(-1) == 1 else a.contiguous()
-    b = b if b.stride(-1) == 1 else b.contiguous()
+    a = a if a.stride(-1) == 1 and _rows_padded_readable(a) else a.contiguous()
+    b = b if b.stride(-1) == 1 and _rows_padded_readable(b) else b.contiguous()
     pa, lda = _lib.mat(a, "a")
     pb, ldb = _lib.mat(b, "b")
     K, M, N = a.size(0), a.size(1), b.size(1)

@@ -215,6 +215,10 @@ def test_models_at_the_reference_default_shapes(dev, name, C, monkeypatch):
     spy = _GatherSpy(monkeypatch)
     model.to(dev).train()
     xd, eid, yd, md, mbd = x.to(dev), ei.to(dev), y.to(dev), mask.to(dev), mask_b.to(dev)
+    if C in (7, 47):  # the layout experiment() gives the features: rows on 16-byte boundaries (stride 1436)
+        from rgb_experiment_amd import ops
+        xd = ops.align_rows(xd)
+        assert xd.stride(0) == 1436 and xd.shape == (n, f)
     loss, stats = model.masked_ce(xd, eid, yd, md)
     assert type(loss.grad_fn).__name__ == grad_fn  # the loss came out of the gather kernel
     loss.backward()
@@ -345,3 +349,46 @@ def test_gin_and_uncached_sgc_transform_first(dev, monkeypatch):
         for k, p in model.named_parameters():
             want = params[k].grad
             assert (p.grad.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item()), (name, k)
+
+
+@pytest.mark.parametrize("K,M,N", [(2708, 64, 1433), (5000, 7, 1433), (4099, 128, 1433), (3000, 47, 66), (70000, 64, 130),
+                                   (1, 3, 5)])
+def test_gemm_tn_reads_aligned_rows_with_odd_widths(dev, K, M, N):
+    """dW = dY^T X for operands kept as [:, :n] views of 16-byte-row buffers (ops.align_rows' layout): the kernel's float4
+    path reads into the rows' padding, whose contents (NaN here) must not reach any stored product."""
+    from rgb_experiment_amd import ops
+    gen = torch.Generator().manual_seed(K + M + N)
+    a, b = torch.randn(K, M, generator=gen), torch.randn(K, N, generator=gen)
+    want = a.double().t() @ b.double()
+
+    def padded(t):
+        base = torch.full((t.size(0), (t.size(1) + 3) // 4 * 4), float("nan"), device=dev)
+        base[:, :t.size(1)] = t.to(dev)
+        return base[:, :t.size(1)]
+
+    ad, bd = padded(a), padded(b)
+    got, sums = ops.gemm_tn(ad, bd, colsum=True)
+    scale = max(1.0, want.abs().max().item())
+    assert torch.isfinite(got).all()
+    assert (got.cpu().double() - want).abs().max().item() < 2e-5 * scale * max(1.0, (K / 1000) ** 0.5)
+    assert (sums.cpu().double() - a.double().sum(0)).abs().max().item() < 1e-3
+    again = ops.gemm_tn(ad, bd)
+    assert torch.equal(again, got)  # slab-ordered reduction: reproducible
+    # a view whose storage ends before the last row's padding is copied, not over-read
+    if N % 4 and K > 1:
+        tight = torch.empty(K * ((N + 3) // 4 * 4) - 1, device=dev)[: (K - 1) * ((N + 3) // 4 * 4) + N]
+        v = tight.as_strided((K, N), ((N + 3) // 4 * 4, 1))
+        v.copy_(b.to(dev))
+        assert not ops._rows_padded_readable(v)
+        assert (ops.gemm_tn(ad, v).cpu().double() - want).abs().max().item() < 2e-5 * scale * max(1.0, (K / 1000) ** 0.5)
+
+
+def test_align_rows_layout(dev):
+    from rgb_experiment_amd import ops
+    x = torch.randn(1000, 1433, device=dev)
+    v = ops.align_rows(x)
+    assert v.shape == x.shape and v.stride() == (1436, 1) and v.data_ptr() % 16 == 0 and torch.equal(v, x)
+    p, d = ops._pad4(v)
+    assert d == 1433 and p.shape == (1000, 1436) and p.data_ptr() == v.data_ptr() and torch.equal(p[:, 1433:], torch.zeros(1000, 3, device=dev))
+    y = torch.randn(10, 64, device=dev)
+    assert ops.align_rows(y) is y
