@@ -921,6 +921,9 @@ def main():
     ap.add_argument("--cache-input-aggregate", action="store_true",
                     help="SECONDARY runs only: keep the first layer's aggregate of the static input features across "
                          "forwards and epochs (experiment(cache_input_aggregate=True)); the line says so in its metric")
+    ap.add_argument("--share-eval-forward", action="store_true",
+                    help="N > 1 / --emulate-rank: val and test statistics from ONE eval forward per epoch (experiment()'s "
+                         "default; the headline keeps the reference's two eval forwards). A SECONDARY line.")
     ap.add_argument("--emulate-rank", type=int, default=0, metavar="P",
                     help="one GPU: rank 0's launches of a P-rank job, exchanges replaced by stand-in rows")
     ap.add_argument("--emulate-contend", type=float, default=60.0, metavar="GBS",
@@ -1021,6 +1024,9 @@ def main():
         wl_name += " [SECONDARY: cache_input_aggregate=True, the first layer's aggregate of the static features kept]"
     emu = args.emulate_rank if world == 1 else 0
     parts = max(world, emu)  # ranks the graph is partitioned over
+    if args.share_eval_forward and parts > 1:
+        n_prop -= kwargs.get("K", 2) if args.model in ("appnpstack", "dagnn", "sgc") else 2  # one eval forward's propagates
+        wl_name += " [SECONDARY: share_eval_forward=True, one eval forward per epoch serves the val and the test statistics]"
     comm_obj = None
     scheme, alg_by_kind, runner = "single GPU", None, None
     group = parts  # ranks ONE copy of the graph is partitioned over (task split: half of them)
@@ -1033,7 +1039,8 @@ def main():
         t_mark = time.perf_counter()
         common = dict(lr=0.01, comm=comm_obj, backend=test_backend, exchange=args.exchange, pieces=args.pieces,
                       interleave_evals=not args.no_interleave, fused=not args.no_fused, pieces_in=args.pieces_in,
-                      cache_input_aggregate=args.cache_input_aggregate, src_split=args.src_split)
+                      cache_input_aggregate=args.cache_input_aggregate, src_split=args.src_split,
+                      share_eval_forward=args.share_eval_forward)
         # auto: where it pays; on two ranks (whole graph on both GPUs: no memory scaling) only when one GPU can hold it
         task_split = args.task_split == "on" or (args.task_split == "auto" and tasksplit.pays(model, parts, d) and (
             parts != 2 or bool(emu) or tasksplit.whole_graph_fits(N, E, [d], dev)))

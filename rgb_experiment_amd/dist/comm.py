@@ -114,8 +114,12 @@ class Comm:
             if send.is_cuda:
                 work = _TimedWait(work)
             return recv, (work if self.turns is None else _TurnWork(work, self.turns))
+        # three statements, so that a stack dump of a stalled rehearsal says WHICH of them it sat in: the device-to-host
+        # copy with its stream wait, the host collective, or the copy back (round 4's dumps could not tell the first two
+        # apart: DESIGN.md 4.6)
+        host_send = self._to_host(send)
         host_recv = self._host_buffer(recv.shape, recv.dtype, recv.is_cuda)
-        dist.all_to_all_single(host_recv, self._to_host(send), list(recv_counts), list(send_counts), group=self.group)
+        dist.all_to_all_single(host_recv, host_send, list(recv_counts), list(send_counts), group=self.group)
         self._from_host(recv, host_recv)
         done = _TimedWait(_Done()) if send.is_cuda else _Done()  # same wrappers as the RCCL path (rehearsals run them)
         return recv, (done if self.turns is None else _TurnWork(done, self.turns))
@@ -130,7 +134,7 @@ class Comm:
             return t.contiguous()
         t = t.contiguous()
         pool = self.__dict__.setdefault("_pinned", {})
-        key = (threading.get_ident(), t.dtype)
+        key = (self._staging_slot(), t.dtype)
         buf = pool.get(key)
         if buf is None or buf.numel() < t.numel():
             buf = torch.empty(max(t.numel(), 1 << 20), dtype=t.dtype, pin_memory=True)
@@ -140,6 +144,14 @@ class Comm:
         torch.cuda.current_stream(t.device).synchronize()
         return host
 
+    def _staging_slot(self):
+        """Which pinned staging buffer the calling thread uses: the forward's index while two eval forwards take turns
+        (TakeTurns hands every thread its `me`), "main" otherwise — a bounded set of keys. (Keyed by thread ident, as in
+        round 4, every epoch's fresh pair of eval threads could leave four more page-locked buffers behind.)"""
+        turns = self.turns
+        me = getattr(turns.local, "me", None) if turns is not None else None
+        return "main" if me is None else int(me)
+
     def _host_buffer(self, shape, dtype, pinned):
         """Receive side of the same staging: one pinned buffer per host thread and dtype, grown on demand."""
         n = 1
@@ -148,7 +160,7 @@ class Comm:
         if not pinned:
             return torch.empty(shape, dtype=dtype)
         pool = self.__dict__.setdefault("_pinned", {})
-        key = (threading.get_ident(), dtype, "recv")
+        key = (self._staging_slot(), dtype, "recv")
         buf = pool.get(key)
         if buf is None or buf.numel() < n:
             buf = torch.empty(max(n, 1 << 20), dtype=dtype, pin_memory=True)
@@ -183,8 +195,9 @@ class Comm:
         sc = [t.numel() for t in send]
         rc = [t.numel() for t in recv]
         flat = torch.cat([t.reshape(-1) for t in send]) if sum(sc) else send[0].new_empty(0)
+        host_send = self._to_host(flat)  # (separate statements: see all_to_all_rows)
         host_recv = self._host_buffer((sum(rc),), flat.dtype, cuda)
-        dist.all_to_all_single(host_recv, self._to_host(flat), rc, sc, group=self.group)
+        dist.all_to_all_single(host_recv, host_send, rc, sc, group=self.group)
         off = 0
         for t, n in zip(recv, rc):
             if n:

@@ -67,7 +67,8 @@ class DistContext:
         dist.broadcast(h, 0)
         return t.copy_(h)
 
-    def runner(self, net, edge_index, features, y, masks, lr, weight_decay, cache_input_aggregate, task_split="auto"):
+    def runner(self, net, edge_index, features, y, masks, lr, weight_decay, cache_input_aggregate, task_split="auto",
+               share_eval_forward=False):
         """DistRunner over this rank's node range. Parameters, buffers and masks are taken from rank 0, so that the
         ranks agree even when the caller seeded nothing (need_to_reappear=False, or a splitter that draws from the
         global generator: utils/mask.py get_random_mask's val / test shuffle, reference mask.py:133)."""
@@ -84,10 +85,11 @@ class DistContext:
             # would fall below the 128-byte line; two ranks when one GPU can hold the whole graph: dist/tasksplit.py);
             # same loop, same numbers. task_split="off" (or a graph one GPU cannot hold) = the partitioned DistRunner
             return tasksplit.TaskSplitRunner(net, edge_index, features, y, masks, self.rank, self.world, self.device,
-                                             lr=lr, weight_decay=weight_decay, comm=Comm(), backend=self.test_backend)
+                                             lr=lr, weight_decay=weight_decay, comm=Comm(), backend=self.test_backend,
+                                             share_eval_forward=share_eval_forward)
         return DistRunner(net, edge_index, features, y, masks, self.rank, self.world, self.device, lr=lr,
                           weight_decay=weight_decay, comm=Comm(), backend=self.test_backend,
-                          cache_input_aggregate=cache_input_aggregate)
+                          cache_input_aggregate=cache_input_aggregate, share_eval_forward=share_eval_forward)
 
     def final_test(self, runner, y, test_mask, need_all_metrics, compare_pred_label):
         """Eval-mode forward of the (best) model on every rank's rows; predictions and labels of the test rows are

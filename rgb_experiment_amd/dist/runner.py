@@ -18,7 +18,10 @@ class DistRunner:
     def __init__(self, model, edge_index, x, y, masks, rank, world, device, lr=0.01, weight_decay=0.0,
                  comm=None, backend=None, exchange="auto", resident_features=True, pieces=None,
                  interleave_evals=True, fused=True, pieces_in=2, cache_input_aggregate=False, src_split=False,
-                 pipeline=True):
+                 pipeline=True, share_eval_forward=False):
+        """`share_eval_forward`: the val and the test statistics of an epoch come from ONE eval forward (the reference's
+        second eval forward, itexperiments.py:470, recomputes the outputs of its first, :464; experiment()'s default on one
+        GPU since round 4) — a third of an epoch's forward exchanges less, the same five numbers."""
         self.comm = comm or Comm()
         self.rank, self.world, self.device = rank, world, device
         if "x" in str(exchange):  # an explicit R x C grid must factor the ranks: said before any structure is built
@@ -38,6 +41,7 @@ class DistRunner:
         import os
         self.interleave_evals = interleave_evals and world > 1 and os.environ.get("RGBX_INTERLEAVE", "auto") != "never"
         self.pipeline = bool(pipeline)  # epoch(more=True) may compute the next training step ahead (fused schedule)
+        self.share_eval_forward = bool(share_eval_forward)
         self._spec = None
         self._streams = None
         self._epochs_done = 0
@@ -195,18 +199,31 @@ class DistRunner:
             return self.engine.eval_stats(which), None  # loss statistics straight from the last layer's kernel
         with torch.no_grad():
             res = self.model(self.x_in, self.token)
-        m = self.masks[which]
-        if res["emb"].is_cuda:
-            from .. import ops
-            stats = ops.masked_ce_accuracy(res["emb"], self.y, m)[::2]  # a view: a list index would go through the host
-        else:  # gloo/CPU tests
-            out = res["out"]
-            stats = torch.stack([F.nll_loss(out[m], self.y[m], reduction="sum"),
-                                 (out[m].max(dim=1)[1] == self.y[m]).sum().float()]).double()
+        stats = self._stats_of(res, self.masks[which])
         if not sync:
             return stats, res
         stats = (self.comm.all_reduce_sum_(stats) / self.mask_counts[which]).tolist()
         return stats[0], stats[1], res
+
+    def _stats_of(self, res, m):
+        """[masked NLL sum, correct count] (float64) of this rank's rows of one eval forward's outputs."""
+        if res["emb"].is_cuda:
+            from .. import ops
+            return ops.masked_ce_accuracy(res["emb"], self.y, m)[::2]  # a view: a list index would go through the host
+        out = res["out"]  # gloo / CPU tests
+        return torch.stack([F.nll_loss(out[m], self.y[m], reduction="sum"),
+                            (out[m].max(dim=1)[1] == self.y[m]).sum().float()]).double()
+
+    def evaluate_pair(self):
+        """(val statistics, test statistics) of this rank's rows from ONE eval forward (share_eval_forward): the fused
+        schedule takes both masks in its last launch (GridStack.eval_shared); the module route forwards once and reads
+        the logits under both masks."""
+        self.model.eval()
+        if self.engine is not None:
+            return self.engine.eval_shared(1, 2)
+        with torch.no_grad():
+            res = self.model(self.x_in, self.token)
+        return self._stats_of(res, self.masks[1]), self._stats_of(res, self.masks[2])
 
     def _interleaved_evals(self):
         """The val and the test forward (itexperiments.py:464-473: two full eval forwards per epoch, both run here)
@@ -303,9 +320,12 @@ class DistRunner:
         # the first epoch builds what the eval forwards use lazily (cost tables, plans / CSRs of widths only the
         # no_grad path aggregates at) — on the MAIN stream, one forward after the other, so that no structure is
         # produced on one of the two eval streams and consumed on the other; interleaving starts with the second epoch
-        if self.interleave_evals and self.engine is not None and more and self.pipeline:
+        if self.share_eval_forward and not (self.interleave_evals and self.engine is not None and more and self.pipeline):
+            v, s = self.evaluate_pair()
+        elif self.interleave_evals and self.engine is not None and more and self.pipeline:
             self.model.eval()
-            v, s, self._spec = self.engine.eval_pair_and_next_step(1, 2)
+            step = self.engine.eval_shared_and_next_step if self.share_eval_forward else self.engine.eval_pair_and_next_step
+            v, s, self._spec = step(1, 2)
             # the gradient all-reduce of the step computed ahead goes out NOW, behind this epoch's work, instead of at the
             # top of the next call, where the queue is empty and every launch is paid at the host's pace (it touches the
             # gradient buffer only: a dropped step drops it too)

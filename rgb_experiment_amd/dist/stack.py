@@ -614,6 +614,22 @@ class GridStack:
         return a, b, t
 
     @torch.no_grad()
+    def eval_shared(self, first, second):
+        """The val and the test statistics of an epoch from ONE eval forward (share_eval_forward: the reference's second
+        eval forward, itexperiments.py:470, recomputes the very outputs of its first, :464): the last layer's return-stage
+        launch takes both masks (rgbx_ce_epilogue_t.mask_groups = 2) — half the eval exchanges of eval_pair, the same
+        four numbers. Returns ([nll sum, hits] under masks[first], the same under masks[second])."""
+        st = _drive(self._eval_g((first, second)))
+        return st[:2], st[2:]
+
+    @torch.no_grad()
+    def eval_shared_and_next_step(self, first, second):
+        """eval_shared interleaved with the forward + backward of the NEXT epoch's training step (see
+        eval_pair_and_next_step): two generators. Returns (stats first, stats second, loss share of the next step)."""
+        t, st = self._interleave([self._train_g(speculative=True), self._eval_g((first, second))], [" tri1", " tri2"])
+        return st[:2], st[2:], t
+
+    @torch.no_grad()
     def eval_pair(self, first, second):
         """The val and the test forward of an epoch (itexperiments.py:464-473: two full eval forwards, both run),
         INTERLEAVED on one host thread and one stream: each forward is a generator that yields the exchange it is about
@@ -625,8 +641,11 @@ class GridStack:
         return self._interleave([self._eval_g(first), self._eval_g(second)], [" paired1", " paired2"])
 
     def _eval_g(self, which, folded=None):
+        """`which`: a mask index -> [nll sum, hits]; a PAIR of mask indices -> the four numbers [nll, hits, nll, hits] of
+        both masks from this one forward (eval_shared)."""
         S, be = self.specs, self.be
         L = len(S)
+        pair = isinstance(which, (tuple, list))
         prev_blk = inbound = None
         folded = self._eval_weights() if folded is None else folded
         for i in range(L):
@@ -639,13 +658,16 @@ class GridStack:
             inbound = None
             root = dict(x_root=prev_blk, wt_root=wtr) if wtr is not None else {}
             if i == L - 1 and wt is None:  # the transform ran before the exchange: logits = aggregate + bias, and the
-                st = be.ce_stats_blocked(u, b, self.y, self.masks[which])  # statistics read the received slices in place
+                if pair:  # statistics read the received slices in place (selected rows only), once per mask
+                    return torch.cat([be.ce_stats_blocked(u, b, self.y, self.masks[w])[::2] for w in which])
+                st = be.ce_stats_blocked(u, b, self.y, self.masks[which])
                 return st[::2]
             if i == L - 1:
-                _, _, st = be.layer(u, wt, bias=b, ce=(self.y, self.masks[which], None), kind="return_linear_fwd", **root)
+                mask = tuple(self.masks[w] for w in which) if pair else self.masks[which]
+                _, _, st = be.layer(u, wt, bias=b, ce=(self.y, mask, None), kind="return_linear_fwd", **root)
                 # (nll sum, hits) as a VIEW: indexing with a list would stage an index tensor through the host and
                 # drain the queue (it did, twice per epoch, until round 3)
-                return st[::2]
+                return st[:, ::2].reshape(-1) if pair else st[::2]
             blk = self._blocked_buffer(i + 1, width=wt.size(1))
             be.layer(u, wt, bias=b, want_out=False, out_blocked=blk, kind="return_linear_fwd", **root)
             prev_blk = blk

@@ -90,8 +90,9 @@ class WholeGraphRunner:
 
     engine, replicated, interleave_evals, interleave_decision, graphs = None, False, False, None, None
 
-    def __init__(self, model, edge_index, x, y, masks, device, lr=0.01, weight_decay=0.0):
+    def __init__(self, model, edge_index, x, y, masks, device, lr=0.01, weight_decay=0.0, share_eval_forward=False):
         self.device = device
+        self.share_eval_forward = bool(share_eval_forward)
         self.model = model.to(device)
         self.fwd = {"x": x.to(device).contiguous(), "edge_index": edge_index.to(device)}
         self.y = y.to(device)
@@ -125,6 +126,14 @@ class WholeGraphRunner:
         with torch.no_grad():
             stats = masked_ce(self.model, self.fwd, self.y, self.masks[which])[1]  # [nll sum, rows, correct]
         return stats[::2], None
+
+    def evaluate_pair(self):
+        """(val statistics, test statistics) from ONE eval forward (models/_stack.masked_ce_pair)."""
+        from ..models._stack import masked_ce_pair
+        self.model.eval()
+        with torch.no_grad():
+            st = masked_ce_pair(self.model, self.fwd, self.y, self.masks[1], self.masks[2])
+        return st[0, ::2], st[1, ::2]
 
     def logits(self, training=False):
         self.model.train(training)
@@ -162,7 +171,8 @@ class TaskSplitRunner:
             groups = [dist.new_group(list(range(half))), dist.new_group(list(range(half, world)))]
             inner = Comm(groups[0 if self.role == "train" else 1])
         if half == 1 and device.type == "cuda" and runner_kw.get("backend") is None:
-            self.inner = WholeGraphRunner(model, edge_index, x, y, masks, device, lr=lr, weight_decay=weight_decay)
+            self.inner = WholeGraphRunner(model, edge_index, x, y, masks, device, lr=lr, weight_decay=weight_decay,
+                                          share_eval_forward=runner_kw.get("share_eval_forward", False))
         else:  # (a group of one rank on the CPU: the gloo rehearsal, through the partitioned path with its injected aggregator)
             self.inner = DistRunner(model, edge_index, x, y, masks, rank % half, half, device, lr=lr,
                                     weight_decay=weight_decay, comm=inner, pipeline=False, **runner_kw)
@@ -252,7 +262,9 @@ class TaskSplitRunner:
             ops.note_weights_changed()  # parameters written from outside (broadcast into raw storage)
             r.model.eval()
             e0 = time.perf_counter()
-            if getattr(r, "engine", None) is not None and r._epochs_done > 0:
+            if getattr(r, "share_eval_forward", False):
+                v, s = r.evaluate_pair()  # one eval forward, both masks
+            elif getattr(r, "engine", None) is not None and r._epochs_done > 0:
                 # a fused schedule inside the group (--task-split on for a conv stack): its ONE-thread interleave of the
                 # two forwards; the two-thread path below would run over engine state that is not thread-safe
                 v, s = r.engine.eval_pair(1, 2)

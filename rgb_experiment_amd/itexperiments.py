@@ -347,7 +347,7 @@ def experiment(model_init_param: dict, *,
         # 1-D node partition: this rank keeps its node range of features / labels / masks and the structures of its
         # share of the graph; parameters are replicated (the seeds above made them equal on every rank)
         runner = dist_ctx.runner(net, data.edge_index, features, y, (train_mask, val_mask, test_mask), learning_rate,
-                                 weight_decay, cache_input_aggregate, task_split)
+                                 weight_decay, cache_input_aggregate, task_split, share_eval_forward)
         use_hip_graph = False
     graphed = None
     # capturable Adam keeps its step count on the device: required for graph capture, and used for the

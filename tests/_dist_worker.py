@@ -101,7 +101,10 @@ class TorchStackBackend:
             extra = torch.stack([od.sum(0), (od * od).sum(0)])
         if out_blocked is not None:
             _store_blocked(out_blocked, out)
-        if ce is not None:
+        if ce is not None and isinstance(ce[1], (tuple, list)):  # two masks, statistics only: [2, 3]
+            extra = torch.stack([self.ce_stats(out, ce[0], m) for m in ce[1]])
+            out = None
+        elif ce is not None:
             y, mask, grad_scale = ce
             sel = (y >= 0) & (y < out.size(1))
             if mask is not None:
@@ -183,6 +186,21 @@ def make_problem(n=97, e=900, f=12, c=5, seed=0):
     return ei, x, y, masks
 
 
+def arm_deadline(seconds):
+    """Hard per-case deadline of a rank process of a multi-rank GPU test: when it passes, the stacks of ALL threads of this
+    rank go to stderr and the process exits (faulthandler, exit=True) — a stall fails the case within about a minute with
+    the evidence, instead of holding the suite until its own limit (round 4: one case sat 5 min in a host-staged
+    exchange). Every rank arms the same deadline, so the peers of a stuck rank end at the same time. Re-arming replaces the
+    previous deadline. RGBX_TEST_DUMP_AFTER overrides the seconds."""
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("RGBX_TEST_DUMP_AFTER", seconds)), exit=True)
+
+
+def disarm_deadline():
+    import faulthandler
+    faulthandler.cancel_dump_traceback_later()
+
+
 def rccl_on_one_gpu_env(rank):
     """Environment of a rank that shares cuda:0 with the other ranks UNDER RCCL (rgb_experiment_amd/dist/sharing.py)."""
     from rgb_experiment_amd.dist.sharing import rccl_env
@@ -194,9 +212,6 @@ def _init(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if os.environ.get("RGBX_TEST_BACKEND") == "rccl":
-        import faulthandler
-        if not os.environ.get("RGBX_TEST_DUMP_AFTER"):  # a rank stuck in a collective ends with its stacks, not silently
-            faulthandler.dump_traceback_later(300, exit=True)
         os.environ.update(rccl_on_one_gpu_env(rank))
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
@@ -313,6 +328,38 @@ def tasksplit_worker(rank, world, port, out_dir, model_name, exchange="reshard",
     dist.destroy_process_group()
 
 
+def shared_eval_worker(rank, world, port, out_dir, model_name, exchange, fused, split):
+    """The same three epochs twice: with the reference's two eval forwards per epoch and with share_eval_forward (one
+    forward, both masks), on DistRunner (module route or fused schedule, the middle epoch announcing its successor) or on
+    TaskSplitRunner. Saved: both histories, final states, exchanges and payload bytes per run."""
+    _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import Comm, DistRunner, TaskSplitRunner
+    ei, x, y, masks = make_problem()
+    res = {}
+    for share in (False, True):
+        torch.manual_seed(14530529)
+        model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
+        if split:
+            r = TaskSplitRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, backend=OracleAggregator(),
+                                exchange=exchange, share_eval_forward=share)
+            comm = r.inner.comm
+        else:
+            comm = Comm()
+            r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=comm,
+                           backend=OracleAggregator(), exchange=exchange, fused=fused, share_eval_forward=share)
+        r.epoch()  # (builds every structure; its own exchanges are not counted)
+        comm.exchanges, comm.bytes_sent = 0, 0
+        hist = [r.epoch(more=True), r.epoch(more=False)]
+        r.discard_speculation()
+        res[share] = {"hist": hist, "exchanges": comm.exchanges, "bytes": comm.bytes_sent,
+                      "engine": getattr(r, "engine", None) is not None, "role": getattr(r, "role", None),
+                      "state": {k: v.clone() for k, v in r.model.state_dict().items()}}
+        dist.barrier()
+    torch.save(res, os.path.join(out_dir, f"shared_{model_name}_{rank}.pt"))
+    dist.destroy_process_group()
+
+
 def failing_eval_worker(rank, world, port, out_dir):
     """Rank 1 raises inside an eval forward of the second epoch (the interleaved pair, on a helper thread): the
     process must END (Comm.abort), so that the job terminates instead of leaving rank 0 in an all-to-all."""
@@ -373,11 +420,11 @@ def experiment_worker(rank, world, port, out_dir, model_name, on_gpu=False, clas
     route of rgb_experiment_amd.itexperiments.experiment."""
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
                        "MASTER_PORT": str(port), "RGBX_DIST_BACKEND": "gloo"})
+    if on_gpu:
+        arm_deadline(120)
     if on_gpu and os.environ.get("RGBX_TEST_BACKEND") == "rccl":
         # the product's own backend, the ranks sharing cuda:0: experiment() sees WORLD_SIZE > visible GPUs and prepares RCCL for
         # it by itself (dist/sharing.py) - nothing but the backend's name is set here
-        import faulthandler
-        faulthandler.dump_traceback_later(300, exit=True)
         os.environ["RGBX_DIST_BACKEND"] = "nccl"
     if not on_gpu:
         os.environ["RGBX_TEST_AGGREGATOR"] = "_dist_worker:OracleAggregator"
@@ -469,9 +516,7 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", h
     """Rehearsal of the real per-rank HIP path: `world` ranks share cuda:0, collectives go through gloo
     with host staging (RCCL cannot put two ranks on one device). `ahead`: the first epoch announces the second
     (epoch(more=True): the fused schedule computes the second training step beside the first epoch's eval forwards)."""
-    if size == "S" or os.environ.get("RGBX_TEST_DUMP_AFTER"):  # a stuck rank ends with the stacks of all its threads
-        import faulthandler                                     # on stderr instead of a silent hang of the test run
-        faulthandler.dump_traceback_later(int(os.environ.get("RGBX_TEST_DUMP_AFTER", "300")), exit=True)
+    arm_deadline(150 if size == "S" else 90)  # a stuck rank ends with the stacks of all its threads on stderr
     _init(rank, world, port)
     from rgb_experiment_amd import models as M
     from rgb_experiment_amd.dist import Comm, DistRunner
@@ -486,13 +531,13 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", h
                 "engine": r.engine is not None, "state": {k: v.cpu() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"gpu_{model_name}_{rank}.pt"))
     dist.destroy_process_group()
-    if size == "S" or os.environ.get("RGBX_TEST_DUMP_AFTER"):
-        faulthandler.cancel_dump_traceback_later()
+    disarm_deadline()
 
 
 def gpu_tasksplit_worker(rank, world, port, out_dir, model_name, exchange="reshard"):
     """dist.TaskSplitRunner on the real kernels: `world` ranks share cuda:0 (gloo staging), two epochs, the first one
     announcing the second (the training group computes the second step ahead)."""
+    arm_deadline(90)
     _init(rank, world, port)
     from rgb_experiment_amd import models as M
     from rgb_experiment_amd.dist import TaskSplitRunner
@@ -507,6 +552,7 @@ def gpu_tasksplit_worker(rank, world, port, out_dir, model_name, exchange="resha
                 "state": {k: v.cpu() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"gpusplit_{model_name}_{rank}.pt"))
     dist.destroy_process_group()
+    disarm_deadline()
 
 
 def comm_selftest_worker(rank, world, port, out_dir, sabotage=False):
@@ -534,14 +580,15 @@ def gpu_runner_worker_multi(rank, world, port, out_dir, cases):
     """gpu_runner_worker for SEVERAL (model_name, exchange) cases in one set of rank processes (one interpreter start-up, one
     process group): every case builds its own model and DistRunner, runs its two epochs, saves
     gpu_<model>_<exchange>_<rank>.pt, and leaves nothing behind for the next one (graph caches dropped)."""
-    import faulthandler
-    faulthandler.dump_traceback_later(int(os.environ.get("RGBX_TEST_DUMP_AFTER", "420")), exit=True)
+    arm_deadline(120)  # imports, process group, the first case
     _init(rank, world, port)
     from rgb_experiment_amd import models as M
     from rgb_experiment_amd.dist import Comm, DistRunner
     from rgb_experiment_amd.graph import clear_cache
     dev = torch.device("cuda:0")
-    for model_name, exchange in cases:
+    for i, (model_name, exchange) in enumerate(cases):
+        if i:
+            arm_deadline(60)  # per case from here on
         base, (ei, x, y, masks) = problem_of(model_name)
         torch.manual_seed(14530529)
         model = build_model(M, base, x.size(1), int(y.max()) + 1)
@@ -556,7 +603,7 @@ def gpu_runner_worker_multi(rank, world, port, out_dir, cases):
         torch.cuda.empty_cache()
         dist.barrier()
     dist.destroy_process_group()
-    faulthandler.cancel_dump_traceback_later()
+    disarm_deadline()
 
 
 def single_gpu_worker(rank, out_path, jobs):
@@ -638,6 +685,7 @@ def gpu_interleave_worker(rank, world, port, out_dir, model_name, exchange, size
     (DistRunner's default from the second epoch on) and one after the other on the caller's stream. Saved: both histories and
     both sets of train-mode logits."""
     os.environ["RGBX_INTERLEAVE"] = "always"  # no host-bound verdict in between (DistRunner._settle_interleave)
+    arm_deadline(150 if size == "S" else 90)
     _init(rank, world, port)
     from rgb_experiment_amd import models as M
     from rgb_experiment_amd.dist import Comm, DistRunner
@@ -658,6 +706,7 @@ def gpu_interleave_worker(rank, world, port, out_dir, model_name, exchange, size
         dist.barrier()
     torch.save(res, os.path.join(out_dir, f"inter_{model_name}_{rank}.pt"))
     dist.destroy_process_group()
+    disarm_deadline()
 
 
 def identity_exchange_worker(rank, world, port, out_dir, idents):

@@ -195,6 +195,31 @@ def test_dist_runner_training_matches_single_process(model_name, world, exchange
     assert parts[0]["lo"] == 0 and parts[-1]["hi"] == 97
 
 
+@pytest.mark.parametrize("model_name,world,exchange,fused,split", [
+    ("gcn_grid", 2, "reshard", True, False), ("graphsage_grid", 4, "2x2", True, False), ("gcn3_grid", 3, "reshard", True, False),
+    ("gcn", 3, "halo", False, False), ("appnpstack", 2, "reshard", False, False), ("appnpstack", 4, "reshard", False, True)])
+def test_shared_eval_forward_on_several_ranks(model_name, world, exchange, fused, split, tmp_path):
+    """share_eval_forward in DistRunner / GridStack / TaskSplitRunner (reference loop: itexperiments.py:464-473 runs two
+    identical eval forwards): the five numbers of every epoch and the trained state equal those of the two-forward epoch
+    bit for bit, with fewer exchanges per epoch (one eval forward's worth)."""
+    mp.spawn(W.shared_eval_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, fused, split),
+             nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"shared_{model_name}_{r}.pt")) for r in range(world)]
+    for p in parts:
+        two, one = p[False], p[True]
+        assert one["hist"] == two["hist"] == parts[0][False]["hist"], (one["hist"], two["hist"])
+        assert one["engine"] == two["engine"] == (fused and not split)
+        for k, v in two["state"].items():
+            assert torch.equal(v, one["state"][k]), k
+    # exchanges: a training rank of a task split makes no eval exchange at all; everybody else saves one eval forward's
+    for p in parts:
+        if p[True]["role"] == "train":
+            assert p[True]["exchanges"] == p[False]["exchanges"]
+        else:
+            assert p[True]["exchanges"] < p[False]["exchanges"], (p[True]["exchanges"], p[False]["exchanges"])
+            assert p[True]["bytes"] < p[False]["bytes"]
+
+
 @pytest.mark.parametrize("model_name,world,exchange,stop_early", [("appnpstack", 4, "reshard", True),
                                                                    ("gcn", 2, "halo", True),
                                                                    # BASELINE configs[4] as the 8-GPU tier runs it: 4 + 4

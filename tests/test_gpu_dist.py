@@ -48,6 +48,20 @@ def test_the_ranks_ran_on_rccl(rank_backend):
         pytest.skip("RCCL did not come up with two ranks on this box's one GPU: the partitioned cases ran on gloo")
 
 
+def _spawn(fn, args, nprocs, limit_s=240):
+    """mp.spawn with a parent-side limit: the rank processes end themselves at their own per-case deadline with their stacks
+    on stderr (W.arm_deadline); should even that not happen, they are killed here and the case fails — a stall costs the
+    suite minutes, never its whole budget."""
+    import time
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    t0 = time.time()
+    while not ctx.join(timeout=2):
+        if time.time() - t0 > limit_s:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail(f"{fn.__name__}{args[-3:]}: {nprocs} rank process(es) still running after {limit_s} s: killed")
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -69,7 +83,7 @@ def _single_gpu(model_name, hub=False, size=None, also=()):
                 del _REF[k]
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "single.pt")
-            mp.spawn(W.single_gpu_worker, args=(path, [(j, *j) for j in jobs]), nprocs=1, join=True)
+            _spawn(W.single_gpu_worker, (path, [(j, *j) for j in jobs]), 1)
             _REF.update(torch.load(path))
     return _REF[(model_name, hub, size)]
 
@@ -99,7 +113,7 @@ def test_partitioned_hip_run_matches_single_gpu(world, tmp_path, rank_backend):
     most of a small case's time; 24 cases used to be 24 spawns); each case is compared with its one-GPU run and every
     failing case is reported."""
     cases = [(m, x) for m, w, x in CASES if w == world]
-    mp.spawn(W.gpu_runner_worker_multi, args=(world, _free_port(), str(tmp_path), cases), nprocs=world, join=True)
+    _spawn(W.gpu_runner_worker_multi, (world, _free_port(), str(tmp_path), cases), world)
     failures = []
     names = sorted({m for m, _ in cases})
     _single_gpu(names[0], also=[(m, False, None) for m in names[1:]])
@@ -131,8 +145,7 @@ def test_partitioned_hip_run_matches_single_gpu_at_S(model_name, world, exchange
     """The partitioned path on BASELINE workload S (|V| = 200 k, |E| = 4 M, d = 128: the models bench.py times), real
     values through the piece-major / blocked layouts, int32 offsets and the 2 x 2 grid at 4 M edges: ranks share the GPU
     over gloo; first-step train loss within 1e-4 and train-mode logits of ALL rows within 1e-3 of the one-GPU run."""
-    mp.spawn(W.gpu_runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, False, True, "S"),
-             nprocs=world, join=True)
+    _spawn(W.gpu_runner_worker, (world, _free_port(), str(tmp_path), model_name, exchange, False, True, "S"), world)
     parts = [torch.load(os.path.join(tmp_path, f"gpu_{model_name}_{r}.pt")) for r in range(world)]
     if exchange != "halo" and not model_name.startswith("appnp"):
         assert all(p["engine"] for p in parts), "the fused schedule was not taken"
@@ -155,11 +168,11 @@ def test_experiment_as_several_ranks_matches_one_gpu(model_name, tmp_path):
     """experiment() under WORLD_SIZE = 2 (the ranks share the one GPU, gloo staging) against experiment() on one GPU:
     same loss curves (train tightly; eval within the +-lr noise of pre-BatchNorm biases, see above), same accuracy to a
     handful of rows."""
-    mp.spawn(W.experiment_worker, args=(2, _free_port(), str(tmp_path), model_name, True), nprocs=2, join=True)
+    _spawn(W.experiment_worker, (2, _free_port(), str(tmp_path), model_name, True), 2)
     parts = [torch.load(os.path.join(tmp_path, f"exp_{model_name}_2_{r}.pt")) for r in range(2)]
     assert parts[0]["metrics"] == parts[1]["metrics"] and parts[0]["distributed"]["world"] == 2
     ref = os.path.join(tmp_path, "one.pt")
-    mp.spawn(W.experiment_single_worker, args=(ref, model_name), nprocs=1, join=True)  # a child: see _single_gpu
+    _spawn(W.experiment_single_worker, (ref, model_name), 1)  # a child: see _single_gpu
     one = torch.load(ref)
     a, b = parts[0]["history"], one["history"]
     # two ranks split the epoch by task, each on the whole graph with the single-GPU kernels and the same optimizer
@@ -177,8 +190,7 @@ def test_fused_schedule_with_hub_rows(model_name, world, exchange, tmp_path):
     """Two hub nodes (3000 extra in-edges / out-edges: rows beyond LONG_ROW_SLOTS in the forward and the transposed
     CSRs of the ranks that own them): the fused schedule takes its whole-group launches for CSRs with a hub-row plan
     (row ranges of such a CSR cannot be launched on their own) and one-piece layer-0 launches; same numbers as one GPU."""
-    mp.spawn(W.gpu_runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, True), nprocs=world,
-             join=True)
+    _spawn(W.gpu_runner_worker, (world, _free_port(), str(tmp_path), model_name, exchange, True), world)
     parts = [torch.load(os.path.join(tmp_path, f"gpu_{model_name}_{r}.pt")) for r in range(world)]
     assert all(p["engine"] for p in parts)
     hist, emb = _single_gpu(model_name, hub=True)
@@ -197,8 +209,7 @@ def test_step_computed_ahead_gives_the_same_bits(model_name, world, exchange, si
     has read it, or a receive view read before it has landed, would show as a difference between the two runs."""
     runs = []
     for ahead in (True, False):
-        mp.spawn(W.gpu_runner_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, False, ahead, size),
-                 nprocs=world, join=True)
+        _spawn(W.gpu_runner_worker, (world, _free_port(), str(tmp_path), model_name, exchange, False, ahead, size), world)
         runs.append([torch.load(os.path.join(tmp_path, f"gpu_{model_name}_{r}.pt")) for r in range(world)])
     for p, q in zip(*runs):
         assert p["engine"] and q["engine"]
@@ -214,8 +225,7 @@ def test_epoch_split_by_task_on_the_real_kernels(model_name, exchange, world, tm
     """dist.TaskSplitRunner on the one GPU: the first half of the ranks trains (second step computed ahead), the other
     half evaluates — 4 ranks: groups of 2 on the partitioned path; 2 ranks: each on the WHOLE graph with the single-GPU
     kernels (WholeGraphRunner). Same numbers as one GPU, the eval group's model is the training group's bit for bit."""
-    mp.spawn(W.gpu_tasksplit_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange), nprocs=world,
-             join=True)
+    _spawn(W.gpu_tasksplit_worker, (world, _free_port(), str(tmp_path), model_name, exchange), world)
     parts = [torch.load(os.path.join(tmp_path, f"gpusplit_{model_name}_{r}.pt")) for r in range(world)]
     half = world // 2
     assert [p["role"] for p in parts] == ["train"] * half + ["eval"] * half
@@ -239,7 +249,7 @@ def test_gloo_staging_of_device_tensors(tmp_path):
     os.environ["RGBX_TEST_BACKEND"] = "gloo"
     try:
         cases = [("gcn_grid", "reshard"), ("graphsage", "halo"), ("appnpstack", "reshard")]
-        mp.spawn(W.gpu_runner_worker_multi, args=(2, _free_port(), str(tmp_path), cases), nprocs=2, join=True)
+        _spawn(W.gpu_runner_worker_multi, (2, _free_port(), str(tmp_path), cases), 2)
     finally:
         if keep is None:
             os.environ.pop("RGBX_TEST_BACKEND", None)
@@ -261,8 +271,7 @@ def test_eval_forwards_on_two_streams_give_the_same_bits(model_name, world, exch
     the other's kernels) against the same forwards one after the other: same launches on the same operands, so every loss,
     every accuracy and every logit is bit-identical. Tolerances elsewhere in this file (5e-3 on eval losses: BatchNorm's
     conditioning) would not see a forward that ran on the previous step's operands — this does (round 4: the cached W^T)."""
-    mp.spawn(W.gpu_interleave_worker, args=(world, _free_port(), str(tmp_path), model_name, exchange, size), nprocs=world,
-             join=True)
+    _spawn(W.gpu_interleave_worker, (world, _free_port(), str(tmp_path), model_name, exchange, size), world)
     for r in range(world):
         p = torch.load(os.path.join(tmp_path, f"inter_{model_name}_{r}.pt"))
         assert p["interleaved"]["threads"] and not p["sequential"]["threads"]
