@@ -754,9 +754,10 @@ def launch_ranks(n):
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    deadline_s = sv.limits()[0]
     attempts = int(os.environ.get("RGBX_LAUNCH_ATTEMPTS", len(sv.ATTEMPTS)))
-    total = attempts * (deadline_s + 90) + 120  # backstop only: the supervisors keep their own, tighter limits
+    # backstop only: the supervisors keep the run's budget themselves (supervise.total_budget: every attempt together at most
+    # 540 s, rank 0's line — benchmark or diagnostic — out before the driver's 600 s)
+    total = sv.total_budget() + 45
     import signal
     # the ranks live in their own process group: whoever ends THIS process (the driver's own timeout, Ctrl-C) must take
     # them along — by the handlers below, or, if this process is killed outright, by the parent-death signal

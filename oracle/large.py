@@ -24,15 +24,17 @@ class CsrGraph:
     per-slot weights of the aggregation and of its adjoint.
     kind 'gcn'  : add_remaining_self_loops + symmetric normalisation (ref_cpu.gcn_norm), aggr = add
     kind 'mean' : loops_mode 2 (my_SAGEConv: remove + add self-loops) or 0 (SAGEConv: edges as given), aggr = mean =
-                  sum / max(count, 1); the adjoint scatters grad[i] / max(count_i, 1) back along every edge."""
+                  sum / max(count, 1); the adjoint scatters grad[i] / max(count_i, 1) back along every edge.
+    kind 'gat'  : loops_mode 2 (GATConv: remove + add self-loops), no fixed weights: the attention coefficients are
+                  functions of the features (gat_aggregate); keeps fwd_slot, the forward slot of every transposed slot."""
 
     def __init__(self, edge_index, num_nodes, kind, loops_mode=1, threads=0):
         n = int(num_nodes)
         self.n, self.kind, self.threads = n, kind, threads
         if kind == "gcn":
             ei, w = O.gcn_norm(edge_index, None, n)
-        elif kind == "mean":
-            ei, _ = O.rewrite_edges(edge_index, n, loops_mode)
+        elif kind in ("mean", "gat"):
+            ei, _ = O.rewrite_edges(edge_index, n, 2 if kind == "gat" else loops_mode)
             w = None
         else:
             raise ValueError(kind)
@@ -42,6 +44,11 @@ class CsrGraph:
         if kind == "gcn":
             self.w = w[perm.long()].contiguous()
             self.w_t = w[perm_t.long()].contiguous()
+        elif kind == "gat":
+            self.w = self.w_t = None
+            inv = torch.empty(ei.size(1), dtype=torch.int64)
+            inv[perm.long()] = torch.arange(ei.size(1))
+            self.fwd_slot = inv[perm_t.long()].contiguous()  # transposed slot -> forward slot of the same edge
         else:
             cnt = torch.bincount(ei[1], minlength=n).clamp(min=1).to(torch.float32)
             self.w = None  # the C function's own mean
@@ -70,6 +77,48 @@ def propagate(x, graph):
     return _Propagate.apply(x, graph)
 
 
+class _GatAggregate(torch.autograd.Function):
+    """out[i,k,:] = sum_p alpha_p h[j,k,:] with alpha the per-target softmax of leaky_relu(a_src[j] + a_dst[i]) —
+    ref_cpu.gat_conv's message + aggregate (GATConv [PyG] behind models/gat.py:28,30; PARITY UNPINNED) through the C
+    restatement (oracle_gat_forward_csr_f32) and its adjoint (target pass over the CSR, source pass over the transposed CSR):
+    no [E', H, C] tensor, so the BASELINE-size graphs fit the host."""
+
+    @staticmethod
+    def forward(ctx, h, a_src, a_dst, graph, H, C, slope):
+        lib = O._c_lib()
+        h, a_src, a_dst = (t.detach().contiguous().float() for t in (h, a_src, a_dst))
+        n = graph.n
+        out = torch.empty((n, H * C), dtype=torch.float32)
+        alpha = torch.empty((max(graph.nnz, 1), H), dtype=torch.float32)
+        lib.oracle_gat_forward_csr_f32(graph.rowptr.data_ptr(), graph.col.data_ptr(), h.data_ptr(), a_src.data_ptr(),
+                                       a_dst.data_ptr(), float(slope), out.data_ptr(), alpha.data_ptr(), n, H, C, graph.threads)
+        ctx.save_for_backward(h, a_src, a_dst, alpha)
+        ctx.graph, ctx.H, ctx.C, ctx.slope = graph, H, C, slope
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = O._c_lib()
+        h, a_src, a_dst, alpha = ctx.saved_tensors
+        g, H, C = ctx.graph, ctx.H, ctx.C
+        gout = gout.contiguous().float()
+        gs = torch.empty_like(alpha)
+        g_ad = torch.empty((g.n, H), dtype=torch.float32)
+        lib.oracle_gat_backward_dst_csr_f32(g.rowptr.data_ptr(), g.col.data_ptr(), h.data_ptr(), a_src.data_ptr(),
+                                            a_dst.data_ptr(), float(ctx.slope), alpha.data_ptr(), gout.data_ptr(),
+                                            gs.data_ptr(), g_ad.data_ptr(), g.n, H, C, g.threads)
+        g_h = torch.empty_like(h)
+        g_as = torch.empty((g.n, H), dtype=torch.float32)
+        lib.oracle_gat_backward_src_csr_f32(g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.fwd_slot.data_ptr(),
+                                            alpha.data_ptr(), gs.data_ptr(), gout.data_ptr(), g_h.data_ptr(),
+                                            g_as.data_ptr(), g.n, H, C, g.threads)
+        return g_h, g_as, g_ad, None, None, None, None
+
+
+def gat_aggregate(h, a_src, a_dst, graph, H, C, slope=0.2):
+    return _GatAggregate.apply(h, a_src, a_dst, graph, H, C, slope)
+
+
 def graphs_for(name, edge_index, num_nodes, threads=0):
     """The CsrGraph each model's conv layers aggregate over."""
     if name in ("gcn", "appnpstack"):
@@ -78,10 +127,12 @@ def graphs_for(name, edge_index, num_nodes, threads=0):
         return CsrGraph(edge_index, num_nodes, "mean", loops_mode=2, threads=threads)
     if name == "graphsage2":
         return CsrGraph(edge_index, num_nodes, "mean", loops_mode=0, threads=threads)
+    if name == "gat":
+        return CsrGraph(edge_index, num_nodes, "gat", threads=threads)
     raise KeyError(name)
 
 
-def forward(name, sd, x, graph, training, num_layers=2, K=10, alpha=0.1):
+def forward(name, sd, x, graph, training, num_layers=2, K=10, alpha=0.1, heads=8):
     """{'out','emb'} of the model `name` from a product state_dict (tensors may require grad), as
     ref_cpu.{gcn,graphsage,graphsage2,appnp_stack}_forward."""
     if name == "gcn":  # ref_cpu.gcn_conv: x W^T, propagate(add), + bias
@@ -97,6 +148,20 @@ def forward(name, sd, x, graph, training, num_layers=2, K=10, alpha=0.1):
         def conv(i, v):
             return (propagate(v, graph) @ sd[f"convs.{i}.lin_l.weight"].t() + sd[f"convs.{i}.lin_l.bias"]
                     + v @ sd[f"convs.{i}.lin_r.weight"].t())
+        return O._stack(sd, x, None, num_layers, training, conv)
+    if name == "gat":  # ref_cpu.gat_forward / gat_conv: hidden layers `heads` heads concatenated, last layer one head
+        n = x.size(0)
+
+        def conv(i, v):
+            last = i == num_layers - 1
+            Hh = 1 if last else heads
+            W = sd[f"convs.{i}.lin_src.weight"]
+            C = W.size(0) // Hh
+            h = v @ W.t()
+            h3 = h.view(n, Hh, C)
+            a_s = (h3 * sd[f"convs.{i}.att_src"].view(1, Hh, C)).sum(-1)
+            a_d = (h3 * sd[f"convs.{i}.att_dst"].view(1, Hh, C)).sum(-1)
+            return gat_aggregate(h, a_s, a_d, graph, Hh, C) + sd[f"convs.{i}.bias"]  # (one head: mean over heads = identity)
         return O._stack(sd, x, None, num_layers, training, conv)
     if name == "appnpstack":  # ref_cpu.appnp_stack_forward
         h = x @ sd["lin1.weight"].t() + sd["lin1.bias"]

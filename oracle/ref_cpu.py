@@ -383,6 +383,13 @@ def _c_lib():
     lib.oracle_propagate_csr_f32.restype = None
     lib.oracle_propagate_csr_f32.argtypes = [P, P, P, P, I64, P, I64, I64, I64, I, I]
     lib.oracle_max_threads.restype = I
+    F = ctypes.c_float
+    lib.oracle_gat_forward_csr_f32.restype = None
+    lib.oracle_gat_forward_csr_f32.argtypes = [P, P, P, P, P, F, P, P, I64, I64, I64, I]
+    lib.oracle_gat_backward_dst_csr_f32.restype = None
+    lib.oracle_gat_backward_dst_csr_f32.argtypes = [P, P, P, P, P, F, P, P, P, P, I64, I64, I64, I]
+    lib.oracle_gat_backward_src_csr_f32.restype = None
+    lib.oracle_gat_backward_src_csr_f32.argtypes = [P, P, P, P, P, P, P, P, I64, I64, I64, I]
     return lib
 
 

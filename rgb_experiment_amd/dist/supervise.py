@@ -50,9 +50,22 @@ def _env_s(name, default):
 
 def limits():
     """(deadline per attempt, stall limit once the worker has reported in, limit for the first report) in seconds.
-    The first `import torch` on a fresh box can take two minutes, hence the separate first limit."""
-    return (_env_s("RGBX_LAUNCH_DEADLINE_S", 900), _env_s("RGBX_LAUNCH_STALL_S", 180),
-            _env_s("RGBX_LAUNCH_IMPORT_S", 360))
+    The first `import torch` on a fresh box can take two minutes, hence the separate first limit. A healthy attempt
+    at the benchmark's size is through in about a minute (setup_s of the rehearsal records: < 10 s after the import)."""
+    return (_env_s("RGBX_LAUNCH_DEADLINE_S", 300), _env_s("RGBX_LAUNCH_STALL_S", 120),
+            _env_s("RGBX_LAUNCH_IMPORT_S", 240))
+
+
+def total_budget():
+    """Seconds the WHOLE supervised run may take, all attempts together (RGBX_LAUNCH_TOTAL_S): the driver ends a bench
+    command after 600 s, and rank 0's line — a benchmark line or the diagnostic one naming what failed — must be out
+    before that. No attempt starts with less than MIN_ATTEMPT_S of it left, and every attempt's deadline is cut to what
+    is left."""
+    return _env_s("RGBX_LAUNCH_TOTAL_S", 540)
+
+
+MIN_ATTEMPT_S = 75.0   # an attempt that cannot even import torch and build the graph is not started
+LINE_RESERVE_S = 15.0  # kept back for ending the workers and printing rank 0's line
 
 
 def run_key():
@@ -215,6 +228,7 @@ def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
     max_attempts = int(_env_s("RGBX_LAUNCH_ATTEMPTS", len(attempts)))
     attempts = attempts[:max(1, max_attempts)]
     deadline_s, stall_s, import_s = limits()
+    budget_s, t_run = total_budget(), time.monotonic()
     d = shared_dir()
     child = [None]
 
@@ -230,6 +244,13 @@ def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
     history = []
     for k, (name, flags) in enumerate(attempts):
         port_file = os.path.join(d, f"attempt{k}.port")
+        left = budget_s - (time.monotonic() - t_run)
+        if rank == 0 and k > 0 and left < _env_s("RGBX_LAUNCH_MIN_ATTEMPT_S", MIN_ATTEMPT_S):
+            history.append({"attempt": k, "settings": name, "extra_flags": flags,
+                            "reason": f"not started: {left:.0f} s of the run's {budget_s:g} s budget left"})
+            break
+        # this attempt's deadline: what is left of the run's budget, so that rank 0's line is out in time either way
+        deadline_k = max(min(deadline_s, left - LINE_RESERVE_S), 5.0)
         if rank == 0:
             _write(os.path.join(d, "sup.0"), str(k))
             with socket.socket() as s:
@@ -274,8 +295,9 @@ def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
             peer = glob.glob(failed_glob)
             if peer:
                 reason = f"a peer failed first ({os.path.basename(peer[0])}: {(_read(peer[0]) or '').strip()[:200]})"
-            elif now - t0 > deadline_s:
-                reason = f"deadline of {deadline_s:g} s passed (last milestone: {(_read(hb) or 'none').strip()})"
+            elif now - t0 > deadline_k:
+                reason = (f"deadline of {deadline_k:.0f} s passed (per attempt {deadline_s:g} s, run budget {budget_s:g} s; "
+                          f"last milestone: {(_read(hb) or 'none').strip()})")
             else:
                 try:  # heartbeat files carry wall-clock mtimes
                     quiet, limit = time.time() - os.stat(hb).st_mtime, stall_s
@@ -299,7 +321,7 @@ def supervise(script, argv, rank, world, attempts=None, out=sys.stdout):
             # worker may still be busy): wait for rank 0's verdict while it is alive, and report success on `ok` alone
             hit = _await_rank0(d, k, [ok_file, os.path.join(d, f"attempt{k}.failed.0"),
                                       os.path.join(d, f"attempt{k + 1}.port"), os.path.join(d, "gave_up")],
-                               stall_s + import_s, max(deadline_s - (time.monotonic() - t0), 0) + 60)
+                               stall_s + import_s, max(deadline_k - (time.monotonic() - t0), 0) + 60)
             if hit == ok_file:
                 return 0
             if hit is None or hit.endswith("gave_up"):

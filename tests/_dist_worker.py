@@ -644,21 +644,85 @@ def single_gpu_worker(rank, out_path, jobs):
     torch.save(out, out_path)
 
 
-def experiment_single_worker(rank, out_path, model_name):
-    """experiment() on one GPU with the data / arguments of experiment_worker(on_gpu=True), in a process of its own."""
+def experiment_single_worker(rank, out_path, model_names):
+    """experiment() on one GPU with the data / arguments of experiment_worker(on_gpu=True), for every model of `model_names`,
+    in ONE process of its own (a process per model was 3 s of interpreter start-up and HIP context each)."""
     for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RGBX_DIST_BACKEND"):
         os.environ.pop(key, None)
     import rgb_experiment_amd as R
-    ei, x, y, masks = make_problem(n=5000, e=60000, f=32, c=8)
-    data = R.Data(x=x, y=y, edge_index=ei)
-    data.train_mask, data.val_mask, data.test_mask = masks
-    params = R.InitialParameters.defaults_for(model_name)
-    params["hidden_unit"] = 32
-    one = R.experiment(params, specify_data=True, data=data, model_name=model_name, learning_rate=0.01, epoch=6,
-                       need_to_reappear=True, print_print=False, return_model=True, need_all_metrics=True,
-                       keep_valid_data_mask=True, use_hip_graph=False)
-    torch.save({"history": one["history"], "ACC": one["ACC"],
-                "state": {k: v.cpu() for k, v in one["model"].state_dict().items()}}, out_path)
+    out = {}
+    for model_name in model_names:
+        ei, x, y, masks = make_problem(n=5000, e=60000, f=32, c=8)
+        data = R.Data(x=x, y=y, edge_index=ei)
+        data.train_mask, data.val_mask, data.test_mask = masks
+        params = R.InitialParameters.defaults_for(model_name)
+        params["hidden_unit"] = 32
+        one = R.experiment(params, specify_data=True, data=data, model_name=model_name, learning_rate=0.01, epoch=6,
+                           need_to_reappear=True, print_print=False, return_model=True, need_all_metrics=True,
+                           keep_valid_data_mask=True, use_hip_graph=False)
+        out[model_name] = {"history": one["history"], "ACC": one["ACC"],
+                           "state": {k: v.cpu() for k, v in one["model"].state_dict().items()}}
+    torch.save(out, out_path)
+
+
+def gpu_ahead_pair_worker(rank, world, port, out_dir, model_name, exchange, size):
+    """The same two epochs twice in one set of rank processes: with the second training step computed ahead of the first
+    epoch's eval forwards (epoch(more=True)) and without. Saved per variant: history, train-mode logits, state."""
+    arm_deadline(180 if size == "S" else 120)
+    _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import Comm, DistRunner
+    from rgb_experiment_amd.graph import clear_cache
+    dev = torch.device("cuda:0")
+    ei, x, y, masks = bench_problem_S() if size == "S" else make_problem(n=5000, e=60000, f=32, c=8)
+    res = {}
+    for ahead in (True, False):
+        torch.manual_seed(14530529)
+        model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
+        r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm(), exchange=exchange)
+        hist = [r.epoch(more=ahead), r.epoch()]
+        torch.cuda.synchronize()
+        res[ahead] = {"hist": hist, "logits_train": r.logits(True).cpu(), "engine": r.engine is not None,
+                      "state": {k: v.cpu() for k, v in r.model.state_dict().items()}}
+        del r, model
+        clear_cache()
+        torch.cuda.empty_cache()
+        dist.barrier()
+    torch.save(res, os.path.join(out_dir, f"ahead_{model_name}_{rank}.pt"))
+    dist.destroy_process_group()
+    disarm_deadline()
+
+
+def gpu_shared_eval_worker(rank, world, port, out_dir, model_name, exchange, size):
+    """share_eval_forward on the real kernels (the ranks sharing cuda:0): the reference's two eval forwards per epoch
+    against one forward serving both masks, two epochs each (the first announcing the second). Saved: histories, states,
+    exchanges and payload bytes of the two epochs."""
+    arm_deadline(180 if size == "S" else 120)
+    _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import Comm, DistRunner
+    from rgb_experiment_amd.graph import clear_cache
+    dev = torch.device("cuda:0")
+    ei, x, y, masks = bench_problem_S() if size == "S" else make_problem(n=5000, e=60000, f=32, c=8)
+    res = {}
+    for share in (False, True):
+        torch.manual_seed(14530529)
+        model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
+        comm = Comm()
+        r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=comm, exchange=exchange,
+                       share_eval_forward=share)
+        comm.exchanges, comm.bytes_sent = 0, 0
+        hist = [r.epoch(more=True), r.epoch()]
+        torch.cuda.synchronize()
+        res[share] = {"hist": hist, "exchanges": comm.exchanges, "bytes": comm.bytes_sent, "engine": r.engine is not None,
+                      "state": {k: v.cpu() for k, v in r.model.state_dict().items()}}
+        del r, model
+        clear_cache()
+        torch.cuda.empty_cache()
+        dist.barrier()
+    torch.save(res, os.path.join(out_dir, f"shared_{model_name}_{rank}.pt"))
+    dist.destroy_process_group()
+    disarm_deadline()
 
 
 def rccl_probe_worker(rank, world, port, out_dir):

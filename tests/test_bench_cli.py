@@ -146,6 +146,23 @@ def test_every_attempt_failing_ends_in_a_diagnostic_line_and_a_nonzero_status():
     assert res["value"] is None and len(res["launcher"]["failed"]) == 2
 
 
+def test_the_run_budget_bounds_all_attempts_together():
+    """RGBX_LAUNCH_TOTAL_S (default 540 s, inside the driver's 600 s): a first attempt that hangs is ended at what the
+    budget leaves it, a further attempt that could not finish is not started, and rank 0's diagnostic line is out in time."""
+    import time
+    t0 = time.time()
+    proc = _run(["--gpus", "2", "--workload", "T", "--steps", "1", "--warmup", "0"],
+                extra_env={"RGBX_TEST_FAULT": "stall:1:*:first_epoch", "RGBX_LAUNCH_TOTAL_S": "45",
+                           "RGBX_LAUNCH_MIN_ATTEMPT_S": "20", "RGBX_LAUNCH_STALL_S": "300", "RGBX_LAUNCH_DEADLINE_S": "300"})
+    took = time.time() - t0
+    assert proc.returncode != 0
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    failed = json.loads(lines[0])["launcher"]["failed"]
+    assert len(failed) == 2 and "deadline of 30 s" in failed[0]["reason"] and "not started" in failed[1]["reason"], failed
+    assert took < 75, took
+
+
 def test_bench_refuses_a_cpu_run_of_the_product_path():
     """No GPU and no test aggregator: an error, not a silent CPU run."""
     env = dict(os.environ)

@@ -163,7 +163,22 @@ def test_partitioned_hip_run_matches_single_gpu_at_S(model_name, world, exchange
     assert err < 1e-3
 
 
-@pytest.mark.parametrize("model_name", ["gcn", "graphsage", "gat", "appnpstack"])  # (graphsage2 passed too; 9 s each)
+_EXPERIMENT_MODELS = ["gcn", "graphsage", "gat", "appnpstack"]  # (graphsage2 passed too; 9 s each)
+_EXP_REF = {}
+
+
+def _experiment_on_one_gpu(model_name):
+    """experiment() on one GPU for every model of the case list, in ONE child process (see _single_gpu), on first use."""
+    import tempfile
+    if not _EXP_REF:
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "one.pt")
+            _spawn(W.experiment_single_worker, (path, _EXPERIMENT_MODELS), 1)
+            _EXP_REF.update(torch.load(path))
+    return _EXP_REF[model_name]
+
+
+@pytest.mark.parametrize("model_name", _EXPERIMENT_MODELS)
 def test_experiment_as_several_ranks_matches_one_gpu(model_name, tmp_path):
     """experiment() under WORLD_SIZE = 2 (the ranks share the one GPU, gloo staging) against experiment() on one GPU:
     same loss curves (train tightly; eval within the +-lr noise of pre-BatchNorm biases, see above), same accuracy to a
@@ -171,9 +186,7 @@ def test_experiment_as_several_ranks_matches_one_gpu(model_name, tmp_path):
     _spawn(W.experiment_worker, (2, _free_port(), str(tmp_path), model_name, True), 2)
     parts = [torch.load(os.path.join(tmp_path, f"exp_{model_name}_2_{r}.pt")) for r in range(2)]
     assert parts[0]["metrics"] == parts[1]["metrics"] and parts[0]["distributed"]["world"] == 2
-    ref = os.path.join(tmp_path, "one.pt")
-    _spawn(W.experiment_single_worker, (ref, model_name), 1)  # a child: see _single_gpu
-    one = torch.load(ref)
+    one = _experiment_on_one_gpu(model_name)
     a, b = parts[0]["history"], one["history"]
     # two ranks split the epoch by task, each on the whole graph with the single-GPU kernels and the same optimizer
     # (dist.tasksplit.WholeGraphRunner): the training rank's weights are the one-GPU run's bit for bit; the eval rank
@@ -207,16 +220,35 @@ def test_step_computed_ahead_gives_the_same_bits(model_name, world, exchange, si
     operands, so every number and every tensor of the state_dict is bit-identical. At workload S too (round 4): two separate
     sets of ranks on RCCL, exchanges of 25-50 MB in flight beside the kernels — a send buffer overwritten before its exchange
     has read it, or a receive view read before it has landed, would show as a difference between the two runs."""
-    runs = []
-    for ahead in (True, False):
-        _spawn(W.gpu_runner_worker, (world, _free_port(), str(tmp_path), model_name, exchange, False, ahead, size), world)
-        runs.append([torch.load(os.path.join(tmp_path, f"gpu_{model_name}_{r}.pt")) for r in range(world)])
-    for p, q in zip(*runs):
+    # both variants in ONE set of rank processes (W.gpu_ahead_pair_worker): half the interpreter / RCCL start-ups
+    _spawn(W.gpu_ahead_pair_worker, (world, _free_port(), str(tmp_path), model_name, exchange, size), world)
+    both = [torch.load(os.path.join(tmp_path, f"ahead_{model_name}_{r}.pt")) for r in range(world)]
+    for p, q in ((b[True], b[False]) for b in both):
         assert p["engine"] and q["engine"]
         assert p["hist"] == q["hist"], (p["hist"], q["hist"])
         assert torch.equal(p["logits_train"], q["logits_train"])
         for k, v in p["state"].items():
             assert torch.equal(v, q["state"][k]), k
+
+
+@pytest.mark.parametrize("model_name,world,exchange,size", [("gcn_bench", 4, "2x2", "S"), ("graphsage_grid", 2, "reshard", None)])
+def test_shared_eval_forward_on_the_real_kernels(model_name, world, exchange, size, tmp_path):
+    """share_eval_forward in DistRunner / GridStack with the ranks on RCCL (sharing the GPU): the return-stage launch takes
+    both masks (rgbx_ce_epilogue_t.mask_groups = 2). The same launches on the same operands up to that last one, whose
+    per-mask statistics are sums over the same rows in the same order: every number of both epochs and the trained state are
+    bit-identical to the two-forward epoch, with one eval forward's exchanges less (reference loop: itexperiments.py:464-473)."""
+    _spawn(W.gpu_shared_eval_worker, (world, _free_port(), str(tmp_path), model_name, exchange, size), world)
+    for r in range(world):
+        p = torch.load(os.path.join(tmp_path, f"shared_{model_name}_{r}.pt"))
+        two, one = p[False], p[True]
+        assert one["engine"] and two["engine"]
+        assert one["hist"] == two["hist"], (one["hist"], two["hist"])
+        for k, v in two["state"].items():
+            assert torch.equal(v, one["state"][k]), k
+        assert one["exchanges"] < two["exchanges"] and one["bytes"] < two["bytes"]
+        if r == 0:
+            print(f"shared eval forward, {model_name} x{world} {exchange}: exchanges per 2 epochs {two['exchanges']} -> "
+                  f"{one['exchanges']}, payload {two['bytes'] / 1e6:.1f} -> {one['bytes'] / 1e6:.1f} MB")
 
 
 @pytest.mark.parametrize("model_name,exchange,world", [("appnpstack", "reshard", 4), ("gcn", "auto", 4), ("gcn", "auto", 2),

@@ -16,6 +16,8 @@ Tolerance: 1e-4 absolute on logits (north_star); gradients 1e-4 * max(1, |g|_inf
 import pytest
 import torch
 
+import _oracle_jobs as J
+from _oracle_jobs import csr_graph, workload  # (kept across the tests of this module; one size at a time)
 from oracle import large as OL
 from oracle import ref_cpu as O
 from oracle import sampled as S
@@ -23,41 +25,12 @@ from oracle import sampled as S
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-SIZES = {"S": (200_000, 4_000_000), "L": (2_000_000, 60_000_000)}
-_CACHE = {}
 
 
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
     return torch.device("cuda:0")
-
-
-def workload(size):
-    """bench.py's synthetic graph of that size (same seeds), built once per module run."""
-    if size not in _CACHE:
-        _CACHE.clear()  # one size at a time in host memory
-        n, e = SIZES[size]
-        ei = torch.randint(0, n, (2, e), generator=torch.Generator().manual_seed(1234567), dtype=torch.int64)
-        x = torch.randn(n, 128, generator=torch.Generator().manual_seed(1234568))
-        y = torch.randint(0, 128, (n,), generator=torch.Generator().manual_seed(1234569))
-        _CACHE[size] = (ei, x, y)
-    return _CACHE[size]
-
-
-_CSR = {}
-
-
-def csr_graph(size, kind, loops_mode=1):
-    """oracle.large.CsrGraph (forward + transposed CSR with their weights) of the benchmark graph, kept across the tests of
-    this module: its two stable sorts of 62 M edge keys are a third of the CPU time of an L-size case."""
-    key = (size, kind, loops_mode)
-    if key not in _CSR:
-        for k in [k for k in _CSR if k[0] != size]:
-            del _CSR[k]
-        ei, x, _ = workload(size)
-        _CSR[key] = OL.CsrGraph(ei, x.size(0), kind, loops_mode=loops_mode, threads=O.c_threads())
-    return _CSR[key]
 
 
 @pytest.mark.parametrize("size", ["S", "L"])
@@ -71,21 +44,17 @@ def test_fused_aggregate_transform_on_the_whole_benchmark_graph(dev, size):
     Wr = torch.randn(128, 128, generator=g) / 128 ** 0.5
     b = torch.randn(128, generator=g)
     ei_d, x_d = ei.to(dev), x.to(dev)
-    threads = O.c_threads()
-    # GCN: A_hat x W^T + b
-    rei, w = O.gcn_norm(ei, None, n)
-    rowptr, col, perm = O.csr_from_edges(rei[1], rei[0], torch.arange(rei.size(1)), n)
-    want = O.propagate_c_csr(rowptr, col, w[perm.long()].contiguous(), x, "add", threads) @ W.t() + b
-    with torch.no_grad():
+    # the oracle half (C restatement's propagate over the whole graph + CPU matmuls): tests/_oracle_jobs.fused_expect, from
+    # the background run when it is there
+    want_gcn, want_sage = J.get(f"fused_expect_{size}")
+    with torch.no_grad():  # GCN: A_hat x W^T + b
         got = ops.propagate_linear(x_d, get_graph(ei_d, n, 1), "gcn", W.to(dev), b.to(dev)).cpu()
-    assert (got - want).abs().max().item() < TOL
-    del rei, w, rowptr, col, perm, want, got
+    assert (got - want_gcn).abs().max().item() < TOL
+    del want_gcn, got
     # SAGEConv form: mean over the in-edges as given (no self-loops), root term in the same kernel
-    rowptr, col, _ = O.csr_from_edges(ei[1], ei[0], torch.arange(ei.size(1)), n)
-    want = O.propagate_c_csr(rowptr, col, None, x, "mean", threads) @ W.t() + b + x @ Wr.t()
     with torch.no_grad():
         got = ops.propagate_linear(x_d, get_graph(ei_d, n, 0), "mean", W.to(dev), b.to(dev), root_weight=Wr.to(dev)).cpu()
-    assert (got - want).abs().max().item() < TOL
+    assert (got - want_sage).abs().max().item() < TOL
     clear_cache()
 
 
@@ -113,7 +82,7 @@ def test_appnp_k10_on_the_whole_benchmark_graph(dev, size):
     ei_d, x_d = ei.to(dev), x.to(dev)
     with torch.no_grad():
         got = ops.appnp_propagate(x_d, get_graph(ei_d, n, 1), K, alpha).cpu()
-    want = appnp_cpu(x)
+    want = J.get(f"appnp_k10_{size}")  # ten iterations of the C restatement (tests/_oracle_jobs.appnp_k10)
     assert (got - want).abs().max().item() < TOL
     del got, want
     if size == "L":  # the whole model at L: test_model_gradients_at_benchmark_size_L[appnpstack] (loss over all rows + every
@@ -197,26 +166,16 @@ def test_model_logits_at_sampled_rows_of_the_benchmark_graph(dev, size, name):
 
 # ---- backward at the BASELINE sizes -----------------------------------------------------------------------------
 
-GRAD_KW = dict(MODEL_KW, appnpstack=dict(hidden_unit=64, K=10, alpha=0.1, dropout_rate=0.5))  # config 5 as stated
 GRAD_TOL, GRAD_REL = 1e-4, 2e-3
 
 
 def _hip_training_step(dev, name, ei, x, y, mask, route):
-    """One train-mode forward + backward of the product model on the GPU. route 'kernel_loss': the loss inside the last
-    conv's kernel where the model has that form (what experiment() and bench.py run); 'logits': log-probabilities
-    materialised, NLLLoss on top (what a foreign loop runs). Returns (loss, {name: grad on the CPU}, initial state)."""
-    from rgb_experiment_amd import models as M
+    """One train-mode forward + backward of the product model on the GPU from the seeded initial state
+    (tests/_oracle_jobs.initial_state: the oracle half starts from the same bits). route 'kernel_loss': the loss inside the
+    last conv's kernel where the model has that form (what experiment() and bench.py run); 'logits': log-probabilities
+    materialised, NLLLoss on top (what a foreign loop runs). Returns (loss, {name: grad on the CPU})."""
     from rgb_experiment_amd.models._stack import masked_ce
-    cls = {"gcn": M.GCN, "graphsage": M.GraphSAGE, "graphsage2": M.GraphSAGE2, "gat": M.GAT,
-           "appnpstack": M.APPNPStack}[name]
-    torch.manual_seed(14530529)
-    model = cls(input_dim=128, output_dim=128, **GRAD_KW[name])
-    with torch.no_grad():  # biases and BatchNorm affine parameters off their zero / one initial values
-        g = torch.Generator().manual_seed(5)
-        for k, p in model.named_parameters():
-            if p.dim() == 1:
-                p.add_(0.1 * torch.randn(p.shape, generator=g))
-    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model, _ = J.initial_state(name)
     model.to(dev).train()
     x_d, ei_d, y_d, m_d = x.to(dev), ei.to(dev), y.to(dev), mask.to(dev)
     if route == "kernel_loss":
@@ -226,7 +185,7 @@ def _hip_training_step(dev, name, ei, x, y, mask, route):
     loss.backward()
     torch.cuda.synchronize()
     grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
-    return float(loss.item()), grads, sd
+    return float(loss.item()), grads
 
 
 def _check(rep, loss, ref_loss, what):
@@ -246,43 +205,30 @@ _GRAD_CASES_S = [(n, r) for n in ("gcn", "graphsage", "graphsage2") for r in ("k
 @pytest.mark.parametrize("name,route", _GRAD_CASES_S)
 def test_model_gradients_at_benchmark_size_S(dev, name, route):
     """S (|V| = 200 k, |E| = 4 M, d = 128): every parameter gradient against the FULL oracle (oracle.ref_cpu, the PyG
-    dataflow under torch autograd: edge-sized temporaries of 2 GB each)."""
+    dataflow under torch autograd: edge-sized temporaries of 2 GB each; tests/_oracle_jobs.grads_S)."""
     from rgb_experiment_amd.graph import clear_cache
     ei, x, y = workload("S")
-    n = x.size(0)
-    mask = (torch.arange(n) % 5) < 3
-    loss, grads, sd = _hip_training_step(dev, name, ei, x, y, mask, route)
-    kw = GRAD_KW[name]
-    fwd = {"gcn": lambda p: O.gcn_forward(p, x, ei, 2, True), "graphsage": lambda p: O.graphsage_forward(p, x, ei, 2, True),
-           "graphsage2": lambda p: O.graphsage2_forward(p, x, ei, 2, True),
-           "gat": lambda p: O.gat_forward(p, x, ei, 2, kw.get("heads", 8), True),
-           "appnpstack": lambda p: O.appnp_stack_forward(p, x, ei, kw.get("K"), kw.get("alpha"), True)}[name]
-    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in sd.items()}
-    ref_loss = OL.masked_nll(fwd(ref_sd), y, mask)
-    ref_loss.backward()
+    loss, grads = _hip_training_step(dev, name, ei, x, y, J.train_mask(x.size(0)), route)
+    ref_loss, ref_grads = J.get(f"grads_S_{name}")
     # state_dict lists GATConv's lin_dst.weight next to lin_src.weight (one shared tensor: one parameter, one gradient)
-    rep = OL.compare_grads(grads, {k: ref_sd[k].grad for k in grads})
-    _check(rep, loss, ref_loss.item(), f"S {name} {route}")
+    rep = OL.compare_grads(grads, {k: ref_grads[k] for k in grads})
+    _check(rep, loss, ref_loss, f"S {name} {route}")
     clear_cache()
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "appnpstack"])
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2", "appnpstack", "gat"])
 def test_model_gradients_at_benchmark_size_L(dev, name):
-    """L (|V| = 2 M, |E| = 60 M, d = 128; BASELINE configs 4 and 5 and the headline GCN): every parameter gradient
-    against oracle/large.py — propagate = C restatement over the CSR, its backward = the same over the transposed CSR,
-    dense layers / BatchNorm / loss under CPU autograd."""
+    """L (|V| = 2 M, |E| = 60 M, d = 128; BASELINE configs 3 (at L), 4 and 5 and the headline GCN): every parameter gradient
+    against oracle/large.py — propagate = C restatement over the CSR, its backward = the same over the transposed CSR
+    (GAT: segment softmax + aggregate in C, its adjoint over both CSRs), dense layers / BatchNorm / loss under CPU autograd
+    (tests/_oracle_jobs.grads_L)."""
     from rgb_experiment_amd.graph import clear_cache
     ei, x, y = workload("L")
-    n = x.size(0)
-    mask = (torch.arange(n) % 5) < 3
-    loss, grads, sd = _hip_training_step(dev, name, ei, x, y, mask, "kernel_loss")
+    loss, grads = _hip_training_step(dev, name, ei, x, y, J.train_mask(x.size(0)), "kernel_loss")
     torch.cuda.empty_cache()
-    graph = csr_graph("L", *{"gcn": ("gcn", 1), "appnpstack": ("gcn", 1), "graphsage": ("mean", 2),
-                             "graphsage2": ("mean", 0)}[name])
-    kw = {k: v for k, v in GRAD_KW[name].items() if k in ("num_layers", "K", "alpha")}
-    ref_loss, ref_grads, _ = OL.loss_and_grads(name, sd, x, y, mask, graph, **kw)
-    rep = OL.compare_grads(grads, ref_grads)
+    ref_loss, ref_grads = J.get(f"grads_L_{name}")
+    rep = OL.compare_grads(grads, {k: ref_grads[k] for k in grads})
     _check(rep, loss, ref_loss, f"L {name}")
     clear_cache()
     torch.cuda.empty_cache()

@@ -180,9 +180,12 @@ def run_case(dev, seed, ref_dtype=torch.float32):
         raise RuntimeError(f"{desc}: {exc}") from exc
 
 
+# Seeds in the suite (round 5: 154 of the 795 seeds rounds 3-4 pinned — the first 8 / 10 / 15 of every block, so every kind
+# and every block's shape family stays; the suite had 590 of its 900 s): the others, and thousands beyond, are
+# tools/fuzz_soak.py's (profiles/r05_fuzz_soak.txt; `python tools/fuzz_soak.py 9000 9320`, `--models 0 75`, `--fused 0 400`).
 @pytest.mark.parametrize("block", range(8))
 def test_conv_layers_against_the_oracle_on_random_shapes(dev, block):
-    for seed in range(block * 40, block * 40 + 40):
+    for seed in range(block * 40, block * 40 + 8):
         run_case(dev, 9000 + seed)
 
 
@@ -319,7 +322,7 @@ def run_model_case(dev, seed):
 
 @pytest.mark.parametrize("block", range(3))
 def test_whole_models_against_the_oracle_on_random_shapes(dev, block):
-    for seed in range(block * 25, block * 25 + 25):  # 75 pinned seeds; tools/fuzz_soak.py --models soaked 3,500
+    for seed in range(block * 25, block * 25 + 10):  # tools/fuzz_soak.py --models soaked 3,500
         run_model_case(dev, seed)
 
 
@@ -447,5 +450,5 @@ def run_fused_layer_case(dev, seed):
 
 @pytest.mark.parametrize("block", range(4))
 def test_fused_layer_forms_on_random_shapes(dev, block):
-    for seed in range(block * 100, block * 100 + 100):
+    for seed in range(block * 100, block * 100 + 15):
         run_fused_layer_case(dev, seed)

@@ -1255,8 +1255,6 @@ def test_experiment_cora_shaped_gcn_300_epochs(dev):
     weights. Rounding differences between the two runs are amplified step by step by Adam, so the curve tolerance
     is looser than the per-forward one."""
     import rgb_experiment_amd as R
-    from rgb_experiment_amd.models import GCN
-    from rgb_experiment_amd.utils import get_whole_mask
     n, pairs, f, c = 2708, 5278, 1433, 7
     gen = torch.Generator().manual_seed(1234567)
     a = torch.randint(0, n, (pairs,), generator=gen)
@@ -1271,22 +1269,10 @@ def test_experiment_cora_shaped_gcn_300_epochs(dev):
                        implement_early_stopping=False)
     hist = res["history"]
     assert len(hist["train_loss"]) == 300
-    # the same 300 steps under the oracle's autograd
+    # the same 300 steps under the oracle's autograd (tests/_oracle_jobs.cora300: from the background run when it is there)
+    import _oracle_jobs as J
+    losses = J.get("cora300")
     xn = x / x.sum(1, keepdim=True).clamp(min=1)
-    train_mask = get_whole_mask(y, "6-2-2", 123456789)[0]
-    torch.manual_seed(14530529)
-    ref = GCN(num_layers=2, hidden_unit=64, input_dim=f, output_dim=c, dropout_rate=0.5)
-    params = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in ref.state_dict().items()}
-    names = [k for k, _ in ref.named_parameters()]
-    opt = torch.optim.Adam([params[k] for k in names], lr=0.01)
-    losses = []
-    for _ in range(300):
-        opt.zero_grad()
-        out = O.gcn_forward(params, xn, ei, 2, training=True)["out"]
-        loss = torch.nn.functional.nll_loss(out[train_mask], y[train_mask])
-        loss.backward()
-        opt.step()
-        losses.append(loss.item())
     diff = max(abs(p - q) for p, q in zip(hist["train_loss"], losses))
     assert diff < 5e-3, diff
     assert abs(hist["train_loss"][0] - losses[0]) < 1e-5 and hist["train_loss"][-1] < hist["train_loss"][0]

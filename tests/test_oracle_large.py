@@ -12,6 +12,8 @@ CASES = {
     "graphsage": (lambda sd, x, ei, tr: O.graphsage_forward(sd, x, ei, 2, tr), dict(num_layers=2)),
     "graphsage2": (lambda sd, x, ei, tr: O.graphsage2_forward(sd, x, ei, 2, tr), dict(num_layers=2)),
     "appnpstack": (lambda sd, x, ei, tr: O.appnp_stack_forward(sd, x, ei, 10, 0.1, tr), dict(K=10, alpha=0.1)),
+    # (GATConv: ref_cpu's own statement is unpinnable here — PyG semantics, nothing in the reference to check it against)
+    "gat": (lambda sd, x, ei, tr: O.gat_forward(sd, x, ei, 2, 4, tr), dict(num_layers=2, heads=4)),
 }
 
 
@@ -34,6 +36,12 @@ def _state(name, f, hid, c, gen):
         for i, (o, k) in enumerate([(hid, f), (c, hid)]):
             sd.update({f"convs.{i}.lin_l.weight": r(o, k), f"convs.{i}.lin_l.bias": 0.1 * r(o),
                        f"convs.{i}.lin_r.weight": r(o, k)})
+        sd.update(bn("bns.0.", hid))
+    elif name == "gat":  # 4 heads x hid / 4 channels, then one head of c
+        H = 4
+        sd = {"convs.0.lin_src.weight": r(hid, f), "convs.0.att_src": r(1, H, hid // H), "convs.0.att_dst": r(1, H, hid // H),
+              "convs.0.bias": 0.1 * r(hid), "convs.1.lin_src.weight": r(c, hid), "convs.1.att_src": r(1, 1, c),
+              "convs.1.att_dst": r(1, 1, c), "convs.1.bias": 0.1 * r(c)}
         sd.update(bn("bns.0.", hid))
     else:
         sd = {"lin1.weight": r(hid, f), "lin1.bias": 0.1 * r(hid), "lin2.weight": r(c, hid), "lin2.bias": 0.1 * r(c)}
