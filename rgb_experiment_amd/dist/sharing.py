@@ -17,9 +17,11 @@ import os
 
 
 def rccl_env(rank):
-    """Variables a rank sets BEFORE the communicator is created (they are read at RCCL's init)."""
-    return {"NCCL_HOSTID": f"rgbx-shared-device-rank{rank}", "NCCL_SOCKET_IFNAME": "lo", "NCCL_IB_DISABLE": "1",
-            "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    """Variables a rank sets BEFORE the communicator is created (the NCCL_* variables are read at RCCL's init, which is later
+    than this process's first GPU call). HSA_ENABLE_IPC_MODE_LEGACY is NOT among them: the HSA runtime reads it when it starts,
+    i.e. before anything here can run — the launcher's environment has to carry it (bench.py sets it before `import torch`,
+    the image exports it; a re-exec of a process that has touched the GPU is not an option on this pool)."""
+    return {"NCCL_HOSTID": f"rgbx-shared-device-rank{rank}", "NCCL_SOCKET_IFNAME": "lo", "NCCL_IB_DISABLE": "1"}
 
 
 def share_a_device(identities):

@@ -40,12 +40,24 @@ def _coalesce_device(edge_index, num_nodes, mirror):
     return out
 
 
+def _check_range(edge_index, num_nodes):
+    """The CPU path refuses what the device path refuses (rgbx_coalesce_keys_i64 counts endpoints outside [0, N) and the
+    result is discarded): the keys row * N + col of such an edge would alias another pair's. The reference's helpers
+    (torch_sparse.coalesce, to_undirected [PyG]) produce a silent wrong result there; one behaviour on both devices."""
+    if edge_index.numel():
+        lo, hi = int(edge_index.min()), int(edge_index.max())
+        if lo < 0 or hi >= num_nodes:
+            bad = int(((edge_index < 0) | (edge_index >= num_nodes)).sum())
+            raise RuntimeError(f"edge_index has {bad} endpoints outside [0, {int(num_nodes)})")
+
+
 def coalesce(edge_index, num_nodes):
     """Sort edges by (row, col) and drop duplicates."""
     if edge_index.numel() == 0:
         return edge_index
     if edge_index.is_cuda:
         return _coalesce_device(edge_index, num_nodes, False)
+    _check_range(edge_index, num_nodes)
     key = edge_index[0] * num_nodes + edge_index[1]
     key = torch.unique(key, sorted=True)
     return torch.stack([torch.div(key, num_nodes, rounding_mode="floor"), key % num_nodes])

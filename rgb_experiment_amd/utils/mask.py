@@ -59,18 +59,19 @@ def check_train_containing(train_mask, y):
     return bool(torch.isin(labels[labels != -1], present).all())
 
 
-def get_whole_mask(y, ratio, seed=1234567):
+def get_whole_mask(y, ratio, seed=1234567, max_seed_tries=20000):
     """Ratio split over all labelled nodes; the seed is bumped by one until the train part holds
-    every class (reference utils/mask.py:10-22)."""
+    every class (reference utils/mask.py:10-22). `max_seed_tries` (an addition): seeds tried before giving up with a
+    ValueError; None = the reference's unbounded loop (splits that are feasible but rare)."""
     labelled = torch.arange(len(y), dtype=torch.int64)[y != -1]
     classes, first_seed = None, seed
     while True:
         masks = get_order(ratio, labelled, len(y), seed)
         if check_train_containing(masks[0], y):
             return masks
-        if seed - first_seed >= 20000:
+        if max_seed_tries is not None and seed - first_seed >= max_seed_tries:
             # feasible on paper, hopeless in practice (130 classes of two nodes each and a 60 % train part: one seed in 1e10)
-            raise ValueError(f"get_whole_mask: 20000 seeds tried from {first_seed}, none puts every class into the train "
+            raise ValueError(f"get_whole_mask: {max_seed_tries} seeds tried from {first_seed}, none puts every class into the train "
                              f"part of ratio {ratio!r} (the reference's loop over seeds would never end in practice)")
         if classes is None:
             # no seed can succeed when the train part has fewer rows than there are classes: the reference spins here for

@@ -915,12 +915,14 @@ def runner_fuzz_worker(rank, world, port, out_dir, seeds, own_group=True):
                   if "lin_dst" not in k}
         trainable = [k for k, _ in model.named_parameters() if "lin_dst" not in k]
         opt = torch.optim.Adam([params[k] for k in trainable], lr=0.01)
-        want = []
+        want, g_first = [], None
         for _ in range(2):
             opt.zero_grad()
             out = fwd(params, True)["out"]
             loss = nll(out[masks[0]], y[masks[0]])
             loss.backward()
+            if g_first is None:  # the first backward's gradients: what the distributed backward is held to, tightly (below)
+                g_first = {k: params[k].grad.detach().clone() for k in trainable}
             opt.step()
             with torch.no_grad():
                 ev = fwd(params, False)["out"]
@@ -945,6 +947,29 @@ def runner_fuzz_worker(rank, world, port, out_dir, seeds, own_group=True):
             else:
                 r = DistRunner(model, ei, x, y, masks, rank, world, torch.device("cpu"), lr=0.01, comm=Comm(),
                                backend=OracleAggregator(), exchange=exchange, pieces=pieces, pieces_in=pieces or 1)
+            #  the distributed BACKWARD on its own, before any optimizer step: halo / transposed exchanges of
+            # the gradient rows, the all-reduce of the parameter gradients — held to the oracle's first-step gradients at the
+            # single-GPU gradient tests' bound, where the loss after an Adam step (below) can only take a gross-error bound.
+            # The probe's forward moves BatchNorm's running statistics: the state is put back before the epochs run.
+            import copy
+            inner = r.inner if split else r
+            if not split or r.role == "train":
+                keep = copy.deepcopy(inner.model.state_dict())
+                inner._forward_backward()
+                inner._sync_grads()
+                from oracle import large as OL
+                got = {k: p.grad.detach().clone() for k, p in inner.model.named_parameters() if "lin_dst" not in k and p.grad is not None}
+                rep = OL.compare_grads(got, {k: g_first[k] for k in got})
+                if rep["max_rel"] > float(os.environ.get("RGBX_FUZZ_GRAD_REL", "2e-3")) and rep["max_vs_bound"] > 1e-5:
+                    bad.append((desc, f"first backward: gradient of {rep['worst']} off by {rep['max_rel']:.2e} of its scale "
+                                      f"({rep['max_abs']:.2e} absolute)", getattr(r, "engine", None) is not None))
+                if "grad" in os.environ.get("RGBX_FUZZ_SHOW", ""):
+                    print(f"[rank {rank}] {desc}: first-backward gradients max_rel {rep['max_rel']:.2e} "
+                          f"max_abs {rep['max_abs']:.2e} ({rep['worst']})", flush=True)
+                inner.model.load_state_dict(keep)
+                inner.opt.zero_grad(set_to_none=False)
+                if getattr(inner, "engine", None) is not None:
+                    inner.engine.discard_speculation()
             hist = [r.epoch(more=True), r.epoch()]
             if split:
                 r.discard_speculation()

@@ -103,7 +103,7 @@ CASES = [("gcn", 2, "halo"), ("gcn", 3, "halo"), ("graphsage", 2, "halo"), ("app
          ("gat@lopsided", 3, "auto"), ("appnpstack@lopsided", 4, "reshard"), ("gcn_wide@lopsided", 3, "replicate")]
 
 
-if os.environ.get("RGBX_DIST_SWEEP"):  # one-off sweep (tools/gpu4/call75.sh): every case again on the lopsided and the hub problem
+if os.environ.get("RGBX_DIST_SWEEP"):  # one-off sweep (RGBX_DIST_SWEEP=1 pytest tests/test_gpu_dist.py): every case again on the lopsided and the hub problem
     CASES = CASES + [(f"{m}@{v}", w, x) for m, w, x in CASES if "@" not in m for v in ("lopsided", "hub")]
 
 

@@ -371,3 +371,50 @@ def test_whole_mask_with_more_classes_than_training_rows_raises_instead_of_spinn
     y2 = torch.arange(400) % 3  # feasible: returns after a few seeds at most
     tr, va, te = M.get_whole_mask(y2, "6-2-2", seed=1)
     assert M.check_train_containing(tr, y2) and int(tr.sum() + va.sum() + te.sum()) == 400
+
+
+def test_whole_mask_seed_cap_is_a_keyword():
+    """max_seed_tries: the cap on the reference's unbounded loop over seeds is the caller's to set; None
+    restores the reference's behaviour (not exercised to the end here: it would not return)."""
+    import pytest
+    import torch
+
+    from rgb_experiment_amd.utils import mask as M
+    y = torch.cat([torch.zeros(300, dtype=torch.int64), torch.tensor([1, 1])])  # class 1: two nodes, 60 % train part
+    fails = lambda s: not M.check_train_containing(M.get_order("6-2-2", torch.arange(302), 302, s)[0], y)
+    first = next(s for s in range(1, 2000) if fails(s) and fails(s + 1) and fails(s + 2))
+    with pytest.raises(ValueError, match="2 seeds tried"):
+        M.get_whole_mask(y, "6-2-2", seed=first, max_seed_tries=2)  # seed, seed + 1, seed + 2 all fail
+    tr, _, _ = M.get_whole_mask(y, "6-2-2", seed=first, max_seed_tries=None)  # the reference's loop: ends at the first good seed
+    assert M.check_train_containing(tr, y)
+
+
+def test_the_shuffle_leaves_the_module_generator_seeded_but_not_advanced():
+    """The reference's `random.seed(seed); random.shuffle(...)` leaves the module-level generator seeded AND advanced by the
+    shuffle's draws; the C++ restatement leaves it seeded only (documented in utils/mask._py_shuffled_range: nothing on the
+    path draws from it before the next reseed). Pinned here so that a caller who starts to depend on the difference sees it."""
+    import random
+
+    from rgb_experiment_amd.utils import mask as M
+    M._py_shuffled_range(1000, 7)
+    after_native = random.getstate()
+    random.seed(7)
+    assert after_native == random.getstate()  # seeded, not advanced
+    ref = list(range(1000))
+    random.shuffle(ref)
+    assert random.getstate() != after_native  # what CPython's own shuffle would have left
+
+
+def test_edge_edits_refuse_out_of_range_endpoints_on_the_cpu_too():
+    """coalesce / to_undirected: an endpoint outside [0, N) is an error on the CPU path as on the device path (one behaviour
+    wherever the tensor lives; the reference's helpers alias such keys silently)."""
+    import pytest
+    import torch
+
+    from rgb_experiment_amd.utils import coalesce, to_undirected
+    ei = torch.tensor([[0, 1, 5], [1, 2, 0]])
+    with pytest.raises(RuntimeError, match="1 endpoints outside"):
+        coalesce(ei, 4)
+    with pytest.raises(RuntimeError, match="outside"):
+        to_undirected(torch.tensor([[0, -1], [1, 2]]), 4)
+    assert to_undirected(ei, 6).size(1) == 6
