@@ -401,6 +401,19 @@ int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const float* rden,
                           const float* out_pos, const float* a_pos, float slope, float* g_a_dst,
                           int64_t N, int H, int C, rgbx_stream_t stream);
 
+/* Hub targets only (the rows of `split`, the FORWARD CSR's row-split plan; no plan / no hub row: a no-op): overwrites
+ * g_a_dst[i, :] of rgbx_gat_bwd_prep_f32 for those rows with the sum taken edge by edge,
+ *   g_a_dst[i,h] = sum_p alpha_p (<gout_i, h_j> - dsum_i) lrelu'(s_p)     (alpha, dsum from `nodeq` as the source pass reads them),
+ * because the per-node form (1 - slope)(<gout_i, out_pos_i> - dsum_i a_pos_i) cancels for targets with thousands of in-edges
+ * (out_pos / a_pos -> out): float32 rounding of the two aggregates becomes 1e-4 .. 1e-3 of the difference there, where the
+ * reference's autograd (GATConv [PyG] behind models/gat.py:28,30; itexperiments.py:439) sums the edges. Call between
+ * rgbx_gat_bwd_prep_f32 and rgbx_gat_bwd_src_f32. `a_src` ([n_src, H]) or, when NULL, `att_src` ([H, C]: the source score is
+ * formed from the gathered row). split->partial: n_chunks * H floats. Chunk sums are added in chunk order (reproducible). */
+int rgbx_gat_bwd_dst_hubs_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat, int64_t ldh,
+                              const float* a_src, const float* att_src, const float* nodeq, const float* gout,
+                              int64_t ldg, float* g_a_dst, int64_t N, int H, int C, float slope,
+                              const rgbx_row_split_t* split, rgbx_stream_t stream);
+
 /* Backward, source side, over the TRANSPOSED CSR (rows = sources j, col = targets i):
  *   g_hfeat[j,h,:] = sum_{p: j->i} alpha_p * gout[i,h,:]
  *   ds_p[h]        = alpha_p * (<gout[i,h,:], hfeat[j,h,:]> - dsum[i,h]) * lrelu'(s_p)

@@ -1282,6 +1282,16 @@ def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope, 
             lib.rgbx_gat_bwd_prep_f32(_lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, _lib.ptr(bias), pg, ldg,
                                       _lib.ptr(nodeq), _lib.ptr(opos), _lib.ptr(apos), float(slope), _lib.ptr(g_ad),
                                       N, H, C, _lib.stream_ptr()), "rgbx_gat_bwd_prep_f32")
+    if per_node and g.fwd.split is not None:
+        # hub TARGETS: the per-node g_a_dst cancels there (thousands of in-edges: out_pos / a_pos -> out); taken edge by edge
+        # for those rows alone (rgbx_gat_bwd_dst_hubs_f32), before the source pass folds g_a_dst into g_hfeat
+        hsplit, _hscratch = g.fwd.split_arg(H, dev)
+        with _Timed("gat_bwd_dst_hubs"):
+            _lib.check(
+                lib.rgbx_gat_bwd_dst_hubs_f32(_lib.ptr(g.fwd.rowptr), _lib.ptr(g.fwd.col), ph, ldh, _lib.ptr(a_src),
+                                              _lib.ptr(att2) if a_src is None else None, _lib.ptr(nodeq), pg, ldg,
+                                              _lib.ptr(g_ad), N, H, C, float(slope), ctypes.byref(hsplit),
+                                              _lib.stream_ptr()), "rgbx_gat_bwd_dst_hubs_f32")
     split, _scratch = g.bwd.split_arg(H * C + 2 * H, dev)
     with _Timed("gat_bwd_src"):
         _lib.check(

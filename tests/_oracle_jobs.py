@@ -177,7 +177,7 @@ for _s in ("S", "L"):
 GROUPS = {
     "small": ["cora300", "fused_expect_S", "appnp_k10_S"] + [f"grads_S_{n}" for n in ("gcn", "graphsage", "graphsage2", "gat",
                                                                                        "appnpstack")],
-    "large": [f"grads_L_{n}" for n in ("gcn", "graphsage", "graphsage2", "appnpstack", "gat")] + ["fused_expect_L", "appnp_k10_L"],
+    "large": ["fused_expect_L", "appnp_k10_L"] + [f"grads_L_{n}" for n in ("gcn", "appnpstack", "graphsage", "graphsage2", "gat")],
 }
 
 

@@ -19,10 +19,18 @@ def pytest_collection_modifyitems(config, items):
     parity modules from running. The BASELINE-size module runs just before it, its S cases before its L cases: the oracle
     halves of those cases are computed on the host cores in the background from session start (oracle_background below),
     while the GPU-bound modules run. (Stable sort: everything else keeps its order.)"""
+    # L cases of the BASELINE-size module in the order the background run finishes their oracle halves: first the cases
+    # whose oracle runs inline on sampled rows, then tests/_oracle_jobs.GROUPS["large"]'s order
+    l_order = ["test_model_logits_at_sampled_rows", "test_fused_aggregate_transform", "test_appnp_k10",
+               "benchmark_size_L[gcn]", "benchmark_size_L[appnpstack]", "benchmark_size_L[graphsage]",
+               "benchmark_size_L[graphsage2]", "benchmark_size_L[gat]"]
+
     def key(it):
         base = it.fspath.basename
-        return (base == "test_gpu_dist.py", base == "test_gpu_fullsize.py", base == "test_gpu_fullsize.py" and "L" in
-                it.name.partition("[")[2].replace("]", "").split("-"))
+        full = base == "test_gpu_fullsize.py"
+        at_l = full and ("benchmark_size_L" in it.name or "L" in it.name.partition("[")[2].replace("]", "").split("-"))
+        rank = next((i for i, tag in enumerate(l_order) if tag in it.name), len(l_order)) if at_l else 0
+        return (base == "test_gpu_dist.py", full, at_l, rank)
     items.sort(key=key)
 
 
@@ -46,11 +54,14 @@ def oracle_background(request):
     d = tempfile.mkdtemp(prefix="rgbx_oracle_bg_")
     env = dict(os.environ)
     # CPU only, a share of the host cores each (a one-GPU box has 16): the foreground keeps the rest for its own small oracles
-    env.update({"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": "", "OMP_NUM_THREADS": "6", "MKL_NUM_THREADS": "6"})
+    env.update({"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
     groups = ["small", "large"] if "test_gpu_fullsize.py" in wanted else ["small"]
+    cores = os.cpu_count() or 8
+    threads = {"small": max(2, cores // 4), "large": max(4, cores * 5 // 8)}  # 16 cores: 4 + 10, two left to the foreground
     procs = []
     for group in groups:
-        p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_oracle_jobs.py"), d, group], env=env,
+        env_g = dict(env, OMP_NUM_THREADS=str(threads[group]), MKL_NUM_THREADS=str(threads[group]))
+        p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_oracle_jobs.py"), d, group], env=env_g,
                              stdout=subprocess.DEVNULL, stderr=open(os.path.join(d, f"{group}.err"), "w"))
         with open(os.path.join(d, f"{group}.pid"), "w") as f:
             f.write(str(p.pid))
@@ -62,6 +73,13 @@ def oracle_background(request):
         if p.poll() is None:
             p.kill()
         p.wait()
+    out = os.path.join(ROOT, "gpurun_out")  # the jobs' timings (seconds per job) next to the run's other scratch records
+    if os.path.isdir(out):
+        for group in groups:
+            try:
+                shutil.copy(os.path.join(d, f"{group}.log"), os.path.join(out, f"oracle_bg_{group}.log"))
+            except OSError:
+                pass
     shutil.rmtree(d, ignore_errors=True)
 
 

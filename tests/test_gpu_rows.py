@@ -392,3 +392,35 @@ def test_align_rows_layout(dev):
     assert d == 1433 and p.shape == (1000, 1436) and p.data_ptr() == v.data_ptr() and torch.equal(p[:, 1433:], torch.zeros(1000, 3, device=dev))
     y = torch.randn(10, 64, device=dev)
     assert ops.align_rows(y) is y
+
+
+def test_gat_gradients_around_a_hub_target(dev):
+    """A 4-layer GAT (8 heads x 16) on 100 nodes around ONE target with 3,617 in-edges (round 4's soak, seed 2528: first-layer
+    attention gradients 7e-4 of their scale off): every parameter gradient against the oracle computing in float64, within
+    1e-4 of the gradient's own scale. The per-node form of the target-side score gradient cancels on such a target; hub
+    targets take it edge by edge (rgbx_gat_bwd_dst_hubs_f32)."""
+    from oracle import large as OL
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.graph import get_graph
+    n, f, c, layers, heads = 100, 33, 3, 4, 8
+    gen = torch.Generator().manual_seed(2528)
+    ei = torch.cat([torch.randint(0, n, (2, 2183), generator=gen),
+                    torch.stack([torch.randint(0, n, (3617,), generator=gen), torch.full((3617,), 17)])], dim=1)
+    x = torch.randn(n, f, generator=gen)
+    y = torch.randint(0, c, (n,), generator=gen)
+    mask = torch.rand(n, generator=gen) < 0.6
+    torch.manual_seed(7)
+    model = M.GAT(num_layers=layers, hidden_unit=16, heads=heads, input_dim=f, output_dim=c, dropout_rate=0.5)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    ref = {k: v.requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in ref.items()}
+    out = O.gat_forward(ref, x.double(), ei, layers, heads, True)["out"]
+    torch.nn.functional.nll_loss(out[mask], y[mask]).backward()
+    model.to(dev).train()
+    assert get_graph(ei.to(dev), n, 2).fwd.split is not None  # the hub target is a row of the split plan
+    loss, _ = model.masked_ce(x.to(dev), ei.to(dev), y.to(dev), mask.to(dev))
+    loss.backward()
+    got = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
+    rep = OL.compare_grads(got, {k: ref[k].grad.float() for k in got})
+    print(f"GAT around a hub target: gradients max_rel {rep['max_rel']:.2e} ({rep['worst']}), max_abs {rep['max_abs']:.2e}")
+    assert rep["max_rel"] < 1e-4, rep
