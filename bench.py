@@ -674,7 +674,7 @@ def cora_shaped(dev, epochs=60):
     return out
 
 
-def real_shape_block(dev, ei, N, F, C, names, steps, warmup):
+def real_shape_block(dev, ei, N, F, C, names, steps, warmup, features="dense", sparse_ok=True):
     """The epoch on the shapes the reference actually ships (initial_params.py:25-29: 2 layers, hidden 64; F > hidden > C
     with C = 7 on Cora, 40 on ogbn-arxiv — 最终结果.csv), on the graph of workload L: every layer transforms first and
     gathers at its OUTPUT width (64, then C padded to a multiple of 4), BatchNorm's column sums and the masked
@@ -684,12 +684,21 @@ def real_shape_block(dev, ei, N, F, C, names, steps, warmup):
     from rgb_experiment_amd import ops
     from rgb_experiment_amd.graph import clear_cache, get_graph
     gen = torch.Generator(device=dev).manual_seed(1234570)
-    x = ops.align_rows(torch.randn((N, F), generator=gen, device=dev))  # as experiment() lays the features out
+    if features == "bag_of_words":  # SURVEY 8d config 1's Cora-shaped features at this size: 18 ones per row, row-normalised
+        x = torch.zeros((N, F), device=dev)
+        x.scatter_(1, torch.randint(0, F, (N, 18), generator=gen, device=dev), 1.0)
+        x = x / x.sum(1, keepdim=True)
+    else:
+        x = torch.randn((N, F), generator=gen, device=dev)
+    # as experiment() lays the features out: 16-byte rows; non-zeros as a CSR when they are few (ops.prepare_features)
+    x = ops.prepare_features(x) if sparse_ok else ops.align_rows(x)
     y = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(1234571))
     masks = split_masks(y)
     out = {"nodes": N, "edges_in": int(ei.size(1)), "features": F, "hidden": 64, "classes": C,
-           "what": "reference default hyper-parameters (initial_params.py:25-29) on workload L's graph; features ~ N(0, 1) "
-                   "drawn on the device", "models": {}}
+           "feature_values": features, "features_multiplied_over_nonzeros": getattr(x, "_rgbx_sparse", None) is not None,
+           "what": "reference default hyper-parameters (initial_params.py:25-29) on workload L's graph; features drawn on the "
+                   "device: 'bag_of_words' = 18 ones per row, row-normalised (what the reference's citation datasets look "
+                   "like; experiment() multiplies such features over their non-zeros), 'dense' ~ N(0, 1)", "models": {}}
     for name in names:
         torch.manual_seed(14530529)
         kwargs, n_prop, loops_mode, kind = MODELS[name]
@@ -935,7 +944,7 @@ def main():
     ap.add_argument("--degree", choices=("uniform", "powerlaw"), default="uniform",
                     help="powerlaw: secondary run on a hub-heavy graph of the same size (row-split plans at work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--real-shape", default=None, metavar="MODEL:F:C",
+    ap.add_argument("--real-shape", default=None, metavar="MODEL:F:C[:bag_of_words|dense]",
                     help="run ONLY the real-shape block (bench.real_shape_block) for one model on workload L's graph, "
                          "e.g. gcn:1433:7 — the command profiled under rocprofv3 for profiles/r05_real_shape_*")
     ap.add_argument("--primary-only", action="store_true",
@@ -1000,10 +1009,10 @@ def main():
     ei, x, y = synth(N, E, d, args.degree)
     sv.beat("synthetic graph drawn")
     if args.real_shape:
-        name, F, C = args.real_shape.split(":")
+        name, F, C, *kind = args.real_shape.split(":")
         del x
-        print(json.dumps({"real_shape": real_shape_block(dev, ei, N, int(F), int(C), [name], args.steps, args.warmup)}),
-              flush=True)
+        print(json.dumps({"real_shape": real_shape_block(dev, ei, N, int(F), int(C), [name], args.steps, args.warmup,
+                                                         features=kind[0] if kind else "dense")}), flush=True)
         return
     train_mask, val_mask, test_mask = split_masks(y)
     sv.beat("masks split")
@@ -1448,8 +1457,10 @@ def main():
         def real_shape_leg():
             # the reference's own shapes (in > out, small odd class counts): never the fused aggregate+transform kernel
             names = ("gcn", "graphsage", "graphsage2")
-            return {"F1433_C7": real_shape_block(dev, ei, N, 1433, 7, names, max(3, args.steps // 2), 2),
-                    "F128_C40": real_shape_block(dev, ei, N, 128, 40, names, max(3, args.steps // 2), 2)}
+            k = max(3, args.steps // 2)
+            return {"F1433_C7_bag_of_words": real_shape_block(dev, ei, N, 1433, 7, names, k, 2, "bag_of_words"),
+                    "F1433_C7_dense": real_shape_block(dev, ei, N, 1433, 7, ("gcn",), k, 2, "dense"),
+                    "F128_C40_dense": real_shape_block(dev, ei, N, 128, 40, names, k, 2, "dense")}
 
         secondary("identical_results_same_run", identical_leg)
         if isinstance(result.get("identical_results_same_run"), dict) and "epochs_per_s" in result["identical_results_same_run"]:

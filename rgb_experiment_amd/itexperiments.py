@@ -301,9 +301,10 @@ def experiment(model_init_param: dict, *,
         features = _normalize_features(features, normalize_feature, normalize_feature_method)
     if dist_ctx is None and features.is_cuda:
         # F = 1433 (Cora) rows start on 4-byte boundaries only: kept at a row stride of 1436 floats every dense product over
-        # the features (x W^T forward, dW = dY^T x backward) reads them with 16-byte loads (ops.align_rows: same values)
+        # the features (x W^T forward, dW = dY^T x backward) reads them with 16-byte loads; bag-of-words features (Cora:
+        # 1.3 % non-zeros) are multiplied over their non-zeros alone (ops.prepare_features: same values, same sums)
         from . import ops
-        features = ops.align_rows(features)
+        features = ops.prepare_features(features)
 
     if need_to_reappear:  # reference :305-310
         random.seed(reappear_seed)

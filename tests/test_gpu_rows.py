@@ -166,7 +166,10 @@ class _GatherSpy:
         raw, epi, appnp = ops.spmm_raw, ops.spmm_epilogue_raw, ops.appnp_raw
 
         def spy_raw(csr, w, rs, x, *a, **k):
-            self.calls.append((x.size(1), None, True))
+            if str(k.get("kind", "")).startswith("features"):  # x W^T over the features' non-zeros: not a graph gather
+                self.feature_products = getattr(self, "feature_products", 0) + 1
+            else:
+                self.calls.append((x.size(1), None, True))
             return raw(csr, w, rs, x, *a, **k)
 
         def spy_epi(csr, w, rs, x, *a, **k):
@@ -215,10 +218,13 @@ def test_models_at_the_reference_default_shapes(dev, name, C, monkeypatch):
     spy = _GatherSpy(monkeypatch)
     model.to(dev).train()
     xd, eid, yd, md, mbd = x.to(dev), ei.to(dev), y.to(dev), mask.to(dev), mask_b.to(dev)
-    if C in (7, 47):  # the layout experiment() gives the features: rows on 16-byte boundaries (stride 1436)
-        from rgb_experiment_amd import ops
+    from rgb_experiment_amd import ops
+    if C == 47:  # rows on 16-byte boundaries (stride 1436), dense products
         xd = ops.align_rows(xd)
         assert xd.stride(0) == 1436 and xd.shape == (n, f)
+    elif C in (3, 7):  # what experiment() does with such features: aligned rows + products over the non-zeros alone
+        xd = ops.prepare_features(xd)
+        assert xd.stride(0) == 1436 and getattr(xd, "_rgbx_sparse", None) is not None
     loss, stats = model.masked_ce(xd, eid, yd, md)
     assert type(loss.grad_fn).__name__ == grad_fn  # the loss came out of the gather kernel
     loss.backward()
@@ -424,3 +430,33 @@ def test_gat_gradients_around_a_hub_target(dev):
     rep = OL.compare_grads(got, {k: ref[k].grad.float() for k in got})
     print(f"GAT around a hub target: gradients max_rel {rep['max_rel']:.2e} ({rep['worst']}), max_abs {rep['max_abs']:.2e}")
     assert rep["max_rel"] < 1e-4, rep
+
+
+@pytest.mark.parametrize("n,f,out,density", [(3000, 1433, 64, 0.0126), (2708, 1433, 128, 0.0126), (500, 40, 8, 0.05),
+                                             (64, 300, 7, 0.0), (1500, 33, 32, 0.09)])
+def test_linear_over_the_nonzeros_of_sparse_features(dev, n, f, out, density):
+    """ops.prepare_features + ops.linear: x W^T + b and dW, db from the non-zeros of a static feature matrix (two launches of
+    the row-gather kernel) against the dense product in float64; empty rows, a dense row and a feature nobody has included."""
+    from rgb_experiment_amd import ops
+    gen = torch.Generator().manual_seed(n + f)
+    x = (torch.rand(n, f, generator=gen) < density).float() * torch.rand(n, f, generator=gen)
+    if density:
+        x[3] = torch.rand(f, generator=gen)  # one dense row
+        x[5] = 0                             # one empty row
+        x[:, 2] = 0                          # one feature without a non-zero
+    W = torch.randn(out, f, generator=gen, requires_grad=True)
+    b = torch.randn(out, generator=gen, requires_grad=True)
+    gy = torch.randn(n, out, generator=gen)
+    want = x.double() @ W.double().t() + b.double()
+    want.backward(gy.double())
+    xd = ops.prepare_features(x.to(dev))
+    assert getattr(xd, "_rgbx_sparse", None) is not None and torch.equal(xd, x.to(dev))
+    Wd, bd = W.detach().to(dev).requires_grad_(True), b.detach().to(dev).requires_grad_(True)
+    got = ops.linear(xd, Wd, bd)
+    assert type(got.grad_fn).__name__ == "_SparseRowsLinearBackward"
+    got.backward(gy.to(dev))
+    assert (got.detach().cpu().double() - want.detach()).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+    assert (Wd.grad.cpu().double() - W.grad).abs().max().item() < 1e-5 * max(1.0, W.grad.abs().max().item())
+    assert (bd.grad.cpu().double() - b.grad).abs().max().item() < 1e-4 * max(1.0, b.grad.abs().max().item())
+    dense = torch.randn(50, 16, device=dev)
+    assert getattr(ops.prepare_features(dense), "_rgbx_sparse", None) is None  # dense features stay dense

@@ -29,7 +29,7 @@ case "$job" in
       timeout -k 10 900 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_${label}_$c" -o "$label" --output-format csv -- python3 bench.py "$@" > "$OUT/pmc_${label}_$c.json" 2> "$OUT/pmc_${label}_$c.err" || exit $?
     done
     python3 tools/profile_summary.py pmc "$OUT/pmc_${label}_FETCH_SIZE" "$OUT/pmc_${label}_WRITE_SIZE" --out "$OUT/pmc_${label}_hbm.csv" --cmd "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py $*"
-    python3 tools/profile_summary.py traffic --fetch "$OUT/pmc_${label}_FETCH_SIZE" --write "$OUT/pmc_${label}_WRITE_SIZE" --kernel "$kernel" --workload "$workload" --model "$model" --out "$OUT/pmc_traffic_${workload}_${model}.json"
+    python3 tools/profile_summary.py traffic --fetch "$OUT/pmc_${label}_FETCH_SIZE" --write "$OUT/pmc_${label}_WRITE_SIZE" --kernel "$kernel" --workload "$workload" --model "$model" --measured "$(date -u +%Y-%m-%d), round 5 (tools/gpu5/run.sh pmc), one MI355X box of the pool ($(hostname)); python3 bench.py $*" --out "$OUT/pmc_traffic_${workload}_${model}.json"
     head -n 20 "$OUT/pmc_${label}_hbm.csv"; cat "$OUT/pmc_traffic_${workload}_${model}.json" ;;
   py)           # py <label> <script args...>
     label="$1"; shift

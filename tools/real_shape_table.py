@@ -6,7 +6,8 @@ import sys
 
 def show(tag, block):
     for name, m in block["models"].items():
-        print(f"{tag} {name}: F={block['features']} C={block['classes']} peak {m['hbm_allocated_peak_gb']:.2f} GB")
+        print(f"{tag} {name}: F={block['features']} ({block.get('feature_values', 'dense')}, over non-zeros: "
+              f"{block.get('features_multiplied_over_nonzeros', False)}) C={block['classes']} peak {m['hbm_allocated_peak_gb']:.2f} GB")
         for lab in ("reference_epoch", "identical_results_epoch"):
             e = m[lab]
             print(f"  {lab}: {e['ms_per_epoch']:.2f} ms/epoch (timed launches {e['timed_launches_ms_per_epoch']:.2f})")
