@@ -41,6 +41,7 @@ class CsrGraph:
         ids = torch.arange(ei.size(1))
         self.rowptr, self.col, perm = O.csr_from_edges(ei[1], ei[0], ids, n)
         self.rowptr_t, self.col_t, perm_t = O.csr_from_edges(ei[0], ei[1], ids, n)
+        self._perm, self._perm_t, self._loops_mode = perm, perm_t, (1 if kind == "gcn" else 2 if kind == "gat" else loops_mode)
         if kind == "gcn":
             self.w = w[perm.long()].contiguous()
             self.w_t = w[perm_t.long()].contiguous()
@@ -54,6 +55,19 @@ class CsrGraph:
             self.w = None  # the C function's own mean
             self.w_t = (1.0 / cnt)[self.col_t.long()].contiguous()  # slot of source j holds target i: 1 / count_i
         self.nnz = int(ei.size(1))
+
+    def as_gat(self):
+        """The 'gat' graph over the same rewritten edge list (a 'mean' graph with loops_mode 2: GATConv and my_SAGEConv both
+        remove + add self-loops): the CSRs are shared, only fwd_slot is added — two stable groupings of 62 M keys saved."""
+        if self.kind != "mean" or self._loops_mode != 2:
+            raise ValueError("as_gat: needs a 'mean' graph built with loops_mode 2")
+        import copy
+        g = copy.copy(self)
+        g.kind, g.w, g.w_t = "gat", None, None
+        inv = torch.empty(self.nnz, dtype=torch.int64)
+        inv[self._perm.long()] = torch.arange(self.nnz)
+        g.fwd_slot = inv[self._perm_t.long()].contiguous()
+        return g
 
     def forward(self, x):
         return O.propagate_c_csr(self.rowptr, self.col, self.w, x, "add" if self.kind == "gcn" else "mean", self.threads)

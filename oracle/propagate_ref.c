@@ -177,3 +177,16 @@ void oracle_gat_backward_src_csr_f32(const int32_t* rowptr_t, const int32_t* col
     }
   }
 }
+
+/* Stable grouping of E items by key in [0, N): order[pos] = the item placed at position pos, items of one key in input
+ * order — what a STABLE sort by key returns (oracle/ref_cpu.py csr_from_edges' torch.sort(stable=True): 6.6 s for 62 M keys
+ * on 8 cores; this counting sort: one histogram, one prefix sum, one in-order placement pass). rowptr [N + 1] (int64). */
+void oracle_stable_group_i64(const int64_t* key, int64_t E, int64_t N, int64_t* rowptr, int64_t* order) {
+  for (int64_t i = 0; i <= N; ++i) rowptr[i] = 0;
+  for (int64_t e = 0; e < E; ++e) rowptr[key[e] + 1]++;
+  for (int64_t i = 0; i < N; ++i) rowptr[i + 1] += rowptr[i];
+  int64_t* next = (int64_t*)__builtin_malloc((size_t)(N > 0 ? N : 1) * sizeof(int64_t));
+  for (int64_t i = 0; i < N; ++i) next[i] = rowptr[i];
+  for (int64_t e = 0; e < E; ++e) order[next[key[e]]++] = e;
+  __builtin_free(next);
+}

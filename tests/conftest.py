@@ -14,23 +14,26 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """The multi-rank GPU module runs LAST: it is the one part of `-m gpu` that depends on more than this process and the card
-    (rank processes, RCCL's socket transport or gloo, rendezvous ports), and under `-x` a failure there must not keep the
-    parity modules from running. The BASELINE-size module runs just before it, its S cases before its L cases: the oracle
-    halves of those cases are computed on the host cores in the background from session start (oracle_background below),
-    while the GPU-bound modules run. (Stable sort: everything else keeps its order.)"""
+    """Order of a `-m gpu` session: the GPU-bound parity modules, the S cases of the BASELINE-size module, the multi-rank module
+    (the one part that depends on more than this process and the card: rank processes, RCCL's socket transport or gloo,
+    rendezvous ports — under `-x` a failure there must not keep the parity modules from running), the L cases last: their
+    oracle halves are computed on the host cores in the background from session start (oracle_background below) and are ready
+    by then. (Stable sort: everything else keeps its order.)"""
     # L cases of the BASELINE-size module in the order the background run finishes their oracle halves: first the cases
     # whose oracle runs inline on sampled rows, then tests/_oracle_jobs.GROUPS["large"]'s order
     l_order = ["test_model_logits_at_sampled_rows", "test_fused_aggregate_transform", "test_appnp_k10",
-               "benchmark_size_L[gcn]", "benchmark_size_L[appnpstack]", "benchmark_size_L[graphsage]",
-               "benchmark_size_L[graphsage2]", "benchmark_size_L[gat]"]
+               "benchmark_size_L[gcn]", "benchmark_size_L[graphsage2]", "benchmark_size_L[appnpstack]",
+               "benchmark_size_L[graphsage]", "benchmark_size_L[gat]"]
 
     def key(it):
         base = it.fspath.basename
         full = base == "test_gpu_fullsize.py"
         at_l = full and ("benchmark_size_L" in it.name or "L" in it.name.partition("[")[2].replace("]", "").split("-"))
         rank = next((i for i, tag in enumerate(l_order) if tag in it.name), len(l_order)) if at_l else 0
-        return (base == "test_gpu_dist.py", full, at_l, rank)
+        # GPU-bound modules, the S cases, the multi-rank module (mostly waiting for its rank processes: the background oracle
+        # has the host cores meanwhile), the L cases last
+        stage = 3 if at_l else 2 if base == "test_gpu_dist.py" else 1 if full else 0
+        return (stage, rank)
     items.sort(key=key)
 
 
@@ -55,9 +58,11 @@ def oracle_background(request):
     env = dict(os.environ)
     # CPU only, a share of the host cores each (a one-GPU box has 16): the foreground keeps the rest for its own small oracles
     env.update({"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
-    groups = ["small", "large"] if "test_gpu_fullsize.py" in wanted else ["small"]
+    groups = ["small", "large_gcn", "large_mean"] if "test_gpu_fullsize.py" in wanted else ["small"]
     cores = os.cpu_count() or 8
-    threads = {"small": max(2, cores // 4), "large": max(4, cores * 5 // 8)}  # 16 cores: 4 + 10, two left to the foreground
+    share = max(2, cores // 4)  # 16 cores: 4 threads per background process, 4 for this process (torch.set_num_threads below)
+    threads = {g: share for g in groups}
+    torch.set_num_threads(share)  # the foreground's own oracles are small; 16 threads of it only fought the background
     procs = []
     for group in groups:
         env_g = dict(env, OMP_NUM_THREADS=str(threads[group]), MKL_NUM_THREADS=str(threads[group]))

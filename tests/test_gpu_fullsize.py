@@ -46,12 +46,13 @@ def test_fused_aggregate_transform_on_the_whole_benchmark_graph(dev, size):
     ei_d, x_d = ei.to(dev), x.to(dev)
     # the oracle half (C restatement's propagate over the whole graph + CPU matmuls): tests/_oracle_jobs.fused_expect, from
     # the background run when it is there
-    want_gcn, want_sage = J.get(f"fused_expect_{size}")
+    want_gcn = J.get(f"fused_expect_gcn_{size}")
     with torch.no_grad():  # GCN: A_hat x W^T + b
         got = ops.propagate_linear(x_d, get_graph(ei_d, n, 1), "gcn", W.to(dev), b.to(dev)).cpu()
     assert (got - want_gcn).abs().max().item() < TOL
     del want_gcn, got
     # SAGEConv form: mean over the in-edges as given (no self-loops), root term in the same kernel
+    want_sage = J.get(f"fused_expect_sage_{size}")
     with torch.no_grad():
         got = ops.propagate_linear(x_d, get_graph(ei_d, n, 0), "mean", W.to(dev), b.to(dev), root_weight=Wr.to(dev)).cpu()
     assert (got - want_sage).abs().max().item() < TOL

@@ -78,3 +78,26 @@ def test_large_graph_checker_equals_the_pinned_oracle(name, n, e):
     # eval mode too (running statistics)
     ev = OL.forward(name, sd, x, graph, False, **kw)["emb"]
     assert (ev - fwd(sd, x, ei, False)["emb"]).abs().max().item() < 2e-5
+
+
+def test_shared_and_c_grouped_structures_equal_the_plain_ones():
+    """Two speed-ups of the BASELINE-size checker leave its structures unchanged: the 'gat' graph derived from a 'mean' graph
+    with loops_mode 2 (CsrGraph.as_gat: shared CSRs) equals the one built directly, and csr_from_edges' C counting sort
+    (taken from 2^20 keys on) returns what torch.sort(stable=True) returns."""
+    gen = torch.Generator().manual_seed(3)
+    n, e = 5000, 60000
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    ei = torch.cat([ei, ei[:, :50], torch.arange(40).repeat(2, 1)], dim=1)
+    direct = OL.CsrGraph(ei, n, "gat", threads=2)
+    shared = OL.CsrGraph(ei, n, "mean", loops_mode=2, threads=2).as_gat()
+    for name in ("rowptr", "col", "rowptr_t", "col_t", "fwd_slot"):
+        assert torch.equal(getattr(direct, name), getattr(shared, name)), name
+    assert shared.kind == "gat" and shared.w is None and shared.nnz == direct.nnz
+    m = (1 << 20) + 17
+    key = torch.randint(0, 70000, (m,), generator=gen)
+    other, ids = torch.randint(0, 70000, (m,), generator=gen), torch.arange(m)
+    rowptr, col, perm = O.csr_from_edges(key, other, ids, 70000)  # C path
+    order = torch.sort(key, stable=True)[1]
+    ptr = torch.zeros(70001, dtype=torch.int64)
+    ptr[1:] = torch.cumsum(torch.bincount(key, minlength=70000), 0)
+    assert torch.equal(rowptr, ptr.int()) and torch.equal(col, other[order].int()) and torch.equal(perm, ids[order].int())
