@@ -245,7 +245,9 @@ def test_shared_eval_forward_on_the_real_kernels(model_name, world, exchange, si
         assert one["hist"] == two["hist"], (one["hist"], two["hist"])
         for k, v in two["state"].items():
             assert torch.equal(v, one["state"][k]), k
-        assert one["exchanges"] < two["exchanges"] and one["bytes"] < two["bytes"]
+        # payload, not the exchange COUNT: the piece count of an exchange follows the link rate each runner measures at start-up
+        # (two runners, two measurements: 25 vs 25 exchanges was seen with fewer bytes)
+        assert one["bytes"] < two["bytes"], (one["bytes"], two["bytes"], one["exchanges"], two["exchanges"])
         if r == 0:
             print(f"shared eval forward, {model_name} x{world} {exchange}: exchanges per 2 epochs {two['exchanges']} -> "
                   f"{one['exchanges']}, payload {two['bytes'] / 1e6:.1f} -> {one['bytes'] / 1e6:.1f} MB")
