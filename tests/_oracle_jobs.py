@@ -178,7 +178,8 @@ for _s in ("S", "L"):
 # one background process per group; a group's jobs share what they build (workload, CSRs): the gcn_norm graph in one, the two
 # mean graphs (edges as given; remove + add self-loops, which GAT shares) in another
 GROUPS = {
-    "small": ["cora300", "fused_expect_gcn_S", "fused_expect_sage_S", "appnp_k10_S"] + [
+    "cora": ["cora300"],
+    "small": ["fused_expect_gcn_S", "fused_expect_sage_S", "appnp_k10_S"] + [
         f"grads_S_{n}" for n in ("gcn", "graphsage", "graphsage2", "gat", "appnpstack")],
     "large_gcn": ["fused_expect_gcn_L", "appnp_k10_L", "grads_L_gcn", "grads_L_appnpstack"],
     "large_mean": ["fused_expect_sage_L", "grads_L_graphsage2", "grads_L_graphsage", "grads_L_gat"],

@@ -58,11 +58,11 @@ def oracle_background(request):
     env = dict(os.environ)
     # CPU only, a share of the host cores each (a one-GPU box has 16): the foreground keeps the rest for its own small oracles
     env.update({"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
-    groups = ["small", "large_gcn", "large_mean"] if "test_gpu_fullsize.py" in wanted else ["small"]
+    groups = ["cora", "small", "large_gcn", "large_mean"] if "test_gpu_fullsize.py" in wanted else ["cora"]
     cores = os.cpu_count() or 8
-    share = max(2, cores // 4)  # 16 cores: 4 threads per background process, 4 for this process (torch.set_num_threads below)
-    threads = {g: share for g in groups}
-    torch.set_num_threads(share)  # the foreground's own oracles are small; 16 threads of it only fought the background
+    share = max(2, cores // 4)  # 16 cores: 4 threads per background process (2 for the small-tensor Cora job), 6 for this one
+    threads = {g: (2 if g == "cora" else share) for g in groups}
+    torch.set_num_threads(max(4, cores * 3 // 8))  # 16 foreground threads only fought the background; 4 starved the ingest checks
     procs = []
     for group in groups:
         env_g = dict(env, OMP_NUM_THREADS=str(threads[group]), MKL_NUM_THREADS=str(threads[group]))
