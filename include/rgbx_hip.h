@@ -391,6 +391,18 @@ int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, const float*
                          int64_t ldg, float* nodeq, float* g_a_dst, int64_t N, int H, int C,
                          float slope, rgbx_stream_t stream);
 
+/* The two-pass backward's target side with a CONSISTENT Jacobian term: as rgbx_gat_bwd_dst_f32, but dsum[i,h] is the
+ * alpha-weighted mean of the edges' own dot products, sum_p alpha_p <gout_i, h_j> / sum_p alpha_p (a first sweep over the
+ * row), not <gout_i, out_i> from the stored aggregate — equal in real arithmetic; in float32 every <gout_i, h_j> - dsum_i is
+ * then taken against the mean of the SAME numbers, as the reference's autograd takes it (GATConv [PyG] behind models/gat.py:
+ * 28,30; itexperiments.py:439). Matters once a hub has made the rows of a deep GAT alike (first-layer attention gradients
+ * 7e-4 of their scale off with the one-pass form, 1e-5 with this one); costs the second gather pass the one-pass form
+ * (rgbx_gat_bwd_prep_f32) saves. Writes `nodeq` (for rgbx_gat_bwd_src_f32) and g_a_dst. a_src or, when NULL, att_src. */
+int rgbx_gat_bwd_dst_consistent_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat, int64_t ldh,
+                                    const float* a_src, const float* att_src, const float* a_dst, const float* m,
+                                    const float* rden, const float* gout, int64_t ldg, float* nodeq, float* g_a_dst,
+                                    int64_t N, int H, int C, float slope, rgbx_stream_t stream);
+
 /* The per-target record alone (no neighbour loop, one streaming pass over out / gout):
  *   nodeq[i,h] = (a_dst[i,h], m[i,h] - log(rden[i,h]), dsum = <gout[i,h,:], out[i,h,:] - bias[h,:]>, 0)
  * (`bias` = the pointer given to the forward, or NULL). With the forward's `out_pos` / `a_pos` (all three of
