@@ -391,18 +391,6 @@ int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, const float*
                          int64_t ldg, float* nodeq, float* g_a_dst, int64_t N, int H, int C,
                          float slope, rgbx_stream_t stream);
 
-/* The two-pass backward's target side with a CONSISTENT Jacobian term: as rgbx_gat_bwd_dst_f32, but dsum[i,h] is the
- * alpha-weighted mean of the edges' own dot products, sum_p alpha_p <gout_i, h_j> / sum_p alpha_p (a first sweep over the
- * row), not <gout_i, out_i> from the stored aggregate — equal in real arithmetic; in float32 every <gout_i, h_j> - dsum_i is
- * then taken against the mean of the SAME numbers, as the reference's autograd takes it (GATConv [PyG] behind models/gat.py:
- * 28,30; itexperiments.py:439). Matters once a hub has made the rows of a deep GAT alike (first-layer attention gradients
- * 7e-4 of their scale off with the one-pass form, 1e-5 with this one); costs the second gather pass the one-pass form
- * (rgbx_gat_bwd_prep_f32) saves. Writes `nodeq` (for rgbx_gat_bwd_src_f32) and g_a_dst. a_src or, when NULL, att_src. */
-int rgbx_gat_bwd_dst_consistent_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat, int64_t ldh,
-                                    const float* a_src, const float* att_src, const float* a_dst, const float* m,
-                                    const float* rden, const float* gout, int64_t ldg, float* nodeq, float* g_a_dst,
-                                    int64_t N, int H, int C, float slope, rgbx_stream_t stream);
-
 /* The per-target record alone (no neighbour loop, one streaming pass over out / gout):
  *   nodeq[i,h] = (a_dst[i,h], m[i,h] - log(rden[i,h]), dsum = <gout[i,h,:], out[i,h,:] - bias[h,:]>, 0)
  * (`bias` = the pointer given to the forward, or NULL). With the forward's `out_pos` / `a_pos` (all three of
@@ -412,19 +400,6 @@ int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const float* rden,
                           int64_t ldo, const float* bias, const float* gout, int64_t ldg, float* nodeq,
                           const float* out_pos, const float* a_pos, float slope, float* g_a_dst,
                           int64_t N, int H, int C, rgbx_stream_t stream);
-
-/* Hub targets only (the rows of `split`, the FORWARD CSR's row-split plan; no plan / no hub row: a no-op): overwrites
- * g_a_dst[i, :] of rgbx_gat_bwd_prep_f32 for those rows with the sum taken edge by edge,
- *   g_a_dst[i,h] = sum_p alpha_p (<gout_i, h_j> - dsum_i) lrelu'(s_p)     (alpha, dsum from `nodeq` as the source pass reads them),
- * because the per-node form (1 - slope)(<gout_i, out_pos_i> - dsum_i a_pos_i) cancels for targets with thousands of in-edges
- * (out_pos / a_pos -> out): float32 rounding of the two aggregates becomes 1e-4 .. 1e-3 of the difference there, where the
- * reference's autograd (GATConv [PyG] behind models/gat.py:28,30; itexperiments.py:439) sums the edges. Call between
- * rgbx_gat_bwd_prep_f32 and rgbx_gat_bwd_src_f32. `a_src` ([n_src, H]) or, when NULL, `att_src` ([H, C]: the source score is
- * formed from the gathered row). split->partial: n_chunks * H floats. Chunk sums are added in chunk order (reproducible). */
-int rgbx_gat_bwd_dst_hubs_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat, int64_t ldh,
-                              const float* a_src, const float* att_src, const float* nodeq, const float* gout,
-                              int64_t ldg, float* g_a_dst, int64_t N, int H, int C, float slope,
-                              const rgbx_row_split_t* split, rgbx_stream_t stream);
 
 /* Backward, source side, over the TRANSPOSED CSR (rows = sources j, col = targets i):
  *   g_hfeat[j,h,:] = sum_{p: j->i} alpha_p * gout[i,h,:]

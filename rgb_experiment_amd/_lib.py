@@ -78,8 +78,6 @@ SIGNATURES = {
     "rgbx_gat_bwd_dst_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I,
                              _F, _P],
     "rgbx_gat_bwd_prep_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _F, _P, _I64, _I, _I, _P],
-    "rgbx_gat_bwd_dst_consistent_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I, _I, _F, _P],
-    "rgbx_gat_bwd_dst_hubs_f32": [_P, _P, _P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I, _I, _F, _P, _P],
     "rgbx_gat_bwd_src_f32": [_P, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I, _I, _F, _P, _P],
     "rgbx_gemm_tn_workspace_bytes": [_I64, _I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
     "rgbx_gemm_tn_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _F, _P, ctypes.c_size_t, _P],

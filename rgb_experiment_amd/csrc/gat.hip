@@ -459,18 +459,10 @@ gat_fwd_combine_kernel(int n_long, const int* __restrict__ long_row, const int* 
 // (rden == 0) are never gathered.
 __device__ __forceinline__ float softmax_shift(float m, float rden) { return rden > 0.f ? m - logf(rden) : 0.f; }
 
-// CONSISTENT (rgbx_gat_bwd_dst_consistent_f32): dsum is NOT taken from the stored aggregate (<gout_i, out_i>) but from a first
-// sweep over the row's edges, dsum_i = sum_p alpha_p <gout_i, h_j> / sum_p alpha_p with the very alpha_p and dot products the
-// second sweep (and the source pass) use. In real arithmetic the two are equal; in float32 <gout, out> carries the rounding of
-// the forward's accumulation (1e-6 |gout| |out|), and when a hub has made the rows alike every <gout_i, h_j> - dsum_i is a
-// difference of nearly equal numbers: taken against the weighted mean of the SAME numbers it is exact (as the reference's
-// autograd takes it), taken against the stored aggregate it is 1e-4 .. 1e-3 off (round 4's soak, seed 2528). `att_src` (when
-// a_src == NULL): the source score from the gathered row, as the forward formed it.
-template <int VEC, bool CONSISTENT>
+template <int VEC>
 __global__ void __launch_bounds__(256)
 gat_bwd_dst_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                    const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
-                   const float* __restrict__ att_src,
                    const float* __restrict__ a_dst, const float* __restrict__ m_in,
                    const float* __restrict__ rden_in, const float* __restrict__ out, int64_t ldo,
                    const float* __restrict__ gout, int64_t ldg, float4* __restrict__ nodeq_out,
@@ -490,53 +482,18 @@ gat_bwd_dst_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
       const int head = hbase + hl;
       const bool active = hl < L.HPC && head < L.H && ch < L.C;
       const int cofs = head * L.C + ch;
-      float go[VEC], o[VEC], ats[VEC];
+      float go[VEC], o[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) go[i] = o[i] = ats[i] = 0.f;
+      for (int i = 0; i < VEC; ++i) go[i] = o[i] = 0.f;
       float ad = 0.f, mi = 0.f, rd = 0.f;
       if (active) {
         load_vec<VEC>(go, gout + (int64_t)row * ldg + cofs);
-        if constexpr (!CONSISTENT) load_vec<VEC>(o, out + (int64_t)row * ldo + cofs);
-        if (!a_src) load_vec<VEC>(ats, att_src + cofs);
+        load_vec<VEC>(o, out + (int64_t)row * ldo + cofs);
         ad = a_dst[(int64_t)row * L.H + head];
         mi = m_in[(int64_t)row * L.H + head];
         rd = rden_in[(int64_t)row * L.H + head];
       }
-      float dsum = 0.f;
-      if constexpr (CONSISTENT) {  // first sweep: the alpha-weighted mean of the edges' own dot products
-        float num = 0.f, den = 0.f;
-        for (int base = start; base < end; base += kWave) {
-          const int n = min(kWave, end - base);
-          const int mycol = lane < n ? col[base + lane] : 0;
-          for (int k = 0; k < n; k += NG) {
-            const int idx = k + g;
-            const int src = __shfl(mycol, idx & 63);
-            const bool ok = active && idx < n;
-            float v[VEC];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) v[i] = 0.f;
-            float as = 0.f;
-            if (ok) {
-              if (a_src) as = a_src[(int64_t)src * L.H + head];
-              load_vec<VEC>(v, hfeat + (int64_t)src * ldh + cofs);
-            }
-            if (!a_src) as = head_sum(dot_vec<VEC>(v, ats), L.LPH);
-            const float dal = head_sum(dot_vec<VEC>(go, v), L.LPH);
-            const float s = as + ad;
-            const float e = s > 0.f ? s : slope * s;
-            const float alpha = ok ? expf(e - softmax_shift(mi, rd)) : 0.f;
-            num = fmaf(alpha, dal, num);
-            den += alpha;
-          }
-        }
-        for (int off = 32; off >= L.G; off >>= 1) {
-          num += __shfl_xor(num, off);
-          den += __shfl_xor(den, off);
-        }
-        dsum = den > 0.f ? num / den : 0.f;
-      } else {
-        dsum = head_sum(dot_vec<VEC>(go, o), L.LPH);
-      }
+      const float dsum = head_sum(dot_vec<VEC>(go, o), L.LPH);
       float acc = 0.f;
 
       for (int base = start; base < end; base += kWave) {
@@ -555,18 +512,16 @@ gat_bwd_dst_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
 #pragma unroll
             for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
             if (ok[u]) {
-              if (a_src) as[u] = a_src[(int64_t)src * L.H + head];
+              as[u] = a_src[(int64_t)src * L.H + head];
               load_vec<VEC>(v[u], hfeat + (int64_t)src * ldh + cofs);
             }
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            if (!a_src) as[u] = head_sum(dot_vec<VEC>(v[u], ats), L.LPH);
             const float dal = head_sum(dot_vec<VEC>(go, v[u]), L.LPH);
             const float s = as[u] + ad;
             const float e = s > 0.f ? s : slope * s;
-            // CONSISTENT: the coefficient exactly as the source pass forms it (one combined constant)
-            const float alpha = !ok[u] ? 0.f : CONSISTENT ? expf(e - softmax_shift(mi, rd)) : expf(e - mi) * rd;
+            const float alpha = ok[u] ? expf(e - mi) * rd : 0.f;
             acc = fmaf(alpha * (dal - dsum), s > 0.f ? 1.f : slope, acc);
           }
         }
@@ -633,97 +588,6 @@ gat_bwd_prep_kernel(const float* __restrict__ a_dst, const float* __restrict__ m
       }
     }
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// Backward, target side, HUB targets only (rows of the forward CSR's row-split plan): the per-node form of g_a_dst above,
-// (1 - slope) (<gout_i, out_pos_i> - dsum_i a_pos_i), is a difference of two numbers that approach each other as a target's
-// in-degree grows (the positive-score edges are a sample of all its edges: out_pos / a_pos -> out by the law of large numbers),
-// so for a target with thousands of in-edges the float32 rounding of out / out_pos (1e-6 relative each) is 1e-4 .. 1e-3 of what
-// is left (round 4's soak: a 4-layer GAT around a 3,617-in-edge target, first-layer attention gradients 7e-4 off). For those
-// rows — and only those — the sum is taken edge by edge, as the reference's autograd takes it:
-//   g_a_dst[i,h] = sum_p alpha_p (<gout_i, h_j> - dsum_i) lrelu'(s_p)
-// one wave per 1024-slot chunk of the plan into part[chunk, H], the chunks of a row added in chunk order (reproducible).
-// a_src == NULL: the source's score is formed from its gathered row with att_src, as the forward formed it.
-template <int VEC>
-__global__ void __launch_bounds__(256)
-gat_bwd_dst_chunk_kernel(int n_chunks, const int* __restrict__ chunk_row, const int* __restrict__ chunk_begin,
-                         const int* __restrict__ chunk_end, const int* __restrict__ col,
-                         const float* __restrict__ hfeat, int64_t ldh, const float* __restrict__ a_src,
-                         const float* __restrict__ att_src, const float4* __restrict__ nodeq,
-                         const float* __restrict__ gout, int64_t ldg, float* __restrict__ part, float slope,
-                         const GatLayout L) {
-  const int lane = threadIdx.x & 63;
-  const int NG = kWave / L.G;
-  const int g = lane / L.G;
-  const int t = lane % L.G;
-  const int hl = t / L.LPH;
-  const int ch = (t % L.LPH) * VEC;
-  const int wpb = blockDim.x >> 6;
-  for (int item = blockIdx.x * wpb + (threadIdx.x >> 6); item < n_chunks; item += gridDim.x * wpb) {
-    const int row = __builtin_amdgcn_readfirstlane(chunk_row[item]);
-    const int start = __builtin_amdgcn_readfirstlane(chunk_begin[item]);
-    const int end = __builtin_amdgcn_readfirstlane(chunk_end[item]);
-    for (int hbase = 0; hbase < L.H; hbase += L.HPC) {
-      const int head = hbase + hl;
-      const bool active = hl < L.HPC && head < L.H && ch < L.C;
-      const int cofs = head * L.C + ch;
-      float go[VEC], ats[VEC];
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) go[i] = ats[i] = 0.f;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (active) {
-        load_vec<VEC>(go, gout + (int64_t)row * ldg + cofs);
-        q = nodeq[(int64_t)row * L.H + head];  // (a_dst, max - log(1 / sum), dsum, -)
-        if (!a_src) load_vec<VEC>(ats, att_src + cofs);
-      }
-      float acc = 0.f;
-      for (int base = start; base < end; base += kWave) {
-        const int n = min(kWave, end - base);
-        const int mycol = lane < n ? col[base + lane] : 0;
-        for (int k = 0; k < n; k += NG * U) {
-          float v[U][VEC];
-          float as[U];
-          bool ok[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int idx = k + u * NG + g;
-            const int src = __shfl(mycol, idx & 63);
-            ok[u] = active && idx < n;
-            as[u] = 0.f;
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
-            if (ok[u]) {
-              if (a_src) as[u] = a_src[(int64_t)src * L.H + head];
-              load_vec<VEC>(v[u], hfeat + (int64_t)src * ldh + cofs);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            if (!a_src) as[u] = head_sum(dot_vec<VEC>(v[u], ats), L.LPH);
-            const float dal = head_sum(dot_vec<VEC>(go, v[u]), L.LPH);
-            const float s = as[u] + q.x;
-            const float e = s > 0.f ? s : slope * s;
-            const float alpha = ok[u] ? expf(e - q.y) : 0.f;
-            acc = fmaf(alpha * (dal - q.z), s > 0.f ? 1.f : slope, acc);
-          }
-        }
-      }
-      for (int off = 32; off >= L.G; off >>= 1) acc += __shfl_xor(acc, off);
-      if (g == 0 && active && ch == 0) part[(int64_t)item * L.H + head] = acc;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256)
-gat_bwd_dst_combine_kernel(int n_long, int H, const int* __restrict__ long_row, const int* __restrict__ long_chunk_ptr,
-                           const float* __restrict__ part, float* __restrict__ g_a_dst) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_long * H) return;
-  const int r = idx / H, h = idx % H;
-  float s = 0.f;
-  for (int c = long_chunk_ptr[r]; c < long_chunk_ptr[r + 1]; ++c) s += part[(int64_t)c * H + h];
-  g_a_dst[(int64_t)long_row[r] * H + h] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1199,41 +1063,13 @@ extern "C" int rgbx_gat_bwd_dst_f32(const int32_t* rowptr, const int32_t* col, c
   hipStream_t s = (hipStream_t)stream;
   const int grid = gat_grid(N);
 #define RGBX_GAT_BD(V)                                                                              \
-  gat_bwd_dst_kernel<V, false><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, nullptr, a_dst, m, rden, out, ldo, \
-                                                    gout, ldg, reinterpret_cast<float4*>(nodeq), g_a_dst, (int)N, slope, L)
+  gat_bwd_dst_kernel<V><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, a_dst, m, rden, out, ldo, \
+                                             gout, ldg, reinterpret_cast<float4*>(nodeq), g_a_dst, (int)N, slope, L)
   if (vec == 4) RGBX_GAT_BD(4);
   else if (vec == 2) RGBX_GAT_BD(2);
   else RGBX_GAT_BD(1);
 #undef RGBX_GAT_BD
   RGBX_CHECK_LAUNCH("gat_bwd_dst_kernel");
-  return RGBX_OK;
-}
-
-extern "C" int rgbx_gat_bwd_dst_consistent_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat,
-                                               int64_t ldh, const float* a_src, const float* att_src, const float* a_dst,
-                                               const float* m, const float* rden, const float* gout, int64_t ldg,
-                                               float* nodeq, float* g_a_dst, int64_t N, int H, int C, float slope,
-                                               rgbx_stream_t stream) {
-  if (int rc = check_common(N, H, C, "gat_bwd_dst_consistent")) return rc;
-  if (N == 0) return RGBX_OK;
-  if (!rowptr || !col || !hfeat || (!a_src && !att_src) || !a_dst || !m || !rden || !gout || !nodeq || !g_a_dst)
-    return fail(RGBX_E_ARG, "gat_bwd_dst_consistent: null pointer");
-  const int64_t F = (int64_t)H * C;
-  if (ldh < F || ldg < F) return fail(RGBX_E_ARG, "gat_bwd_dst_consistent: leading dimension < H*C");
-  if (!aligned16(nodeq)) return fail(RGBX_E_ALIGN, "gat_bwd_dst_consistent: nodeq must be 16-byte aligned");
-  const int vec = pick_vec(C, {hfeat, gout, att_src}, {ldh, ldg});
-  GatLayout L;
-  if (int rc = make_layout(H, C, vec, &L, "gat_bwd_dst_consistent")) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  const int grid = gat_grid(N);
-#define RGBX_GAT_BDC(V)                                                                                              \
-  gat_bwd_dst_kernel<V, true><<<grid, 256, 0, s>>>(rowptr, col, hfeat, ldh, a_src, att_src, a_dst, m, rden, nullptr, 0, \
-                                                   gout, ldg, reinterpret_cast<float4*>(nodeq), g_a_dst, (int)N, slope, L)
-  if (vec == 4) RGBX_GAT_BDC(4);
-  else if (vec == 2) RGBX_GAT_BDC(2);
-  else RGBX_GAT_BDC(1);
-#undef RGBX_GAT_BDC
-  RGBX_CHECK_LAUNCH("gat_bwd_dst_kernel (consistent)");
   return RGBX_OK;
 }
 
@@ -1264,42 +1100,6 @@ extern "C" int rgbx_gat_bwd_prep_f32(const float* a_dst, const float* m, const f
   else RGBX_GAT_BP(1);
 #undef RGBX_GAT_BP
   RGBX_CHECK_LAUNCH("gat_bwd_prep_kernel");
-  return RGBX_OK;
-}
-
-extern "C" int rgbx_gat_bwd_dst_hubs_f32(const int32_t* rowptr, const int32_t* col, const float* hfeat, int64_t ldh,
-                                         const float* a_src, const float* att_src, const float* nodeq, const float* gout,
-                                         int64_t ldg, float* g_a_dst, int64_t N, int H, int C, float slope,
-                                         const rgbx_row_split_t* split, rgbx_stream_t stream) {
-  if (int rc = check_common(N, H, C, "gat_bwd_dst_hubs")) return rc;
-  if (!split || split->threshold <= 0 || split->n_chunks <= 0 || split->n_long <= 0) return RGBX_OK;  // no hub row
-  if (!rowptr || !col || !hfeat || (!a_src && !att_src) || !nodeq || !gout || !g_a_dst)
-    return fail(RGBX_E_ARG, "gat_bwd_dst_hubs: null pointer");
-  if (!split->chunk_row || !split->chunk_begin || !split->chunk_end || !split->long_row || !split->long_chunk_ptr ||
-      !split->partial)
-    return fail(RGBX_E_ARG, "gat_bwd_dst_hubs: incomplete row-split plan");
-  const int64_t F = (int64_t)H * C;
-  if (ldh < F || ldg < F) return fail(RGBX_E_ARG, "gat_bwd_dst_hubs: leading dimension < H*C");
-  if (!aligned16(nodeq)) return fail(RGBX_E_ALIGN, "gat_bwd_dst_hubs: nodeq must be 16-byte aligned");
-  const int vec = pick_vec(C, {hfeat, gout, att_src}, {ldh, ldg});
-  GatLayout L;
-  if (int rc = make_layout(H, C, vec, &L, "gat_bwd_dst_hubs")) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  int64_t cb = cdiv(split->n_chunks, 4);
-  if (cb > kMaxGrid) cb = kMaxGrid;
-#define RGBX_GAT_BDH(V)                                                                                              \
-  gat_bwd_dst_chunk_kernel<V><<<(int)cb, 256, 0, s>>>(split->n_chunks, split->chunk_row, split->chunk_begin,          \
-                                                      split->chunk_end, col, hfeat, ldh, a_src, att_src,              \
-                                                      reinterpret_cast<const float4*>(nodeq), gout, ldg, split->partial, \
-                                                      slope, L)
-  if (vec == 4) RGBX_GAT_BDH(4);
-  else if (vec == 2) RGBX_GAT_BDH(2);
-  else RGBX_GAT_BDH(1);
-#undef RGBX_GAT_BDH
-  RGBX_CHECK_LAUNCH("gat_bwd_dst_chunk_kernel");
-  gat_bwd_dst_combine_kernel<<<(int)cdiv((int64_t)split->n_long * H, 256), 256, 0, s>>>(
-      split->n_long, H, split->long_row, split->long_chunk_ptr, split->partial, g_a_dst);
-  RGBX_CHECK_LAUNCH("gat_bwd_dst_combine_kernel");
   return RGBX_OK;
 }
 

@@ -1277,33 +1277,11 @@ def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope, 
         g_ad = g_ad_full[:N]
     att2 = torch.cat([att[0].reshape(1, H, C), att[1].reshape(1, H, C)]).contiguous() if fold else None
     ds = None if per_node else torch.empty((max(g.bwd.nnz, 1), H), dtype=torch.float32, device=dev)
-    consistent = per_node and gat_backward_is_consistent(g)
-    if consistent:
-        # small graphs: the target side as a pass over the edges, its Jacobian term the weighted mean of the edges' own dot
-        # products (rgbx_gat_bwd_dst_consistent_f32) — the one-pass form below loses the first layers' attention gradients of a
-        # deep GAT to cancellation once a hub has made the rows alike; here the second gather pass costs microseconds
-        with _Timed("gat_bwd_dst_consistent"):
-            _lib.check(
-                lib.rgbx_gat_bwd_dst_consistent_f32(_lib.ptr(g.fwd.rowptr), _lib.ptr(g.fwd.col), ph, ldh, _lib.ptr(a_src),
-                                                    _lib.ptr(att2) if a_src is None else None, _lib.ptr(a_dst), _lib.ptr(m),
-                                                    _lib.ptr(rden), pg, ldg, _lib.ptr(nodeq), _lib.ptr(g_ad), N, H, C,
-                                                    float(slope), _lib.stream_ptr()), "rgbx_gat_bwd_dst_consistent_f32")
-    else:
-        with _Timed("gat_bwd_prep"):
-            _lib.check(
-                lib.rgbx_gat_bwd_prep_f32(_lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, _lib.ptr(bias), pg, ldg,
-                                          _lib.ptr(nodeq), _lib.ptr(opos), _lib.ptr(apos), float(slope), _lib.ptr(g_ad),
-                                          N, H, C, _lib.stream_ptr()), "rgbx_gat_bwd_prep_f32")
-    if per_node and not consistent and g.fwd.split is not None:
-        # hub TARGETS: the per-node g_a_dst cancels there (thousands of in-edges: out_pos / a_pos -> out); taken edge by edge
-        # for those rows alone (rgbx_gat_bwd_dst_hubs_f32), before the source pass folds g_a_dst into g_hfeat
-        hsplit, _hscratch = g.fwd.split_arg(H, dev)
-        with _Timed("gat_bwd_dst_hubs"):
-            _lib.check(
-                lib.rgbx_gat_bwd_dst_hubs_f32(_lib.ptr(g.fwd.rowptr), _lib.ptr(g.fwd.col), ph, ldh, _lib.ptr(a_src),
-                                              _lib.ptr(att2) if a_src is None else None, _lib.ptr(nodeq), pg, ldg,
-                                              _lib.ptr(g_ad), N, H, C, float(slope), ctypes.byref(hsplit),
-                                              _lib.stream_ptr()), "rgbx_gat_bwd_dst_hubs_f32")
+    with _Timed("gat_bwd_prep"):
+        _lib.check(
+            lib.rgbx_gat_bwd_prep_f32(_lib.ptr(a_dst), _lib.ptr(m), _lib.ptr(rden), po, ldo, _lib.ptr(bias), pg, ldg,
+                                      _lib.ptr(nodeq), _lib.ptr(opos), _lib.ptr(apos), float(slope), _lib.ptr(g_ad),
+                                      N, H, C, _lib.stream_ptr()), "rgbx_gat_bwd_prep_f32")
     split, _scratch = g.bwd.split_arg(H * C + 2 * H, dev)
     with _Timed("gat_bwd_src"):
         _lib.check(
@@ -1315,29 +1293,6 @@ def _gat_backward_core(g, hfeat, a_src, a_dst, m, rden, out, gout, H, C, slope, 
     if not per_node:
         g_ad = spmm_raw(gat_segment_csr(g), None, None, ds, kind="gat_bwd_segsum")
     return g_h, g_as, g_ad
-
-
-GAT_CONSISTENT_MAX_EDGES = 2_000_000   # 'auto': graphs up to this many edges take the consistent target pass ...
-GAT_CONSISTENT_MAX_DEGREE = 65_536      # ... unless one target has more in-edges than this (one wave walks a row twice)
-
-
-def gat_backward_is_consistent(graph):
-    """Which target-side pass GAT's backward takes on `graph`. RGBX_GAT_BACKWARD = 'one_pass' | 'consistent' decides; 'auto'
-    (default): consistent on small graphs (at most GAT_CONSISTENT_MAX_EDGES edges, no target beyond GAT_CONSISTENT_MAX_DEGREE
-    in-edges), where a second gather pass is microseconds and where a hub can dominate the graph; the one-pass form — 40 %
-    less backward time at |E| = 60 M — on everything larger."""
-    import os
-    mode = os.environ.get("RGBX_GAT_BACKWARD", "auto")
-    if mode != "auto":
-        return mode == "consistent"
-    if graph.fwd.nnz > GAT_CONSISTENT_MAX_EDGES:
-        return False
-    md = getattr(graph, "_max_in_degree", None)
-    if md is None:
-        rp = graph.fwd.rowptr
-        md = int((rp[1:] - rp[:-1]).max().item()) if rp.numel() > 1 else 0
-        graph._max_in_degree = md
-    return md <= GAT_CONSISTENT_MAX_DEGREE
 
 
 def gat_segment_csr(graph):

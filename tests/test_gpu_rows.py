@@ -401,10 +401,10 @@ def test_align_rows_layout(dev):
 
 
 def test_gat_gradients_around_a_hub_target(dev):
-    """A 4-layer GAT (8 heads x 16) on 100 nodes around ONE target with 3,617 in-edges (round 4's soak, seed 2528: first-layer
-    attention gradients 7e-4 of their scale off): every parameter gradient against the oracle computing in float64, within
-    1e-4 of the gradient's own scale. The per-node form of the target-side score gradient cancels on such a target; hub
-    targets take it edge by edge (rgbx_gat_bwd_dst_hubs_f32)."""
+    """A 4-layer GAT (8 heads x 16) on 100 nodes around ONE target with 3,617 in-edges: every parameter gradient against the
+    oracle computing in float64, within 1e-4 of the gradient's own scale (measured 2e-5: the one-gather backward's per-node
+    form of the target-side score gradient holds on a hub). Round 4 blamed that form for the whole-model fuzz's seed 2528
+    (first-layer attention gradients 7e-4 off); round 5 traced the seed to a LeakyReLU kink instead, see the next test."""
     from oracle import large as OL
     from rgb_experiment_amd import models as M
     from rgb_experiment_amd.graph import get_graph
@@ -428,8 +428,37 @@ def test_gat_gradients_around_a_hub_target(dev):
     loss.backward()
     got = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
     rep = OL.compare_grads(got, {k: ref[k].grad.float() for k in got})
-    print(f"GAT around a hub target: gradients max_rel {rep['max_rel']:.2e} ({rep['worst']}), max_abs {rep['max_abs']:.2e}")
     assert rep["max_rel"] < 1e-4, rep
+
+
+def test_the_hub_seed_of_round_4_is_a_leaky_relu_kink(dev):
+    """Whole-model fuzz seed 2528 (4-layer GAT, 100 nodes, a 3,600-in-edge target, an 1,800-out-edge source): convs.0.att_dst's
+    gradient 7e-4 of its scale off, whatever the row-split settings and whichever form the target-side pass takes
+    (tools/gat_layer_probe.py, profiles/r05_gat_seed2528_kink.txt). Stage by stage every forward activation and every output
+    gradient down to layer 1 is closer to float64 than the float32 oracle's; layer 1's backward alone, on float64's inputs, is
+    at 1e-6. What differs in the chain: ONE of layer 1's 46,744 pre-activation scores sits 1.2e-6 from zero, float32 rounding
+    of the score decides on which side of LeakyReLU's kink it falls, and the DERIVATIVE there is 0.2 or 1. With layer 1's
+    att_src scaled by 1 +- 1e-3 (the scores move off the kink, the model is otherwise the same) every gradient of the same
+    seed is within 1e-4 of its scale — here pinned; the unmoved seed stays in tools/fuzz_soak.py's range as a known kink."""
+    import test_gpu_fuzz as F
+    from oracle import large as OL
+    from rgb_experiment_amd.graph import clear_cache
+    from rgb_experiment_amd.models._stack import masked_ce
+    for t in (1e-3, -1e-3):
+        desc, model, ref_fn, ei, x, y, masks = F.make_model_case(2528)
+        with torch.no_grad():
+            model.convs[1].att_src.mul_(1.0 + t)
+        sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        sd = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point()) for k, v in sd0.items()}
+        out = ref_fn(sd, x.double(), True)["out"]
+        torch.nn.functional.nll_loss(out[masks[0]], y[masks[0]]).backward()
+        clear_cache()
+        model.to(dev).train()
+        loss, _ = masked_ce(model, {"x": x.to(dev), "edge_index": ei.to(dev)}, y.to(dev), masks[0].to(dev))
+        loss.backward()
+        got = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
+        rep = OL.compare_grads(got, {k: sd[k].grad.float() for k in got})
+        assert rep["max_rel"] < 1e-4, (t, rep["max_rel"], rep["worst"])
 
 
 @pytest.mark.parametrize("n,f,out,density", [(3000, 1433, 64, 0.0126), (2708, 1433, 128, 0.0126), (500, 40, 8, 0.05),
@@ -460,29 +489,3 @@ def test_linear_over_the_nonzeros_of_sparse_features(dev, n, f, out, density):
     assert (bd.grad.cpu().double() - b.grad).abs().max().item() < 1e-4 * max(1.0, b.grad.abs().max().item())
     dense = torch.randn(50, 16, device=dev)
     assert getattr(ops.prepare_features(dense), "_rgbx_sparse", None) is None  # dense features stay dense
-
-
-def test_deep_gat_on_a_hub_dominated_graph_meets_the_fuzz_bounds(dev, monkeypatch):
-    """Round 4's soak, whole-model seed 2528 (4-layer GAT, 100 nodes, a 3,600-in-edge target and an 1,800-out-edge source:
-    after two layers every row looks alike): with the one-pass backward the first layers' attention gradients were 7e-4 of
-    their scale off (bound 3e-4) whatever the row-split settings; small graphs now take the consistent target pass
-    (ops.gat_backward_is_consistent). Both forms agree on a generic graph."""
-    import test_gpu_fuzz as F
-    from rgb_experiment_amd import models as M
-    from rgb_experiment_amd.graph import clear_cache
-    F.run_model_case(dev, 2528)
-    # the two forms on a generic graph: same gradients to rounding
-    n, f, c = 3000, 24, 5
-    ei = graph_with_isolated_nodes(n, 30000, 77, hub=1500)
-    gen = torch.Generator().manual_seed(1)
-    x, y = torch.randn(n, f, generator=gen).to(dev), torch.randint(0, c, (n,), generator=gen).to(dev)
-    grads = {}
-    for mode in ("one_pass", "consistent"):
-        monkeypatch.setenv("RGBX_GAT_BACKWARD", mode)
-        clear_cache()
-        torch.manual_seed(3)
-        model = M.GAT(num_layers=2, hidden_unit=8, heads=4, input_dim=f, output_dim=c, dropout_rate=0.5).to(dev).train()
-        torch.nn.functional.cross_entropy(model(x, ei.to(dev))["emb"], y).backward()
-        grads[mode] = {k: p.grad.clone() for k, p in model.named_parameters()}
-    for k, g in grads["one_pass"].items():
-        assert (g - grads["consistent"][k]).abs().max().item() < 2e-5 * max(1.0, g.abs().max().item()), k
