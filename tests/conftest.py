@@ -31,10 +31,28 @@ def pytest_collection_modifyitems(config, items):
         at_l = full and ("benchmark_size_L" in it.name or "L" in it.name.partition("[")[2].replace("]", "").split("-"))
         rank = next((i for i, tag in enumerate(l_order) if tag in it.name), len(l_order)) if at_l else 0
         # GPU-bound modules, the S cases, the multi-rank module (mostly waiting for its rank processes: the background oracle
-        # has the host cores meanwhile), the L cases last
-        stage = 3 if at_l else 2 if base == "test_gpu_dist.py" else 1 if full else 0
+        # has the host cores meanwhile), the L cases, and last the cases whose CPU side is heavy (sorts of 10^8 keys, float64
+        # oracles of hub graphs): by then the background processes are through and this process takes all cores again
+        late = base == "test_gpu_ingest.py" or any(tag in it.name for tag in _CPU_HEAVY)
+        stage = 4 if late else 3 if at_l else 2 if base == "test_gpu_dist.py" else 1 if full else 0
         return (stage, rank)
     items.sort(key=key)
+
+
+_CPU_HEAVY = ("test_spmm_hub_rows_are_split_and_reproducible", "test_csr_build_bit_exact", "test_index_arithmetic_beyond_2_31")
+_BG = {"dir": None, "groups": (), "all_cores": True}
+
+
+def pytest_runtest_setup(item):
+    """Once every background oracle process has ended, the foreground gets the host's cores back."""
+    if _BG["all_cores"] or _BG["dir"] is None:
+        return
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _oracle_jobs as J
+    if not any(J._alive(_BG["dir"], J.GROUPS[g][0]) for g in _BG["groups"]):
+        import torch
+        torch.set_num_threads(os.cpu_count() or 8)
+        _BG["all_cores"] = True
 
 
 @pytest.fixture(scope="session", autouse=True)
@@ -72,7 +90,9 @@ def oracle_background(request):
             f.write(str(p.pid))
         procs.append(p)
     os.environ["RGBX_ORACLE_BG"] = d
+    _BG.update(dir=d, groups=tuple(groups), all_cores=False)
     yield d
+    _BG.update(dir=None, all_cores=True)
     os.environ.pop("RGBX_ORACLE_BG", None)
     for p in procs:
         if p.poll() is None:
