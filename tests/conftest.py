@@ -32,7 +32,8 @@ def pytest_collection_modifyitems(config, items):
         rank = next((i for i, tag in enumerate(l_order) if tag in it.name), len(l_order)) if at_l else 0
         # GPU-bound modules, the S cases, the multi-rank module (mostly waiting for its rank processes: the background oracle
         # has the host cores meanwhile), the L cases, and last the cases whose CPU side is heavy (sorts of 10^8 keys, float64
-        # oracles of hub graphs): by then the background processes are through and this process takes all cores again
+        # oracles of hub graphs): by then the background processes are through and the cores are this process's alone
+        # (its thread count stays what the fixture below set: raising it mid-session stalled two runs, full7 / full8 of round 5)
         late = base == "test_gpu_ingest.py" or any(tag in it.name for tag in _CPU_HEAVY)
         stage = 4 if late else 3 if at_l else 2 if base == "test_gpu_dist.py" else 1 if full else 0
         return (stage, rank)
@@ -40,21 +41,6 @@ def pytest_collection_modifyitems(config, items):
 
 
 _CPU_HEAVY = ("test_spmm_hub_rows_are_split_and_reproducible", "test_csr_build_bit_exact", "test_index_arithmetic_beyond_2_31")
-_BG = {"dir": None, "groups": (), "all_cores": True}
-
-
-def pytest_runtest_setup(item):
-    """Once every background oracle process has ended, the foreground gets the host's cores back."""
-    if _BG["all_cores"] or _BG["dir"] is None:
-        return
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    import _oracle_jobs as J
-    if not any(J._alive(_BG["dir"], J.GROUPS[g][0]) for g in _BG["groups"]):
-        import torch
-        torch.set_num_threads(os.cpu_count() or 8)
-        _BG["all_cores"] = True
-
-
 @pytest.fixture(scope="session", autouse=True)
 def oracle_background(request):
     """`-m gpu` sessions on a box with a GPU: two CPU-only processes (the GPU hidden from them) work through the oracle halves
@@ -80,7 +66,7 @@ def oracle_background(request):
     cores = os.cpu_count() or 8
     share = max(2, cores // 4)  # 16 cores: 4 threads per background process (2 for the small-tensor Cora job), 6 for this one
     threads = {g: (2 if g == "cora" else share) for g in groups}
-    torch.set_num_threads(max(4, cores * 3 // 8))  # 16 foreground threads only fought the background; 4 starved the ingest checks
+    torch.set_num_threads(max(4, cores // 2))  # 16 foreground threads only fought the background; 4 starved the ingest checks
     procs = []
     for group in groups:
         env_g = dict(env, OMP_NUM_THREADS=str(threads[group]), MKL_NUM_THREADS=str(threads[group]))
@@ -90,9 +76,7 @@ def oracle_background(request):
             f.write(str(p.pid))
         procs.append(p)
     os.environ["RGBX_ORACLE_BG"] = d
-    _BG.update(dir=d, groups=tuple(groups), all_cores=False)
     yield d
-    _BG.update(dir=None, all_cores=True)
     os.environ.pop("RGBX_ORACLE_BG", None)
     for p in procs:
         if p.poll() is None:
