@@ -63,13 +63,18 @@ MODEL_KW = {
 }
 
 
-def initial_state(name):
+# S only: APPNP at K = 4 under the FULL oracle's autograd (K = 10 there is 100 s of host time for ten [E', d] temporaries each
+# way; config 5's K = 10 is checked at its own size L, gradients by oracle/large.py and all rows of the forward)
+MODEL_KW_S = dict(MODEL_KW, appnpstack=dict(hidden_unit=64, K=4, alpha=0.1, dropout_rate=0.5))
+
+
+def initial_state(name, size="L"):
     """The seeded initial state_dict of the gradient cases (biases and BatchNorm affine parameters off their zero / one
     initial values) — built on the CPU, the same bits wherever it is called."""
     from rgb_experiment_amd import models as M
     cls = {"gcn": M.GCN, "graphsage": M.GraphSAGE, "graphsage2": M.GraphSAGE2, "gat": M.GAT, "appnpstack": M.APPNPStack}[name]
     torch.manual_seed(14530529)
-    model = cls(input_dim=128, output_dim=128, **MODEL_KW[name])
+    model = cls(input_dim=128, output_dim=128, **(MODEL_KW_S if size == "S" else MODEL_KW)[name])
     with torch.no_grad():
         g = torch.Generator().manual_seed(5)
         for k, p in model.named_parameters():
@@ -88,8 +93,8 @@ def grads_S(name):
     """(loss, {parameter: gradient}) of one training step at S under the FULL oracle (PyG dataflow, torch autograd)."""
     ei, x, y = workload("S")
     mask = train_mask(x.size(0))
-    _, sd = initial_state(name)
-    kw = MODEL_KW[name]
+    _, sd = initial_state(name, "S")
+    kw = MODEL_KW_S[name]
     fwd = {"gcn": lambda p: O.gcn_forward(p, x, ei, 2, True), "graphsage": lambda p: O.graphsage_forward(p, x, ei, 2, True),
            "graphsage2": lambda p: O.graphsage2_forward(p, x, ei, 2, True),
            "gat": lambda p: O.gat_forward(p, x, ei, 2, kw.get("heads", 8), True),

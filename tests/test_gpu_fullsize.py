@@ -170,13 +170,13 @@ def test_model_logits_at_sampled_rows_of_the_benchmark_graph(dev, size, name):
 GRAD_TOL, GRAD_REL = 1e-4, 2e-3
 
 
-def _hip_training_step(dev, name, ei, x, y, mask, route):
+def _hip_training_step(dev, name, ei, x, y, mask, route, size="L"):
     """One train-mode forward + backward of the product model on the GPU from the seeded initial state
     (tests/_oracle_jobs.initial_state: the oracle half starts from the same bits). route 'kernel_loss': the loss inside the
     last conv's kernel where the model has that form (what experiment() and bench.py run); 'logits': log-probabilities
     materialised, NLLLoss on top (what a foreign loop runs). Returns (loss, {name: grad on the CPU})."""
     from rgb_experiment_amd.models._stack import masked_ce
-    model, _ = J.initial_state(name)
+    model, _ = J.initial_state(name, size)
     model.to(dev).train()
     x_d, ei_d, y_d, m_d = x.to(dev), ei.to(dev), y.to(dev), mask.to(dev)
     if route == "kernel_loss":
@@ -209,7 +209,7 @@ def test_model_gradients_at_benchmark_size_S(dev, name, route):
     dataflow under torch autograd: edge-sized temporaries of 2 GB each; tests/_oracle_jobs.grads_S)."""
     from rgb_experiment_amd.graph import clear_cache
     ei, x, y = workload("S")
-    loss, grads = _hip_training_step(dev, name, ei, x, y, J.train_mask(x.size(0)), route)
+    loss, grads = _hip_training_step(dev, name, ei, x, y, J.train_mask(x.size(0)), route, "S")
     ref_loss, ref_grads = J.get(f"grads_S_{name}")
     # state_dict lists GATConv's lin_dst.weight next to lin_src.weight (one shared tensor: one parameter, one gradient)
     rep = OL.compare_grads(grads, {k: ref_grads[k] for k in grads})
