@@ -40,6 +40,20 @@ def pytest_collection_modifyitems(config, items):
     items.sort(key=key)
 
 
+def usable_cpus():
+    """CPUs this session may keep busy: the cgroup quota where there is one. A one-GPU box of the pool reports 256 from
+    os.cpu_count() and grants 16 (`cpu.max` = 1600000 100000): thread counts taken from cpu_count() had 22+ threads throttled
+    in three of five scheduler periods (cpu.stat, round 5) — the whole-model fuzz blocks then took 54 s instead of 6."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 _CPU_HEAVY = ("test_spmm_hub_rows_are_split_and_reproducible", "test_csr_build_bit_exact", "test_index_arithmetic_beyond_2_31")
 @pytest.fixture(scope="session", autouse=True)
 def oracle_background(request):
@@ -50,12 +64,11 @@ def oracle_background(request):
     import shutil
     import subprocess
     import tempfile
-    wanted = {"test_gpu_fullsize.py", "test_gpu_parity.py"} & {it.fspath.basename for it in request.session.items}
-    if not wanted or os.environ.get("RGBX_ORACLE_BG") == "off":
-        yield None
-        return
     import torch
-    if not torch.cuda.is_available():
+    if torch.get_num_threads() > usable_cpus():  # set once, before the first parallel region, and never again (see above)
+        torch.set_num_threads(usable_cpus())
+    wanted = {"test_gpu_fullsize.py", "test_gpu_parity.py"} & {it.fspath.basename for it in request.session.items}
+    if not wanted or os.environ.get("RGBX_ORACLE_BG") == "off" or not torch.cuda.is_available():
         yield None
         return
     d = tempfile.mkdtemp(prefix="rgbx_oracle_bg_")
@@ -63,10 +76,12 @@ def oracle_background(request):
     # CPU only, a share of the host cores each (a one-GPU box has 16): the foreground keeps the rest for its own small oracles
     env.update({"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
     groups = ["cora", "small", "large_gcn", "large_mean"] if "test_gpu_fullsize.py" in wanted else ["cora"]
-    cores = os.cpu_count() or 8
-    share = max(2, cores // 4)  # 16 cores: 4 threads per background process (2 for the small-tensor Cora job), 6 for this one
+    # the quota split so that everything busy at once stays within it (16: 2 + 3 + 3 + 3 in the background, 5 here; the
+    # multi-rank stage's rank processes take 1 thread each and mostly wait for the card)
+    cores = usable_cpus()
+    share = max(2, (cores - 2) // 5 + 1)
     threads = {g: (2 if g == "cora" else share) for g in groups}
-    torch.set_num_threads(max(4, cores // 2))  # 16 foreground threads only fought the background; 4 starved the ingest checks
+    torch.set_num_threads(max(4, cores - sum(threads.values())))
     procs = []
     for group in groups:
         env_g = dict(env, OMP_NUM_THREADS=str(threads[group]), MKL_NUM_THREADS=str(threads[group]))

@@ -53,7 +53,17 @@ def _spawn(fn, args, nprocs, limit_s=240):
     on stderr (W.arm_deadline); should even that not happen, they are killed here and the case fails — a stall costs the
     suite minutes, never its whole budget."""
     import time
-    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    # rank processes inherit the environment: 2 host threads each (torch's default is one per CPU the HOST has — 256 on a box
+    # whose quota is 16 — and four ranks of those are throttled by the cgroup for most of their run)
+    before = os.environ.get("OMP_NUM_THREADS")
+    os.environ["OMP_NUM_THREADS"] = "2"
+    try:
+        ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    finally:
+        if before is None:
+            os.environ.pop("OMP_NUM_THREADS", None)
+        else:
+            os.environ["OMP_NUM_THREADS"] = before
     t0 = time.time()
     while not ctx.join(timeout=2):
         if time.time() - t0 > limit_s:
