@@ -9,9 +9,9 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 job="$1"; shift
 case "$job" in
-  tests)        # tests <label> <pytest args...>
+  tests)        # tests <label> <pytest args...>   (NOX=-q: do not stop at the first failure)
     label="$1"; shift
-    timeout -k 10 1100 python3 -m pytest "$@" -x -q -m gpu --durations=${DUR:-25} --durations-min=0.2 -p no:cacheprovider > "$OUT/tests_$label.log" 2>&1
+    timeout -k 10 1100 python3 -m pytest "$@" ${NOX:--x} -q -m gpu --durations=${DUR:-25} --durations-min=0.2 -p no:cacheprovider > "$OUT/tests_$label.log" 2>&1
     rc=$?; tail -n 40 "$OUT/tests_$label.log"; exit $rc ;;
   bench)        # bench <label> <bench.py args...>
     label="$1"; shift
