@@ -14,13 +14,15 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """Order of a `-m gpu` session: the GPU-bound parity modules, the S cases of the BASELINE-size module, the multi-rank module
-    (the one part that depends on more than this process and the card: rank processes, RCCL's socket transport or gloo,
-    rendezvous ports — under `-x` a failure there must not keep the parity modules from running), the L cases last: their
-    oracle halves are computed on the host cores in the background from session start (oracle_background below) and are ready
-    by then. (Stable sort: everything else keeps its order.)"""
-    # L cases of the BASELINE-size module in the order the background run finishes their oracle halves: first the cases
-    # whose oracle runs inline on sampled rows, then tests/_oracle_jobs.GROUPS["large"]'s order
+    """Order of a `-m gpu` session: the GPU-bound parity modules, the S cases of the BASELINE-size module, its L cases (their
+    oracle halves are computed on the host cores in the background from session start, oracle_background below), the cases
+    whose CPU side is heavy, and LAST the multi-rank module — the one part that depends on more than this process and the
+    card (rank processes, RCCL's socket transport or gloo, rendezvous ports: under `-x` a failure there must not keep the
+    parity modules from running), and the one part that needs the background processes GONE: a process that has run
+    autograd's backward has the GPU's device files open (the engine counts the devices of every backend, hidden or not), and
+    the box allows six such processes at once — run full12 of round 5 was ended by that guard with four ranks, this process
+    and two background processes alive. (Stable sort: everything else keeps its order.)"""
+    # L cases in the order the background processes finish their oracle halves (tests/_oracle_jobs.GROUPS)
     l_order = ["test_model_logits_at_sampled_rows", "test_fused_aggregate_transform", "test_appnp_k10",
                "benchmark_size_L[gcn]", "benchmark_size_L[graphsage2]", "benchmark_size_L[appnpstack]",
                "benchmark_size_L[graphsage]", "benchmark_size_L[gat]"]
@@ -30,14 +32,29 @@ def pytest_collection_modifyitems(config, items):
         full = base == "test_gpu_fullsize.py"
         at_l = full and ("benchmark_size_L" in it.name or "L" in it.name.partition("[")[2].replace("]", "").split("-"))
         rank = next((i for i, tag in enumerate(l_order) if tag in it.name), len(l_order)) if at_l else 0
-        # GPU-bound modules, the S cases, the multi-rank module (mostly waiting for its rank processes: the background oracle
-        # has the host cores meanwhile), the L cases, and last the cases whose CPU side is heavy (sorts of 10^8 keys, float64
-        # oracles of hub graphs): by then the background processes are through and the cores are this process's alone
-        # (its thread count stays what the fixture below set: raising it mid-session stalled two runs, full7 / full8 of round 5)
+        # (this process's thread count stays what the fixture below set: raising it mid-session stalled two runs, full7 / full8)
         late = base == "test_gpu_ingest.py" or any(tag in it.name for tag in _CPU_HEAVY)
-        stage = 4 if late else 3 if at_l else 2 if base == "test_gpu_dist.py" else 1 if full else 0
+        stage = 4 if base == "test_gpu_dist.py" else 3 if late else 2 if at_l else 1 if full else 0
         return (stage, rank)
     items.sort(key=key)
+
+
+_BG_PROCS = []
+
+
+def background_oracle_finished(limit_s=240):
+    """Block until the background oracle processes have exited (tests/test_gpu_dist.py calls this before its first rank
+    process starts); one still running after `limit_s` is killed — its remaining jobs are then computed inline by whoever
+    asks for them."""
+    import time
+    t0 = time.time()
+    for p in _BG_PROCS:
+        while p.poll() is None:
+            if time.time() - t0 > limit_s:
+                p.kill()
+                p.wait()
+                break
+            time.sleep(0.2)
 
 
 def usable_cpus():
@@ -93,9 +110,11 @@ def oracle_background(request):
         with open(os.path.join(d, f"{group}.pid"), "w") as f:
             f.write(str(p.pid))
         procs.append(p)
+        _BG_PROCS.append(p)
     os.environ["RGBX_ORACLE_BG"] = d
     yield d
     os.environ.pop("RGBX_ORACLE_BG", None)
+    del _BG_PROCS[:]
     for p in procs:
         if p.poll() is None:
             p.kill()

@@ -21,6 +21,8 @@ def rank_backend(tmp_path_factory):
     processes with a deadline); otherwise gloo with host staging, as in rounds 1-3, and test_the_ranks_ran_on_rccl says so.
     RGBX_TEST_BACKEND=gloo|rccl in the environment decides without a probe."""
     import time
+    from conftest import background_oracle_finished
+    background_oracle_finished()  # the card is this module's rank processes' (at most 5 at once) and nobody else's
     given = os.environ.get("RGBX_TEST_BACKEND")
     if given:
         yield given
