@@ -224,7 +224,7 @@ def test_fused_schedule_with_hub_rows(model_name, world, exchange, tmp_path):
     assert (torch.cat([p["logits_train"] for p in parts]) - emb).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("model_name,world,exchange,size", [("graphsage2_grid", 2, "reshard", None),
+@pytest.mark.parametrize("model_name,world,exchange,size", [("gcn_grid", 4, "2x2", None), ("graphsage2_grid", 2, "reshard", None),
                                                              ("gcn_bench", 4, "2x2", "S"), ("graphsage_bench", 2, "reshard", "S")])
 def test_step_computed_ahead_gives_the_same_bits(model_name, world, exchange, size, tmp_path):
     """Real kernels: the second training step computed beside the first epoch's eval forwards (epoch(more=True), the
@@ -266,7 +266,7 @@ def test_shared_eval_forward_on_the_real_kernels(model_name, world, exchange, si
 
 
 @pytest.mark.parametrize("model_name,exchange,world", [("appnpstack", "reshard", 4), ("gcn", "auto", 4), ("gcn", "auto", 2),
-                                                       ("gat", "auto", 2)])  # (graphsage x 2: same route as gcn x 2; passed)
+                                                       ("gat", "auto", 2), ("graphsage", "auto", 2)])
 def test_epoch_split_by_task_on_the_real_kernels(model_name, exchange, world, tmp_path):
     """dist.TaskSplitRunner on the one GPU: the first half of the ranks trains (second step computed ahead), the other
     half evaluates — 4 ranks: groups of 2 on the partitioned path; 2 ranks: each on the WHOLE graph with the single-GPU
@@ -310,6 +310,7 @@ def test_gloo_staging_of_device_tensors(tmp_path):
 
 
 @pytest.mark.parametrize("model_name,world,exchange,size", [("gcn_bench", 2, "replicate", "S"), ("gcn_bench", 3, "halo", "S"),
+                                                             ("graphsage_bench", 2, "reshard", "S"),
                                                              ("appnpstack_bench", 4, "reshard", "S"), ("gat", 3, "auto", None)])
 def test_eval_forwards_on_two_streams_give_the_same_bits(model_name, world, exchange, size, tmp_path, rank_backend):
     """The val and the test forward issued by two host threads on two HIP streams (RCCL: one forward's exchange in flight beside
