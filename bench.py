@@ -968,6 +968,10 @@ def main():
         # failure) — so that a hang or an error in one rank ends in a JSON line, not in silence
         sys.exit(sv.supervise(os.path.abspath(__file__), sys.argv[1:], rank, world))
     t_start = time.perf_counter()
+    if torch.get_num_threads() > host_cores():
+        # host side of the set-up (synthetic graph, oracle legs): torch sizes its pool by the CPUs the HOST has (256 on a box
+        # of the pool whose cgroup grants 16); threads beyond the quota are throttled, not run
+        torch.set_num_threads(host_cores())
     sv.beat("worker started, torch imported")
     backend = os.environ.get("RGBX_DIST_BACKEND", "nccl")
     test_backend = None
