@@ -1659,12 +1659,21 @@ class SparseRows:
         from .graph import CSR, make_row_split
         _lib.require_device(x)
         n, f = x.shape
-        nz = x.nonzero(as_tuple=False)  # row-major order
-        rows, cols = nz[:, 0].contiguous(), nz[:, 1].contiguous()
+        # row-major order, in row blocks of at most 2^28 entries: torch's nonzero() indexes with 32 bits (2 M x 1433 entries
+        # in one call ended in an allocation of 2^56 bytes, round 5)
+        step = max(1, (1 << 28) // max(f, 1))
+        rows, cols, vals = [], [], []
+        for r0 in range(0, n, step):
+            blk = x[r0:r0 + step]
+            nz = blk.nonzero(as_tuple=False)
+            rows.append(nz[:, 0] + r0)
+            cols.append(nz[:, 1].contiguous())
+            vals.append(blk[nz[:, 0], nz[:, 1]])
+        rows, cols, vals = (torch.cat(t).contiguous() if t else x.new_zeros(0, dtype=dt)
+                            for t, dt in ((rows, torch.int64), (cols, torch.int64), (vals, x.dtype)))
         self.n, self.f, self.nnz = n, f, int(rows.numel())
         if self.nnz >= 2 ** 31 - 1:
             raise RuntimeError("SparseRows: more than 2^31 non-zeros")
-        vals = x[rows, cols].contiguous()
         i32 = lambda t: t.to(torch.int32).contiguous()
 
         def rowptr_of(idx, m):
@@ -1710,7 +1719,8 @@ def prepare_features(x, max_density=0.1):
     SparseRows riding on the tensor — ops.linear then multiplies over the non-zeros alone. Same values, same shape."""
     x = align_rows(x)
     if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad and x.numel():
-        nnz = int(torch.count_nonzero(x))
+        step = max(1, (1 << 28) // x.size(1))  # (row blocks: see SparseRows)
+        nnz = sum(int(torch.count_nonzero(x[r0:r0 + step])) for r0 in range(0, x.size(0), step))
         if nnz <= max_density * x.numel() and nnz < 2 ** 31 - 1:
             x._rgbx_sparse = SparseRows(x)  # (this Python object only: a slice or a copy is an ordinary dense tensor)
     return x
