@@ -729,7 +729,13 @@ def real_shape_block(dev, ei, N, F, C, names, steps, warmup, features="dense", s
             if "[rows+" not in key:
                 continue
             d = int(key.split("+d")[-1].rstrip("]"))
-            alg = spmm_alg_bytes(N, nnz, d) - (0 if key.startswith("gcn") else 4 * nnz)  # per-edge weights: A_hat only
+            if key.startswith("features"):
+                # the feature matrix's own non-zeros (ops.SparseRows): x W^T gathers rows of W^T [F, d] (L2-resident) into N
+                # output rows, dW gathers rows of dY [N, d] into F output rows; the feature values are the per-entry weights
+                sp = x._rgbx_sparse
+                alg = spmm_alg_bytes(N if key.startswith("features_fwd") else F, sp.nnz, d)
+            else:
+                alg = spmm_alg_bytes(N, nnz, d) - (0 if key.startswith("gcn") else 4 * nnz)  # per-edge weights: A_hat only
             roof[key] = {"width": d, "algorithmic_bytes": alg, "avg_ms": t["avg_ms"],
                          "achieved_gbs": alg / (t["avg_ms"] * 1e-3) / 1e9,
                          "frac_of_8TBs": alg / (t["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
