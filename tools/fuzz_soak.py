@@ -15,6 +15,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 
 import test_gpu_fuzz as F
+from conftest import usable_cpus
+
+torch.set_num_threads(min(torch.get_num_threads(), usable_cpus()))  # the oracle half: the cgroup's CPUs, not the host's
 
 
 def main():
