@@ -298,7 +298,9 @@ __global__ void __launch_bounds__(256) spmm_tile_epilogue_kernel(const SpmmArgs 
   const int c = t * VEC;
   const bool active = c < A.d;
   const int row_base = blockIdx.x * kTileRows;
-  float s1[VEC] = {0.f, 0.f, 0.f, 0.f}, s2[VEC] = {0.f, 0.f, 0.f, 0.f};
+  // column statistics: sums of (x - cw) and (x - cw)^2 with cw = the wave's first row (a sample of the column: no
+  // cancellation against the column's mean, see the tile records below)
+  float s1[VEC] = {0.f, 0.f, 0.f, 0.f}, s2[VEC] = {0.f, 0.f, 0.f, 0.f}, cw[VEC] = {0.f, 0.f, 0.f, 0.f};
   double nll = 0.0, nll2 = 0.0;
   int cnt = 0, hit = 0, cnt2 = 0, hit2 = 0;
   const float sc = (CE && E.ce_scale) ? E.ce_scale[0] : 0.f;
@@ -352,10 +354,15 @@ __global__ void __launch_bounds__(256) spmm_tile_epilogue_kernel(const SpmmArgs 
           f4v o = {r[0], r[1], r[2], r[3]};
           __builtin_nontemporal_store(o, reinterpret_cast<f4v*>(A.out + (int64_t)row * A.ldo + c));
         }
+        if (rr == 0) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) cw[i] = r[i];
+        }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-          s1[i] += r[i];
-          s2[i] = fmaf(r[i], r[i], s2[i]);
+          const float dv = r[i] - cw[i];
+          s1[i] += dv;
+          s2[i] = fmaf(dv, dv, s2[i]);
         }
       }
     } else {
@@ -410,17 +417,43 @@ __global__ void __launch_bounds__(256) spmm_tile_epilogue_kernel(const SpmmArgs 
   }
   if constexpr (!CE) {
     if (!E.stats_part) return;
-    __shared__ float sh[4][512];
+    __shared__ float sh[4][768];
     if (g == 0 && active) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         sh[wave][c + i] = s1[i];
         sh[wave][A.d + c + i] = s2[i];
+        sh[wave][2 * A.d + c + i] = cw[i];
       }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < 2 * A.d; k += 256)
-      E.stats_part[(int64_t)blockIdx.x * 2 * A.d + k] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
+    // The tile's record per column: (S = sum x, M2 = sum (x - S/n)^2), as the fused kernel's MFMA tiles write it
+    // (spmm_linear.hip store_tile; the reducers form sum x^2 = M2 + S^2 / n in fp64). From the waves' shifted sums in fp64:
+    // wave w with n_w rows has mean_w = cw + s1 / n_w and M2_w = s2 - s1^2 / n_w, the tile adds the spread of the wave means.
+    const int n_t = A.N - row_base < kTileRows ? A.N - row_base : kTileRows;
+    for (int k = threadIdx.x; k < A.d; k += 256) {
+      double mean_w[4], m2 = 0.0, S = 0.0;
+      int n_w[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int left = n_t - w * RPW;
+        n_w[w] = left <= 0 ? 0 : (left < RPW ? left : RPW);
+        mean_w[w] = 0.0;
+        if (n_w[w]) {
+          const double a = (double)sh[w][k] / n_w[w];
+          mean_w[w] = (double)sh[w][2 * A.d + k] + a;
+          const double within = (double)sh[w][A.d + k] - (double)sh[w][k] * a;
+          m2 += within > 0.0 ? within : 0.0;
+          S += n_w[w] * mean_w[w];
+        }
+      }
+      const double mean_t = S / n_t;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (n_w[w]) m2 += n_w[w] * (mean_w[w] - mean_t) * (mean_w[w] - mean_t);
+      E.stats_part[(int64_t)blockIdx.x * 2 * A.d + k] = (float)S;
+      E.stats_part[(int64_t)blockIdx.x * 2 * A.d + A.d + k] = (float)m2;
+    }
   } else {
     __shared__ double cew[4][6];
     if (lane == 0) {
@@ -630,5 +663,5 @@ extern "C" int rgbx_spmm_csr_epilogue_f32(const int32_t* rowptr, const int32_t* 
   else rc = launch_epilogue<64>(A, E, s);
   if (rc) return rc;
   if (ce) return reduce_ce_tiles(ce->scratch, tiles, ce->stats, ce->mask_groups == 2 ? 6 : 3, s);
-  return reduce_tile_stats(stats_part, tiles, (int)(2 * d), stats_part2, epi->out_colsums, s);
+  return reduce_tile_stats(stats_part, tiles, (int)(2 * d), stats_part2, epi->out_colsums, N, s);
 }

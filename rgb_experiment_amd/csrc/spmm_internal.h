@@ -21,6 +21,6 @@ constexpr int kTileRows = 32;
 constexpr int kCeGather = 64;
 constexpr int kStatsGather = 1024;
 int reduce_ce_tiles(double* scratch, int tiles, double* stats, int W, hipStream_t s);
-int reduce_tile_stats(const float* part, int tiles, int width2, double* part2, double* sums, hipStream_t s);
+int reduce_tile_stats(const float* part, int tiles, int width2, double* part2, double* sums, int64_t n_rows, hipStream_t s);
 
 }  // namespace rgbx

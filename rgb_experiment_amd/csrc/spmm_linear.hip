@@ -163,7 +163,7 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __res
                                            int tile = -1) {
   if (tile < 0) tile = blockIdx.x;  // one tile per workgroup unless the caller walks several
   const float bb = bias ? bias[n0 + cc] : 0.f;
-  float s1 = 0.f, s2 = 0.f;
+  float s1 = 0.f;
   // blocked copy: this lane's column n0 + cc sits in block (n0 + cc) / ob_c at offset (n0 + cc) % ob_c
   float* ob = BLK && out_blk ? out_blk + (int64_t)((n0 + cc) / (int)ob_c) * ob_s + ((n0 + cc) % (int)ob_c) : nullptr;
 #pragma unroll
@@ -174,35 +174,62 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __res
       if (!BLK || out) nt_store1(&out[(int64_t)row * ldo + n0 + cc], v);
       if constexpr (BLK) { if (ob) ob[(int64_t)row * ob_c] = v; }
       s1 += v;
-      s2 = fmaf(v, v, s2);
     }
   }
-  if (stats_part) {  // lanes l and l + 32 hold the two row halves of column cc: one record per workgroup and column
+  if (stats_part) {
+    // One record per tile and column: (sum, sum of squared deviations from the TILE's mean) — the tile's values are all
+    // in registers, so the second moment is taken around their own mean. A record of (sum x, sum x^2) in fp32 loses the
+    // variance of a nearly constant column (|mean| >> std: x^2 rounds at 6e-8 mean^2, BatchNorm divides by
+    // sqrt(var + 1e-5)); the reducers restore sum x^2 = M2 + S^2 / n per tile in fp64 (tile_stats_gather_kernel).
+    // Lanes l and l + 32 hold the two row halves of column cc.
     s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 32);
+    const int n_t = N - row_base < kTileRows ? N - row_base : kTileRows;
+    const float mean = s1 / (float)n_t;
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * kr;
+      if (row < N) {
+        const float dv = (acc[r] + bb) - mean;
+        m2 = fmaf(dv, dv, m2);
+      }
+    }
+    m2 += __shfl_xor(m2, 32);
     if (kr == 0) {
       float* rec = stats_part + (int64_t)tile * 2 * Nout;
       rec[n0 + cc] = s1;
-      rec[Nout + n0 + cc] = s2;
+      rec[Nout + n0 + cc] = m2;
     }
   }
 }
 
 // Second stage of the output statistics: workgroup g adds the per-tile records g, g + G, ... in fp64 (thread = column of
-// the [2, Nout] record), a third stage adds the G sums in order: fixed summation order, reproducible.
+// the [2, Nout] record), a third stage adds the G sums in order: fixed summation order, reproducible. A tile's record is
+// (S = sum x, M2 = sum (x - S/n)^2) over its n rows (kTileRows, the last tile the rest of n_rows); what is added up is
+// (sum x, sum x^2) with sum x^2 = M2 + S^2 / n formed in fp64 from the SAME rounded S — so the variance the consumer takes
+// from the totals is the within-tile part exactly plus the spread of the tile means, whatever the column's mean.
+__device__ __forceinline__ double tile_stat(const float* __restrict__ part, int b, int width2, int c, int n_rows) {
+  const int half = width2 >> 1;
+  const double v = (double)part[(int64_t)b * width2 + c];
+  if (c < half) return v;
+  const double S = (double)part[(int64_t)b * width2 + c - half];
+  const int left = n_rows - b * kTileRows;
+  return v + S * S / (double)(left < kTileRows ? left : kTileRows);
+}
+
 __global__ void __launch_bounds__(256)
-tile_stats_gather_kernel(const float* __restrict__ part, int n_tiles, int width2, double* __restrict__ part2) {
+tile_stats_gather_kernel(const float* __restrict__ part, int n_tiles, int width2, double* __restrict__ part2, int n_rows) {
   const int G = gridDim.x;
   for (int c = threadIdx.x; c < width2; c += 256) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains: the loads of a trip are all in flight
     int b = blockIdx.x;
     for (; b + 3 * G < n_tiles; b += 4 * G) {
-      s0 += (double)part[(int64_t)b * width2 + c];
-      s1 += (double)part[(int64_t)(b + G) * width2 + c];
-      s2 += (double)part[(int64_t)(b + 2 * G) * width2 + c];
-      s3 += (double)part[(int64_t)(b + 3 * G) * width2 + c];
+      s0 += tile_stat(part, b, width2, c, n_rows);
+      s1 += tile_stat(part, b + G, width2, c, n_rows);
+      s2 += tile_stat(part, b + 2 * G, width2, c, n_rows);
+      s3 += tile_stat(part, b + 3 * G, width2, c, n_rows);
     }
-    for (; b < n_tiles; b += G) s0 += (double)part[(int64_t)b * width2 + c];
+    for (; b < n_tiles; b += G) s0 += tile_stat(part, b, width2, c, n_rows);
     part2[(int64_t)blockIdx.x * width2 + c] = (s0 + s1) + (s2 + s3);
   }
 }
@@ -917,9 +944,9 @@ int reduce_ce_tiles(double* scratch, int tiles, double* stats, int W, hipStream_
   return RGBX_OK;
 }
 
-int reduce_tile_stats(const float* part, int tiles, int width2, double* part2, double* sums, hipStream_t s) {
+int reduce_tile_stats(const float* part, int tiles, int width2, double* part2, double* sums, int64_t n_rows, hipStream_t s) {
   const int G = tiles < kStatsGather ? tiles : kStatsGather;
-  tile_stats_gather_kernel<<<G, 256, 0, s>>>(part, tiles, width2, part2);
+  tile_stats_gather_kernel<<<G, 256, 0, s>>>(part, tiles, width2, part2, (int)n_rows);
   RGBX_CHECK_LAUNCH("tile_stats_gather_kernel");
   tile_stats_finish_kernel<<<(int)cdiv(width2, 8), 256, 0, s>>>(part2, G, width2, sums);
   RGBX_CHECK_LAUNCH("tile_stats_finish_kernel");
@@ -1075,7 +1102,7 @@ extern "C" int rgbx_fused_layer_f32(const rgbx_fused_layer_t* Lp, rgbx_stream_t 
     if (int rc2 = reduce_ce_tiles(ce->scratch, (int)cdiv(N, TM), ce->stats, ce->mask_groups == 2 ? 6 : 3, s)) return rc2;
   }
   if (!L.out_colsums) return RGBX_OK;
-  return reduce_tile_stats(stats_part, (int)cdiv(N, TM), (int)(2 * Nout), stats_part2, L.out_colsums, s);
+  return reduce_tile_stats(stats_part, (int)cdiv(N, TM), (int)(2 * Nout), stats_part2, L.out_colsums, N, s);
 }
 
 extern "C" int rgbx_spmm_linear_stats_workspace_bytes(int64_t N, int64_t Nout, size_t* bytes) {

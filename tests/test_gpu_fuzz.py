@@ -326,6 +326,14 @@ def test_whole_models_against_the_oracle_on_random_shapes(dev, block):
         run_model_case(dev, seed)
 
 
+@pytest.mark.parametrize("seed", [557])
+def test_whole_model_seeds_the_soaks_found(dev, seed):
+    """557 (tools/fuzz_soak.py --models 75 1500, round 5): graphsage2 on 2 nodes, hidden 100 — BatchNorm statistics handed over
+    by the row kernel's epilogue on columns with std 4e-4 under a mean of 1 (tests/test_gpu_rows.py
+    test_column_statistics_of_nearly_constant_columns)."""
+    run_model_case(dev, seed)
+
+
 # ---- rgbx_fused_layer_f32 by option: dense or aggregating, blocked or plain rows, pre-affine, root term, stored z, column
 # sums, blocked output, loss statistics (one or two masks) or loss gradient -----------------------------------------------
 

@@ -65,6 +65,48 @@ def test_row_kernel_column_sums(dev, d, kind, monkeypatch):
         assert torch.equal(cs, again)  # fixed summation order
 
 
+@pytest.mark.parametrize("n", [2, 3, 33, 4133])
+@pytest.mark.parametrize("route", ["rows", "fused", "dense"])
+def test_column_statistics_of_nearly_constant_columns(dev, n, route):
+    """The variance a BatchNorm takes from handed-over column sums, on columns whose spread is far below their mean (means
+    0.5 .. 3, standard deviations 1e-4 .. 1): within 1e-4 of var + eps of the float64 statistics of the same output, from
+    the row kernel's epilogue, from the fused kernel's MFMA tiles and from the dense launch. A per-tile record of
+    (sum x, sum x^2) in float32 lost it: x^2 rounds at 6e-8 mean^2, the difference var = E[x^2] - mean^2 of a column with
+    std 4e-4 was off by a third, and whole-model fuzz seed 557 (graphsage2, 2 nodes, hidden 100: the first shape whose
+    statistics came from the row kernel) had its logits 2e-2 off; the records now hold the squared deviations from the
+    tile's own mean."""
+    from rgb_experiment_amd import nn as RN
+    from rgb_experiment_amd import ops
+    d = 128
+    gen = torch.Generator().manual_seed(n)
+    mean = torch.rand(d, generator=gen) * 2.5 + 0.5
+    std = 10 ** (-4 * torch.rand(d, generator=gen))
+    x = (mean + std * torch.randn(n, d, generator=gen)).to(dev)
+    ei = torch.arange(n).repeat(2, 1)  # every node aggregates itself: the layer's output is x
+    g = _kind_graph(dev, ei, n, "sum")
+    if route == "rows":
+        out, cs = ops.spmm_epilogue_raw(g.fwd, None, None, x, want_colsums=True)
+    else:
+        eye = torch.eye(d, device=dev)
+        out, cs = _fused_with_sums(ops, x, eye, g.fwd if route == "fused" else None)
+    assert torch.equal(out, x)
+    xd = x.double()
+    var64 = xd.var(0, unbiased=False)
+    got_mean = cs[0] / n
+    got_var = cs[1] / n - got_mean ** 2
+    assert (got_mean - xd.mean(0)).abs().max().item() < 1e-6
+    rel = ((got_var - var64).abs() / (var64 + 1e-5)).max().item()
+    assert rel < 1e-4, (rel, n, route)
+    bn_a, bn_b = RN.BatchNorm1d(d).to(dev), RN.BatchNorm1d(d).to(dev)
+    ya, yb = bn_a(x, colsums=cs), bn_b(x)
+    assert (ya - yb).abs().max().item() < 2e-4 * max(1.0, yb.abs().max().item())
+
+
+def _fused_with_sums(ops, x, wt, csr):
+    res = ops.fused_layer(x, wt, csr=csr, want_colsums=True)
+    return res[0], res[-1]
+
+
 @pytest.mark.parametrize("C", [1, 3, 7, 40, 47, 128, 130, 256])
 @pytest.mark.parametrize("kind", ["gcn", "mean"])
 def test_row_kernel_cross_entropy(dev, C, kind, monkeypatch):
