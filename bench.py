@@ -940,6 +940,10 @@ def main():
     ap.add_argument("--share-eval-forward", action="store_true",
                     help="N > 1 / --emulate-rank: val and test statistics from ONE eval forward per epoch (experiment()'s "
                          "default; the headline keeps the reference's two eval forwards). A SECONDARY line.")
+    ap.add_argument("--plan-from-slices", action="store_true",
+                    help="N > 1: every rank builds its halo / grid plans from its own 1/N of the edge list and one all-to-all "
+                         "of edge records per direction (RGBX_PLAN_FROM_SLICES=1, dist/plan.py subsets_from_slices) instead of "
+                         "scanning the whole list; the same plans bit for bit")
     ap.add_argument("--emulate-rank", type=int, default=0, metavar="P",
                     help="one GPU: rank 0's launches of a P-rank job, exchanges replaced by stand-in rows")
     ap.add_argument("--emulate-contend", type=float, default=60.0, metavar="GBS",
@@ -974,6 +978,8 @@ def main():
         # failure) — so that a hang or an error in one rank ends in a JSON line, not in silence
         sys.exit(sv.supervise(os.path.abspath(__file__), sys.argv[1:], rank, world))
     t_start = time.perf_counter()
+    if args.plan_from_slices:
+        os.environ["RGBX_PLAN_FROM_SLICES"] = "1"
     if torch.get_num_threads() > host_cores():
         # host side of the set-up (synthetic graph, oracle legs): torch sizes its pool by the CPUs the HOST has (256 on a box
         # of the pool whose cgroup grants 16); threads beyond the quota are throttled, not run
@@ -1231,7 +1237,8 @@ def main():
                     "its own targets, no activation exchange (RCCL all-reduces of loss / gradients only)" % parts)
                    if scheme == "replicate" else
                    f"1-D node partition x{parts}, RCCL all-to-all ({scheme} exchange; boundary rows of the static "
-                   "input features resident in HBM)"},
+                   "input features resident in HBM)",
+                   "plans_from_edge_list_slices": bool(args.plan_from_slices and parts > 1)},
         "epochs_per_s": args.steps / elapsed,
         "spmm_edges_per_s": nnz_total / agg_avg_s if parts == 1 and agg_avg_s else None,
         "spmm_ms": agg_avg_s * 1e3,

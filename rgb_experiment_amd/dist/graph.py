@@ -4,7 +4,7 @@ import torch
 
 from .. import graph as _graph
 from .comm import Comm
-from .plan import GridPlan, PartitionPlan, partition_bounds, rewrite_global
+from .plan import GridPlan, PartitionPlan, partition_bounds, rewrite_global, subsets_from_slices
 
 
 class HipAggregator:
@@ -156,9 +156,21 @@ class DistGraph:
     appnp_return_in_pieces = True
     _appnp_return_pieces = 1
 
-    def __init__(self, edge_index, num_nodes, loops_mode, comm=None, backend=None, exchange="auto", pieces=None):
+    def __init__(self, edge_index, num_nodes, loops_mode, comm=None, backend=None, exchange="auto", pieces=None,
+                 plan_from_slices=None):
         self.edge_index, self.N_global, self.loops_mode = edge_index, int(num_nodes), loops_mode
         self.comm = comm or Comm()
+        # OPT-IN (RGBX_PLAN_FROM_SLICES=1): the halo and grid plans from this rank's 1/P of the edge list + one all-to-all
+        # of edge records per direction (plan.subsets_from_slices), instead of every rank scanning the whole list. The same
+        # plans bit for bit (tests/test_dist_gloo.py); a COLLECTIVE at the first plan of a group size — every rank builds its
+        # plans at the same points of the same model code, as it reaches the exchanges themselves. Off by default: every
+        # rank holds the whole edge list anyway (experiment()'s interface hands it over), the 1 x P transpose needs all of
+        # it, and no multi-GPU hardware has been there to show the collective pays for the scan it saves.
+        import os
+        if plan_from_slices is None:
+            plan_from_slices = os.environ.get("RGBX_PLAN_FROM_SLICES", "0") == "1"
+        self.plan_from_slices = bool(plan_from_slices)
+        self._subsets = {}
         self.backend = backend or HipAggregator()
         self.exchange = exchange
         self._kinds, self._grid, self._choice = {}, {}, {}
@@ -179,6 +191,26 @@ class DistGraph:
                                "was not built before the release is being asked for")
         return self.edge_index
 
+    def _edge_subsets(self, group):
+        """This rank's group's EdgeSubsets built from the ranks' slices, or None (option off, one rank, an emulated run)."""
+        if not self.plan_from_slices or self.comm.world == 1 or self.comm.backend == "emulated":
+            return None
+        if group not in self._subsets:
+            self._subsets[group] = subsets_from_slices(self._edges(), self.N_global, self.loops_mode, self.comm, group)
+        return self._subsets[group]
+
+    def _partition_plan(self, kind):
+        sub = self._edge_subsets(1)
+        if sub is not None:
+            return PartitionPlan.from_subsets(sub, self.N_global, self.comm.world, self.comm.rank, kind)
+        return PartitionPlan(self._edges(), self.N_global, self.comm.world, self.comm.rank, self.loops_mode, kind)
+
+    def _grid_plan(self, kind, C, pieces):
+        sub = self._edge_subsets(C)
+        if sub is not None:
+            return GridPlan.from_subsets(sub, self.N_global, self.comm.world, self.comm.rank, kind, C, pieces)
+        return GridPlan(self._edges(), self.N_global, self.comm.world, self.comm.rank, self.loops_mode, kind, C, pieces)
+
     def release_edges(self):
         """Drop the global edge list: from here on only the structures already built (this rank's CSRs, send /
         receive lists, resident boundary rows) stay in HBM."""
@@ -188,9 +220,7 @@ class DistGraph:
     def _get(self, kind):
         st = self._kinds.get(kind)
         if st is None:
-            plan = PartitionPlan(self._edges(), self.N_global, self.comm.world, self.comm.rank,
-                                 self.loops_mode, kind)
-            st = {"plan": plan}
+            st = {"plan": self._partition_plan(kind)}
             self._kinds[kind] = st
         return st
 
@@ -288,9 +318,7 @@ class DistGraph:
         key = (kind, C, pieces)
         st = self._grid.get(key)
         if st is None:
-            plan = GridPlan(self._edges(), self.N_global, self.comm.world, self.comm.rank, self.loops_mode, kind,
-                            C, pieces)
-            st = {"plan": plan}
+            st = {"plan": self._grid_plan(kind, C, pieces)}
             self._grid[key] = st
         return st
 
@@ -309,8 +337,7 @@ class DistGraph:
         key = (kind, C, pieces, "split", src_pieces)
         st = self._grid.get(key)
         if st is None:
-            st = {"plan": GridPlan(self._edges(), self.N_global, self.comm.world, self.comm.rank, self.loops_mode, kind,
-                                   C, pieces)}
+            st = {"plan": self._grid_plan(kind, C, pieces)}
             self._grid[key] = st
         if direction not in st:
             half = getattr(st["plan"], direction)
@@ -432,12 +459,19 @@ class DistGraph:
         """(boundary rows this rank receives per forward propagate, its local-source edges, its remote-source
         edges) under the halo scheme."""
         if "halo_stats" not in self._choice:
-            src, dst = rewrite_global(self._edges(), self.N_global, self.loops_mode)
             lo, hi = self.bounds[self.comm.rank], self.bounds[self.comm.rank + 1]
-            mine = (dst >= lo) & (dst < hi)
-            remote = mine & ((src < lo) | (src >= hi))
+            sub = self._edge_subsets(1)
+            if sub is not None:  # the edges into this rank's nodes are already here
+                src = sub.by_dst[0]
+                remote = (src < lo) | (src >= hi)
+                n_mine = int(src.numel())
+            else:
+                src, dst = rewrite_global(self._edges(), self.N_global, self.loops_mode)
+                mine = (dst >= lo) & (dst < hi)
+                remote = mine & ((src < lo) | (src >= hi))
+                n_mine = int(mine.sum())
             n_rem = int(remote.sum())
-            self._choice["halo_stats"] = (int(torch.unique(src[remote]).numel()), int(mine.sum()) - n_rem, n_rem)
+            self._choice["halo_stats"] = (int(torch.unique(src[remote]).numel()), n_mine - n_rem, n_rem)
         return self._choice["halo_stats"]
 
     def halo_rows(self):
@@ -558,8 +592,7 @@ class DistGraph:
         transform is applied here, to local and halo rows alike."""
         st = self._kinds.get("gat")
         if st is None:
-            plan = PartitionPlan(self._edges(), self.N_global, self.comm.world, self.comm.rank,
-                                 self.loops_mode, "sum")
+            plan = self._partition_plan("sum")
             f = plan.fwd
             agg = torch.cat([f.loc_agg, f.rem_agg])
             gather = torch.cat([f.loc_gather, f.n_local + f.rem_gather])

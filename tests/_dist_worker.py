@@ -247,6 +247,75 @@ def propagate_worker(rank, world, port, out_dir, exchange="halo"):
     dist.destroy_process_group()
 
 
+def plan_slices_worker(rank, world, port, out_dir):
+    """Plans built from the ranks' slices of the edge list (plan.subsets_from_slices: bucketing of 1/P of the edges + one
+    all-to-all of edge records per direction) against the plans every rank builds from the whole list: every tensor and every
+    count of both halves, halo plans and every R x C grid of the world, all rewrite modes and weightings — bit for bit.
+    Then the propagate itself through a DistGraph with the option on."""
+    _init(rank, world, port)
+    from rgb_experiment_amd.dist import Comm, DistGraph, partition_bounds
+    from rgb_experiment_amd.dist import plan as P
+    comm = Comm()
+    checked = 0
+
+    def same(a, b, where):
+        nonlocal checked
+        for k, v in vars(a).items():
+            w = getattr(b, k)
+            if torch.is_tensor(v):
+                assert v.dtype == w.dtype and torch.equal(v, w), (where, k)
+            else:
+                assert v == w, (where, k, v, w)
+            checked += 1
+
+    for seed, (n, e) in enumerate([(103, 1200), (64, 40), (7, 300), (world, 3 * world)]):
+        ei, _, _, _ = make_problem(n=n, e=e, f=4)
+        g = torch.Generator().manual_seed(seed)
+        ei = torch.cat([ei, torch.randint(0, n, (5,), generator=g).repeat(2, 1), ei[:, :9]], dim=1)  # self-loops, duplicates
+        b = partition_bounds(n, world)
+        for mode in (0, 1, 2):
+            for group in [c for c in range(1, world + 1) if world % c == 0]:
+                sub = P.subsets_from_slices(ei, n, mode, comm, group)
+                glo, ghi = b[rank // group * group], b[(rank // group + 1) * group]
+                ref = P.subsets_from_global(ei, n, mode, glo, ghi)
+                assert (sub.lo, sub.hi, sub.nnz_total) == (glo, ghi, ref.nnz_total)
+                assert torch.equal(sub.deg, ref.deg)
+                for x, y in zip(sub.by_dst + sub.by_src, ref.by_dst + ref.by_src):
+                    assert torch.equal(x, y), (n, mode, group)
+                for kind in ("gcn", "mean", "sum"):
+                    if group == 1:
+                        whole = P.PartitionPlan(ei, n, world, rank, mode, kind)
+                        mine = P.PartitionPlan.from_subsets(sub, n, world, rank, kind)
+                        assert (whole.nnz_total, whole.nnz_local, whole.n_local) == (mine.nnz_total, mine.nnz_local, mine.n_local)
+                        same(whole.fwd, mine.fwd, (n, mode, kind, "fwd"))
+                        same(whole.bwd, mine.bwd, (n, mode, kind, "bwd"))
+                    for pieces in (1, 3):
+                        whole = P.GridPlan(ei, n, world, rank, mode, kind, group, pieces)
+                        mine = P.GridPlan.from_subsets(sub, n, world, rank, kind, group, pieces)
+                        assert whole.nnz_total == mine.nnz_total
+                        same(whole.fwd, mine.fwd, (n, mode, kind, group, pieces, "fwd"))
+                        same(whole.bwd, mine.bwd, (n, mode, kind, group, pieces, "bwd"))
+    # the option on a DistGraph: same schemes, same rows, same gradients as with the option off
+    ei, x, _, _ = make_problem()
+    n = x.size(0)
+    lo, hi = partition_bounds(n, world)[rank:rank + 2]
+    go = torch.randn(n, x.size(1), generator=torch.Generator().manual_seed(5))
+    exchanges = ["halo", "reshard", "auto"] + [f"{world // c}x{c}" for c in range(2, world) if world % c == 0]
+    for exchange in exchanges:
+        for mode, kind in ((1, "gcn"), (2, "mean"), (0, "sum")):
+            got = []
+            for on in (False, True):
+                dg = DistGraph(ei, n, mode, comm, OracleAggregator(), exchange, plan_from_slices=on)
+                xl = x[lo:hi].clone().requires_grad_(True)
+                out = dg.propagate(xl, kind)
+                out.backward(go[lo:hi])
+                got.append((dg.scheme(x.size(1)), out.detach(), xl.grad))
+                assert bool(dg._subsets) == on
+            assert got[0][0] == got[1][0] and torch.equal(got[0][1], got[1][1]) and torch.equal(got[0][2], got[1][2]), exchange
+    torch.save({"checked": checked}, os.path.join(out_dir, f"slices_{rank}.pt"))
+    dist.destroy_process_group()
+
+
 def reshard_chunk_worker(rank, world, port, out_dir, exchange="reshard"):
     """The column-shard propagate with the outgoing exchange in 1, 3 (ragged) and 4 pieces: identical rows."""
     _init(rank, world, port)
@@ -530,6 +599,35 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", h
     torch.save({"hist": hist, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi, "backend": dist.get_backend(),
                 "engine": r.engine is not None, "state": {k: v.cpu() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"gpu_{model_name}_{rank}.pt"))
+    dist.destroy_process_group()
+    disarm_deadline()
+
+
+def gpu_plan_slices_worker(rank, world, port, out_dir, model_name, exchange):
+    """Two epochs of the per-rank HIP path with the plans built from the whole edge list, then again (same seeds) with
+    RGBX_PLAN_FROM_SLICES=1: the edge records travel as int64 rows through the run's own backend (RCCL with the ranks sharing
+    the GPU, or gloo with host staging)."""
+    arm_deadline(120)
+    _init(rank, world, port)
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd.dist import Comm, DistRunner
+    from rgb_experiment_amd.graph import clear_cache
+    dev = torch.device("cuda:0")
+    ei, x, y, masks = hub_problem()
+    out = {}
+    for on in (False, True):
+        os.environ["RGBX_PLAN_FROM_SLICES"] = "1" if on else "0"
+        clear_cache()
+        torch.manual_seed(14530529)
+        model = build_model(M, model_name, x.size(1), int(y.max()) + 1)
+        r = DistRunner(model, ei, x, y, masks, rank, world, dev, lr=0.01, comm=Comm(), exchange=exchange)
+        hist = [r.epoch(more=True), r.epoch()]
+        torch.cuda.synchronize()
+        used = any(bool(g._subsets) for g in r.graphs.values()) if hasattr(r, "graphs") else None
+        out[on] = {"hist": hist, "logits": r.logits(True).cpu(), "used": used,
+                   "state": {k: v.cpu() for k, v in r.model.state_dict().items()}}
+    os.environ.pop("RGBX_PLAN_FROM_SLICES", None)
+    torch.save(out, os.path.join(out_dir, f"gpuslices_{model_name}_{rank}.pt"))
     dist.destroy_process_group()
     disarm_deadline()
 

@@ -265,6 +265,23 @@ def test_shared_eval_forward_on_the_real_kernels(model_name, world, exchange, si
                   f"{one['exchanges']}, payload {two['bytes'] / 1e6:.1f} -> {one['bytes'] / 1e6:.1f} MB")
 
 
+@pytest.mark.parametrize("model_name,world,exchange", [("gcn", 4, "2x2"), ("gat", 2, "halo")])
+def test_plans_from_edge_list_slices_on_the_real_kernels(model_name, world, exchange, tmp_path):
+    """RGBX_PLAN_FROM_SLICES=1 with the ranks on the module's backend: the edge records cross as int64 rows, the halo /
+    grid plans are built from them on the device, and two epochs (hub rows in both CSRs) give the same five numbers, logits
+    and trained state as with the plans from the whole list, bit for bit (the plans are the same tensors:
+    tests/test_dist_gloo.py test_plans_from_edge_list_slices_are_the_plans_from_the_whole_list)."""
+    _spawn(W.gpu_plan_slices_worker, (world, _free_port(), str(tmp_path), model_name, exchange), world)
+    for r in range(world):
+        p = torch.load(os.path.join(tmp_path, f"gpuslices_{model_name}_{r}.pt"))
+        off, on = p[False], p[True]
+        assert on["used"] and not off["used"]
+        assert on["hist"] == off["hist"], (on["hist"], off["hist"])
+        assert torch.equal(on["logits"], off["logits"])
+        for k, v in off["state"].items():
+            assert torch.equal(v, on["state"][k]), k
+
+
 @pytest.mark.parametrize("model_name,exchange,world", [("appnpstack", "reshard", 4), ("gcn", "auto", 4), ("gcn", "auto", 2),
                                                        ("gat", "auto", 2), ("graphsage", "auto", 2)])
 def test_epoch_split_by_task_on_the_real_kernels(model_name, exchange, world, tmp_path):
