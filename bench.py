@@ -702,7 +702,9 @@ def real_shape_block(dev, ei, N, F, C, names, steps, warmup, features="dense", s
     for name in names:
         torch.manual_seed(14530529)
         kwargs, n_prop, loops_mode, kind = MODELS[name]
-        kwargs = dict(kwargs, hidden_unit=64)
+        # initial_params.py:25-37: hidden 64 everywhere but GAT (8 heads of 8); APPNP K = 10, alpha = 0.1; SGC K = 2
+        kwargs = dict(kwargs, **({"hidden_unit": 8, "heads": 8} if name == "gat" else
+                                 {"hidden_dim": 64} if name == "dagnn" else {} if name == "sgc" else {"hidden_unit": 64}))
         model = model_class(name)(input_dim=F, output_dim=C, **kwargs)
         torch.cuda.reset_peak_memory_stats(dev)
         step, nnz, _ = build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, C)

@@ -50,7 +50,7 @@ class DAGNN(nn.Module):
         self.prop.reset_parameters()
 
     def forward(self, x, edge_index):
-        x = F.dropout(x, p=self.dropout_rate, training=self.training)
+        x = ops.dropout(x, self.dropout_rate, self.training)  # features carried by their non-zeros stay on them
         x = F.relu(self.lin1(x))
         x = F.dropout(x, p=self.dropout_rate, training=self.training)
         x = self.lin2(x)

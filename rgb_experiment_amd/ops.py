@@ -140,6 +140,13 @@ def align_rows(x):
     return view
 
 
+def _aligned_rows(t):
+    """`t` itself when its rows sit on 16-byte boundaries (or nothing would be gained), else align_rows' padded copy."""
+    if t.dim() != 2 or t.dtype != torch.float32 or t.size(1) % 4 == 0 or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0):
+        return t
+    return align_rows(t)
+
+
 def _rows_padded_readable(t):
     """A [K, n] matrix whose 16-byte-aligned rows may be read up to the next multiple of 4 columns (rgbx_gemm_tn_f32's
     contract): contiguous rows, stride % 4 == 0, and the storage holds the last row's padding too."""
@@ -1590,6 +1597,11 @@ def gemm_tn(a, b, alpha=1.0, colsum=False, out=None, sums_out=None):
     _lib.require_device(a, b)
     a = a if a.stride(-1) == 1 and _rows_padded_readable(a) else a.contiguous()
     b = b if b.stride(-1) == 1 and _rows_padded_readable(b) else b.contiguous()
+    # rows off the 16-byte grid (width % 4 != 0 at its natural stride: dY [N, 7], a dropout copy of [N, 1433] features) take
+    # the kernel's 4-byte path: 16.5 ms against 5.0 for 2 M x 64 x 1433, 0.83 against 0.37 for 2 M x 7 x 64. One padded copy
+    # (align_rows: a read and a write of the operand) buys the 16-byte path — 3 ms for the 11.5 GB operand.
+    if a.size(0) >= 4096:
+        a, b = (_aligned_rows(t) for t in (a, b))
     pa, lda = _lib.mat(a, "a")
     pb, ldb = _lib.mat(b, "b")
     K, M, N = a.size(0), a.size(1), b.size(1)
@@ -1647,6 +1659,37 @@ def linear(x, weight, bias=None):
     return _Linear.apply(x, weight, bias)
 
 
+class SparseFeatures:
+    """What ops.dropout returns for features that ride on their non-zeros: not a tensor — only ops.linear (nn.Linear of this
+    package) takes it; anything else fails loudly instead of reading undropped dense values."""
+    requires_grad = False
+
+    def __init__(self, sp, like):
+        self._rgbx_sparse, self.shape, self.device, self.dtype, self.is_cuda = sp, like.shape, like.device, like.dtype, True
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return len(self.shape)
+
+
+def dropout(x, p, training):
+    """F.dropout for a model's INPUT features (reference models/dagnn.py:72: dropout before the first Linear). Dense
+    features: torch's. Features carried by their non-zeros (prepare_features) in a training forward: dropout leaves a zero a
+    zero, so the Bernoulli mask is drawn for the non-zeros alone — the same distribution of outputs, from nnz draws instead
+    of a fresh dense [N, F] matrix per step (11.5 GB written and read again at N = 2 M, F = 1433) — and the product stays on
+    the non-zeros. (The mask comes from torch's device generator: reproducible under manual_seed; no implementation on
+    another device reproduces the reference's CUDA Philox stream anyway.)"""
+    sp = getattr(x, "_rgbx_sparse", None)
+    if sp is None or not training or p <= 0.0 or x.requires_grad:
+        return torch.nn.functional.dropout(x, p=p, training=training)
+    if p >= 1.0:
+        return SparseFeatures(sp.with_values(torch.zeros_like(sp.val)), x)
+    keep = torch.rand(sp.val.numel(), device=sp.val.device) >= p
+    return SparseFeatures(sp.with_values(sp.val * keep * (1.0 / (1.0 - p))), x)
+
+
 class SparseRows:
     """The non-zeros of a STATIC feature matrix [n, f] as a CSR (rows -> (column, value)) and its transpose (columns ->
     (row, value)), built once per matrix with torch index ops (plumbing: one pass over the matrix and one stable sort of the
@@ -1686,9 +1729,18 @@ class SparseRows:
         self.fwd = CSR(ptr, pad(i32(cols)), None, n, self.nnz, make_row_split(ptr))
         self.val = pad(vals)
         order = torch.argsort(cols, stable=True)
+        self.order = order  # slot of the transposed CSR -> slot of the forward CSR
         ptr_t = rowptr_of(cols, f)
         self.bwd = CSR(ptr_t, pad(i32(rows[order])), None, f, self.nnz, make_row_split(ptr_t))
         self.val_t = pad(vals[order].contiguous())
+
+    def with_values(self, vals):
+        """The same structure (shared, not copied) under other values per non-zero, given in the forward CSR's slot order."""
+        import copy
+        other = copy.copy(self)
+        other.val = vals.contiguous()
+        other.val_t = vals[self.order].contiguous() if self.nnz else vals
+        return other
 
 
 class _SparseRowsLinear(torch.autograd.Function):

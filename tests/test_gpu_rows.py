@@ -531,3 +531,99 @@ def test_linear_over_the_nonzeros_of_sparse_features(dev, n, f, out, density):
     assert (bd.grad.cpu().double() - b.grad).abs().max().item() < 1e-4 * max(1.0, b.grad.abs().max().item())
     dense = torch.randn(50, 16, device=dev)
     assert getattr(ops.prepare_features(dense), "_rgbx_sparse", None) is None  # dense features stay dense
+
+
+@pytest.mark.parametrize("p", [0.5, 0.1, 1.0])
+def test_dropout_on_features_carried_by_their_nonzeros(dev, p):
+    """ops.dropout on prepare_features' output in a training forward (reference models/dagnn.py:72): the Bernoulli mask is
+    drawn for the non-zeros only; the product and its weight gradient equal the dense product with the SAME dropped matrix
+    (rebuilt from the values kept), the kept fraction and the 1 / (1 - p) scale are dropout's, an eval forward and p = 0
+    return the features themselves, and a consumer other than this package's Linear cannot read the carrier as a tensor."""
+    from rgb_experiment_amd import nn as RN
+    from rgb_experiment_amd import ops
+    n, f, out = 5000, 1433, 64
+    gen = torch.Generator().manual_seed(11)
+    x = (torch.rand(n, f, generator=gen) < 0.0126).float() * (0.5 + torch.rand(n, f, generator=gen))
+    xd = ops.prepare_features(x.to(dev))
+    sp = xd._rgbx_sparse
+    assert ops.dropout(xd, p, False) is xd and ops.dropout(xd, 0.0, True) is xd
+    torch.manual_seed(3)
+    dropped = ops.dropout(xd, p, True)
+    assert isinstance(dropped, ops.SparseFeatures) and tuple(dropped.shape) == (n, f)
+    sp2 = dropped._rgbx_sparse
+    assert sp2.fwd is sp.fwd and sp2.bwd is sp.bwd  # structure shared, values replaced
+    kept = sp2.val != 0
+    if p < 1.0:
+        assert abs(kept.float().mean().item() - (1 - p)) < 0.02
+        assert torch.allclose(sp2.val[kept], sp.val[kept] / (1 - p), rtol=1e-6)
+    else:
+        assert not kept.any()
+    assert torch.equal(sp2.val_t, sp2.val[sp.order])
+    # the same dropped matrix, dense
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), (sp.fwd.rowptr[1:] - sp.fwd.rowptr[:-1]).long())
+    dense = torch.zeros(n, f, device=dev)
+    dense[rows, sp.fwd.col.long()[:sp.nnz]] = sp2.val[:sp.nnz]
+    lin = RN.Linear(f, out).to(dev)
+    gy = torch.randn(n, out, generator=gen).to(dev)
+    got = lin(dropped)
+    got.backward(gy)
+    gw = lin.weight.grad.clone()
+    lin.weight.grad = None
+    want = torch.nn.functional.linear(dense.double(), lin.weight.detach().double(), lin.bias.detach().double())
+    assert (got.detach().double() - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+    want_gw = gy.double().t() @ dense.double()
+    assert (gw.double() - want_gw).abs().max().item() < 1e-5 * max(1.0, want_gw.abs().max().item())
+    with pytest.raises(Exception):
+        torch.relu(dropped)
+    # dense features: torch's dropout
+    d2 = torch.randn(100, 8, device=dev)
+    assert torch.is_tensor(ops.dropout(d2, 0.5, True))
+
+
+def test_dagnn_trains_on_the_nonzeros_of_bag_of_words_features(dev):
+    """DAGNN at the reference's defaults (hidden 64, K = 10, dropout 0.5; models/dagnn.py:68-76) on bag-of-words features:
+    the training forward's input dropout and first Linear stay on the non-zeros (no dense [N, F] product, no dense weight
+    gradient launch); eval logits equal the float64 oracle's."""
+    from oracle import ref_cpu as O
+    from rgb_experiment_amd import models as M
+    from rgb_experiment_amd import ops
+    n, f, c = 3000, 1433, 7
+    gen = torch.Generator().manual_seed(5)
+    x = torch.zeros(n, f)
+    x.scatter_(1, torch.randint(0, f, (n, 18), generator=gen), 1.0)
+    x = x / x.sum(1, keepdim=True)
+    ei = graph_with_isolated_nodes(n, 20000, 3)
+    y = torch.randint(0, c, (n,), generator=gen)
+    torch.manual_seed(2)
+    model = M.DAGNN(input_dim=f, hidden_dim=64, output_dim=c, K=10, dropout_rate=0.5).to(dev)
+    xd = ops.prepare_features(x.to(dev))
+    events = []
+    ops.set_event_sink(events)
+    model.train()
+    out = model(xd, ei.to(dev))
+    torch.nn.functional.nll_loss(out["out"], y.to(dev)).backward()
+    ops.set_event_sink(None)
+    kinds = [f"{k}[{getattr(k, 'variant', None)}]" for k, _, _ in events]
+    assert any(k.startswith("features_fwd") for k in kinds) and any(k.startswith("features_bwd") for k in kinds), kinds
+    assert not any("1433" in k for k in kinds), kinds  # no dense product over the feature width, forward or backward
+    assert model.lin1.weight.grad is not None and torch.isfinite(model.lin1.weight.grad).all()
+    model.eval()
+    with torch.no_grad():
+        emb = model(xd, ei.to(dev))["emb"].cpu().double()
+    sd = {k: (v.detach().cpu().double() if v.is_floating_point() else v.cpu()) for k, v in model.state_dict().items()}
+    ref = O.dagnn_forward(sd, x.double(), ei, 10)["emb"]
+    assert (emb - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_tn_aligns_operands_whose_rows_are_off_the_16_byte_grid(dev):
+    """dW = dY^T X with contiguous [K, 7] and [K, 1433] operands (odd widths at their natural stride: what a dropout copy of
+    the features or a 7-class logits gradient looks like): ops.gemm_tn makes padded copies and takes the 16-byte path — same
+    product as float64, bit-equal to the product of operands aligned beforehand."""
+    from rgb_experiment_amd import ops
+    K = 20000
+    gen = torch.Generator().manual_seed(8)
+    a, b = torch.randn(K, 7, generator=gen).to(dev), torch.randn(K, 1433, generator=gen).to(dev)
+    got = ops.gemm_tn(a, b)
+    want = a.double().t() @ b.double()
+    assert (got.double() - want).abs().max().item() < 2e-5 * want.abs().max().item() * (K / 1000) ** 0.5
+    assert torch.equal(got, ops.gemm_tn(ops.align_rows(a), ops.align_rows(b)))
