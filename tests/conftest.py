@@ -13,6 +13,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: a long-running case (still part of -m gpu)")
 
 
+def pytest_xdist_auto_num_workers(config):
+    """`-n auto` (pytest.ini): workers for a CPU session, NONE for a session that selects GPU tests — those run in this one
+    process (at most six processes may hold the card, and the rank processes of the multi-rank module are five of them).
+    RGBX_TEST_WORKERS overrides (0 = no workers)."""
+    given = os.environ.get("RGBX_TEST_WORKERS")
+    if given is not None:
+        return int(given)
+    expr = (config.getoption("markexpr", "") or "").replace(" ", "")
+    cpu_only = "notgpu" in expr and "gpu" not in expr.replace("notgpu", "")
+    if not cpu_only:
+        return 0
+    cpus = usable_cpus()
+    return 3 if cpus >= 8 else 2 if cpus >= 4 else 0
+
+
 def pytest_collection_modifyitems(config, items):
     """Order of a `-m gpu` session: the GPU-bound parity modules, the S cases of the BASELINE-size module, its L cases (their
     oracle halves are computed on the host cores in the background from session start, oracle_background below), the cases
