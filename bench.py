@@ -562,24 +562,65 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
     return step, nnz_total, alg
 
 
+SLOW_STEPS = []  # (time_steps call #, step index, ms, median ms of the call, host-side counters): see _host_counters
+
+
+def _host_counters():
+    """What could hold the HOST thread of a step: the cgroup's CPU throttling (a one-GPU box grants 16 of the host's 256 CPUs;
+    a throttled period parks every thread of the cgroup for up to 100 ms) and Python's full garbage collections."""
+    out = {}
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = line.split()
+            if k in ("nr_throttled", "throttled_usec", "usage_usec"):
+                out[k] = int(v)
+    except (OSError, ValueError):
+        pass
+    import gc
+    out["gc_gen2"] = gc.get_stats()[2]["collections"]
+    return out
+
+
 def time_steps(step, steps, warmup, fence=None, tick=None, per_step=True):
     """(seconds for exactly `steps` steps between two fences, the last step's result, per-step milliseconds).
     Every step ends with its own host read of the epoch's five numbers (one copy), so the wall clock between two
-    returns IS that step's duration: the per-step list costs no extra synchronisation."""
+    returns IS that step's duration: the per-step list costs no extra synchronisation. A step beyond twice the call's
+    median is recorded in SLOW_STEPS with what the host-side counters did during it (the line's `slow_steps`)."""
     fence = fence or torch.cuda.synchronize
     last = None
     for _ in range(warmup):
         step()
+    # CPython's FULL garbage collection walks every container object of the process: 100-180 ms with torch loaded (measured:
+    # profiles/r05_host_gc_stall.txt). It runs when enough NEW long-lived objects have piled up — i.e. once, some steps after
+    # a leg's set-up (models, graphs, caches), and then not again in steady state (400 steps without one). Which step it
+    # lands on follows the allocation count, so with other --steps / --warmup values it lands inside the timed region.
+    # Collect now, and move what survives to the permanent generation: the timed steps then see only their own garbage.
+    import gc
+    gc.collect()
+    gc.freeze()
     fence()
     marks = [time.perf_counter()]
+    counters = [_host_counters()]
     for i in range(steps):
         last = step()
         marks.append(time.perf_counter())
+        counters.append(_host_counters())
         if tick is not None:
             tick(f"timed step {i + 1}/{steps}")
     fence()
     total = time.perf_counter() - marks[0]
-    return total, last, [(b - a) * 1e3 for a, b in zip(marks, marks[1:])]
+    per = [(b - a) * 1e3 for a, b in zip(marks, marks[1:])]
+    time_steps.calls = getattr(time_steps, "calls", 0) + 1
+    med = median(per)
+    for i, ms in enumerate(per):
+        if med and ms > 2.0 * med:
+            a, b = counters[i], counters[i + 1]
+            SLOW_STEPS.append({"timed_loop": time_steps.calls, "step": i, "ms": ms, "median_ms": med,
+                               "throttled_periods": b.get("nr_throttled", 0) - a.get("nr_throttled", 0),
+                               "throttled_ms": (b.get("throttled_usec", 0) - a.get("throttled_usec", 0)) / 1e3,
+                               "cgroup_cpu_ms": (b.get("usage_usec", 0) - a.get("usage_usec", 0)) / 1e3,
+                               "gc_full_collections": b["gc_gen2"] - a["gc_gen2"]})
+    return total, last, per
 
 
 def median(v):
@@ -1490,6 +1531,9 @@ def main():
         secondary("configs_1_same_run", configs_1_leg)
         secondary("configs_0_same_run", lambda: cora_shaped(dev))
         secondary("real_shape_same_run", real_shape_leg)
+    # steps beyond twice their loop's median, in any timed loop of this run (loop 1 = the headline's), with the host-side
+    # counters over that step: a throttled cgroup period or a full garbage collection explains a stall of the HOST thread
+    result["slow_steps"] = SLOW_STEPS
     if rank == 0:
         print(json.dumps(result), flush=True)
     # from here on only the teardown is left: a supervisor that has to end this worker later (a process group that does
