@@ -143,7 +143,9 @@ int rgbx_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w,
  * whose last kernel is this gather and not the fused aggregate+transform one. A lane group holds a target's complete
  * output row, so what the reference runs next as separate passes over [N, d] comes out of the registers:
  *   out_colsums ([2, d] doubles): column sums of out and out^2 — the statistics of the training-mode BatchNorm1d
- *     behind the layer (models/gcn.py:27 then :28); fp32 per 32-row tile, tiles added in fp64 in a fixed order;
+ *     behind the layer (models/gcn.py:27 then :28); per 32-row tile an fp32 record (sum, squared deviations from the
+ *     tile's own mean), the tiles' sum x and sum x^2 = M2 + S^2 / n added in fp64 in a fixed order (a column whose
+ *     spread is far below its mean keeps its variance);
  *     stats_ws: rgbx_spmm_linear_stats_workspace_bytes(N, d) bytes, 8-byte aligned. `out` is written as usual.
  *   ce: log_softmax + NLLLoss on out[mask] + arg-max (models/gcn.py:31, itexperiments.py:400,429,434,624-626) exactly as
  *     rgbx_ce_epilogue_t describes: statistics only (out not written, may be NULL; rows no mask selects are not even
@@ -190,7 +192,8 @@ int rgbx_spmm_csr_epilogue_f32(const int32_t* rowptr, const int32_t* col, const 
  * they are loaded; z_out receives the mapped aggregate (what dW = dy^T z needs).
  * `out_colsums` ([2, Nout] doubles, optional): out_colsums[0,c] = sum_i out[i,c], [1,c] = sum_i out[i,c]^2 — the
  * statistics of a training-mode BatchNorm1d that follows the layer (models/gcn.py:27 then :28), taken from the
- * MFMA accumulators of the 32-row tiles (fp32 per tile, tiles added in fp64 in a fixed order) instead of a pass
+ * MFMA accumulators of the 32-row tiles (per tile an fp32 record of the sum and of the squared deviations from the
+ * tile's mean; sum x and sum x^2 = M2 + S^2 / n over the tiles in fp64 in a fixed order) instead of a pass
  * over `out`; needs `stats_ws` of rgbx_spmm_linear_stats_workspace_bytes(N, Nout) bytes (8-byte aligned). */
 /* Optional cross-entropy epilogue of rgbx_spmm_linear_f32, for the model's LAST layer (models/gcn.py:29-31: the
  * logits go straight into log_softmax + NLLLoss on out[mask], itexperiments.py:400,429, or into the arg-max /
