@@ -627,3 +627,35 @@ def test_gemm_tn_aligns_operands_whose_rows_are_off_the_16_byte_grid(dev):
     want = a.double().t() @ b.double()
     assert (got.double() - want).abs().max().item() < 2e-5 * want.abs().max().item() * (K / 1000) ** 0.5
     assert torch.equal(got, ops.gemm_tn(ops.align_rows(a), ops.align_rows(b)))
+
+
+def test_experiment_on_bag_of_words_features(dev):
+    """experiment() end to end on Cora-shaped data (F = 1433 bag-of-words rows, row-normalised as itexperiments.py:296, C = 7,
+    a homophilous graph) for the models whose first Linear meets the features directly: the features are multiplied over
+    their non-zeros (ops.prepare_features inside experiment()), DAGNN's input dropout included, with the harness's default
+    epoch replay; the runs learn (accuracy far above 1/7) and record every epoch."""
+    import rgb_experiment_amd as R
+    n, f, c = 2708, 1433, 7
+    gen = torch.Generator().manual_seed(21)
+    y = torch.randint(0, c, (n,), generator=gen)
+    words = torch.randint(0, f, (c, 60), generator=gen)  # every class draws most of its words from its own 60
+    pick = torch.where(torch.rand(n, 18, generator=gen) < 0.7, words[y][torch.arange(n).view(-1, 1), torch.randint(0, 60, (n, 18), generator=gen)],
+                       torch.randint(0, f, (n, 18), generator=gen))
+    x = torch.zeros(n, f)
+    x.scatter_(1, pick, 1.0)
+    same = (y.view(-1, 1) == y.view(1, -1)) & (torch.rand(n, n, generator=gen) < 0.002)
+    ei = same.nonzero().t().contiguous()
+    data = R.Data(x=x, y=y, edge_index=ei)
+    seen = []
+    real_prepare = R.ops.prepare_features
+    try:
+        R.ops.prepare_features = lambda t, *a, **k: seen.append(real_prepare(t, *a, **k)) or seen[-1]
+        for name, params in (("DAGNN", R.InitialParameters.defaults_for("dagnn")), ("GCN", R.InitialParameters.defaults_for("gcn")),
+                             ("GraphSAGE2", R.InitialParameters.defaults_for("graphsage2"))):
+            res = R.experiment(params, specify_data=True, data=data, model_name=name, learning_rate=0.01, epoch=30,
+                               need_to_reappear=True, print_print=False, return_model=True)
+            assert res["ACC"] > 0.5, (name, res["ACC"])
+            assert len(res["history"]["val_acc"]) == 30
+    finally:
+        R.ops.prepare_features = real_prepare
+    assert len(seen) == 3 and all(getattr(t, "_rgbx_sparse", None) is not None for t in seen)
