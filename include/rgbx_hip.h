@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RGBX_VERSION 500 /* major*10000 + minor*100 + patch */
+#define RGBX_VERSION 501 /* major*10000 + minor*100 + patch */
 
 #define RGBX_OK 0
 #define RGBX_E_ARG (-1)    /* null pointer / negative size / bad enum */
@@ -169,6 +169,18 @@ int rgbx_spmm_csr_epilogue_f32(const int32_t* rowptr, const int32_t* col, const 
                                float* out, int64_t ldo, int64_t N, int64_t d, float a, float b,
                                const rgbx_row_split_t* split, const rgbx_spmm_epilogue_t* epi,
                                rgbx_stream_t stream);
+
+/* The same weighted row gather for SHORT rows over a SMALL table, one lane group per target row (a wave takes 64 / G rows):
+ *   out[i,:] = sum_{p in row i} w[p] * x[col[p],:] + bias      (w optional: NULL = 1; slot order, deterministic)
+ * What it replaces: the first Linear of every reference model applied to bag-of-words features — x W^T with x the
+ * row-normalised counts of itexperiments.py:296 (models/gcn.py:27, graphsage.py:49-50, appnp_stack.py:25, dagnn.py:73) —
+ * computed over the features' non-zeros: CSR rows = nodes, col = feature ids, w = feature values, the gathered table
+ * W^T [F, d] (L2-resident). rgbx_spmm_csr_f32 gives the same sums (up to summation order) with one wave per row; with the
+ * table in cache that form is bound by wave issue. d % 4 == 0, d <= 256; x, out, bias 16-byte aligned, ldx, ldo % 4 == 0.
+ * No row-split plan: a long row is walked by its one lane group. */
+int rgbx_spmm_csr_short_rows_supported(int64_t d);
+int rgbx_spmm_csr_short_rows_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* x, int64_t ldx,
+                                 const float* bias, float* out, int64_t ldo, int64_t N, int64_t d, rgbx_stream_t stream);
 
 /* Fused aggregate-then-transform for layers whose propagate commutes with their Linear
  * (GCNConv, the mean branch of SAGEConv / my_SAGEConv):

@@ -1659,6 +1659,32 @@ def linear(x, weight, bias=None):
     return _Linear.apply(x, weight, bias)
 
 
+SHORT_ROWS_TABLE_BYTES = 2 << 20  # half of one XCD's 4 MB L2: the gathered table must stay cache-resident beside the streams
+SHORT_ROWS_MEAN_SLOTS = 64
+
+
+def short_rows_ok(csr, table):
+    """rgbx_spmm_csr_short_rows_f32 (a lane group per target row) is the better form: rows of tens of slots over a table that
+    stays in L2 — the product over a bag-of-words matrix's non-zeros. Measured at N = 2 M, 36 M non-zeros (profiles/
+    r05_short_rows.txt)."""
+    d = table.size(1)
+    return (table.is_cuda and d % 4 == 0 and 4 <= d <= 256 and table.numel() * 4 <= SHORT_ROWS_TABLE_BYTES
+            and csr.nnz <= SHORT_ROWS_MEAN_SLOTS * max(csr.N, 1))
+
+
+def spmm_short_rows_raw(csr, w, x, bias=None, kind="spmm"):
+    """out[i,:] = sum_p w[p] x[col[p],:] (+ bias) on rgbx_spmm_csr_short_rows_f32 (no autograd)."""
+    _lib.require_device(x, w, bias)
+    px, ldx = _lib.mat(x, "x")
+    N, d = csr.N, x.size(1)
+    out = torch.empty((N, d), dtype=torch.float32, device=x.device)
+    with _Timed(kind, f"shortrows+d{d}" if _EVENT_SINK is not None else None):
+        _lib.check(_lib.load().rgbx_spmm_csr_short_rows_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), px, ldx,
+                                                            _lib.ptr(bias), _lib.ptr(out), d, N, d, _lib.stream_ptr()),
+                   "rgbx_spmm_csr_short_rows_f32")
+    return out
+
+
 class SparseFeatures:
     """What ops.dropout returns for features that ride on their non-zeros: not a tensor — only ops.linear (nn.Linear of this
     package) takes it; anything else fails loudly instead of reading undropped dense values."""
@@ -1751,6 +1777,8 @@ class _SparseRowsLinear(torch.autograd.Function):
         ctx.sp, ctx.has_bias = sp, bias is not None
         wt = weight.detach().t().contiguous()  # [f, out]: the gathered table (L2-resident: 367 KB for 1433 x 64)
         b = None if bias is None else bias.detach().contiguous()
+        if short_rows_ok(sp.fwd, wt):
+            return spmm_short_rows_raw(sp.fwd, sp.val, wt, bias=b, kind="features_fwd")
         return spmm_raw(sp.fwd, sp.val, None, wt, kind="features_fwd", bias=b)
 
     @staticmethod

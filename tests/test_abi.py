@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in rgbx_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == declared_symbols()
-    assert lib.rgbx_version() == 500
+    assert lib.rgbx_version() == 501
 
 
 def test_argument_errors_do_not_need_a_gpu():

@@ -659,3 +659,39 @@ def test_experiment_on_bag_of_words_features(dev):
     finally:
         R.ops.prepare_features = real_prepare
     assert len(seen) == 3 and all(getattr(t, "_rgbx_sparse", None) is not None for t in seen)
+
+
+@pytest.mark.parametrize("d", [4, 8, 16, 40, 64, 128, 256])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_short_rows_gather_matches_the_row_per_wave_kernel(dev, d, weighted):
+    """rgbx_spmm_csr_short_rows_f32 (a lane group per target row, slot order) against float64 and against rgbx_spmm_csr_f32
+    on the same CSR: empty rows, rows of one slot, one row of 3,000 slots, a row count that fills no whole wave, a bias;
+    reproducible; refuses widths it has no form for."""
+    from rgb_experiment_amd import _lib, ops
+    from rgb_experiment_amd.graph import CSR
+    n, n_src = 3001, 700
+    gen = torch.Generator().manual_seed(d)
+    lens = torch.randint(0, 40, (n,), generator=gen)
+    lens[5], lens[6], lens[17] = 0, 1, 3000
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(lens, 0)
+    nnz = int(rowptr[-1])
+    col = torch.randint(0, n_src, (nnz,), generator=gen)
+    w = torch.rand(nnz, generator=gen) + 0.1 if weighted else None
+    x = torch.randn(n_src, d, generator=gen)
+    bias = torch.randn(d, generator=gen)
+    csr = CSR(rowptr.to(torch.int32).to(dev), col.to(torch.int32).to(dev), None, n, nnz, None)
+    wd = None if w is None else w.to(dev)
+    got = ops.spmm_short_rows_raw(csr, wd, x.to(dev), bias=bias.to(dev))
+    rows = torch.repeat_interleave(torch.arange(n), lens)
+    vals = x.double()[col] * (w.double().view(-1, 1) if weighted else 1.0)
+    want = torch.zeros(n, d, dtype=torch.float64).index_add_(0, rows, vals) + bias.double()
+    assert (got.cpu().double() - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+    other = ops.spmm_raw(csr, wd, None, x.to(dev), bias=bias.to(dev))
+    assert (got - other).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    assert torch.equal(got, ops.spmm_short_rows_raw(csr, wd, x.to(dev), bias=bias.to(dev)))
+    assert ops.short_rows_ok(csr, x.to(dev)) == (True)
+    assert not ops.short_rows_ok(csr, torch.empty(700, 6, device=dev))       # width not a multiple of 4
+    assert not ops.short_rows_ok(csr, torch.empty(200000, 64, device=dev))   # a table beyond the cache budget
+    with pytest.raises(RuntimeError):
+        ops.spmm_short_rows_raw(csr, wd, torch.randn(n_src, 6, device=dev))
