@@ -1668,7 +1668,8 @@ def short_rows_ok(csr, table):
     stays in L2 — the product over a bag-of-words matrix's non-zeros. Measured at N = 2 M, 36 M non-zeros (profiles/
     r05_short_rows.txt)."""
     d = table.size(1)
-    return (table.is_cuda and d % 4 == 0 and 4 <= d <= 256 and table.numel() * 4 <= SHORT_ROWS_TABLE_BYTES
+    # d <= 64: beyond, both forms read nnz * d * 4 bytes from L2 at its rate (d = 128: 1.13 ms row per wave, 1.20 ms here)
+    return (table.is_cuda and d % 4 == 0 and 4 <= d <= 64 and table.numel() * 4 <= SHORT_ROWS_TABLE_BYTES
             and csr.nnz <= SHORT_ROWS_MEAN_SLOTS * max(csr.N, 1))
 
 
