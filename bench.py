@@ -769,7 +769,7 @@ def real_shape_block(dev, ei, N, F, C, names, steps, warmup, features="dense", s
         # the row-gather kernels by width: algorithmic bytes (SURVEY 8d formula; 'mean' / 'sum' carry no per-edge weight)
         roof = {}
         for key, t in rec["reference_epoch"]["launches"].items():
-            if "[rows+" not in key and "[shortrows+" not in key and "[ldstable+" not in key:
+            if "[rows+" not in key and "[shortrows+" not in key:
                 continue
             d = int(key.split("+d")[-1].rstrip("]"))
             if key.startswith("features"):

@@ -182,15 +182,6 @@ int rgbx_spmm_csr_short_rows_supported(int64_t d);
 int rgbx_spmm_csr_short_rows_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* x, int64_t ldx,
                                  const float* bias, float* out, int64_t ldo, int64_t N, int64_t d, rgbx_stream_t stream);
 
-/* The same product with the table kept in LDS: a workgroup holds a slice of 16 (8, 4) columns of all n_src table rows and
- * walks its share of the target rows for that slice — for tables whose column slice fits a CU's LDS (n_src * 16 B <= 150 KB:
- * F <= 9600 features). Both forms above read nnz * d * 4 bytes from L2, at L2's rate; this one reads them from LDS and the
- * slot lists once per slice. Same slot order as rgbx_spmm_csr_short_rows_f32: the same bits. `n_src` = rows of `x`. */
-int rgbx_spmm_csr_lds_table_supported(int64_t n_src, int64_t d);
-int rgbx_spmm_csr_lds_table_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* x, int64_t ldx,
-                                int64_t n_src, const float* bias, float* out, int64_t ldo, int64_t N, int64_t d,
-                                rgbx_stream_t stream);
-
 /* Fused aggregate-then-transform for layers whose propagate commutes with their Linear
  * (GCNConv, the mean branch of SAGEConv / my_SAGEConv):
  *   z[i,:]   = rs[i] * sum_{p in row i} w[p] * x[col[p],:]          (w, rs optional as above)

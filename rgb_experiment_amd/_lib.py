@@ -60,8 +60,6 @@ SIGNATURES = {
     "rgbx_spmm_csr_epilogue_f32": [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _F, _F, _P, _P, _P],
     "rgbx_spmm_csr_short_rows_supported": [_I64],
     "rgbx_spmm_csr_short_rows_f32": [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P],
-    "rgbx_spmm_csr_lds_table_supported": [_I64, _I64],
-    "rgbx_spmm_csr_lds_table_f32": [_P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _I64, _I64, _P],
     "rgbx_spmm_linear_supported": [_I64, _I64, _I],
     "rgbx_spmm_linear_stats_workspace_bytes": [_I64, _I64, ctypes.POINTER(ctypes.c_size_t)],
     "rgbx_spmm_linear_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P,

@@ -69,85 +69,6 @@ __global__ void __launch_bounds__(256) spmm_short_rows_kernel(const ShortArgs A)
   __builtin_nontemporal_store(o, reinterpret_cast<f4v*>(A.out + (int64_t)row * A.ldo + c));
 }
 
-// The same sums with the TABLE IN LDS: a workgroup of 16 waves keeps SW columns of all n_src table rows ([n_src][SW] floats,
-// <= 150 KB of the CU's 160 KB) and walks its share of the target rows for that column slice; a row's slice is SW / 4 lanes
-// (SW = 16: four lanes, sixteen rows per wave). At d = 64 both forms above read 36 M x 256 B from L2 at 14.7 TB/s (0.63 ms):
-// L2's rate is the bound, LDS (128 B per clock and CU) is not. The slot lists are re-read once per column slice (8 B per
-// slot and slice). Same slot order as spmm_short_rows_kernel: the same bits.
-template <int SW, bool HAS_W>
-__global__ void __launch_bounds__(1024) spmm_lds_table_kernel(const ShortArgs A, int n_src, int n_slices, int rows_per_part) {
-  extern __shared__ float tab[];  // [n_src][SW]
-  constexpr int VEC = 4;
-  constexpr int G = SW / VEC;          // lanes per row
-  constexpr int NG = kWave / G;        // rows per wave
-  constexpr int U = 4;
-  const int slice = blockIdx.x % n_slices, part = blockIdx.x / n_slices;
-  const int c0 = slice * SW;
-  for (int q = threadIdx.x; q < n_src * G; q += blockDim.x) {
-    const int r = q / G, k = q % G;
-    float v[VEC];
-    load_vec<VEC>(v, A.x + (int64_t)r * A.ldx + c0 + k * VEC);
-    store_vec<VEC>(tab + r * SW + k * VEC, v);
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-  const int g = lane / G, t = lane % G;
-  const int row_end = min(A.N, (part + 1) * rows_per_part);
-  float bv[VEC] = {0.f, 0.f, 0.f, 0.f};
-  if (A.bias) load_vec<VEC>(bv, A.bias + c0 + t * VEC);
-  for (int row = part * rows_per_part + wave * NG + g; row < row_end; row += waves * NG) {
-    const int start = A.rowptr[row], end = A.rowptr[row + 1];
-    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
-    for (int p = start; p < end; p += U) {
-      int src[U];
-      float ww[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool ok = p + u < end;
-        src[u] = ok ? A.col[p + u] : 0;
-        ww[u] = ok ? (HAS_W ? A.w[p + u] : 1.f) : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        float v[VEC];
-        load_vec<VEC>(v, tab + src[u] * SW + t * VEC);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(ww[u], v[i], acc[i]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] += bv[i];
-    using f4v = __attribute__((ext_vector_type(4))) float;
-    f4v o = {acc[0], acc[1], acc[2], acc[3]};
-    __builtin_nontemporal_store(o, reinterpret_cast<f4v*>(A.out + (int64_t)row * A.ldo + c0 + t * VEC));
-  }
-}
-
-constexpr size_t kLdsTableBytes = 150 * 1024;
-
-// Slice width for a table of n_src rows and d columns: the widest of 16 / 8 / 4 that divides d and fits, or 0.
-int lds_slice_width(int64_t n_src, int64_t d) {
-  for (int sw : {16, 8, 4})
-    if (d % sw == 0 && (size_t)n_src * sw * sizeof(float) <= kLdsTableBytes) return sw;
-  return 0;
-}
-
-template <int SW>
-int launch_lds_table(const ShortArgs& A, int n_src, hipStream_t s) {
-  const int n_slices = A.d / SW;
-  // one workgroup (16 waves) per CU and slice share: ~2 workgroups per CU in total keep the tail short
-  int parts = 512 / n_slices;
-  if (parts < 1) parts = 1;
-  const int rows_per_part = (int)cdiv(A.N, parts);
-  parts = (int)cdiv(A.N, rows_per_part);
-  const size_t lds = (size_t)n_src * SW * sizeof(float);
-  auto kern = A.w ? spmm_lds_table_kernel<SW, true> : spmm_lds_table_kernel<SW, false>;
-  RGBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  kern<<<parts * n_slices, 1024, lds, s>>>(A, n_src, n_slices, rows_per_part);
-  RGBX_CHECK_LAUNCH("spmm_lds_table_kernel");
-  return RGBX_OK;
-}
-
 template <int G>
 int launch_short(const ShortArgs& A, hipStream_t s) {
   constexpr int rows_per_block = 4 * (kWave / G);
@@ -186,30 +107,4 @@ extern "C" int rgbx_spmm_csr_short_rows_f32(const int32_t* rowptr, const int32_t
   if (d <= 64) return launch_short<16>(A, s);
   if (d <= 128) return launch_short<32>(A, s);
   return launch_short<64>(A, s);
-}
-
-extern "C" int rgbx_spmm_csr_lds_table_supported(int64_t n_src, int64_t d) {
-  return d >= 4 && d % 4 == 0 && d <= 1024 && n_src > 0 && lds_slice_width(n_src, d) > 0;
-}
-
-extern "C" int rgbx_spmm_csr_lds_table_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* x,
-                                           int64_t ldx, int64_t n_src, const float* bias, float* out, int64_t ldo, int64_t N,
-                                           int64_t d, rgbx_stream_t stream) {
-  if (N < 0 || d < 0 || n_src < 0) return fail(RGBX_E_ARG, "spmm_lds_table: negative size");
-  if (N == 0 || d == 0) return RGBX_OK;
-  if (!rowptr || !col || !x || !out) return fail(RGBX_E_ARG, "spmm_lds_table: null pointer");
-  if (N >= INT32_MAX || n_src >= INT32_MAX) return fail(RGBX_E_RANGE, "spmm_lds_table: N or n_src exceeds int32");
-  if (!rgbx_spmm_csr_lds_table_supported(n_src, d))
-    return fail(RGBX_E_ARG, "spmm_lds_table: no column slice of the [%lld, %lld] table fits LDS", (long long)n_src, (long long)d);
-  if (ldx < d || ldo < d || ldx % 4 || ldo % 4) return fail(RGBX_E_ARG, "spmm_lds_table: leading dimensions (>= d, multiples of 4)");
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias)) % 16)
-    return fail(RGBX_E_ALIGN, "spmm_lds_table: x, out, bias must be 16-byte aligned");
-  if (out == x) return fail(RGBX_E_ARG, "spmm_lds_table: out must not alias x");
-  ShortArgs A{rowptr, col, w, x, bias, out, ldx, ldo, (int)N, (int)d};
-  hipStream_t s = (hipStream_t)stream;
-  switch (lds_slice_width(n_src, d)) {
-    case 16: return launch_lds_table<16>(A, (int)n_src, s);
-    case 8: return launch_lds_table<8>(A, (int)n_src, s);
-    default: return launch_lds_table<4>(A, (int)n_src, s);
-  }
 }

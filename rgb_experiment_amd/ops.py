@@ -1686,26 +1686,6 @@ def spmm_short_rows_raw(csr, w, x, bias=None, kind="spmm"):
     return out
 
 
-def lds_table_ok(csr, table):
-    """rgbx_spmm_csr_lds_table_f32 can take the product: short rows, and a 16- / 8- / 4-column slice of the table fits a CU's LDS."""
-    d = table.size(1)
-    return (table.is_cuda and table.dim() == 2 and d % 4 == 0 and csr.nnz <= SHORT_ROWS_MEAN_SLOTS * max(csr.N, 1)
-            and bool(_lib.load().rgbx_spmm_csr_lds_table_supported(table.size(0), d)))
-
-
-def spmm_lds_table_raw(csr, w, x, bias=None, kind="spmm"):
-    """out[i,:] = sum_p w[p] x[col[p],:] (+ bias) on rgbx_spmm_csr_lds_table_f32 (no autograd)."""
-    _lib.require_device(x, w, bias)
-    px, ldx = _lib.mat(x, "x")
-    N, d = csr.N, x.size(1)
-    out = torch.empty((N, d), dtype=torch.float32, device=x.device)
-    with _Timed(kind, f"ldstable+d{d}" if _EVENT_SINK is not None else None):
-        _lib.check(_lib.load().rgbx_spmm_csr_lds_table_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(w), px, ldx,
-                                                           x.size(0), _lib.ptr(bias), _lib.ptr(out), d, N, d,
-                                                           _lib.stream_ptr()), "rgbx_spmm_csr_lds_table_f32")
-    return out
-
-
 class SparseFeatures:
     """What ops.dropout returns for features that ride on their non-zeros: not a tensor — only ops.linear (nn.Linear of this
     package) takes it; anything else fails loudly instead of reading undropped dense values."""
@@ -1798,8 +1778,6 @@ class _SparseRowsLinear(torch.autograd.Function):
         ctx.sp, ctx.has_bias = sp, bias is not None
         wt = weight.detach().t().contiguous()  # [f, out]: the gathered table (L2-resident: 367 KB for 1433 x 64)
         b = None if bias is None else bias.detach().contiguous()
-        if lds_table_ok(sp.fwd, wt):
-            return spmm_lds_table_raw(sp.fwd, sp.val, wt, bias=b, kind="features_fwd")
         if short_rows_ok(sp.fwd, wt):
             return spmm_short_rows_raw(sp.fwd, sp.val, wt, bias=b, kind="features_fwd")
         return spmm_raw(sp.fwd, sp.val, None, wt, kind="features_fwd", bias=b)

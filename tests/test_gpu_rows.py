@@ -695,36 +695,3 @@ def test_short_rows_gather_matches_the_row_per_wave_kernel(dev, d, weighted):
     assert not ops.short_rows_ok(csr, torch.empty(200000, 64, device=dev))   # a table beyond the cache budget
     with pytest.raises(RuntimeError):
         ops.spmm_short_rows_raw(csr, wd, torch.randn(n_src, 6, device=dev))
-
-
-@pytest.mark.parametrize("n_src,d", [(1433, 64), (1433, 128), (700, 8), (3703, 16), (500, 4), (9000, 40), (2500, 256), (20000, 64)])
-@pytest.mark.parametrize("weighted", [True, False])
-def test_lds_table_gather_gives_the_short_rows_kernels_bits(dev, n_src, d, weighted):
-    """rgbx_spmm_csr_lds_table_f32 (a column slice of the table in LDS, targets walked per slice) against
-    rgbx_spmm_csr_short_rows_f32: the same slot order, so the same bits — slice widths 16 / 8 / 4 by what fits, several
-    slices, empty rows, a 3,000-slot row, more parts than rows would fill, a bias; a table too tall for any slice is refused
-    (and ops.lds_table_ok says so)."""
-    from rgb_experiment_amd import ops
-    from rgb_experiment_amd.graph import CSR
-    n = 5003
-    gen = torch.Generator().manual_seed(n_src + d)
-    lens = torch.randint(0, 30, (n,), generator=gen)
-    lens[5], lens[6], lens[17] = 0, 1, 3000
-    rowptr = torch.zeros(n + 1, dtype=torch.int64)
-    rowptr[1:] = torch.cumsum(lens, 0)
-    nnz = int(rowptr[-1])
-    col = torch.randint(0, n_src, (nnz,), generator=gen)
-    w = (torch.rand(nnz, generator=gen) + 0.1).to(dev) if weighted else None
-    x = torch.randn(n_src, d, generator=gen).to(dev)
-    bias = torch.randn(d, generator=gen).to(dev)
-    csr = CSR(rowptr.to(torch.int32).to(dev), col.to(torch.int32).to(dev), None, n, nnz, None)
-    fits = n_src * 4 * 4 <= 150 * 1024
-    assert ops.lds_table_ok(csr, x) == fits
-    if not fits:
-        with pytest.raises(RuntimeError):
-            ops.spmm_lds_table_raw(csr, w, x)
-        return
-    want = ops.spmm_short_rows_raw(csr, w, x, bias=bias)
-    got = ops.spmm_lds_table_raw(csr, w, x, bias=bias)
-    assert torch.equal(got, want)
-    assert torch.equal(ops.spmm_lds_table_raw(csr, w, x), ops.spmm_short_rows_raw(csr, w, x))
