@@ -584,7 +584,7 @@ def _host_counters():
 def time_steps(step, steps, warmup, fence=None, tick=None, per_step=True):
     """(seconds for exactly `steps` steps between two fences, the last step's result, per-step milliseconds).
     Every step ends with its own host read of the epoch's five numbers (one copy), so the wall clock between two
-    returns IS that step's duration: the per-step list costs no extra synchronisation. A step beyond twice the call's
+    returns IS that step's duration: the per-step list costs no extra synchronisation. A step beyond 1.5 x the call's
     median is recorded in SLOW_STEPS with what the host-side counters did during it (the line's `slow_steps`)."""
     fence = fence or torch.cuda.synchronize
     last = None
@@ -613,7 +613,7 @@ def time_steps(step, steps, warmup, fence=None, tick=None, per_step=True):
     time_steps.calls = getattr(time_steps, "calls", 0) + 1
     med = median(per)
     for i, ms in enumerate(per):
-        if med and ms > 2.0 * med:
+        if med and ms > 1.5 * med:
             a, b = counters[i], counters[i + 1]
             SLOW_STEPS.append({"timed_loop": time_steps.calls, "step": i, "ms": ms, "median_ms": med,
                                "throttled_periods": b.get("nr_throttled", 0) - a.get("nr_throttled", 0),
@@ -763,7 +763,8 @@ def real_shape_block(dev, ei, N, F, C, names, steps, warmup, features="dense", s
                 by.setdefault(key, []).append(s.elapsed_time(e))
             table = {k: {"n_per_epoch": len(v) / steps, "avg_ms": sum(v) / len(v), "ms_per_epoch": sum(v) / steps}
                      for k, v in sorted(by.items())}
-            rec[label] = {"ms_per_epoch": dt / steps * 1e3, "median_ms_per_epoch": median(per), "epochs_per_s": steps / dt,
+            rec[label] = {"ms_per_epoch": dt / steps * 1e3, "median_ms_per_epoch": median(per), "per_epoch_ms": per,
+                          "epochs_per_s": steps / dt,
                           "timed_launches_ms_per_epoch": sum(t["ms_per_epoch"] for t in table.values()),
                           "launches": table, "final_train_loss": last[0]}
         # the row-gather kernels by width: algorithmic bytes (SURVEY 8d formula; 'mean' / 'sum' carry no per-edge weight)
@@ -1071,7 +1072,8 @@ def main():
         name, F, C, *kind = args.real_shape.split(":")
         del x
         print(json.dumps({"real_shape": real_shape_block(dev, ei, N, int(F), int(C), [name], args.steps, args.warmup,
-                                                         features=kind[0] if kind else "dense")}), flush=True)
+                                                         features=kind[0] if kind else "dense"),
+                          "slow_steps": SLOW_STEPS}), flush=True)
         return
     train_mask, val_mask, test_mask = split_masks(y)
     sv.beat("masks split")
@@ -1531,7 +1533,7 @@ def main():
         secondary("configs_1_same_run", configs_1_leg)
         secondary("configs_0_same_run", lambda: cora_shaped(dev))
         secondary("real_shape_same_run", real_shape_leg)
-    # steps beyond twice their loop's median, in any timed loop of this run (loop 1 = the headline's), with the host-side
+    # steps beyond 1.5 x their loop's median, in any timed loop of this run (loop 1 = the headline's), with the host-side
     # counters over that step: a throttled cgroup period or a full garbage collection explains a stall of the HOST thread
     result["slow_steps"] = SLOW_STEPS
     if rank == 0:
