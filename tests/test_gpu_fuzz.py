@@ -225,6 +225,14 @@ def make_model_case(seed):
     masks = [r < 0.5, (r >= 0.5) & (r < 0.75), r >= 0.75]
     masks[0][rng.randrange(n)] = True  # at least one training row
     desc = f"seed={seed} model={kind} n={n} E={ei.size(1)} in={f_in} hidden={hidden} classes={classes} layers={layers}"
+    if seed >= 6000 and seed % 3 == 0:
+        # bag-of-words-like features (round 5; seeds below 6000 keep the cases earlier soaks ran): about 8 % of the entries
+        # non-zero, one all-zero row — run_model_case hands them to ops.prepare_features, so the first Linear runs over the
+        # non-zeros (row-gather / short-rows kernels, transposed gather for its weight gradient)
+        keep = torch.rand(n, f_in, generator=torch.Generator().manual_seed(seed + 1_000_000)) < 0.08
+        keep[0] = False
+        x = x.abs() * keep
+        desc += " sparse-features"
     torch.manual_seed(seed)
     if kind == "gcn":
         model = M.GCN(num_layers=layers, hidden_unit=hidden, input_dim=f_in, output_dim=classes, dropout_rate=0.5)
@@ -288,6 +296,10 @@ def run_model_case(dev, seed):
     model.to(dev)
     clear_cache()
     xd, eid, yd = x.to(dev), ei.to(dev), y.to(dev)
+    if "sparse-features" in desc:
+        from rgb_experiment_amd import ops
+        xd = ops.prepare_features(xd)
+        assert getattr(xd, "_rgbx_sparse", None) is not None or int((x != 0).sum()) > 0.1 * x.numel()
     md = [m.to(dev) for m in masks]
     try:
         model.train()
@@ -323,6 +335,12 @@ def run_model_case(dev, seed):
 @pytest.mark.parametrize("block", range(3))
 def test_whole_models_against_the_oracle_on_random_shapes(dev, block):
     for seed in range(block * 25, block * 25 + 10):  # tools/fuzz_soak.py --models soaked 3,500
+        run_model_case(dev, seed)
+
+
+def test_whole_models_on_sparse_features(dev):
+    """Seeds 6000 .. 6089, every third with bag-of-words-like features multiplied over their non-zeros (make_model_case)."""
+    for seed in range(6000, 6090, 3):
         run_model_case(dev, seed)
 
 
