@@ -225,7 +225,7 @@ def make_model_case(seed):
     masks = [r < 0.5, (r >= 0.5) & (r < 0.75), r >= 0.75]
     masks[0][rng.randrange(n)] = True  # at least one training row
     desc = f"seed={seed} model={kind} n={n} E={ei.size(1)} in={f_in} hidden={hidden} classes={classes} layers={layers}"
-    if seed >= 6000 and seed % 3 == 0:
+    if seed >= 6000 and seed % 3 == 0 and n >= 33 and f_in >= 8:  # (smaller: 8 % of nothing is an all-zero matrix)
         # bag-of-words-like features (round 5; seeds below 6000 keep the cases earlier soaks ran): about 8 % of the entries
         # non-zero, one all-zero row — run_model_case hands them to ops.prepare_features, so the first Linear runs over the
         # non-zeros (row-gather / short-rows kernels, transposed gather for its weight gradient)
