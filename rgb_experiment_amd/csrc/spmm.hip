@@ -307,19 +307,34 @@ __global__ void __launch_bounds__(256) spmm_tile_epilogue_kernel(const SpmmArgs 
   float bv[VEC] = {0.f, 0.f, 0.f, 0.f};
   if (A.bias && active) load_vec<VEC>(bv, A.bias + c);
 
+  // The wave's RPW rows' slot ranges, mask bits and labels in ONE round of loads (lane l holds row l's): read row by row
+  // they are three dependent global loads in front of every row — also of the rows no mask selects, which are most rows of an
+  // eval forward (statistics under one mask, d = 8 at L: 0.55 -> see profiles/r05_epilogue_preload.txt).
+  const int row0 = row_base + wave * RPW;
+  int my_ptr = 0, my_bits = 1, my_tgt = -1;
+  if (lane <= RPW && row0 + lane <= A.N) my_ptr = A.rowptr[row0 + lane];
+  if constexpr (CE) {
+    if (lane < RPW && row0 + lane < A.N) {
+      my_bits = E.ce_mask ? (int)E.ce_mask[row0 + lane] : 1;
+      my_bits = E.ce_groups == 2 ? (my_bits & 3) : (my_bits ? 1 : 0);
+      if (my_bits) {
+        const int64_t ti = E.ce_y[row0 + lane];
+        if (ti >= 0 && ti < E.C) my_tgt = (int)ti;
+      }
+    }
+  }
+
+  // (unrolled for the loss forms only: 50-61 registers instead of 59-71 there, 70 instead of 64 for the statistics forms)
+#pragma unroll CE ? RPW : 1
   for (int rr = 0; rr < RPW; ++rr) {
-    const int row = row_base + wave * RPW + rr;
+    const int row = row0 + rr;
     if (row >= A.N) break;  // wave-uniform
-    const int start = __builtin_amdgcn_readfirstlane(A.rowptr[row]);
-    const int end = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
+    const int start = __builtin_amdgcn_readlane(my_ptr, rr);
+    const int end = __builtin_amdgcn_readlane(my_ptr, rr + 1);
     int tgt = -1, bits = 1;
     if constexpr (CE) {
-      bits = E.ce_mask ? (int)E.ce_mask[row] : 1;
-      bits = E.ce_groups == 2 ? (bits & 3) : (bits ? 1 : 0);
-      if (bits) {
-        const int64_t ti = E.ce_y[row];
-        if (ti >= 0 && ti < E.C) tgt = (int)ti;
-      }
+      bits = __builtin_amdgcn_readlane(my_bits, rr);
+      tgt = __builtin_amdgcn_readlane(my_tgt, rr);
       if (tgt < 0 && !E.ce_scale) continue;  // not selected and nothing to store: the row is not even gathered
     }
     float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
