@@ -751,10 +751,12 @@ def real_shape_block(dev, ei, N, F, C, names, steps, warmup, features="dense", s
         step, nnz, _ = build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, C)
         rec = {}
         for label, fn in (("reference_epoch", step), ("identical_results_epoch", step.identical)):
+            events = []
+            ops.set_event_sink(events)  # (before the warm-up: the first step that records events pays for their creation)
             for _ in range(warmup):
                 fn()
-            events = []
-            ops.set_event_sink(events)
+            torch.cuda.synchronize()
+            events.clear()
             dt, last, per = time_steps(fn, steps, 0)
             ops.set_event_sink(None)
             by = {}
