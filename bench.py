@@ -562,22 +562,22 @@ def build_single_gpu(model, ei, x, y, masks, dev, loops_mode, kind, N, d):
     return step, nnz_total, alg
 
 
-SLOW_STEPS = []  # (time_steps call #, step index, ms, median ms of the call, host-side counters): see _host_counters
+SLOW_STEPS = []  # (time_steps call #, step index, ms, median ms of the call, host-side counters): see _cgroup_cpu
 
 
-def _host_counters():
-    """What could hold the HOST thread of a step: the cgroup's CPU throttling (a one-GPU box grants 16 of the host's 256 CPUs;
-    a throttled period parks every thread of the cgroup for up to 100 ms) and Python's full garbage collections."""
+def _cgroup_cpu():
+    """The cgroup's CPU throttling counters (a one-GPU box grants 16 of the host's 256 CPUs; a throttled period parks every
+    thread of the cgroup for up to 100 ms). Read once before and once after a timed loop, never per step: the read makes the
+    kernel fold the per-CPU statistics of 256 CPUs and took 15-60 ms now and then when it sat between the steps (round 5:
+    profiles/r05_host_gc_stall.txt)."""
     out = {}
     try:
         for line in open("/sys/fs/cgroup/cpu.stat"):
             k, v = line.split()
-            if k in ("nr_throttled", "throttled_usec", "usage_usec"):
+            if k in ("nr_throttled", "throttled_usec"):
                 out[k] = int(v)
     except (OSError, ValueError):
         pass
-    import gc
-    out["gc_gen2"] = gc.get_stats()[2]["collections"]
     return out
 
 
@@ -585,7 +585,9 @@ def time_steps(step, steps, warmup, fence=None, tick=None, per_step=True):
     """(seconds for exactly `steps` steps between two fences, the last step's result, per-step milliseconds).
     Every step ends with its own host read of the epoch's five numbers (one copy), so the wall clock between two
     returns IS that step's duration: the per-step list costs no extra synchronisation. A step beyond 1.5 x the call's
-    median is recorded in SLOW_STEPS with what the host-side counters did during it (the line's `slow_steps`)."""
+    median is recorded in SLOW_STEPS with the full garbage collections that ran during it and the loop's cgroup throttling
+    (the line's `slow_steps`)."""
+    import gc
     fence = fence or torch.cuda.synchronize
     last = None
     for _ in range(warmup):
@@ -595,31 +597,30 @@ def time_steps(step, steps, warmup, fence=None, tick=None, per_step=True):
     # a leg's set-up (models, graphs, caches), and then not again in steady state (400 steps without one). Which step it
     # lands on follows the allocation count, so with other --steps / --warmup values it lands inside the timed region.
     # Collect now, and move what survives to the permanent generation: the timed steps then see only their own garbage.
-    import gc
     gc.collect()
     gc.freeze()
+    before = _cgroup_cpu()
     fence()
     marks = [time.perf_counter()]
-    counters = [_host_counters()]
+    full = [gc.get_stats()[2]["collections"]]
     for i in range(steps):
         last = step()
         marks.append(time.perf_counter())
-        counters.append(_host_counters())
+        full.append(gc.get_stats()[2]["collections"])
         if tick is not None:
             tick(f"timed step {i + 1}/{steps}")
     fence()
     total = time.perf_counter() - marks[0]
+    after = _cgroup_cpu()
     per = [(b - a) * 1e3 for a, b in zip(marks, marks[1:])]
     time_steps.calls = getattr(time_steps, "calls", 0) + 1
     med = median(per)
     for i, ms in enumerate(per):
         if med and ms > 1.5 * med:
-            a, b = counters[i], counters[i + 1]
             SLOW_STEPS.append({"timed_loop": time_steps.calls, "step": i, "ms": ms, "median_ms": med,
-                               "throttled_periods": b.get("nr_throttled", 0) - a.get("nr_throttled", 0),
-                               "throttled_ms": (b.get("throttled_usec", 0) - a.get("throttled_usec", 0)) / 1e3,
-                               "cgroup_cpu_ms": (b.get("usage_usec", 0) - a.get("usage_usec", 0)) / 1e3,
-                               "gc_full_collections": b["gc_gen2"] - a["gc_gen2"]})
+                               "gc_full_collections": full[i + 1] - full[i],
+                               "loop_throttled_periods": after.get("nr_throttled", 0) - before.get("nr_throttled", 0),
+                               "loop_throttled_ms": (after.get("throttled_usec", 0) - before.get("throttled_usec", 0)) / 1e3})
     return total, last, per
 
 
@@ -1535,8 +1536,8 @@ def main():
         secondary("configs_1_same_run", configs_1_leg)
         secondary("configs_0_same_run", lambda: cora_shaped(dev))
         secondary("real_shape_same_run", real_shape_leg)
-    # steps beyond 1.5 x their loop's median, in any timed loop of this run (loop 1 = the headline's), with the host-side
-    # counters over that step: a throttled cgroup period or a full garbage collection explains a stall of the HOST thread
+    # steps beyond 1.5 x their loop's median, in any timed loop of this run (loop 1 = the headline's), with the full garbage
+    # collections during the step and the loop's cgroup throttling: what can hold the HOST thread
     result["slow_steps"] = SLOW_STEPS
     if rank == 0:
         print(json.dumps(result), flush=True)
