@@ -263,21 +263,6 @@ __device__ __forceinline__ void ce_epilogue(const FusedArgs& A, const f32x16& ac
   const int kr = lane >> 5, cc = lane & 31;
   const int ldq = A.Nout + 4;
   const int n0 = wave * 32;
-  // this wave's eight rows' mask bits and labels, one round of loads issued ahead of the barriers (lane l holds row l's): row
-  // by row they are two dependent global loads in front of every row, at the end of a workgroup's life where nothing of its
-  // own overlaps them (the same change took spmm_tile_epilogue_kernel's loss statistics from 0.55 to 0.29 ms)
-  int my_bits = 1, my_t = -1;
-  {
-    const int row = row_base + wave * (TM / 4) + lane;
-    if (lane < TM / 4 && row < A.N) {
-      my_bits = A.ce_mask ? (int)A.ce_mask[row] : 1;
-      my_bits = A.ce_groups == 2 ? (my_bits & 3) : (my_bits ? 1 : 0);
-      if (my_bits) {
-        const int64_t ti = A.ce_y[row];
-        if (ti >= 0 && ti < A.Nout) my_t = (int)ti;
-      }
-    }
-  }
   __syncthreads();  // every wave is done reading the aggregate (or root) tile
   if (n0 < A.Nout) {
     const float bb = A.bias ? A.bias[n0 + cc] : 0.f;
@@ -294,8 +279,13 @@ __device__ __forceinline__ void ce_epilogue(const FusedArgs& A, const f32x16& ac
     const int rl = wave * (TM / 4) + rr;
     const int row = row_base + rl;
     if (row >= A.N) break;  // wave-uniform
-    const int bits = __builtin_amdgcn_readlane(my_bits, rr);
-    const int t = __builtin_amdgcn_readlane(my_t, rr);
+    int t = -1;
+    int bits = A.ce_mask ? (int)A.ce_mask[row] : 1;
+    bits = A.ce_groups == 2 ? (bits & 3) : (bits ? 1 : 0);
+    if (bits) {
+      const int64_t ti = A.ce_y[row];
+      if (ti >= 0 && ti < A.Nout) t = (int)ti;
+    }
     if (t < 0 && !A.ce_scale) continue;  // not selected, nothing to store: wave-uniform
     const float v0 = c0 ? ot[rl * ldq + lane] : -INFINITY;
     const float v1 = c1 ? ot[rl * ldq + lane + 64] : -INFINITY;
