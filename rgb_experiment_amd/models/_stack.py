@@ -118,6 +118,10 @@ class ConvStack(nn.Module):
             self._train_forwards = getattr(self, "_train_forwards", 0) + 1  # statistics and weights are about to move
         folded = self._eval_operands() if (not torch.is_grad_enabled() and not self.training and x.is_cuda) else None
         agg0 = self._input_aggregate(x, edge_index) if getattr(self, "cache_input_aggregate", False) else None
+        if folded is not None and agg0 is None and getattr(self, "collapse_eval", True):
+            out = self._run_collapsed(x, edge_index, ce)
+            if out is not None:
+                return out
         for i, conv in enumerate(self.convs):
             bn = self.bns[i] if i < last else None
             if i == 0 and agg0 is not None and i < last:
@@ -164,6 +168,75 @@ class ConvStack(nn.Module):
         if ce is not None and not isinstance(x, tuple):  # a last conv without the loss epilogue (GATConv)
             x = ops.ce_from_logits(x, ce[0], ce[1])
         return x
+
+
+def _collapsed_operands(self):
+    """A GCN stack in eval mode is ONE linear map per propagation step: the reference's stacks apply no activation between
+    their layers (models/gcn.py:25-31: conv -> BatchNorm -> conv; dropout_rate is stored and never used), an eval-mode
+    BatchNorm is a per-column affine map, and A_hat acts on rows — so
+        logits = A_hat( ... A_hat( A_hat(X P) + c_0 ) + c_1 ... ) + b_last,
+        P = W_0^T diag(s_0) W_1^T diag(s_1) ... W_last^T   [F, C],     c_l = (b_l * s_l + t_l) (W_{l+1}^T diag(s_{l+1}) ... W_last^T)
+    with (s_l, t_l) the BatchNorm's eval scale and shift. Every propagation then runs at the CLASS width (C = 7 -> rows of
+    8 floats) instead of the hidden width (64), and the input product is [N, F] x [F, C]. Returns (P^T padded [C', F] as a
+    Linear's weight, [c_l padded], b_last padded, C, C') or None where this does not apply or does not pay: layers other than
+    GCNConv, a BatchNorm without the affine eval form, C' >= a hidden width. Cached per model state like _eval_operands."""
+    from .. import ops
+    tensors = list(self.parameters()) + list(self.buffers())
+    key = (getattr(self, "_train_forwards", 0), ops.weights_epoch()) + tuple((t._version, t.data_ptr()) for t in tensors)
+    cached = getattr(self, "_collapsed", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    out = None
+    convs, last = list(self.convs), self.num_layers - 1
+    C = convs[-1].out_channels if hasattr(convs[-1], "out_channels") else 0
+    Cp = (C + 3) // 4 * 4
+    if (all(type(c).__name__ == "GCNConv" for c in convs) and 0 < Cp <= 256
+            and all(c.out_channels > Cp for c in convs[:-1])):
+        affines = [getattr(self.bns[i], "eval_affine", lambda: None)() for i in range(last)]
+        if all(a is not None for a in affines):
+            with torch.no_grad():
+                suffix = torch.eye(C, device=convs[-1].lin.weight.device)  # product of the maps BEHIND layer l, [out_l, C]
+                shifts = [None] * last
+                for l in range(last, -1, -1):
+                    wt = convs[l].lin.weight.t()  # [in_l, out_l]
+                    if l < last:
+                        scale, shift = affines[l]
+                        shifts[l] = (convs[l].bias * scale + shift) @ suffix
+                        wt = wt * scale[None, :]
+                    suffix = wt @ suffix  # [in_l, C]
+                pad = torch.nn.functional.pad
+                weight = pad(suffix.t(), (0, 0, 0, Cp - C)).contiguous()  # [C', F]
+                out = (weight, [pad(c, (0, Cp - C)).contiguous() for c in shifts],
+                       pad(convs[-1].bias.detach(), (0, Cp - C)).contiguous(), C, Cp)
+    self._collapsed = (key, out)
+    return out
+
+
+def _run_collapsed(self, x, edge_index, ce):
+    """The eval forward (no_grad) through _collapsed_operands: one product at the class width, one row gather per layer, the
+    masked cross-entropy (one or two masks) taken in the last gather. None where the collapsed form does not apply."""
+    from .. import ops
+    from ..graph import LOOPS_ADD_REMAINING, get_graph
+    operands = self._collapsed_operands()
+    if operands is None:
+        return None
+    weight, shifts, b_last, C, Cp = operands
+    graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
+    if getattr(graph, "is_distributed", False) or not ops.rows_epilogue_ok(graph, Cp, x, None if ce is None else ce[0]):
+        return None
+    y = ops.linear(x, weight)  # [N, C']: over the non-zeros of bag-of-words features (ops.prepare_features)
+    for c in shifts:
+        y = ops.spmm_raw(graph.fwd, graph.w, None, y, bias=c, kind="gcn_fwd")
+    if ce is None:
+        return ops.spmm_raw(graph.fwd, graph.w, None, y, bias=b_last, kind="gcn_fwd")[:, :C]
+    labels, mask = ce
+    _, stats = ops.spmm_epilogue_raw(graph.fwd, graph.w, None, y, bias=b_last, ce=(labels, mask, None), n_classes=C,
+                                     kind="gcn_fwd")
+    return None, stats
+
+
+ConvStack._collapsed_operands = _collapsed_operands
+ConvStack._run_collapsed = _run_collapsed
 
 
 def _eval_operands(self):
