@@ -170,16 +170,35 @@ class ConvStack(nn.Module):
         return x
 
 
+def _layer_maps(conv):
+    """(W_l [out, in], W_r [out, in] or None, b [out], aggregation kind, self-loop rewrite) of a conv layer that is
+    `A(x) W_l^T + x W_r^T + b` with a row-wise aggregation A, or None: GCNConv (A = A_hat, no root term), my_SAGEConv (mean
+    over N(i) and i itself — its b_l sits inside the mean, whose rows sum to 1: models/graphsage.py:49-62), SAGEConv (mean over
+    N(i), lin_l's bias outside it [PyG])."""
+    from ..graph import LOOPS_ADD_REMAINING, LOOPS_KEEP, LOOPS_REMOVE_ADD
+    name = type(conv).__name__
+    if name == "GCNConv":
+        return conv.lin.weight, None, conv.bias, "gcn", LOOPS_ADD_REMAINING
+    if name == "MySAGEConv" and conv.add_self_loops:
+        return conv.lin_l.weight, conv.lin_r.weight, conv.lin_l.bias + conv.lin_r.bias, "mean", LOOPS_REMOVE_ADD
+    if name == "SAGEConv":
+        return conv.lin_l.weight, conv.lin_r.weight, conv.lin_l.bias, "mean", LOOPS_KEEP
+    return None
+
+
 def _collapsed_operands(self):
-    """A GCN stack in eval mode is ONE linear map per propagation step: the reference's stacks apply no activation between
-    their layers (models/gcn.py:25-31: conv -> BatchNorm -> conv; dropout_rate is stored and never used), an eval-mode
-    BatchNorm is a per-column affine map, and A_hat acts on rows — so
-        logits = A_hat( ... A_hat( A_hat(X P) + c_0 ) + c_1 ... ) + b_last,
-        P = W_0^T diag(s_0) W_1^T diag(s_1) ... W_last^T   [F, C],     c_l = (b_l * s_l + t_l) (W_{l+1}^T diag(s_{l+1}) ... W_last^T)
-    with (s_l, t_l) the BatchNorm's eval scale and shift. Every propagation then runs at the CLASS width (C = 7 -> rows of
-    8 floats) instead of the hidden width (64), and the input product is [N, F] x [F, C]. Returns (P^T padded [C', F] as a
-    Linear's weight, [c_l padded], b_last padded, C, C') or None where this does not apply or does not pay: layers other than
-    GCNConv, a BatchNorm without the affine eval form, C' >= a hidden width. Cached per model state like _eval_operands."""
+    """A conv stack in eval mode is a POLYNOMIAL in its aggregation operator: the reference's stacks apply no activation between
+    their layers (models/gcn.py:25-31, graphsage.py:26-32, graphsage2.py:27-33: conv -> BatchNorm -> conv; dropout_rate is stored
+    and never used), an eval-mode BatchNorm is a per-column affine map x * s + t, and A (A_hat, or the mean) acts on rows while
+    the weights act on columns — the two commute. With layer l = A(h) W_l^T + h W_r^T + b_l:
+        logits = sum_k A^k X Q_k + sum_k A^k 1 d_k^T,    Q_k [F, C], d_k [C]: sums over the weight paths that aggregate k times,
+    evaluated by Horner's rule: U = X Q_L; U = A(U) + X Q_k + d_k for k = L-1 .. 0. Every aggregation then runs at the CLASS
+    width (C = 7 -> rows of 8 floats) instead of the hidden width (64), and the input meets ONE product [N, F] x [F, (L+1) C']
+    (GCN: W_r = 0, only Q_L is there). Recurrence per layer (S = diag(s), identity behind the last layer):
+        Q'_k = Q_k W_r^T S + Q_{k-1} W_l^T S,   d'_k = d_k W_r^T S + d_{k-1} W_l^T S,   d'_0 += b * s + t.
+    Returns (weight [(blocks * C'), F] for ops.linear, which k have a block, [d_k padded or None], C, C', kind, loops_mode) or
+    None where this does not apply or does not pay: other layer types, mixed aggregations, a BatchNorm without the affine eval
+    form, C' not below every hidden width. Cached per model state like _eval_operands."""
     from .. import ops
     tensors = list(self.parameters()) + list(self.buffers())
     key = (getattr(self, "_train_forwards", 0), ops.weights_epoch()) + tuple((t._version, t.data_ptr()) for t in tensors)
@@ -188,50 +207,67 @@ def _collapsed_operands(self):
         return cached[1]
     out = None
     convs, last = list(self.convs), self.num_layers - 1
-    C = convs[-1].out_channels if hasattr(convs[-1], "out_channels") else 0
+    maps = [_layer_maps(c) for c in convs]
+    C = getattr(convs[-1], "out_channels", 0)
     Cp = (C + 3) // 4 * 4
-    if (all(type(c).__name__ == "GCNConv" for c in convs) and 0 < Cp <= 256
+    if (all(m is not None for m in maps) and len({(m[3], m[4]) for m in maps}) == 1 and 0 < Cp <= 256
             and all(c.out_channels > Cp for c in convs[:-1])):
         affines = [getattr(self.bns[i], "eval_affine", lambda: None)() for i in range(last)]
         if all(a is not None for a in affines):
             with torch.no_grad():
-                suffix = torch.eye(C, device=convs[-1].lin.weight.device)  # product of the maps BEHIND layer l, [out_l, C]
-                shifts = [None] * last
-                for l in range(last, -1, -1):
-                    wt = convs[l].lin.weight.t()  # [in_l, out_l]
-                    if l < last:
-                        scale, shift = affines[l]
-                        shifts[l] = (convs[l].bias * scale + shift) @ suffix
-                        wt = wt * scale[None, :]
-                    suffix = wt @ suffix  # [in_l, C]
+                Q, d = None, None  # Q[k] [F, width] / d[k] [width], None = zero
+                for l, (wl, wr, b, _, _) in enumerate(maps):
+                    scale, shift = affines[l] if l < last else (None, None)
+                    ml = wl.t() if scale is None else wl.t() * scale[None, :]  # W_l^T S  [in, out]
+                    mr = None if wr is None else (wr.t() if scale is None else wr.t() * scale[None, :])
+                    if Q is None:  # first layer: H = A X M_l + X M_r + 1 b'
+                        Q, d = [mr, ml], [None, None]
+                    else:
+                        nq, nd = [None] * (len(Q) + 1), [None] * (len(Q) + 1)
+                        for k in range(len(Q)):
+                            for src, m, dst in ((Q, mr, k), (Q, ml, k + 1)):
+                                if src[k] is not None and m is not None:
+                                    nq[dst] = src[k] @ m if nq[dst] is None else nq[dst] + src[k] @ m
+                            for m, dst in ((mr, k), (ml, k + 1)):
+                                if d[k] is not None and m is not None:
+                                    nd[dst] = d[k] @ m if nd[dst] is None else nd[dst] + d[k] @ m
+                        Q, d = nq, nd
+                    const = b if scale is None else b * scale + shift
+                    d[0] = const if d[0] is None else d[0] + const
                 pad = torch.nn.functional.pad
-                weight = pad(suffix.t(), (0, 0, 0, Cp - C)).contiguous()  # [C', F]
-                out = (weight, [pad(c, (0, Cp - C)).contiguous() for c in shifts],
-                       pad(convs[-1].bias.detach(), (0, Cp - C)).contiguous(), C, Cp)
+                have = [k for k, q in enumerate(Q) if q is not None]
+                weight = torch.cat([pad(Q[k].t(), (0, 0, 0, Cp - C)) for k in have], dim=0).contiguous()  # [blocks * C', F]
+                shifts = [None if v is None else pad(v.detach(), (0, Cp - C)).contiguous() for v in d]
+                out = (weight, have, shifts, C, Cp, maps[0][3], maps[0][4])
     self._collapsed = (key, out)
     return out
 
 
 def _run_collapsed(self, x, edge_index, ce):
-    """The eval forward (no_grad) through _collapsed_operands: one product at the class width, one row gather per layer, the
-    masked cross-entropy (one or two masks) taken in the last gather. None where the collapsed form does not apply."""
+    """The eval forward (no_grad) through _collapsed_operands: one product at (blocks x) the class width, one row gather per
+    layer with the lower-order block as its additive operand, the masked cross-entropy (one or two masks) taken in the last
+    gather. None where the collapsed form does not apply."""
     from .. import ops
-    from ..graph import LOOPS_ADD_REMAINING, get_graph
+    from ..graph import get_graph
     operands = self._collapsed_operands()
     if operands is None:
         return None
-    weight, shifts, b_last, C, Cp = operands
-    graph = get_graph(edge_index, x.size(0), LOOPS_ADD_REMAINING)
+    weight, have, shifts, C, Cp, kind, loops_mode = operands
+    graph = get_graph(edge_index, x.size(0), loops_mode)
     if getattr(graph, "is_distributed", False) or not ops.rows_epilogue_ok(graph, Cp, x, None if ce is None else ce[0]):
         return None
-    y = ops.linear(x, weight)  # [N, C']: over the non-zeros of bag-of-words features (ops.prepare_features)
-    for c in shifts:
-        y = ops.spmm_raw(graph.fwd, graph.w, None, y, bias=c, kind="gcn_fwd")
+    z = ops.linear(x, weight)  # [N, blocks * C']: over the non-zeros of bag-of-words features (ops.prepare_features)
+    block = {k: z[:, j * Cp:(j + 1) * Cp] for j, k in enumerate(have)}
+    w, rs = ops._kind_weights(graph, kind)
+    top = len(shifts) - 1  # = number of layers: the highest power of A
+    u = block[top]
+    for k in range(top - 1, 0, -1):
+        u = ops.spmm_raw(graph.fwd, w, rs, u, y=block.get(k), a=1.0, b=1.0, bias=shifts[k], kind=f"{kind}_fwd")
     if ce is None:
-        return ops.spmm_raw(graph.fwd, graph.w, None, y, bias=b_last, kind="gcn_fwd")[:, :C]
+        return ops.spmm_raw(graph.fwd, w, rs, u, y=block.get(0), a=1.0, b=1.0, bias=shifts[0], kind=f"{kind}_fwd")[:, :C]
     labels, mask = ce
-    _, stats = ops.spmm_epilogue_raw(graph.fwd, graph.w, None, y, bias=b_last, ce=(labels, mask, None), n_classes=C,
-                                     kind="gcn_fwd")
+    _, stats = ops.spmm_epilogue_raw(graph.fwd, w, rs, u, y=block.get(0), a=1.0, b=1.0, bias=shifts[0],
+                                     ce=(labels, mask, None), n_classes=C, kind=f"{kind}_fwd")
     return None, stats
 
 

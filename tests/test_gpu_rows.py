@@ -697,13 +697,16 @@ def test_short_rows_gather_matches_the_row_per_wave_kernel(dev, d, weighted):
         ops.spmm_short_rows_raw(csr, wd, torch.randn(n_src, 6, device=dev))
 
 
+@pytest.mark.parametrize("name", ["gcn", "graphsage", "graphsage2"])
 @pytest.mark.parametrize("layers,f,hid,c", [(2, 1433, 64, 7), (3, 300, 64, 3), (4, 128, 32, 7), (2, 128, 64, 40)])
-def test_gcn_eval_forward_collapsed_to_the_class_width(dev, layers, f, hid, c):
-    """ConvStack._run_collapsed: a GCN stack has no activation between its layers (models/gcn.py:25-31), so its eval forward is
-    A_hat(... A_hat(X P) + c_0 ...) + b with P = W_0^T diag(s_0) ... W_last^T [F, C] — every gather at the class width. Eval
-    logits, one-mask and two-mask statistics against the float64 oracle and against the layer-by-layer route
-    (collapse_eval = False), after a training step has moved the running statistics; every aggregation launch of the
-    collapsed forward at width pad4(C); training forwards and wide-class models keep the layer-by-layer route."""
+def test_eval_forward_collapsed_to_the_class_width(dev, name, layers, f, hid, c):
+    """ConvStack._run_collapsed: the reference's stacks have no activation between their layers (models/gcn.py:25-31,
+    graphsage.py:26-32, graphsage2.py:27-33), so an eval forward is a polynomial in the aggregation operator, evaluated by
+    Horner's rule with every gather at the class width: GCN A_hat(... A_hat(X P) + c ...) + b, the SAGE stacks
+    U = A(U) + X Q_k + d_k with one product X [Q_0 | .. | Q_L]. Eval logits, one-mask and two-mask statistics against the
+    float64 oracle and against the layer-by-layer route (collapse_eval = False), after a training step has moved the running
+    statistics; isolated targets (SAGEConv aggregates 0 there) and a hub row; every aggregation launch of the collapsed
+    forward at width pad4(C); wide-class models keep the layer-by-layer route."""
     from oracle import ref_cpu as O
     from rgb_experiment_amd import models as M
     from rgb_experiment_amd import ops
@@ -716,7 +719,9 @@ def test_gcn_eval_forward_collapsed_to_the_class_width(dev, layers, f, hid, c):
     r = torch.rand(n, generator=gen)
     m_a, m_b = r < 0.3, r > 0.6
     torch.manual_seed(7)
-    model = M.GCN(num_layers=layers, hidden_unit=hid, input_dim=f, output_dim=c, dropout_rate=0.5).to(dev)
+    cls = {"gcn": M.GCN, "graphsage": M.GraphSAGE, "graphsage2": M.GraphSAGE2}[name]
+    oracle_forward = {"gcn": O.gcn_forward, "graphsage": O.graphsage_forward, "graphsage2": O.graphsage2_forward}[name]
+    model = cls(num_layers=layers, hidden_unit=hid, input_dim=f, output_dim=c, dropout_rate=0.5).to(dev)
     with torch.no_grad():
         for p in model.parameters():
             if p.dim() == 1:
@@ -726,7 +731,7 @@ def test_gcn_eval_forward_collapsed_to_the_class_width(dev, layers, f, hid, c):
     masked_ce(model, {"x": xd, "edge_index": eid}, yd, m_a.to(dev))[0].backward()  # running statistics move off their init
     model.eval()
     sd = {k: (v.detach().cpu().double() if v.is_floating_point() else v.cpu()) for k, v in model.state_dict().items()}
-    ref = O.gcn_forward(sd, x.double(), ei, layers, False)
+    ref = oracle_forward(sd, x.double(), ei, layers, False)
     want = torch.stack([torch.stack([torch.nn.functional.nll_loss(ref["out"][m], y[m], reduction="sum"),
                                      m.sum().double(), (ref["out"][m].argmax(1) == y[m]).sum().double()]) for m in (m_a, m_b)])
     events = []
@@ -750,8 +755,9 @@ def test_gcn_eval_forward_collapsed_to_the_class_width(dev, layers, f, hid, c):
         assert (got[:, 0] - want[:, 0]).abs().max().item() < 1e-4 * max(1.0, want[:, 0].abs().max().item())
         assert (got[:, 2] - want[:, 2]).abs().max().item() <= 2
     assert torch.equal(one.cpu()[1], want[0, 1]) and abs(one.cpu()[0].item() - want[0, 0].item()) < 1e-4 * max(1.0, want[0, 0].item())
-    widths = [int(str(getattr(k, "variant", "")).split("+d")[-1]) for k, _, _ in events if str(k).startswith("gcn_")]
+    widths = [int(str(getattr(k, "variant", "")).split("+d")[-1]) for k, _, _ in events
+              if str(k).startswith(("gcn_", "mean_")) and "+d" in str(getattr(k, "variant", ""))]
     assert len(widths) == 3 * layers and set(widths) == {(c + 3) // 4 * 4}, widths
-    # a training forward is never collapsed; a model whose classes are as wide as its hidden layers is not either
-    wide = M.GCN(num_layers=2, hidden_unit=32, input_dim=f, output_dim=40, dropout_rate=0.5).to(dev).eval()
+    # a model whose classes are as wide as its hidden layers is not collapsed
+    wide = cls(num_layers=2, hidden_unit=32, input_dim=f, output_dim=40, dropout_rate=0.5).to(dev).eval()
     assert wide._collapsed_operands() is None
