@@ -186,6 +186,28 @@ def make_problem(n=97, e=900, f=12, c=5, seed=0):
     return ei, x, y, masks
 
 
+def leave_group():
+    """End of a rank process of a test (its results are on disk by now): a barrier, so that no rank closes its sockets while a
+    peer is still inside its own last collective; the process group destroyed; and the process left at once with status 0.
+    Without the last step a rank now and then died in interpreter shutdown — "terminate called without an active exception",
+    SIGABRT, with every assertion of the case already passed (round 5, under three pytest-xdist workers: a C++ thread of the
+    backend still joinable when its owner is torn down). mp.spawn reads status 0 as a normal return."""
+    import faulthandler
+    import sys
+    try:
+        if dist.is_initialized():
+            try:
+                dist.barrier()
+            except Exception:  # noqa: BLE001 - a peer that already failed: the spawn reports ITS error
+                pass
+            dist.destroy_process_group()
+    finally:
+        faulthandler.cancel_dump_traceback_later()
+        sys.stdout.flush()
+        sys.stderr.flush()
+    os._exit(0)
+
+
 def arm_deadline(seconds):
     """Hard per-case deadline of a rank process of a multi-rank GPU test: when it passes, the stacks of ALL threads of this
     rank go to stderr and the process exits (faulthandler, exit=True) — a stall fails the case within about a minute with
@@ -244,7 +266,7 @@ def propagate_worker(rank, world, port, out_dir, exchange="halo"):
     out.backward(go[lo:hi])
     res["appnp"] = (out.detach(), xl.grad)
     torch.save(res, os.path.join(out_dir, f"prop_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
 
 
 def plan_slices_worker(rank, world, port, out_dir):
@@ -313,7 +335,7 @@ def plan_slices_worker(rank, world, port, out_dir):
                 assert bool(dg._subsets) == on
             assert got[0][0] == got[1][0] and torch.equal(got[0][1], got[1][1]) and torch.equal(got[0][2], got[1][2]), exchange
     torch.save({"checked": checked}, os.path.join(out_dir, f"slices_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
 
 
 def reshard_chunk_worker(rank, world, port, out_dir, exchange="reshard"):
@@ -332,7 +354,7 @@ def reshard_chunk_worker(rank, world, port, out_dir, exchange="reshard"):
         out.sum().backward()
         outs[chunks] = (out.detach(), xl.grad)
     torch.save(outs, os.path.join(out_dir, f"chunks_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
 
 
 def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", interleave=True, release=False, fused=True,
@@ -374,7 +396,7 @@ def runner_worker(rank, world, port, out_dir, model_name, exchange="halo", inter
                 "eval_both": both,
                 "state": {k: v.clone() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"run_{model_name}_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
 
 
 def tasksplit_worker(rank, world, port, out_dir, model_name, exchange="reshard", stop_early=False):
@@ -394,7 +416,7 @@ def tasksplit_worker(rank, world, port, out_dir, model_name, exchange="reshard",
     torch.save({"hist": hist, "role": r.role, "lo": r.lo, "hi": r.hi,
                 "state": {k: v.clone() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"split_{model_name}_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
 
 
 def shared_eval_worker(rank, world, port, out_dir, model_name, exchange, fused, split):
@@ -426,7 +448,7 @@ def shared_eval_worker(rank, world, port, out_dir, model_name, exchange, fused, 
                       "state": {k: v.clone() for k, v in r.model.state_dict().items()}}
         dist.barrier()
     torch.save(res, os.path.join(out_dir, f"shared_{model_name}_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
 
 
 def failing_eval_worker(rank, world, port, out_dir):
@@ -455,7 +477,7 @@ def failing_eval_worker(rank, world, port, out_dir):
     Failing.armed = rank == 1
     r.epoch()
     open(os.path.join(out_dir, f"second_epoch_done_{rank}"), "w").close()  # must not be reached by rank 1
-    dist.destroy_process_group()
+    leave_group()
 
 
 def exchange_count_worker(rank, world, port, out_dir, model_name, resident):
@@ -481,7 +503,7 @@ def exchange_count_worker(rank, world, port, out_dir, model_name, resident):
     hist.append(r.epoch())
     torch.save({"hist": hist, "exchanges": CountingComm.calls},
                os.path.join(out_dir, f"cnt_{model_name}_{int(resident)}_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
 
 
 def experiment_worker(rank, world, port, out_dir, model_name, on_gpu=False, classes=None):
@@ -512,7 +534,7 @@ def experiment_worker(rank, world, port, out_dir, model_name, on_gpu=False, clas
                 "history": res["history"], "distributed": res["distributed"],
                 "state": {k: v.cpu().clone() for k, v in res["model"].state_dict().items()}},
                os.path.join(out_dir, f"exp_{model_name}_{world}_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
 
 
 def build_model(M, name, f, c):
@@ -599,7 +621,7 @@ def gpu_runner_worker(rank, world, port, out_dir, model_name, exchange="halo", h
     torch.save({"hist": hist, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi, "backend": dist.get_backend(),
                 "engine": r.engine is not None, "state": {k: v.cpu() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"gpu_{model_name}_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
     disarm_deadline()
 
 
@@ -628,7 +650,7 @@ def gpu_plan_slices_worker(rank, world, port, out_dir, model_name, exchange):
                    "state": {k: v.cpu() for k, v in r.model.state_dict().items()}}
     os.environ.pop("RGBX_PLAN_FROM_SLICES", None)
     torch.save(out, os.path.join(out_dir, f"gpuslices_{model_name}_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
     disarm_deadline()
 
 
@@ -649,7 +671,7 @@ def gpu_tasksplit_worker(rank, world, port, out_dir, model_name, exchange="resha
     torch.save({"hist": hist, "role": r.role, "logits_train": r.logits(True).cpu(), "lo": r.lo, "hi": r.hi,
                 "state": {k: v.cpu() for k, v in r.model.state_dict().items()}},
                os.path.join(out_dir, f"gpusplit_{model_name}_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
     disarm_deadline()
 
 
@@ -671,7 +693,7 @@ def comm_selftest_worker(rank, world, port, out_dir, sabotage=False):
         comm.all_to_all_views = wrong
     ok = comm.self_test_views(torch.device("cpu"))
     torch.save({"ok": ok, "exchanges": comm.exchanges}, os.path.join(out_dir, f"selftest_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
 
 
 def gpu_runner_worker_multi(rank, world, port, out_dir, cases):
@@ -700,7 +722,7 @@ def gpu_runner_worker_multi(rank, world, port, out_dir, cases):
         clear_cache()
         torch.cuda.empty_cache()
         dist.barrier()
-    dist.destroy_process_group()
+    leave_group()
     disarm_deadline()
 
 
@@ -787,7 +809,7 @@ def gpu_ahead_pair_worker(rank, world, port, out_dir, model_name, exchange, size
         torch.cuda.empty_cache()
         dist.barrier()
     torch.save(res, os.path.join(out_dir, f"ahead_{model_name}_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
     disarm_deadline()
 
 
@@ -819,7 +841,7 @@ def gpu_shared_eval_worker(rank, world, port, out_dir, model_name, exchange, siz
         torch.cuda.empty_cache()
         dist.barrier()
     torch.save(res, os.path.join(out_dir, f"shared_{model_name}_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
     disarm_deadline()
 
 
@@ -839,7 +861,7 @@ def rccl_probe_worker(rank, world, port, out_dir):
     ok = t[0].item() == world * (world + 1) / 2 and all(bool((recv[q] == 10 * q + rank).all()) for q in range(world) if q != rank)
     if ok:
         torch.save({"backend": dist.get_backend(), "nccl": torch.cuda.nccl.version()}, os.path.join(out_dir, f"probe_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
 
 
 def gpu_interleave_worker(rank, world, port, out_dir, model_name, exchange, size):
@@ -867,7 +889,7 @@ def gpu_interleave_worker(rank, world, port, out_dir, model_name, exchange, size
         clear_cache()
         dist.barrier()
     torch.save(res, os.path.join(out_dir, f"inter_{model_name}_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
     disarm_deadline()
 
 
@@ -884,7 +906,7 @@ def identity_exchange_worker(rank, world, port, out_dir, idents):
     dist.all_reduce(t)
     torch.save({"got": got, "shared": sharing.share_a_device(got), "sum": t.item(), "rank": r, "world": w},
                os.path.join(out_dir, f"ident_{rank}.pt"))
-    dist.destroy_process_group()
+    leave_group()
 
 
 def propagate_fuzz_worker(rank, world, port, out_dir, seeds, own_group=True):
@@ -952,7 +974,7 @@ def propagate_fuzz_worker(rank, world, port, out_dir, seeds, own_group=True):
         # (an exception ends this rank; its peers then fail in the next collective and the spawn reports it)
     torch.save(bad, os.path.join(out_dir, f"propfuzz_{rank}.pt"))
     if own_group:
-        dist.destroy_process_group()
+        leave_group()
 
 
 def runner_fuzz_worker(rank, world, port, out_dir, seeds, own_group=True):
@@ -1099,7 +1121,7 @@ def runner_fuzz_worker(rank, world, port, out_dir, seeds, own_group=True):
         del r
     torch.save(bad, os.path.join(out_dir, f"runfuzz_{rank}.pt"))
     if own_group:
-        dist.destroy_process_group()
+        leave_group()
 
 
 def dist_fuzz_worker(rank, world, port, out_dir, prop_seeds, run_seeds):
@@ -1110,5 +1132,5 @@ def dist_fuzz_worker(rank, world, port, out_dir, prop_seeds, run_seeds):
     _init(rank, world, port)
     propagate_fuzz_worker(rank, world, port, out_dir, prop_seeds, own_group=False)
     runner_fuzz_worker(rank, world, port, out_dir, run_seeds, own_group=False)
-    dist.destroy_process_group()
+    leave_group()
     faulthandler.cancel_dump_traceback_later()
